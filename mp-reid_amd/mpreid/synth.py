@@ -1,0 +1,83 @@
+"""Seeded synthetic inputs shared by the golden-vector script, the tests and bench.py.
+
+Nothing here comes from the reference: the recipes are SURVEY.md §8(d) ("Synthetic inputs").
+Everything is generated with numpy's PCG64 ``default_rng`` so that the same seed gives the
+same bytes in this container and on the GPU box (same image, same numpy).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+__all__ = ["clustered_features", "labels_for", "vit_state_dict", "synthetic_images", "VIT_B16"]
+
+
+def clustered_features(n: int, dim: int, sigma: float, seed: int = 1234, per_id: int = 20,
+                       normalize: bool = True):
+    """Clustered re-id style features: ``n // per_id`` identity centroids ~ N(0, I), each sample is
+    its centroid plus ``sigma`` * N(0, I); rows L2-normalised.  Returns (feat fp32 [n, dim], pid int64 [n])."""
+    rng = np.random.default_rng(seed)
+    n_ids = max(1, n // per_id)
+    cent = rng.standard_normal((n_ids, dim)).astype(np.float32)
+    pid = rng.integers(0, n_ids, size=n).astype(np.int64)
+    x = cent[pid] + np.float32(sigma) * rng.standard_normal((n, dim)).astype(np.float32)
+    if normalize:
+        x = x / np.maximum(np.linalg.norm(x, axis=1, keepdims=True), 1e-12)
+    return np.ascontiguousarray(x, dtype=np.float32), pid
+
+
+def labels_for(n: int, n_cams: int = 6, seed: int = 99):
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, n_cams, size=n).astype(np.int64)
+
+
+# (h_res, w_res, patch, stride, width, layers, heads, out_dim)
+VIT_B16 = dict(h_res=16, w_res=8, patch=16, stride=16, width=768, layers=12, heads=12, out_dim=512)
+
+
+def vit_state_dict(cfg: dict, seed: int = 7, std: float = 0.02, ln_jitter: float = 0.0):
+    """Deterministic random-init weights in the CLIP ``VisionTransformer`` state-dict layout
+    (key names as in the checkpoint layout listed in SURVEY.md §5 "Checkpoint / resume").
+
+    normal(0, std) for linear/conv weights, small normal biases, LN gamma=1 beta=0 (optionally
+    jittered so that gamma/beta handling is actually exercised), class/pos/proj ~ width**-0.5 * N(0,1).
+    Returned as a dict of float32 numpy arrays."""
+    rng = np.random.default_rng(seed)
+    w, L, od = cfg["width"], cfg["layers"], cfg["out_dim"]
+    p = cfg["patch"]
+    ntok = cfg["h_res"] * cfg["w_res"] + 1
+    scale = w ** -0.5
+
+    def nrm(*shape, s=std):
+        return (rng.standard_normal(shape) * s).astype(np.float32)
+
+    def ln(prefix, sd):
+        sd[prefix + ".weight"] = (1.0 + ln_jitter * rng.standard_normal(w)).astype(np.float32)
+        sd[prefix + ".bias"] = (ln_jitter * rng.standard_normal(w)).astype(np.float32)
+
+    sd = {}
+    sd["conv1.weight"] = nrm(w, 3, p, p)
+    sd["class_embedding"] = nrm(w, s=scale)
+    sd["positional_embedding"] = nrm(ntok, w, s=scale)
+    ln("ln_pre", sd)
+    for i in range(L):
+        b = f"transformer.resblocks.{i}"
+        sd[b + ".attn.in_proj_weight"] = nrm(3 * w, w)
+        sd[b + ".attn.in_proj_bias"] = nrm(3 * w, s=0.01)
+        sd[b + ".attn.out_proj.weight"] = nrm(w, w)
+        sd[b + ".attn.out_proj.bias"] = nrm(w, s=0.01)
+        ln(b + ".ln_1", sd)
+        sd[b + ".mlp.c_fc.weight"] = nrm(4 * w, w)
+        sd[b + ".mlp.c_fc.bias"] = nrm(4 * w, s=0.01)
+        sd[b + ".mlp.c_proj.weight"] = nrm(w, 4 * w)
+        sd[b + ".mlp.c_proj.bias"] = nrm(w, s=0.01)
+        ln(b + ".ln_2", sd)
+    ln("ln_post", sd)
+    sd["proj"] = nrm(w, od, s=scale)
+    return sd
+
+
+def synthetic_images(n: int, h: int, w: int, seed: int = 1234):
+    """``randn`` clamped to [-1, 1] — the value range after mean=std=0.5 normalisation. fp32 NCHW."""
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n, 3, h, w)).astype(np.float32)
+    return np.clip(x, -1.0, 1.0)
