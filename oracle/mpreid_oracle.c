@@ -1,0 +1,478 @@
+/* mpreid_oracle.c — CPU ORACLE (test infrastructure, NOT the product).
+ *
+ * A plain-C restatement of the arithmetic of the reference's evaluation hot path, used only by
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg to CHECK the HIP path.  The
+ * product (mp-reid_amd/) never imports, links or calls anything in this directory.
+ *
+ * Pinning: every function below is checked against golden vectors produced by importing the
+ * reference itself in the build container (tests/golden/make_goldens.py -> tests/golden/ npz files,
+ * tests/test_oracle.py).  The reference has no tests or fixtures of its own.
+ *
+ * What is restated (reference file:line):
+ *   orc_euclid        utils/metrics.py:7-13     squared L2 = |q|^2 + |g|^2 - 2 q.g   (no sqrt, no clamp)
+ *   orc_cosine        utils/metrics.py:15-25    arccos(clip(q.g / (|q||g|), -1+1e-5, 1-1e-5))
+ *   orc_l2_normalize  utils/metrics.py:112-114  torch.nn.functional.normalize(dim=1, p=2, eps=1e-12)
+ *   orc_rerank        utils/reranking.py:29-100 k-reciprocal re-ranking, every rounding point of
+ *                                               SURVEY.md §8a row a7 (1)-(11), sparse V
+ *   orc_eval_func     utils/metrics.py:28-88    CMC / mAP without same-camera filtering
+ *   orc_pairwise_sum* numpy 2.2.6 (pinned in this image; not in /root/reference) pairwise
+ *                     summation used by np.sum on contiguous float arrays: n<8 sequential,
+ *                     n<=128 eight strided accumulators, else split at n/2 rounded down to x8.
+ *
+ * Third-party arithmetic that cannot be restated bit-for-bit (documented tolerance instead):
+ *   - the fp32 GEMM summation order of MKL (torch CPU addmm)  -> we DEFINE the order as a
+ *     k-ascending fmaf chain from 0 (which is what v_mfma_f32_32x32x2_f32 computes, so the HIP
+ *     kernel matches this oracle bit for bit); |delta| vs MKL ~ 4e-7 on unit-norm rows.
+ *   - np.exp float32 (numpy SIMD, not correctly rounded) -> mpreid_expf (include/mpreid_numerics.h).
+ *   - np.argsort's unstable order on exact ties -> ties broken by ascending index.
+ *   - np.arccos float32 -> libm acosf.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -mfma -ffp-contract=off -fopenmp -shared -fPIC).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <float.h>
+
+#include "../include/mpreid_numerics.h"
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------ */
+/* numpy pairwise summation (numpy/_core/src/umath/loops_utils.h.src, *_pairwise_sum)          */
+/* ------------------------------------------------------------------------------------------ */
+ORC_API float orc_pairwise_sum_f32(const float *a, long n) {
+    if (n < 8) {
+        float res = 0.0f;
+        for (long i = 0; i < n; i++) res += a[i];
+        return res;
+    } else if (n <= 128) {
+        float r[8], res;
+        long i;
+        for (int j = 0; j < 8; j++) r[j] = a[j];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    } else {
+        long n2 = n / 2;
+        n2 -= n2 % 8;
+        return orc_pairwise_sum_f32(a, n2) + orc_pairwise_sum_f32(a + n2, n - n2);
+    }
+}
+
+ORC_API double orc_pairwise_sum_f64(const double *a, long n) {
+    if (n < 8) {
+        double res = 0.0;
+        for (long i = 0; i < n; i++) res += a[i];
+        return res;
+    } else if (n <= 128) {
+        double r[8], res;
+        long i;
+        for (int j = 0; j < 8; j++) r[j] = a[j];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    } else {
+        long n2 = n / 2;
+        n2 -= n2 % 8;
+        return orc_pairwise_sum_f64(a, n2) + orc_pairwise_sum_f64(a + n2, n - n2);
+    }
+}
+
+/* exposed so that the tests can pin the shared scalar numerics against numpy */
+ORC_API float orc_expf(float x) { return mpreid_expf(x); }
+ORC_API uint16_t orc_f32_to_f16(float x) { return mpreid_f32_to_f16(x); }
+ORC_API float orc_f16_to_f32(uint16_t h) { return mpreid_f16_to_f32(h); }
+ORC_API int orc_half_k1(int k1) { return mpreid_half_k1(k1); }
+
+/* double -> half, single rounding (numpy casts the Python float (1 - lambda) straight to float16) */
+ORC_API uint16_t orc_f64_to_f16(double d) {
+    /* round d to a value with 11 significant bits (or to the half subnormal grid) in one step */
+    if (d != d) return 0x7e00u;
+    uint16_t sign = 0;
+    if (d < 0 || (d == 0 && 1.0 / d < 0)) { sign = 0x8000u; d = -d; }
+    if (d >= 65520.0) return (uint16_t)(sign | 0x7c00u);
+    if (d == 0.0) return sign;
+    int e;
+    double m = frexp(d, &e); /* d = m * 2^e, m in [0.5,1) */
+    int ue = e - 1;          /* unbiased exponent of d */
+    double q;                /* quantum */
+    if (ue < -14) q = ldexp(1.0, -24); else q = ldexp(1.0, ue - 10);
+    double k = nearbyint(d / q); /* exact scaling by a power of two; RNE under default mode */
+    double r = k * q;
+    (void)m;
+    float rf = (float)r;     /* exactly representable */
+    return (uint16_t)(sign | mpreid_f32_to_f16(rf));
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* squared row norms: the order is DEFINED here and mirrored by the HIP kernel                 */
+/*   lane l (0..63) runs s_l = fmaf(x[k], x[k], s_l) over k = l, l+64, l+128, ...              */
+/*   then a butterfly over lane distances 32,16,8,4,2,1: s_l = s_l + s_{l^off}                 */
+/* ------------------------------------------------------------------------------------------ */
+static float sqnorm_row(const float *x, int d) {
+    float s[64];
+    for (int l = 0; l < 64; l++) {
+        float acc = 0.0f;
+        for (int k = l; k < d; k += 64) acc = fmaf(x[k], x[k], acc);
+        s[l] = acc;
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        float t[64];
+        for (int l = 0; l < 64; l++) t[l] = s[l] + s[l ^ off];
+        memcpy(s, t, sizeof(s));
+    }
+    return s[0];
+}
+
+ORC_API void orc_sqnorm(const float *x, long n, int d, float *out) {
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < n; i++) out[i] = sqnorm_row(x + i * (long)d, d);
+}
+
+/* F.normalize(x, dim=1, p=2, eps): x / max(||x||, eps) */
+ORC_API void orc_l2_normalize(const float *x, long n, int d, float eps, float *out) {
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < n; i++) {
+        float nrm = sqrtf(sqnorm_row(x + i * (long)d, d));
+        float den = nrm > eps ? nrm : eps;
+        for (int k = 0; k < d; k++) out[i * (long)d + k] = x[i * (long)d + k] / den;
+    }
+}
+
+/* dot products as k-ascending fmaf chains from 0, written so that gcc vectorises over j. */
+static void dot_block(const float *a_row, const float *bt /* [d][nb] */, int d, long nb, float *acc) {
+    for (long j = 0; j < nb; j++) acc[j] = 0.0f;
+    for (int k = 0; k < d; k++) {
+        const float ak = a_row[k];
+        const float *bk = bt + (long)k * nb;
+        for (long j = 0; j < nb; j++) acc[j] = fmaf(ak, bk[j], acc[j]);
+    }
+}
+
+static float *transpose_f32(const float *b, long n, int d) {
+    float *bt = (float *)malloc(sizeof(float) * (size_t)n * d);
+    if (!bt) return NULL;
+    for (long j = 0; j < n; j++)
+        for (int k = 0; k < d; k++) bt[(long)k * n + j] = b[j * (long)d + k];
+    return bt;
+}
+
+#define JB 512
+/* utils/metrics.py:7-13 — out[i][j] = fmaf(-2, q_i.g_j, |q_i|^2 + |g_j|^2) */
+ORC_API int orc_euclid(const float *q, const float *g, long nq, long ng, int d, float *out) {
+    float *qq = (float *)malloc(sizeof(float) * nq), *gg = (float *)malloc(sizeof(float) * ng);
+    float *gt = transpose_f32(g, ng, d);
+    if (!qq || !gg || !gt) return -1;
+    orc_sqnorm(q, nq, d, qq);
+    orc_sqnorm(g, ng, d, gg);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (long i = 0; i < nq; i++) {
+        float *acc = out + i * ng;
+        dot_block(q + i * (long)d, gt, d, ng, acc);
+        for (long j = 0; j < ng; j++) acc[j] = fmaf(-2.0f, acc[j], qq[i] + gg[j]);
+    }
+    free(qq); free(gg); free(gt);
+    return 0;
+}
+
+/* utils/metrics.py:15-25 */
+ORC_API int orc_cosine(const float *q, const float *g, long nq, long ng, int d, float *out) {
+    const float lo = (float)(-1.0 + 0.00001), hi = (float)(1.0 - 0.00001);
+    float *qq = (float *)malloc(sizeof(float) * nq), *gg = (float *)malloc(sizeof(float) * ng);
+    float *gt = transpose_f32(g, ng, d);
+    if (!qq || !gg || !gt) return -1;
+    orc_sqnorm(q, nq, d, qq);
+    orc_sqnorm(g, ng, d, gg);
+    for (long i = 0; i < nq; i++) qq[i] = sqrtf(qq[i]);
+    for (long j = 0; j < ng; j++) gg[j] = sqrtf(gg[j]);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (long i = 0; i < nq; i++) {
+        float *acc = out + i * ng;
+        dot_block(q + i * (long)d, gt, d, ng, acc);
+        for (long j = 0; j < ng; j++) {
+            float c = acc[j] * (1.0f / (qq[i] * gg[j])); /* dist_mat.mul(1 / qg_normdot) */
+            c = c < lo ? lo : (c > hi ? hi : c);
+            acc[j] = acosf(c);
+        }
+    }
+    free(qq); free(gg); free(gt);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* re-ranking                                                                                   */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { int *idx; uint16_t *val; int n; } sprow;
+
+static int cmp_int(const void *a, const void *b) {
+    int x = *(const int *)a, y = *(const int *)b;
+    return (x > y) - (x < y);
+}
+
+/* ascending (value, index) selection of the kk smallest entries of row[0..n) */
+static void topk_row(const float *row, long n, int kk, int *out_idx) {
+    float *bv = (float *)malloc(sizeof(float) * (kk + 1));
+    int *bi = (int *)malloc(sizeof(int) * (kk + 1));
+    int cnt = 0;
+    for (long j = 0; j < n; j++) {
+        float v = row[j];
+        if (cnt == kk) {
+            /* candidate must beat the current worst (last) in (value, index) order; index j is larger */
+            if (!(v < bv[kk - 1])) continue;
+        }
+        int p = cnt < kk ? cnt : kk - 1;
+        while (p > 0 && (v < bv[p - 1])) { bv[p] = bv[p - 1]; bi[p] = bi[p - 1]; p--; }
+        bv[p] = v; bi[p] = (int)j;
+        if (cnt < kk) cnt++;
+    }
+    for (int t = 0; t < kk; t++) out_idx[t] = t < cnt ? bi[t] : -1;
+    free(bv); free(bi);
+}
+
+/* Optional debug outputs may be NULL.
+ *   rank_out   [N][k1+1] int32      initial_rank[:, :k1+1]
+ *   v_cnt      [N] int32            nnz per row of V before query expansion
+ *   vqe_cnt    [N] int32            nnz per row after query expansion
+ * local: N x N fp32 or NULL.  lam_h = float16 bits of (1 - lambda) cast from double; lam32 = (float)lambda.
+ * Returns 0, or <0 on allocation failure / bad arguments. */
+ORC_API int orc_rerank(const float *q, const float *g, long nq, long ng, int d, int k1, int k2,
+                       double lambda_value, const float *local, int only_local, float *out,
+                       int *rank_out, int *v_cnt, int *vqe_cnt) {
+    const long N = nq + ng;
+    const int K = k1 + 1;
+    if (K > N || k2 > N || k2 < 1) return -2;
+    const int h = mpreid_half_k1(k1);
+    const uint16_t one_minus_lam_h = orc_f64_to_f16(1.0 - lambda_value);
+    const float lam32 = (float)lambda_value;
+    int rc = 0;
+
+    /* (1) original_dist, utils/reranking.py:33-44 */
+    float *orig = (float *)malloc(sizeof(float) * (size_t)N * N);
+    if (!orig) return -1;
+    int symmetric = 1;
+    if (only_local) {
+        if (!local) { free(orig); return -2; }
+        memcpy(orig, local, sizeof(float) * (size_t)N * N);
+        symmetric = 0;
+    } else {
+        float *feat = (float *)malloc(sizeof(float) * (size_t)N * d);
+        if (!feat) { free(orig); return -1; }
+        memcpy(feat, q, sizeof(float) * (size_t)nq * d);
+        memcpy(feat + (size_t)nq * d, g, sizeof(float) * (size_t)ng * d);
+        rc = orc_euclid(feat, feat, N, N, d, orig);
+        free(feat);
+        if (rc) { free(orig); return rc; }
+        if (local) {
+            for (size_t t = 0; t < (size_t)N * N; t++) orig[t] = orig[t] + local[t];
+            symmetric = 0;
+        }
+    }
+    /* (2) O = transpose(orig / max(orig, axis=0)), utils/reranking.py:46.
+     *     O[i][j] = orig[j][i] / colmax[i].  Stored as a dense N x N (row i contiguous). */
+    float *colmax = (float *)malloc(sizeof(float) * N);
+    float *O = (float *)malloc(sizeof(float) * (size_t)N * N);
+    if (!colmax || !O) { free(orig); free(colmax); free(O); return -1; }
+    for (long j = 0; j < N; j++) colmax[j] = -FLT_MAX;
+    for (long i = 0; i < N; i++)
+        for (long j = 0; j < N; j++)
+            if (orig[i * N + j] > colmax[j]) colmax[j] = orig[i * N + j];
+    (void)symmetric;
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < N; i++)
+        for (long j = 0; j < N; j++) O[i * N + j] = orig[j * N + i] / colmax[i];
+    free(orig);
+
+    /* (3) initial_rank[:, :k1+1], utils/reranking.py:48 (ties -> ascending index) */
+    int *rank = (int *)malloc(sizeof(int) * (size_t)N * K);
+    if (!rank) { free(colmax); free(O); return -1; }
+#pragma omp parallel for schedule(dynamic, 16)
+    for (long i = 0; i < N; i++) topk_row(O + i * N, N, K, rank + i * K);
+    if (rank_out) memcpy(rank_out, rank, sizeof(int) * (size_t)N * K);
+
+    /* (4)-(6) k-reciprocal sets, expansion, V rows; utils/reranking.py:51-71 */
+    sprow *V = (sprow *)calloc(N, sizeof(sprow));
+    const int cap = K + K * h;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (long i = 0; i < N; i++) {
+        int *R = (int *)malloc(sizeof(int) * K);
+        int *E = (int *)malloc(sizeof(int) * cap);
+        int *Rc = (int *)malloc(sizeof(int) * h);
+        float *w = (float *)malloc(sizeof(float) * cap);
+        int nR = 0, nE = 0;
+        const int *fwd = rank + i * K;
+        for (int a = 0; a < K; a++) { /* k_reciprocal_index, in rank order */
+            const int *bwd = rank + (long)fwd[a] * K;
+            for (int b = 0; b < K; b++) if (bwd[b] == (int)i) { R[nR++] = fwd[a]; break; }
+        }
+        for (int a = 0; a < nR; a++) E[nE++] = R[a];
+        for (int a = 0; a < nR; a++) {
+            const int cand = R[a];
+            const int *cf = rank + (long)cand * K; /* first h entries */
+            int nRc = 0;
+            for (int b = 0; b < h; b++) {
+                const int *cb = rank + (long)cf[b] * K;
+                for (int c = 0; c < h; c++) if (cb[c] == cand) { Rc[nRc++] = cf[b]; break; }
+            }
+            int inter = 0; /* len(np.intersect1d(Rc, R)) — both duplicate-free */
+            for (int b = 0; b < nRc; b++)
+                for (int c = 0; c < nR; c++) if (Rc[b] == R[c]) { inter++; break; }
+            if ((double)inter > (2.0 / 3.0) * (double)nRc) /* compared against the ORIGINAL R */
+                for (int b = 0; b < nRc; b++) E[nE++] = Rc[b];
+        }
+        qsort(E, nE, sizeof(int), cmp_int); /* np.unique */
+        int u = 0;
+        for (int a = 0; a < nE; a++) if (a == 0 || E[a] != E[a - 1]) E[u++] = E[a];
+        nE = u;
+        for (int a = 0; a < nE; a++) w[a] = mpreid_expf(-O[i * N + E[a]]);
+        const float s = orc_pairwise_sum_f32(w, nE);
+        V[i].idx = (int *)malloc(sizeof(int) * (nE ? nE : 1));
+        V[i].val = (uint16_t *)malloc(sizeof(uint16_t) * (nE ? nE : 1));
+        int m = 0;
+        for (int a = 0; a < nE; a++) {
+            uint16_t hv = mpreid_f32_to_f16(w[a] / s);
+            if (hv & 0x7fffu) { V[i].idx[m] = E[a]; V[i].val[m] = hv; m++; } /* V != 0 only */
+        }
+        V[i].n = m;
+        if (v_cnt) v_cnt[i] = m;
+        free(R); free(E); free(Rc); free(w);
+    }
+
+    /* (7) local query expansion, utils/reranking.py:73-78 */
+    if (k2 != 1) {
+        sprow *Vq = (sprow *)calloc(N, sizeof(sprow));
+        const float k2f = (float)k2;
+#pragma omp parallel for schedule(dynamic, 16)
+        for (long i = 0; i < N; i++) {
+            int tot = 0;
+            for (int m = 0; m < k2; m++) tot += V[rank[i * K + m]].n;
+            int *ci = (int *)malloc(sizeof(int) * (tot ? tot : 1));
+            int nc = 0;
+            for (int m = 0; m < k2; m++) {
+                const sprow *r = &V[rank[i * K + m]];
+                memcpy(ci + nc, r->idx, sizeof(int) * r->n);
+                nc += r->n;
+            }
+            qsort(ci, nc, sizeof(int), cmp_int);
+            int u = 0;
+            for (int a = 0; a < nc; a++) if (a == 0 || ci[a] != ci[a - 1]) ci[u++] = ci[a];
+            nc = u;
+            float *acc = (float *)calloc(nc ? nc : 1, sizeof(float));
+            for (int m = 0; m < k2; m++) { /* fp32 sum in rank order */
+                const sprow *r = &V[rank[i * K + m]];
+                int p = 0;
+                for (int a = 0; a < r->n; a++) {
+                    while (ci[p] != r->idx[a]) p++;
+                    acc[p] = acc[p] + mpreid_f16_to_f32(r->val[a]);
+                }
+            }
+            Vq[i].idx = (int *)malloc(sizeof(int) * (nc ? nc : 1));
+            Vq[i].val = (uint16_t *)malloc(sizeof(uint16_t) * (nc ? nc : 1));
+            int mcnt = 0;
+            for (int a = 0; a < nc; a++) {
+                uint16_t hv = mpreid_f32_to_f16(acc[a] / k2f);
+                if (hv & 0x7fffu) { Vq[i].idx[mcnt] = ci[a]; Vq[i].val[mcnt] = hv; mcnt++; }
+            }
+            Vq[i].n = mcnt;
+            free(ci); free(acc);
+        }
+        for (long i = 0; i < N; i++) { free(V[i].idx); free(V[i].val); }
+        free(V);
+        V = Vq;
+    }
+    if (vqe_cnt) for (long i = 0; i < N; i++) vqe_cnt[i] = V[i].n;
+    free(rank);
+
+    /* inverted index, utils/reranking.py:80-82: column c -> (row, value) ascending row */
+    long *cptr = (long *)calloc(N + 1, sizeof(long));
+    for (long i = 0; i < N; i++) for (int a = 0; a < V[i].n; a++) cptr[V[i].idx[a] + 1]++;
+    for (long c = 0; c < N; c++) cptr[c + 1] += cptr[c];
+    const long nnz = cptr[N];
+    int *crow = (int *)malloc(sizeof(int) * (nnz ? nnz : 1));
+    uint16_t *cval = (uint16_t *)malloc(sizeof(uint16_t) * (nnz ? nnz : 1));
+    long *fill = (long *)malloc(sizeof(long) * N);
+    memcpy(fill, cptr, sizeof(long) * N);
+    for (long i = 0; i < N; i++)
+        for (int a = 0; a < V[i].n; a++) {
+            long p = fill[V[i].idx[a]]++;
+            crow[p] = (int)i; cval[p] = V[i].val[a];
+        }
+    free(fill);
+
+    /* (8)-(11) Jaccard + blend, utils/reranking.py:84-100 */
+    const uint16_t H1 = 0x3c00u, H2 = 0x4000u;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (long i = 0; i < nq; i++) {
+        uint16_t *t = (uint16_t *)calloc(N, sizeof(uint16_t));
+        for (int a = 0; a < V[i].n; a++) { /* ascending column */
+            const int c = V[i].idx[a];
+            const uint16_t vic = V[i].val[a];
+            for (long p = cptr[c]; p < cptr[c + 1]; p++) {
+                const int r = crow[p];
+                t[r] = mpreid_h_add(t[r], mpreid_h_min_nonneg(vic, cval[p]));
+            }
+        }
+        for (long j = nq; j < N; j++) {
+            uint16_t den = mpreid_h_sub(H2, t[j]);   /* 2 - temp_min            */
+            uint16_t qt = mpreid_h_div(t[j], den);   /* temp_min / (2 - temp_min) */
+            uint16_t jac = mpreid_h_sub(H1, qt);     /* 1 - ...                  */
+            uint16_t jl = mpreid_h_mul(jac, one_minus_lam_h);
+            out[i * ng + (j - nq)] = mpreid_f16_to_f32(jl) + O[i * N + j] * lam32;
+        }
+        free(t);
+    }
+    for (long i = 0; i < N; i++) { free(V[i].idx); free(V[i].val); }
+    free(V); free(cptr); free(crow); free(cval); free(colmax); free(O);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* eval_func, utils/metrics.py:28-88                                                           */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { float v; int i; } vi_t;
+static int cmp_vi(const void *a, const void *b) {
+    const vi_t *x = (const vi_t *)a, *y = (const vi_t *)b;
+    if (x->v < y->v) return -1;
+    if (x->v > y->v) return 1;
+    return (x->i > y->i) - (x->i < y->i);
+}
+
+/* cmc: float32[max_rank_eff]; returns number of valid queries (0 => the reference asserts),
+ * *max_rank_eff = min(max_rank, ng).  all_ap (optional) receives the AP of each valid query. */
+ORC_API long orc_eval_func(const float *dist, const int64_t *q_pid, const int64_t *g_pid, long nq, long ng,
+                           int max_rank, float *cmc, double *mAP, int *max_rank_eff, double *all_ap) {
+    if (ng < max_rank) max_rank = (int)ng;
+    *max_rank_eff = max_rank;
+    float *cmc_sum = (float *)calloc(max_rank, sizeof(float));
+    double *aps = (double *)malloc(sizeof(double) * (nq ? nq : 1));
+    long nvalid = 0;
+    vi_t *row = (vi_t *)malloc(sizeof(vi_t) * ng);
+    double *tmp = (double *)malloc(sizeof(double) * ng);
+    for (long qi = 0; qi < nq; qi++) {
+        for (long j = 0; j < ng; j++) { row[j].v = dist[qi * ng + j]; row[j].i = (int)j; }
+        qsort(row, ng, sizeof(vi_t), cmp_vi);
+        long num_rel = 0;
+        for (long j = 0; j < ng; j++) num_rel += (g_pid[row[j].i] == q_pid[qi]);
+        if (num_rel == 0) continue;
+        long cum = 0;
+        for (long j = 0; j < ng; j++) {
+            int m = (g_pid[row[j].i] == q_pid[qi]);
+            cum += m;
+            if (j < max_rank) cmc_sum[j] += (cum > 0) ? 1.0f : 0.0f; /* float32 column sums of 0/1 */
+            tmp[j] = ((double)cum / (double)(j + 1)) * (double)m;
+        }
+        aps[nvalid++] = orc_pairwise_sum_f64(tmp, ng) / (double)num_rel;
+    }
+    if (nvalid > 0) {
+        for (int r = 0; r < max_rank; r++) cmc[r] = cmc_sum[r] / (float)nvalid;
+        *mAP = orc_pairwise_sum_f64(aps, nvalid) / (double)nvalid;
+        if (all_ap) memcpy(all_ap, aps, sizeof(double) * nvalid);
+    }
+    free(cmc_sum); free(aps); free(row); free(tmp);
+    return nvalid;
+}

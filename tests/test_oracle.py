@@ -1,0 +1,158 @@
+"""CPU oracle vs the golden vectors captured from the reference (tests/golden/make_goldens.py).
+
+Tolerances (SURVEY.md §7 "Hard parts" 1):
+  * euclid / cosine entries: 1e-5 (fp32 GEMM order differs from MKL's)
+  * re-ranked entries: frac(|d| > 1e-5) <= 1e-4 on these small fixtures and max |d| <= one fp16
+    quantum of J*(1-lambda) (4.9e-4 * ... ) — isolated single-quantum flips come from np.exp not
+    being correctly rounded and from 1-ulp differences in the fp32 GEMM.
+  * mAP / CMC: 1e-4
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+
+def test_pairwise_sum_matches_numpy():
+    rng = np.random.default_rng(0)
+    for n in list(range(0, 140)) + [255, 256, 257, 300, 511, 777, 1000, 1377, 2048, 4099]:
+        a = rng.random(n).astype(np.float32) * np.float32(0.9) + np.float32(0.05)
+        assert orc.pairwise_sum_f32(a) == np.sum(a), n
+
+
+def test_f16_conversion_matches_numpy():
+    rng = np.random.default_rng(1)
+    x = np.concatenate([
+        rng.standard_normal(20000).astype(np.float32),
+        (rng.random(20000).astype(np.float32) * 1e-4).astype(np.float32),
+        (rng.random(5000).astype(np.float32) * 2e-7).astype(np.float32),
+        np.array([0.0, -0.0, 65504.0, 65519.9, 65520.0, 1e6, 6.1035156e-05, 5.9604645e-08, 2.9802322e-08,
+                  2.98023259e-08, 8.9406967e-08, 1.0, 0.7, 0.3, 2.0], np.float32)])
+    want = x.astype(np.float16).view(np.uint16)
+    got = np.array([orc.f32_to_f16_bits(v) for v in x], np.uint16)
+    assert np.array_equal(want, got)
+    L = orc.lib()
+    h = np.arange(0, 0x7c00, 7, dtype=np.uint16)
+    back = np.array([L.orc_f16_to_f32(int(v)) for v in h], np.float32)
+    assert np.array_equal(back, h.view(np.float16).astype(np.float32))
+    for d in [0.7, 0.3, 1.0, 0.0, 0.5, 1 - 0.3, 1 - 0.1, 1e-5, 1 - 1e-3, 0.9999, 3.14159]:
+        assert orc.f64_to_f16_bits(d) == int(np.float16(d).view(np.uint16)), d
+
+
+def test_expf_accuracy():
+    rng = np.random.default_rng(2)
+    x = np.concatenate([-rng.random(200000), rng.standard_normal(20000) * 20]).astype(np.float32)
+    got = np.array([orc.expf(v) for v in x[:40000]], np.float32)
+    ref = np.exp(x[:40000].astype(np.float64))
+    ulp = np.spacing(ref.astype(np.float32)).astype(np.float64)
+    err = np.abs(got.astype(np.float64) - ref) / ulp
+    assert err.max() < 1.0, err.max()
+
+
+def test_half_k1_rounding():
+    for k1 in range(1, 200):
+        assert orc.lib().orc_half_k1(k1) == int(np.around(k1 / 2)) + 1
+
+
+def test_euclid_cosine_vs_reference(golden):
+    from mpreid import synth
+    g = golden("distance.npz")
+    feat, _ = synth.clustered_features(int(g["n"]), int(g["dim"]), float(g["sigma"]), seed=int(g["seed"]),
+                                       per_id=int(g["per_id"]))
+    nq = int(g["nq"])
+    d = orc.euclidean_distance(feat[:nq], feat[nq:])
+    assert np.abs(d - g["euclid"]).max() < 1e-5
+    c = orc.cosine_similarity(feat[:nq], feat[nq:])
+    assert np.abs(c - g["cosine"]).max() < 1e-5
+    raw, _ = synth.clustered_features(int(g["n"]), int(g["dim"]), float(g["sigma"]), seed=int(g["seed"]),
+                                      per_id=int(g["per_id"]), normalize=False)
+    d = orc.euclidean_distance(raw[:nq], raw[nq:])
+    assert np.abs(d - g["euclid_raw"]).max() / np.abs(g["euclid_raw"]).max() < 1e-6
+    c = orc.cosine_similarity(raw[:nq], raw[nq:])
+    assert np.abs(c - g["cosine_raw"]).max() < 1e-5
+
+
+def test_eval_func_vs_reference(golden):
+    g = golden("eval_func.npz")
+    d = golden("distance.npz")["euclid"]
+    cmc, mAP = orc.eval_func(d, g["q_pid"], g["g_pid"], g["q_cam"], g["g_cam"])
+    assert np.array_equal(cmc, g["cmc"])
+    assert mAP == float(g["mAP"])
+    cmc, mAP = orc.eval_func(d[:, :30], g["q_pid"], g["g_pid"][:30], g["q_cam"], g["g_cam"][:30])
+    assert cmc.shape == g["cmc_small"].shape and np.array_equal(cmc, g["cmc_small"])
+    assert mAP == float(g["mAP_small"])
+
+
+def _rr_check(got, want, lam):
+    d = np.abs(got - want)
+    frac = float((d > 1e-5).mean())
+    return frac, float(d.max())
+
+
+@pytest.mark.parametrize("case", ["50_15_0.3", "20_6_0.3", "5_1_0.3", "20_6_0.0", "20_6_1.0", "7_3_0.5", "10_1_0.3"])
+def test_rerank_vs_reference(golden, case):
+    g = golden("rerank.npz")
+    k1, k2, lam = case.split("_")
+    k1, k2, lam = int(k1), int(k2), float(lam)
+    nq = int(g["nq"])
+    feat = g["feat"]
+    got = orc.re_ranking(feat[:nq], feat[nq:], k1, k2, lam)
+    frac, mx = _rr_check(got, g[f"rr_{case}"], lam)
+    assert frac <= 1e-4 and mx <= 5e-4, (frac, mx)
+
+
+def test_rerank_local_vs_reference(golden):
+    g = golden("rerank.npz")
+    nq = int(g["nq"])
+    feat = g["feat"]
+    local = g["local"].astype(np.float32)
+    got = orc.re_ranking(feat[:nq], feat[nq:], 20, 6, 0.3, local_distmat=local)
+    frac, mx = _rr_check(got, g["rr_local_20_6_0.3"], 0.3)
+    assert frac <= 1e-4 and mx <= 5e-4, (frac, mx)
+    got = orc.re_ranking(feat[:nq], feat[nq:], 20, 6, 0.3, local_distmat=local, only_local=True)
+    frac, mx = _rr_check(got, g["rr_onlylocal_20_6_0.3"], 0.3)
+    assert frac <= 1e-4 and mx <= 5e-4, (frac, mx)
+
+
+def test_r1_map_eval_pipeline_vs_reference(golden):
+    g = golden("r1_map_eval.npz")
+    nq = int(g["nq"])
+    raw, pid = g["raw"], g["pid"]
+    for rr in (0, 1):
+        for fn in (0, 1):
+            f = orc.l2_normalize(raw) if fn else raw
+            if rr:
+                d = orc.re_ranking(f[:nq], f[nq:], 50, 15, 0.3)
+            else:
+                d = orc.euclidean_distance(f[:nq], f[nq:])
+            cmc, mAP = orc.eval_func(d, pid[:nq], pid[nq:])
+            tag = f"rr{rr}_fn{fn}"
+            assert abs(mAP - float(g[f"mAP_{tag}"])) < 1e-4, tag
+            assert np.abs(cmc - g[f"cmc_{tag}"]).max() < 1e-4, tag
+            want = g[f"distmat_{tag}"]
+            scale = max(1.0, float(np.abs(want).max()))
+            dd = np.abs(d - want) / scale
+            if rr:
+                assert (dd > 1e-5).mean() <= 1e-4 and dd.max() <= 5e-4, (tag, (dd > 1e-5).mean(), dd.max())
+            else:
+                assert dd.max() < 1e-5, (tag, dd.max())
+
+
+def test_vit_oracle_vs_reference(golden):
+    from mpreid import synth
+    g = golden("vit.npz")
+    small = dict(h_res=4, w_res=2, patch=16, stride=16, width=128, layers=2, heads=2, out_dim=64)
+    sd = synth.vit_state_dict(small, seed=7, std=0.05, ln_jitter=0.1)
+    f = orc.vit_features(sd, small, synth.synthetic_images(3, 64, 32, seed=3))
+    assert np.abs(f - g["small_feat"]).max() < 2e-5
+    big = synth.VIT_B16
+    sd = synth.vit_state_dict(big, seed=7, std=0.02, ln_jitter=0.05)
+    imgs = synth.synthetic_images(4, 256, 128, seed=1234)
+    f = orc.vit_features(sd, big, imgs[:2])
+    assert np.abs(f - g["b16_feat"][:2]).max() < 5e-5
+    f = orc.vit_features(sd, big, imgs[:1], cv_emb=g["b16_cv"][:1])
+    assert np.abs(f - g["b16_feat_cv"][:1]).max() < 5e-5
+    s12 = dict(big, h_res=21, w_res=10, stride=12)
+    sd12 = synth.vit_state_dict(s12, seed=8, std=0.02, ln_jitter=0.05)
+    f = orc.vit_features(sd12, s12, imgs[:1])
+    assert np.abs(f - g["b16_s12_feat"][:1]).max() < 5e-5
