@@ -1,0 +1,146 @@
+/* mpreid.h — C ABI of libmpreid_hip.so: the MI355X (gfx950) implementation of MP-ReID's evaluation
+ * hot path.  Plain pointers and sizes only; every pointer named "device" is HBM memory of the
+ * current HIP device; every call is ordered on `stream` (a hipStream_t passed as void*).
+ *
+ * The reference (a pure-Python repo) has no FFI layer; the interface each entry point stands
+ * behind is the Python function cited next to it.  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add (it is the one mp-reid_amd/mpreid/_lib.py uses).
+ *
+ * Return value: 0 on success, otherwise a negative mpreid error or a positive hipError_t;
+ * mpreid_last_error() returns a thread-local description.  Nothing falls back to the CPU.
+ */
+#ifndef MPREID_H
+#define MPREID_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPREID_OK 0
+#define MPREID_ERR_ARG (-1)
+#define MPREID_ERR_WORKSPACE (-2)
+#define MPREID_ERR_UNSUPPORTED (-3)
+#define MPREID_ERR_NODEVICE (-4)
+
+typedef void *mpreid_stream_t; /* hipStream_t */
+
+int mpreid_version(void);
+const char *mpreid_last_error(void);
+/* number of visible HIP devices (0 when there is none); never throws, does not create a context */
+int mpreid_device_count(void);
+/* name/CU count of the current device */
+int mpreid_device_info(char *name, int name_len, int *cu_count, size_t *hbm_bytes);
+
+/* ---- distance path ----------------------------------------------------------------------- */
+/* Arithmetic modes of the feat x feat^T GEMM */
+#define MPREID_GEMM_F32_EXACT 0 /* v_mfma_f32_32x32x2_f32: k-ascending fmaf chain, bit-reproducible  */
+#define MPREID_GEMM_F16_FAST 1  /* fp16 inputs, fp32 accumulate, one pass (|err| ~1e-4 on unit rows)  */
+
+/* squared L2 norm of each row, out[n].  Order of summation is fixed (see oracle/mpreid_oracle.c). */
+int mpreid_sqnorm_f32(const float *x_dev, int64_t n, int d, float *out_dev, mpreid_stream_t stream);
+
+/* utils/metrics.py:112-114 — torch.nn.functional.normalize(feats, dim=1, p=2) with eps (1e-12). */
+int mpreid_l2_normalize_f32(const float *x_dev, int64_t n, int d, float eps, float *out_dev,
+                            mpreid_stream_t stream);
+
+/* utils/metrics.py:7-13 euclidean_distance(qf, gf): out[i*ldo + j] = |q_i|^2 + |g_j|^2 - 2 q_i.g_j
+ * q [nq][d], g [ng][d] fp32 row-major; out fp32, leading dimension ldo >= ng (lets a rank write its
+ * gallery shard's column block of a wider matrix).  ws: mpreid_distance_workspace_bytes(). */
+size_t mpreid_distance_workspace_bytes(int64_t nq, int64_t ng, int d, int mode);
+int mpreid_euclidean_distance_f32(const float *q_dev, const float *g_dev, int64_t nq, int64_t ng, int d,
+                                  float *out_dev, int64_t ldo, int mode, void *ws_dev, size_t ws_bytes,
+                                  mpreid_stream_t stream);
+/* utils/metrics.py:15-25 cosine_similarity(qf, gf): arccos(clip(q.g/(|q||g|), -1+1e-5, 1-1e-5)) */
+int mpreid_cosine_similarity_f32(const float *q_dev, const float *g_dev, int64_t nq, int64_t ng, int d,
+                                 float *out_dev, int64_t ldo, int mode, void *ws_dev, size_t ws_bytes,
+                                 mpreid_stream_t stream);
+
+/* ---- k-reciprocal re-ranking, utils/reranking.py:29-100 ------------------------------------ */
+typedef struct {
+    int64_t n;            /* nq + ng */
+    int32_t k1, k2, half_k1;
+    int32_t v_cap;        /* ELL row capacity of V before query expansion */
+    int32_t vqe_cap;      /* row capacity after query expansion (max union size, measured) */
+    int64_t v_nnz;        /* nnz(V) before query expansion */
+    int64_t vqe_nnz;      /* nnz(V) after query expansion (== v_nnz when k2 == 1) */
+    int64_t jaccard_pairs;/* sum over queries i, columns c in nz(V[i]) of nnz(V[:,c]) */
+    float ms_gemm, ms_topk, ms_krecip, ms_qe, ms_csc, ms_jaccard, ms_total; /* filled when timing != 0 */
+} mpreid_rerank_stats;
+
+/* Bytes of device workspace re_ranking needs for this problem (dominated by the N x N fp32
+ * distance matrix that stays resident in HBM: 4*N*N). */
+size_t mpreid_rerank_workspace_bytes(int64_t nq, int64_t ng, int d, int k1, int k2, int has_local);
+
+/* re_ranking(probFea, galFea, k1, k2, lambda_value, local_distmat=None, only_local=False)
+ *   q [nq][d], g [ng][d] fp32 device; local_dev: NULL or [N][N] fp32 device (N = nq+ng);
+ *   out_dev [nq][ldo] fp32 receives final_dist[:nq, nq:]  (ldo >= ng).
+ * lambda is a double because the reference rounds (1 - lambda) from a Python float straight to
+ * float16 and lambda to float32.  The call synchronises `stream` internally (sizes of the sparse
+ * structures are read back) and returns after the result is complete.
+ * stats may be NULL; with timing != 0 per-stage times are measured with hipEvents on `stream`. */
+int mpreid_rerank_f32(const float *q_dev, const float *g_dev, int64_t nq, int64_t ng, int d, int k1, int k2,
+                      double lambda_value, const float *local_dev, int only_local, float *out_dev,
+                      int64_t ldo, void *ws_dev, size_t ws_bytes, mpreid_stream_t stream,
+                      mpreid_rerank_stats *stats, int timing);
+
+/* debug/inspection taps used by the parity tests: copies of intermediate results of the LAST
+ * mpreid_rerank_f32 call that used workspace ws_dev (valid until the workspace is reused).
+ *   rank_out [N][k1+1] int32 (initial_rank[:, :k1+1]); v_cnt/vqe_cnt [N] int32 nnz per row. */
+int mpreid_rerank_debug_copy(const void *ws_dev, int64_t nq, int64_t ng, int d, int k1, int k2, int has_local,
+                             int32_t *rank_out_host, int32_t *v_cnt_host, int32_t *vqe_cnt_host,
+                             mpreid_stream_t stream);
+
+/* ---- CLIP ViT-B/16 image encoder, model/clip/model.py:415-479 + model/make_model.py:81-115 -- */
+typedef struct {
+    int32_t img_h, img_w;   /* INPUT.SIZE_TEST */
+    int32_t patch, stride;  /* 16, MODEL.STRIDE_SIZE[0] */
+    int32_t h_res, w_res;   /* patch grid; tokens L = h_res*w_res + 1 */
+    int32_t width, layers, heads, out_dim; /* 768, 12, 12, 512 */
+    int32_t neck_after;     /* TEST.NECK_FEAT == 'after': apply the eval BatchNorm necks */
+    int32_t cls_only_last;  /* 1: last block computes only the CLS row (the only row the output uses) */
+} mpreid_vit_cfg;
+
+typedef struct { /* device pointers; *_w are fp16 [out][in] row-major (torch Linear layout) */
+    const void *in_proj_w;   /* [3*width][width] fp16 */
+    const float *in_proj_b;  /* [3*width] */
+    const void *out_proj_w;  /* [width][width] fp16 */
+    const float *out_proj_b;
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    const void *fc_w;        /* [4*width][width] fp16 */
+    const float *fc_b;
+    const void *proj_w;      /* [width][4*width] fp16 */
+    const float *proj_b;
+} mpreid_vit_layer;
+
+typedef struct { /* device pointers */
+    const void *conv_w;         /* [width][3*patch*patch] fp16, inner order (c, kh, kw) */
+    const float *class_emb;     /* [width] */
+    const float *pos_emb;       /* [L][width] */
+    const float *ln_pre_g, *ln_pre_b, *ln_post_g, *ln_post_b;
+    const float *proj;          /* [width][out_dim] fp32 */
+    const float *bn_scale, *bn_shift;           /* [width]   eval BN folded: y = x*scale + shift (or NULL) */
+    const float *bn_proj_scale, *bn_proj_shift; /* [out_dim] */
+    const mpreid_vit_layer *layers;             /* HOST array of cfg.layers entries */
+} mpreid_vit_weights;
+
+size_t mpreid_vit_workspace_bytes(const mpreid_vit_cfg *cfg, int batch);
+/* img_dev [B][3][img_h][img_w] fp32 (already mean/std normalised); cv_emb_dev NULL or [B][width]
+ * (SIE_COE * cv_embed[idx], model/make_model.py:89-96); out_dev [B][width+out_dim] fp32. */
+int mpreid_vit_forward(const mpreid_vit_cfg *cfg, const mpreid_vit_weights *w, const float *img_dev, int batch,
+                       const float *cv_emb_dev, float *out_dev, void *ws_dev, size_t ws_bytes,
+                       mpreid_stream_t stream);
+
+/* fp16 GEMM used by the encoder, exposed for the roofline bench and unit tests:
+ * C[M][N] (fp32) = A[M][K] (fp16) x B[N][K]^T (fp16).  M, N multiples of 128... see DESIGN.md. */
+int mpreid_gemm_f16_nt(const void *a_dev, const void *b_dev, float *c_dev, int64_t m, int64_t n, int64_t k,
+                       mpreid_stream_t stream);
+/* fp32 -> fp16 (RNE) conversion of a flat array */
+int mpreid_cast_f32_to_f16(const float *x_dev, void *y_dev, int64_t n, mpreid_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPREID_H */

@@ -1,0 +1,58 @@
+// common.h — shared host/device helpers of libmpreid_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/mpreid.h"
+#include "../../include/mpreid_numerics.h"
+
+void mpreid_set_error(const char *fmt, ...);
+
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            mpreid_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return (int)e_;                                                                         \
+        }                                                                                           \
+    } while (0)
+#define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
+#define ARG_CHECK(cond)                                                                             \
+    do {                                                                                            \
+        if (!(cond)) {                                                                              \
+            mpreid_set_error("bad argument: %s (%s:%d)", #cond, __FILE__, __LINE__);               \
+            return MPREID_ERR_ARG;                                                                  \
+        }                                                                                           \
+    } while (0)
+
+__host__ __device__ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Bijective XCD-aware remap of a 1-D block id: blocks b and b+8 share an XCD (round-robin
+// dispatch), so give each XCD a contiguous chunk of the logical tile order (L2 locality only;
+// correctness never depends on it).  cdna_hip_programming.md §5 "XCD swizzle must be bijective".
+__device__ __forceinline__ unsigned xcd_remap(unsigned orig, unsigned nwg) {
+    const unsigned q = nwg >> 3, r = nwg & 7u, xcd = orig & 7u;
+    const unsigned base = (xcd < r) ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+    return base + (orig >> 3);
+}
+
+// grouped tile order: walk GM tile-rows at a time so concurrently resident blocks share B panels
+__device__ __forceinline__ void tile_coords(unsigned id, int tiles_m, int tiles_n, int GM, int &tm, int &tn) {
+    const unsigned per_group = (unsigned)GM * (unsigned)tiles_n;
+    const unsigned group = id / per_group;
+    const int first_m = (int)group * GM;
+    const int gsize = min(tiles_m - first_m, GM);
+    const unsigned in_group = id % per_group;
+    tm = first_m + (int)(in_group % (unsigned)gsize);
+    tn = (int)(in_group / (unsigned)gsize);
+}
+
+__device__ __forceinline__ float wave_bfly_add(float s) {
+    // fixed butterfly 32,16,8,4,2,1 — the order the oracle mirrors (oracle/mpreid_oracle.c sqnorm_row)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s = s + __shfl_xor(s, off, 64);
+    return s;
+}

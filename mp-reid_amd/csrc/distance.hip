@@ -1,0 +1,264 @@
+// distance.hip — L2-normalise, squared norms and the feat x feat^T distance GEMM (exact fp32 mode).
+//
+// Reference behaviour: utils/metrics.py:7-13 (euclidean_distance), :15-25 (cosine_similarity),
+// :112-114 (F.normalize), utils/reranking.py:36-41 (all-pairs distance of cat(q,g)).
+//
+// Exact mode = v_mfma_f32_32x32x2_f32: per output element a k-ascending fp32 fmaf chain from 0
+// (cdna_hip_programming.md §3 "FP32-input MFMA"), so D[i][j] is bit-identical to the oracle's
+// scalar chain and D is bit-symmetric when q == g (the re-ranking path relies on that: column max
+// == row max).  Roofline: MFMA fp32, 157 TFLOP/s peak.
+//
+// Tile: 128x128 per 256-thread workgroup (2x2 waves of 64x64 = 2x2 MFMA 32x32 tiles), BK = 16,
+// LDS [k][m] fp32 double-buffered (33 KB -> 4 workgroups/CU), register-staged prefetch of the next
+// K tile (global loads issued before the MFMA block, LDS writes after it), one barrier per K tile.
+#include "common.h"
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// ---------------------------------------------------------------------------------------------
+// squared norms / normalisation: one wave per row, lane-strided fmaf chains + fixed butterfly
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float row_sqnorm(const float *__restrict__ x, int d, int lane) {
+    float acc = 0.0f;
+    for (int k = lane; k < d; k += 64) {
+        const float v = x[k];
+        acc = fmaf(v, v, acc);
+    }
+    return wave_bfly_add(acc);
+}
+
+// mode 0: |x|^2, mode 1: |x|
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float *__restrict__ x, int64_t n, int d,
+                                                     float *__restrict__ out, int mode) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    float s = row_sqnorm(x + row * (int64_t)d, d, lane);
+    if (mode == 1) s = __fsqrt_rn(s);
+    if (lane == 0) out[row] = s;
+}
+
+__global__ __launch_bounds__(256) void l2_normalize_kernel(const float *__restrict__ x, int64_t n, int d, float eps,
+                                                           float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const float *xr = x + row * (int64_t)d;
+    float *orow = out + row * (int64_t)d;
+    const float nrm = __fsqrt_rn(row_sqnorm(xr, d, lane));
+    const float den = nrm > eps ? nrm : eps;
+    for (int k = lane; k < d; k += 64) orow[k] = __fdiv_rn(xr[k], den);
+}
+
+// ---------------------------------------------------------------------------------------------
+// exact fp32 MFMA GEMM with distance epilogues
+// ---------------------------------------------------------------------------------------------
+enum { EPI_EUCLID = 0, EPI_COSINE = 1 };
+
+constexpr int XBM = 128, XBN = 128, XBK = 16, XLD = 132;
+
+__device__ __forceinline__ float4 load_k4(const float *__restrict__ base, int64_t row, int64_t nrows, int k, int K,
+                                          bool vec_ok) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < nrows) {
+        const float *p = base + row * (int64_t)K + k;
+        if (vec_ok && k + 3 < K) {
+            v = *reinterpret_cast<const float4 *>(p);
+        } else {
+            if (k + 0 < K) v.x = p[0];
+            if (k + 1 < K) v.y = p[1];
+            if (k + 2 < K) v.z = p[2];
+            if (k + 3 < K) v.w = p[3];
+        }
+    }
+    return v;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_exact_kernel(const float *__restrict__ A, const float *__restrict__ B,
+                                                             int64_t M, int64_t N, int K,
+                                                             const float *__restrict__ an,
+                                                             const float *__restrict__ bn, float *__restrict__ C,
+                                                             int64_t ldc, int tiles_m, int tiles_n, int vec_ok) {
+    __shared__ float As[2][XBK][XLD];
+    __shared__ float Bs[2][XBK][XLD];
+
+    int tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, 8, tm, tn);
+    const int64_t m0 = (int64_t)tm * XBM, n0 = (int64_t)tn * XBN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    // staging map: each thread moves 2 float4 of A and 2 of B per K tile; idx -> (row, kc)
+    const int r0 = tid >> 2, kc = tid & 3; // rows r0 and r0 + 64
+    float4 ra[2], rb[2];
+    const int nkt = (K + XBK - 1) / XBK;
+
+    auto gload = [&](int kt) {
+        const int k = kt * XBK + kc * 4;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            ra[r] = load_k4(A, m0 + r0 + 64 * r, M, k, K, vec_ok != 0);
+            rb[r] = load_k4(B, n0 + r0 + 64 * r, N, k, K, vec_ok != 0);
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int row = r0 + 64 * r;
+            As[buf][kc * 4 + 0][row] = ra[r].x;
+            As[buf][kc * 4 + 1][row] = ra[r].y;
+            As[buf][kc * 4 + 2][row] = ra[r].z;
+            As[buf][kc * 4 + 3][row] = ra[r].w;
+            Bs[buf][kc * 4 + 0][row] = rb[r].x;
+            Bs[buf][kc * 4 + 1][row] = rb[r].y;
+            Bs[buf][kc * 4 + 2][row] = rb[r].z;
+            Bs[buf][kc * 4 + 3][row] = rb[r].w;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    gload(0);
+    sstore(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) gload(kt + 1);
+#pragma unroll
+        for (int kp = 0; kp < XBK / 2; ++kp) {
+            // lane l holds A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; k ascends across MFMAs
+            const float a0 = As[buf][2 * kp + lh][wm * 64 + li];
+            const float a1 = As[buf][2 * kp + lh][wm * 64 + 32 + li];
+            const float b0 = Bs[buf][2 * kp + lh][wn * 64 + li];
+            const float b1 = Bs[buf][2 * kp + lh][wn * 64 + 32 + li];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (kt + 1 < nkt) sstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue.  C/D map of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int64_t col = n0 + wn * 64 + j * 32 + li;
+        if (col >= N) continue;
+        const float bnv = bn[col];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row >= M) continue;
+                const float dot = acc[i][j][r];
+                float v;
+                if (EPI == EPI_EUCLID) {
+                    v = fmaf(-2.0f, dot, an[row] + bnv);
+                } else {
+                    float c = dot * __fdiv_rn(1.0f, an[row] * bnv);
+                    const float lo = (float)(-1.0 + 0.00001), hi = (float)(1.0 - 0.00001);
+                    c = c < lo ? lo : (c > hi ? hi : c);
+                    v = acosf(c);
+                }
+                C[row * ldc + col] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host entry points
+// ---------------------------------------------------------------------------------------------
+extern "C" int mpreid_sqnorm_f32(const float *x, int64_t n, int d, float *out, mpreid_stream_t stream) {
+    ARG_CHECK(x && out && n >= 0 && d > 0);
+    if (n == 0) return MPREID_OK;
+    hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, n, d, out,
+                       0);
+    LAUNCH_CHECK();
+    return MPREID_OK;
+}
+
+extern "C" int mpreid_l2_normalize_f32(const float *x, int64_t n, int d, float eps, float *out,
+                                       mpreid_stream_t stream) {
+    ARG_CHECK(x && out && n >= 0 && d > 0);
+    if (n == 0) return MPREID_OK;
+    hipLaunchKernelGGL(l2_normalize_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, n, d,
+                       eps, out);
+    LAUNCH_CHECK();
+    return MPREID_OK;
+}
+
+// implemented in gemm_f16.hip: fp16 one-pass distance (mode MPREID_GEMM_F16_FAST)
+int mpreid_distance_f16_fast(const float *q, const float *g, int64_t nq, int64_t ng, int d, const float *qn,
+                             const float *gn, float *out, int64_t ldo, int epi, void *ws, size_t ws_bytes,
+                             hipStream_t stream);
+size_t mpreid_distance_f16_ws_bytes(int64_t nq, int64_t ng, int d);
+
+extern "C" size_t mpreid_distance_workspace_bytes(int64_t nq, int64_t ng, int d, int mode) {
+    size_t b = align_up((size_t)(nq + ng) * sizeof(float), 256);
+    if (mode == MPREID_GEMM_F16_FAST) b += mpreid_distance_f16_ws_bytes(nq, ng, d);
+    return b;
+}
+
+int mpreid_distance_launch(const float *q, const float *g, int64_t nq, int64_t ng, int d, const float *qn,
+                           const float *gn, float *out, int64_t ldo, int epi, hipStream_t stream) {
+    const int tiles_m = (int)((nq + XBM - 1) / XBM), tiles_n = (int)((ng + XBN - 1) / XBN);
+    const int vec_ok = (d % 4 == 0) && (((uintptr_t)q | (uintptr_t)g) % 16 == 0);
+    const dim3 grid((unsigned)tiles_m * (unsigned)tiles_n);
+    if (epi == EPI_EUCLID)
+        hipLaunchKernelGGL(gemm_f32_exact_kernel<EPI_EUCLID>, grid, dim3(256), 0, stream, q, g, nq, ng, d, qn, gn, out,
+                           ldo, tiles_m, tiles_n, vec_ok);
+    else
+        hipLaunchKernelGGL(gemm_f32_exact_kernel<EPI_COSINE>, grid, dim3(256), 0, stream, q, g, nq, ng, d, qn, gn, out,
+                           ldo, tiles_m, tiles_n, vec_ok);
+    LAUNCH_CHECK();
+    return MPREID_OK;
+}
+
+static int distance_common(const float *q, const float *g, int64_t nq, int64_t ng, int d, float *out, int64_t ldo,
+                           int mode, void *ws, size_t ws_bytes, mpreid_stream_t stream_, int epi) {
+    ARG_CHECK(q && g && out && nq >= 0 && ng >= 0 && d > 0 && ldo >= ng);
+    ARG_CHECK(mode == MPREID_GEMM_F32_EXACT || mode == MPREID_GEMM_F16_FAST);
+    if (nq == 0 || ng == 0) return MPREID_OK;
+    if (ws == nullptr || ws_bytes < mpreid_distance_workspace_bytes(nq, ng, d, mode)) {
+        mpreid_set_error("distance workspace too small: %zu < %zu", ws_bytes,
+                         mpreid_distance_workspace_bytes(nq, ng, d, mode));
+        return MPREID_ERR_WORKSPACE;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    float *qn = (float *)ws, *gn = qn + nq;
+    const int nmode = (epi == EPI_COSINE) ? 1 : 0;
+    hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, q, nq, d, qn, nmode);
+    hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)((ng + 3) / 4)), dim3(256), 0, stream, g, ng, d, gn, nmode);
+    LAUNCH_CHECK();
+    if (mode == MPREID_GEMM_F16_FAST) {
+        char *rest = (char *)ws + align_up((size_t)(nq + ng) * sizeof(float), 256);
+        return mpreid_distance_f16_fast(q, g, nq, ng, d, qn, gn, out, ldo, epi, rest,
+                                        ws_bytes - (size_t)(rest - (char *)ws), stream);
+    }
+    return mpreid_distance_launch(q, g, nq, ng, d, qn, gn, out, ldo, epi, stream);
+}
+
+extern "C" int mpreid_euclidean_distance_f32(const float *q, const float *g, int64_t nq, int64_t ng, int d, float *out,
+                                             int64_t ldo, int mode, void *ws, size_t ws_bytes,
+                                             mpreid_stream_t stream) {
+    return distance_common(q, g, nq, ng, d, out, ldo, mode, ws, ws_bytes, stream, EPI_EUCLID);
+}
+
+extern "C" int mpreid_cosine_similarity_f32(const float *q, const float *g, int64_t nq, int64_t ng, int d, float *out,
+                                            int64_t ldo, int mode, void *ws, size_t ws_bytes,
+                                            mpreid_stream_t stream) {
+    return distance_common(q, g, nq, ng, d, out, ldo, mode, ws, ws_bytes, stream, EPI_COSINE);
+}

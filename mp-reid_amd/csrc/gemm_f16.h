@@ -1,0 +1,52 @@
+// gemm_f16.h — fp16-in / fp32-accumulate MFMA GEMM for gfx950:  C[M][N] = A[M][K] x W[N][K]^T
+// Both operands are K-contiguous (activations row-major, weights in torch Linear layout), which is
+// the natural MFMA operand order: no transposes anywhere.
+//
+//   tile      128 x 128 per 256-thread workgroup (2x2 waves, 64x64 per wave = 4x4 MFMA 16x16x32)
+//   K step    64 halfs (128-byte LDS rows); A and B tiles double-buffered: 2 x 32 KB = 64 KB LDS,
+//             so two workgroups share a CU and overlap each other's barriers
+//   staging   global_load_lds_dwordx4 (LDS-DMA): one wave-instruction = 8 rows x 128 B, no VGPRs;
+//             LDS image is lane-linear, the bank-conflict swizzle (16-byte chunk ^= row & 7) is
+//             applied to the per-lane SOURCE address and again on the ds_read_b128 address
+//             (cdna_hip_programming.md §5.4 rule 21, T2)
+//   loop      issue DMA for tile t+1 -> ds_read + 32 MFMA on tile t -> vmcnt(0) + barrier
+//   epilogue  fused (bias / QuickGELU / residual / positional embedding / distance), fp16
+//             outputs are transposed through LDS so that every store is a full 128-byte row piece
+//
+// Requirements: M, N multiples of 128 and K a multiple of 64 at the buffer level (callers pad);
+// logical bounds are passed separately where the epilogue needs them.
+#pragma once
+#include "common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int GBM = 128, GBN = 128, GBK = 64;
+constexpr int G_TILE_BYTES = GBM * GBK * 2;        // 16 KB per operand tile
+constexpr int G_STAGE_BYTES = 2 * G_TILE_BYTES;    // A + B
+constexpr int G_LDS_BYTES = 2 * G_STAGE_BYTES;     // double buffered: 64 KB
+
+enum GemmEpi {
+    GE_F32 = 0,        // C fp32 = acc
+    GE_BIAS_F16 = 1,   // out fp16 = acc + bias[n]
+    GE_BIAS_RES = 2,   // x fp32 += acc + bias[n]                       (out-proj, MLP c_proj)
+    GE_BIAS_GELU = 3,  // out fp16 = quickgelu(acc + bias[n])           (MLP c_fc)
+    GE_PATCH = 4,      // x fp32[b*L + 1 + p][n] = acc + pos[1 + p][n]  (patch embed; m = b*P + p)
+    GE_EUCLID = 5,     // out fp32 = fmaf(-2, acc, an[m] + bn[n])       (bounds checked)
+    GE_COSINE = 6      // out fp32 = acos(clip(acc / (an[m]*bn[n])))    (bounds checked)
+};
+
+struct GemmArgs {
+    const _Float16 *A;   // [M][K]
+    const _Float16 *W;   // [N][K]
+    int M, N, K;         // padded sizes (multiples of 128 / 128 / 64)
+    void *out;           // fp16 or fp32 output, row stride ldo elements
+    int64_t ldo;
+    const float *bias;   // [N]                       (GE_BIAS_*)
+    const float *aux;    // pos emb [L][N] (GE_PATCH) / an [M] (distance)
+    const float *aux2;   // bn [N] (distance)
+    int m_valid, n_valid; // logical bounds for the bounds-checked epilogues
+    int P, L;            // GE_PATCH: patches per image, tokens per image
+};
+
+int launch_gemm_f16(const GemmArgs &a, int epi, hipStream_t stream);

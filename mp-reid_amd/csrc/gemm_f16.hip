@@ -1,0 +1,270 @@
+// gemm_f16.hip — see gemm_f16.h for the design.  Roofline: MFMA fp16 (2.5 PFLOP/s dense peak).
+#include "gemm_f16.h"
+
+typedef __attribute__((address_space(3))) void lds_ptr_t;
+typedef const __attribute__((address_space(1))) void glb_ptr_t;
+
+__device__ __forceinline__ void dma16(const void *gsrc, unsigned char *lds_dst_wave_base) {
+    // LDS destination = wave-uniform base + lane*16; the global source is per lane.
+    __builtin_amdgcn_global_load_lds((glb_ptr_t *)gsrc, (lds_ptr_t *)lds_dst_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float quick_gelu(float h) {
+    // model/clip/model.py:159-161  x * sigmoid(1.702 x)
+    return h / (1.0f + __expf(-1.702f * h));
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    int tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, 8, tm, tn);
+    const int m0 = tm * GBM, n0 = tn * GBN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int K = g.K;
+
+    // ---- staging: wave w moves rows [32w, 32w+32) of both tiles, 8 rows per DMA instruction ----
+    const int srow = lane >> 3;
+    const int gchunk = (lane & 7) ^ srow; // source chunk that lands in LDS slot (lane & 7) of row srow
+    const _Float16 *a_src = g.A + (int64_t)(m0 + wave * 32 + srow) * K + gchunk * 8;
+    const _Float16 *b_src = g.W + (int64_t)(n0 + wave * 32 + srow) * K + gchunk * 8;
+    auto stage = [&](int s, int kt) {
+        unsigned char *abase = smem + s * G_STAGE_BYTES + wave * 4096;
+        unsigned char *bbase = abase + G_TILE_BYTES;
+        const int koff = kt * GBK;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            dma16(a_src + (int64_t)t * 8 * K + koff, abase + t * 1024);
+            dma16(b_src + (int64_t)t * 8 * K + koff, bbase + t * 1024);
+        }
+    };
+
+    // ---- fragment addresses (bytes inside a tile) ----
+    const int frow = lane & 15, fq = lane >> 4;
+    const int a_row_off = (wm * 64 + frow) * 128;
+    const int b_row_off = (wn * 64 + frow) * 128;
+    int ksw[2];
+    ksw[0] = ((0 + fq) ^ (lane & 7)) << 4;
+    ksw[1] = ((4 + fq) ^ (lane & 7)) << 4;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](int s) {
+        const unsigned char *at = smem + s * G_STAGE_BYTES;
+        const unsigned char *bt = at + G_TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const f16x8 *>(at + a_row_off + i * 2048 + ksw[ks]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f16x8 *>(bt + b_row_off + j * 2048 + ksw[ks]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int nkt = K / GBK;
+    stage(0, 0);
+    __syncthreads(); // drains the DMA (vmcnt(0)) and publishes tile 0
+    int cur = 0;
+    for (int kt = 0; kt < nkt - 1; ++kt) {
+        stage(cur ^ 1, kt + 1);
+        compute(cur);
+        __syncthreads();
+        cur ^= 1;
+    }
+    compute(cur);
+
+    // ---- epilogue.  C/D map of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg ----
+    if constexpr (EPI == GE_BIAS_F16 || EPI == GE_BIAS_GELU) {
+        __syncthreads(); // every wave is done reading the staging buffers
+        _Float16 *wreg = reinterpret_cast<_Float16 *>(smem) + wave * (64 * 72);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float bias = g.bias[n0 + wn * 64 + j * 16 + frow];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[i][j][r] + bias;
+                    if (EPI == GE_BIAS_GELU) v = quick_gelu(v);
+                    wreg[(i * 16 + fq * 4 + r) * 72 + j * 16 + frow] = (_Float16)v;
+                }
+        }
+        __syncthreads();
+        _Float16 *out = reinterpret_cast<_Float16 *>(g.out);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int lr = it * 8 + (lane >> 3), ch = lane & 7;
+            const uint4 v = *reinterpret_cast<const uint4 *>(wreg + lr * 72 + ch * 8);
+            *reinterpret_cast<uint4 *>(out + (int64_t)(m0 + wm * 64 + lr) * g.ldo + n0 + wn * 64 + ch * 8) = v;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + frow;
+            float bias = 0.f, bnv = 0.f;
+            if (EPI == GE_BIAS_RES) bias = g.bias[n];
+            if (EPI == GE_EUCLID || EPI == GE_COSINE) bnv = (n < g.n_valid) ? g.aux2[n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * 64 + i * 16 + fq * 4 + r;
+                    const float a = acc[i][j][r];
+                    if (EPI == GE_F32) {
+                        reinterpret_cast<float *>(g.out)[(int64_t)m * g.ldo + n] = a;
+                    } else if (EPI == GE_BIAS_RES) {
+                        float *x = reinterpret_cast<float *>(g.out) + (int64_t)m * g.ldo + n;
+                        *x = *x + (a + bias);
+                    } else if (EPI == GE_PATCH) {
+                        if (m < g.m_valid) {
+                            const int b = m / g.P, p = m - b * g.P;
+                            reinterpret_cast<float *>(g.out)[((int64_t)b * g.L + 1 + p) * g.ldo + n] =
+                                a + g.aux[(int64_t)(1 + p) * g.N + n];
+                        }
+                    } else if (EPI == GE_EUCLID) {
+                        if (m < g.m_valid && n < g.n_valid)
+                            reinterpret_cast<float *>(g.out)[(int64_t)m * g.ldo + n] = fmaf(-2.0f, a, g.aux[m] + bnv);
+                    } else if (EPI == GE_COSINE) {
+                        if (m < g.m_valid && n < g.n_valid) {
+                            float c = a * __fdiv_rn(1.0f, g.aux[m] * bnv);
+                            const float lo = (float)(-1.0 + 0.00001), hi = (float)(1.0 - 0.00001);
+                            c = c < lo ? lo : (c > hi ? hi : c);
+                            reinterpret_cast<float *>(g.out)[(int64_t)m * g.ldo + n] = acosf(c);
+                        }
+                    }
+                }
+        }
+    }
+}
+
+template <int EPI>
+static int launch_one(const GemmArgs &a, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_kernel<EPI>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES));
+        attr_set = true;
+    }
+    const int tiles_m = a.M / GBM, tiles_n = a.N / GBN;
+    hipLaunchKernelGGL(gemm_f16_kernel<EPI>, dim3((unsigned)tiles_m * (unsigned)tiles_n), dim3(256), G_LDS_BYTES, stream,
+                       a, tiles_m, tiles_n);
+    LAUNCH_CHECK();
+    return MPREID_OK;
+}
+
+int launch_gemm_f16(const GemmArgs &a, int epi, hipStream_t stream) {
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.M % GBM || a.N % GBN || a.K % GBK) {
+        mpreid_set_error("gemm_f16: M=%d N=%d K=%d must be positive multiples of %d/%d/%d", a.M, a.N, a.K, GBM, GBN,
+                         GBK);
+        return MPREID_ERR_ARG;
+    }
+    switch (epi) {
+    case GE_F32: return launch_one<GE_F32>(a, stream);
+    case GE_BIAS_F16: return launch_one<GE_BIAS_F16>(a, stream);
+    case GE_BIAS_RES: return launch_one<GE_BIAS_RES>(a, stream);
+    case GE_BIAS_GELU: return launch_one<GE_BIAS_GELU>(a, stream);
+    case GE_PATCH: return launch_one<GE_PATCH>(a, stream);
+    case GE_EUCLID: return launch_one<GE_EUCLID>(a, stream);
+    case GE_COSINE: return launch_one<GE_COSINE>(a, stream);
+    }
+    mpreid_set_error("gemm_f16: unknown epilogue %d", epi);
+    return MPREID_ERR_ARG;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 -> fp16 helpers
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cast_f32_f16_kernel(const float *__restrict__ x, _Float16 *__restrict__ y,
+                                                           int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const float4 v = *reinterpret_cast<const float4 *>(x + i);
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        h4 o = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+        *reinterpret_cast<h4 *>(y + i) = o;
+    } else {
+        for (int64_t k = i; k < n; ++k) y[k] = (_Float16)x[k];
+    }
+}
+
+// x [n][d] fp32 -> y [n_pad][d_pad] fp16, zero padded
+__global__ __launch_bounds__(256) void cast_pad_kernel(const float *__restrict__ x, int64_t n, int d,
+                                                       _Float16 *__restrict__ y, int64_t n_pad, int d_pad) {
+    const int64_t row = blockIdx.x;
+    for (int k = threadIdx.x; k < d_pad; k += 256) {
+        float v = 0.f;
+        if (row < n && k < d) v = x[row * (int64_t)d + k];
+        y[row * (int64_t)d_pad + k] = (_Float16)v;
+    }
+}
+
+extern "C" int mpreid_cast_f32_to_f16(const float *x, void *y, int64_t n, mpreid_stream_t stream) {
+    ARG_CHECK(x && y && n >= 0);
+    if (n == 0) return MPREID_OK;
+    ARG_CHECK(((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 8 == 0));
+    hipLaunchKernelGGL(cast_f32_f16_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, x,
+                       (_Float16 *)y, n);
+    LAUNCH_CHECK();
+    return MPREID_OK;
+}
+
+extern "C" int mpreid_gemm_f16_nt(const void *a, const void *b, float *c, int64_t m, int64_t n, int64_t k,
+                                  mpreid_stream_t stream) {
+    ARG_CHECK(a && b && c);
+    GemmArgs g{};
+    g.A = (const _Float16 *)a;
+    g.W = (const _Float16 *)b;
+    g.M = (int)m;
+    g.N = (int)n;
+    g.K = (int)k;
+    g.out = c;
+    g.ldo = n;
+    return launch_gemm_f16(g, GE_F32, (hipStream_t)stream);
+}
+
+size_t mpreid_distance_f16_ws_bytes(int64_t nq, int64_t ng, int d) {
+    const size_t dp = align_up((size_t)d, GBK);
+    return align_up(align_up((size_t)nq, GBM) * dp * 2, 256) + align_up(align_up((size_t)ng, GBN) * dp * 2, 256);
+}
+
+int mpreid_distance_f16_fast(const float *q, const float *g, int64_t nq, int64_t ng, int d, const float *qn,
+                             const float *gn, float *out, int64_t ldo, int epi, void *ws, size_t ws_bytes,
+                             hipStream_t stream) {
+    if (ws_bytes < mpreid_distance_f16_ws_bytes(nq, ng, d)) {
+        mpreid_set_error("fp16 distance workspace too small");
+        return MPREID_ERR_WORKSPACE;
+    }
+    const int dp = (int)align_up((size_t)d, GBK);
+    const int64_t mp = (int64_t)align_up((size_t)nq, GBM), np = (int64_t)align_up((size_t)ng, GBN);
+    _Float16 *qh = (_Float16 *)ws;
+    _Float16 *gh = (_Float16 *)((char *)ws + align_up((size_t)mp * dp * 2, 256));
+    hipLaunchKernelGGL(cast_pad_kernel, dim3((unsigned)mp), dim3(256), 0, stream, q, nq, d, qh, mp, dp);
+    hipLaunchKernelGGL(cast_pad_kernel, dim3((unsigned)np), dim3(256), 0, stream, g, ng, d, gh, np, dp);
+    LAUNCH_CHECK();
+    GemmArgs a{};
+    a.A = qh;
+    a.W = gh;
+    a.M = (int)mp;
+    a.N = (int)np;
+    a.K = dp;
+    a.out = out;
+    a.ldo = ldo;
+    a.aux = qn;
+    a.aux2 = gn;
+    a.m_valid = (int)nq;
+    a.n_valid = (int)ng;
+    return launch_gemm_f16(a, epi == 0 ? GE_EUCLID : GE_COSINE, stream);
+}

@@ -1,0 +1,909 @@
+// rerank.hip — k-reciprocal re-ranking on gfx950 (reference: utils/reranking.py:29-100).
+//
+// Data layout in HBM (all inside the caller's workspace, see make_layout()):
+//   feat  [N][d] fp32          cat(probFea, galFea)                                  (:36)
+//   D     [N][ld] fp32         all-pairs squared distance, exact fp32 MFMA GEMM      (:36-41)
+//                              ld = N rounded up to 64 floats; D is bit-symmetric
+//   MT    [N][ld] fp32         only with local_distmat: (D + local)^T                (:43-46)
+//   rowmax[N]                  max over column i of original_dist == row max of MT   (:46)
+//   rank  [N][KR] int32        first KR = max(k1+1, k2) entries of argsort(O[i,:])   (:48)
+//                              O[i][j] = MT[i][j] / rowmax[i] is recomputed where needed
+//   V     ELL  idx[N][vcap] int32 ascending, val[N][vcap] fp16 bits, cnt[N]           (:51-71)
+//   Vqe   ELL  same, row stride = measured max union size                             (:73-78)
+//   CSC of Vqe: cptr[N+1] int64, crow[nnz] int32, cval[nnz] fp16 bits                  (:80-82)
+//   out   [nq][ldo] fp32       final_dist[:nq, nq:]                                   (:84-100)
+//
+// Every rounding point of SURVEY.md §8a row a7 is taken through include/mpreid_numerics.h, the
+// same code the CPU oracle runs, so the result is bit-identical to oracle/mpreid_oracle.c.
+// All kernels here are HBM/L2-bound integer+fp16 work (no MFMA); the GEMM is in distance.hip.
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+
+int mpreid_distance_launch(const float *q, const float *g, int64_t nq, int64_t ng, int d, const float *qn,
+                           const float *gn, float *out, int64_t ldo, int epi, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// workspace layout
+// ---------------------------------------------------------------------------------------------
+struct RerankLayout {
+    int64_t N, ld;
+    int K, KR, h, vcap;
+    int64_t qcap_bound;
+    size_t feat, norms, D, MT, rowmax, rank, vcnt, vidx, vval, ucnt, qcnt, qidx, qval, ccnt, cptr, crow, cval,
+        counters, total;
+};
+
+static RerankLayout make_layout(int64_t nq, int64_t ng, int d, int k1, int k2, int has_local) {
+    RerankLayout L{};
+    L.N = nq + ng;
+    L.ld = (int64_t)align_up((size_t)L.N, 64);
+    L.K = k1 + 1;
+    L.KR = std::max(k1 + 1, k2);
+    L.h = mpreid_half_k1(k1);
+    int64_t cap = (int64_t)L.K * (1 + L.h);
+    L.vcap = (int)std::min<int64_t>(cap, L.N);
+    L.qcap_bound = std::min<int64_t>(L.N, (int64_t)std::max(k2, 1) * L.vcap);
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += align_up(bytes, 256);
+        return o;
+    };
+    const size_t N = (size_t)L.N;
+    L.feat = take(N * (size_t)d * 4);
+    L.norms = take(N * 4);
+    L.D = take(N * (size_t)L.ld * 4);
+    L.MT = has_local ? take(N * (size_t)L.ld * 4) : L.D;
+    L.rowmax = take(N * 4);
+    L.rank = take(N * (size_t)L.KR * 4);
+    L.vcnt = take(N * 4);
+    L.vidx = take(N * (size_t)L.vcap * 4);
+    L.vval = take(N * (size_t)L.vcap * 2);
+    L.ucnt = take(N * 4);
+    L.qcnt = take(N * 4);
+    L.qidx = take(N * (size_t)L.qcap_bound * 4);
+    L.qval = take(N * (size_t)L.qcap_bound * 2);
+    L.ccnt = take((N + 1) * 4);
+    L.cptr = take((N + 1) * 8);
+    L.crow = take(N * (size_t)L.qcap_bound * 4);
+    L.cval = take(N * (size_t)L.qcap_bound * 2);
+    L.counters = take(64);
+    L.total = off;
+    return L;
+}
+
+extern "C" size_t mpreid_rerank_workspace_bytes(int64_t nq, int64_t ng, int d, int k1, int k2, int has_local) {
+    if (nq < 0 || ng < 0 || d <= 0 || k1 < 0 || k2 < 1) return 0;
+    return make_layout(nq, ng, d, k1, k2, has_local).total;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
+    int x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int y = __shfl_up(x, off, 64);
+        if (lane >= off) x += y;
+    }
+    total = __shfl(x, 63, 64);
+    return x - v;
+}
+
+// orderable key of a float: ascending unsigned order == ascending float order (-0 folded into +0)
+__device__ __forceinline__ uint32_t fkey(float f) {
+    f = f + 0.0f;
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// numpy pairwise sum of a[0..n) (LDS or global), evaluated redundantly by every 8-lane group of
+// the calling wave; all lanes return the same value.  Mirrors orc_pairwise_sum_f32.
+__device__ float wave_pairwise_sum(const float *a, int n, int lane) {
+    const int j = lane & 7;
+    // explicit post-order traversal of the recursion  pw(o,n) = pw(o,n2) + pw(o+n2,n-n2)
+    int st_off[24], st_n[24];
+    float st_val[24];
+    unsigned char st_state[24];
+    int sp = 0;
+    st_off[0] = 0; st_n[0] = n; st_state[0] = 0;
+    float ret = 0.0f;
+    while (sp >= 0) {
+        const int o = st_off[sp], m = st_n[sp];
+        if (st_state[sp] == 0) {
+            if (m <= 128) {
+                float res;
+                if (m < 8) {
+                    res = 0.0f;
+                    for (int i = 0; i < m; ++i) res = res + a[o + i];
+                } else {
+                    float r = a[o + j];
+                    const int lim = m - (m % 8);
+                    int i;
+                    for (i = 8; i < lim; i += 8) r = r + a[o + i + j];
+                    r = r + __shfl_xor(r, 1, 64);
+                    r = r + __shfl_xor(r, 2, 64);
+                    r = r + __shfl_xor(r, 4, 64);
+                    res = r;
+                    for (i = lim; i < m; ++i) res = res + a[o + i];
+                }
+                ret = res;
+                --sp;
+            } else {
+                int n2 = m / 2;
+                n2 -= n2 % 8;
+                st_state[sp] = 1;
+                ++sp;
+                st_off[sp] = o; st_n[sp] = n2; st_state[sp] = 0;
+            }
+        } else if (st_state[sp] == 1) {
+            int n2 = m / 2;
+            n2 -= n2 % 8;
+            st_val[sp] = ret;
+            st_state[sp] = 2;
+            ++sp;
+            st_off[sp] = o + n2; st_n[sp] = m - n2; st_state[sp] = 0;
+        } else {
+            ret = st_val[sp] + ret;
+            --sp;
+        }
+    }
+    return ret;
+}
+
+// ---------------------------------------------------------------------------------------------
+// (D + local)^T  /  local^T  (only when local_distmat is given; utils/reranking.py:33-34,43-46)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void make_mt_kernel(const float *__restrict__ D, int64_t ldD,
+                                                      const float *__restrict__ local, int64_t N,
+                                                      float *__restrict__ MT, int64_t ld) {
+    __shared__ float tile[32][33];
+    const int64_t bx = (int64_t)blockIdx.x * 32, by = (int64_t)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int64_t i = by + r, j = bx + tx;
+        float v = 0.0f;
+        if (i < N && j < N) {
+            v = local[i * N + j];
+            if (D) v = D[i * ldD + j] + v; // original_dist + local_distmat
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int64_t i = bx + r, j = by + tx; // MT[i][j] = orig[j][i]
+        if (i < N && j < N) MT[i * ld + j] = tile[tx][r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// row max + top-KR selection by (O value, index) ascending; one 256-thread workgroup per row.
+// HBM/L2-bound: the row is read 5 times (max, 3 radix histograms, collect); 4*N bytes algorithmic.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int block_excl_scan_256(int v, int tid, int *s_wave, int &total) {
+    const int lane = tid & 63, wave = tid >> 6;
+    int wtot;
+    const int ex = wave_excl_scan(v, lane, wtot);
+    __syncthreads();
+    if (lane == 0) s_wave[wave] = wtot;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int t = s_wave[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    total = tot;
+    return base + ex;
+}
+
+__global__ __launch_bounds__(256) void rowmax_topk_kernel(const float *__restrict__ MT, int64_t ld, int64_t N, int KR,
+                                                          float *__restrict__ rowmax, int *__restrict__ rank) {
+    __shared__ unsigned hist[2048];
+    __shared__ unsigned long long sel[256];
+    __shared__ float s_red[4];
+    __shared__ int s_wave[4];
+    __shared__ unsigned s_bin, s_below, s_cnt;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t i = blockIdx.x;
+    const float *row = MT + i * ld;
+    const int n = (int)N;
+
+    // pass 0: row max (== max over column i of original_dist)
+    float mx = -3.402823466e+38f;
+    for (int j = tid; j < n; j += 256) mx = fmaxf(mx, row[j]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if (lane == 0) s_red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    if (tid == 0) rowmax[i] = mx;
+
+    // radix select of the KR-th smallest key, 11 + 11 + 10 bits
+    unsigned prefix = 0;
+    int kk = KR; // 1-based rank still to find inside the current prefix class
+    int bits_done = 0;
+    unsigned cnt_eq = 0;
+#pragma unroll 1
+    for (int pass = 0; pass < 3; ++pass) {
+        const int width = (pass == 2) ? 10 : 11;
+        const int shift = 32 - bits_done - width;
+        const unsigned mask = (1u << width) - 1u;
+        for (int b = tid; b < 2048; b += 256) hist[b] = 0;
+        __syncthreads();
+        for (int j = tid; j < n; j += 256) {
+            const unsigned key = fkey(__fdiv_rn(row[j], mx));
+            if (bits_done == 0 || (key >> (32 - bits_done)) == prefix) atomicAdd(&hist[(key >> shift) & mask], 1u);
+        }
+        __syncthreads();
+        // each thread owns 8 consecutive bins
+        unsigned loc[8];
+        int sum = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            loc[b] = hist[tid * 8 + b];
+            sum += (int)loc[b];
+        }
+        int total;
+        const int ex = block_excl_scan_256(sum, tid, s_wave, total);
+        if (kk > ex && kk <= ex + sum) {
+            int run = ex;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                if (kk > run && kk <= run + (int)loc[b]) {
+                    s_bin = (unsigned)(tid * 8 + b);
+                    s_below = (unsigned)run;
+                    s_cnt = loc[b];
+                }
+                run += (int)loc[b];
+            }
+        }
+        __syncthreads();
+        prefix = (prefix << width) | s_bin;
+        kk -= (int)s_below;
+        cnt_eq = s_cnt;
+        bits_done += width;
+        __syncthreads();
+    }
+    const unsigned T = prefix; // exact key of the KR-th smallest; kk of the cnt_eq equal keys are needed
+
+    // collect (key, index) of the KR selected entries
+    if (tid == 0) s_cnt = 0;
+    for (int b = tid; b < 256; b += 256) sel[b] = ~0ull;
+    __syncthreads();
+    if ((int)cnt_eq == kk) {
+        // no tie straddles the cut: take every key <= T, order fixed later by the sort
+        for (int j = tid; j < n; j += 256) {
+            const unsigned key = fkey(__fdiv_rn(row[j], mx));
+            if (key <= T) {
+                const unsigned p = atomicAdd(&s_cnt, 1u);
+                if (p < 256u) sel[p] = ((unsigned long long)key << 32) | (unsigned)j;
+            }
+        }
+    } else {
+        // ties at the cut: the kk smallest INDICES among the equal keys are taken (ordered scans)
+        int run_acc = 0, run_eq = 0;
+        for (int j0 = 0; j0 < n; j0 += 256) {
+            const int j = j0 + tid;
+            unsigned key = 0xffffffffu;
+            bool lt = false, eq = false;
+            if (j < n) {
+                key = fkey(__fdiv_rn(row[j], mx));
+                lt = key < T;
+                eq = key == T;
+            }
+            int eq_tot, acc_tot;
+            const int eq_rank = run_eq + block_excl_scan_256(eq ? 1 : 0, tid, s_wave, eq_tot);
+            const bool accept = lt || (eq && eq_rank < kk);
+            const int p = run_acc + block_excl_scan_256(accept ? 1 : 0, tid, s_wave, acc_tot);
+            if (accept && p < 256) sel[p] = ((unsigned long long)key << 32) | (unsigned)j;
+            run_acc += acc_tot;
+            run_eq += eq_tot;
+        }
+    }
+    __syncthreads();
+    // bitonic sort of 256 64-bit keys (padding = ~0) ascending => (value, index) order
+    for (int size = 2; size <= 256; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const int partner = tid ^ stride;
+            if (partner > tid) {
+                const unsigned long long a = sel[tid], b = sel[partner];
+                const bool up = ((tid & size) == 0);
+                if ((a > b) == up) {
+                    sel[tid] = b;
+                    sel[partner] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid < KR) rank[i * KR + tid] = (int)(unsigned)(sel[tid] & 0xffffffffull);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k-reciprocal sets + 2/3-overlap expansion + exp weights -> V row (ELL).  One wave per row.
+// utils/reranking.py:51-71
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int extract_bits_sorted(const unsigned *mask, int nw, int *list, int lane) {
+    int base = 0;
+    for (int w0 = 0; w0 < nw; w0 += 64) {
+        const int w = w0 + lane;
+        unsigned word = (w < nw) ? mask[w] : 0u;
+        if (__ballot(word != 0u) == 0ull) continue;
+        int tot;
+        int pos = base + wave_excl_scan(__popc(word), lane, tot);
+        while (word) {
+            const int b = __ffs((int)word) - 1;
+            word &= word - 1u;
+            list[pos++] = w * 32 + b;
+        }
+        base += tot;
+    }
+    return base;
+}
+
+__global__ __launch_bounds__(64) void krecip_kernel(const float *__restrict__ MT, int64_t ld, int64_t N,
+                                                    const float *__restrict__ rowmax, const int *__restrict__ rank,
+                                                    int K, int KR, int h, int vcap, int *__restrict__ vcnt,
+                                                    int *__restrict__ vidx, uint16_t *__restrict__ vval) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nw = (int)((N + 31) >> 5);
+    unsigned *Rmask = (unsigned *)smem;
+    unsigned *Emask = Rmask + nw;
+    int *fwd = (int *)(Emask + nw);
+    int *R = fwd + K;
+    int *Elist = R + K;
+    float *wbuf = (float *)(Elist + vcap);
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x;
+
+    for (int w = lane; w < nw; w += 64) {
+        Rmask[w] = 0u;
+        Emask[w] = 0u;
+    }
+    for (int a = lane; a < K; a += 64) fwd[a] = rank[(int64_t)i * KR + a];
+    __syncthreads();
+
+    // k_reciprocal_index: fwd[a] such that i is among the first K neighbours of fwd[a]; rank order kept
+    int nR = 0;
+    for (int a0 = 0; a0 < K; a0 += 64) {
+        const int a = a0 + lane;
+        bool f = false;
+        int c = -1;
+        if (a < K) {
+            c = fwd[a];
+            const int *br = rank + (int64_t)c * KR;
+            for (int b = 0; b < K; ++b) f |= (br[b] == i);
+        }
+        const unsigned long long m = __ballot(f);
+        if (f) {
+            const int pos = nR + __popcll(m & ((1ull << lane) - 1ull));
+            R[pos] = c;
+            atomicOr(&Rmask[c >> 5], 1u << (c & 31));
+            atomicOr(&Emask[c >> 5], 1u << (c & 31));
+        }
+        nR += __popcll(m);
+    }
+    __syncthreads();
+
+    // expansion: candidates in R order; their own k/2-reciprocal sets, accepted on > 2/3 overlap with R
+    for (int a = 0; a < nR; ++a) {
+        const int cand = R[a];
+        const int *cf = rank + (int64_t)cand * KR;
+        int nRc = 0, inter = 0;
+        unsigned okbits = 0u;
+        for (int b0 = 0, ch = 0; b0 < h; b0 += 64, ++ch) {
+            const int b = b0 + lane;
+            bool ok = false, inr = false;
+            if (b < h) {
+                const int f = cf[b];
+                const int *cb = rank + (int64_t)f * KR;
+                for (int c = 0; c < h; ++c) ok |= (cb[c] == cand);
+                inr = ok && ((Rmask[f >> 5] >> (f & 31)) & 1u);
+            }
+            nRc += __popcll(__ballot(ok));
+            inter += __popcll(__ballot(inr));
+            if (ok) okbits |= (1u << ch);
+        }
+        if ((double)inter > (2.0 / 3.0) * (double)nRc) {
+            for (int b0 = 0, ch = 0; b0 < h; b0 += 64, ++ch) {
+                const int b = b0 + lane;
+                if (b < h && ((okbits >> ch) & 1u)) {
+                    const int f = cf[b];
+                    atomicOr(&Emask[f >> 5], 1u << (f & 31));
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // np.unique(expansion index) == set bits of Emask in ascending order
+    const int nE = extract_bits_sorted(Emask, nw, Elist, lane);
+    __syncthreads();
+    const float mx = rowmax[i];
+    const float *row = MT + (int64_t)i * ld;
+    for (int t = lane; t < nE; t += 64) wbuf[t] = mpreid_expf(-__fdiv_rn(row[Elist[t]], mx));
+    __syncthreads();
+    const float s = wave_pairwise_sum(wbuf, nE, lane);
+    // V[i, E] = fp16(weight / sum); only non-zero halves are kept (V != 0 tests later)
+    int out = 0;
+    for (int t0 = 0; t0 < nE; t0 += 64) {
+        const int t = t0 + lane;
+        uint16_t hv = 0;
+        if (t < nE) hv = mpreid_f32_to_f16(__fdiv_rn(wbuf[t], s));
+        const bool nz = (hv & 0x7fffu) != 0;
+        const unsigned long long m = __ballot(nz);
+        if (nz) {
+            const int p = out + __popcll(m & ((1ull << lane) - 1ull));
+            vidx[(int64_t)i * vcap + p] = Elist[t];
+            vval[(int64_t)i * vcap + p] = hv;
+        }
+        out += __popcll(m);
+    }
+    if (lane == 0) vcnt[i] = out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// local query expansion (utils/reranking.py:73-78): V_qe[i] = fp16( sum_{m<k2} V[rank[i][m]] / k2 )
+// fp32 sum in rank order, true divide by fp32(k2).  One wave per row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void qe_count_kernel(int64_t N, const int *__restrict__ rank, int KR, int k2,
+                                                      const int *__restrict__ vcnt, const int *__restrict__ vidx,
+                                                      int vcap, int *__restrict__ ucnt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned *mask = (unsigned *)smem;
+    const int nw = (int)((N + 31) >> 5);
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x;
+    for (int w = lane; w < nw; w += 64) mask[w] = 0u;
+    __syncthreads();
+    for (int m = 0; m < k2; ++m) {
+        const int r = rank[(int64_t)i * KR + m];
+        const int cnt = vcnt[r];
+        const int *ix = vidx + (int64_t)r * vcap;
+        for (int a = lane; a < cnt; a += 64) {
+            const int c = ix[a];
+            atomicOr(&mask[c >> 5], 1u << (c & 31));
+        }
+    }
+    __syncthreads();
+    int tot = 0;
+    for (int w = lane; w < nw; w += 64) tot += __popc(mask[w]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off, 64);
+    if (lane == 0) ucnt[i] = tot;
+}
+
+__global__ __launch_bounds__(64) void qe_fill_kernel(int64_t N, const int *__restrict__ rank, int KR, int k2,
+                                                     const int *__restrict__ vcnt, const int *__restrict__ vidx,
+                                                     const uint16_t *__restrict__ vval, int vcap, int qcap,
+                                                     int *__restrict__ qcnt, int *__restrict__ qidx,
+                                                     uint16_t *__restrict__ qval) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nw = (int)((N + 31) >> 5);
+    unsigned *mask = (unsigned *)smem;
+    int *wpre = (int *)(mask + nw);
+    float *acc = (float *)(wpre + nw);
+    int *ulist = (int *)(acc + qcap);
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x;
+    for (int w = lane; w < nw; w += 64) mask[w] = 0u;
+    for (int t = lane; t < qcap; t += 64) acc[t] = 0.0f;
+    __syncthreads();
+    for (int m = 0; m < k2; ++m) {
+        const int r = rank[(int64_t)i * KR + m];
+        const int cnt = vcnt[r];
+        const int *ix = vidx + (int64_t)r * vcap;
+        for (int a = lane; a < cnt; a += 64) {
+            const int c = ix[a];
+            atomicOr(&mask[c >> 5], 1u << (c & 31));
+        }
+    }
+    __syncthreads();
+    // word prefix (exclusive popcount) so that slot(c) = wpre[c>>5] + popc(mask[c>>5] & below(c))
+    int base = 0;
+    for (int w0 = 0; w0 < nw; w0 += 64) {
+        const int w = w0 + lane;
+        const int pc = (w < nw) ? __popc(mask[w]) : 0;
+        int tot;
+        const int ex = wave_excl_scan(pc, lane, tot);
+        if (w < nw) wpre[w] = base + ex;
+        base += tot;
+    }
+    const int nU = base;
+    __syncthreads();
+    for (int m = 0; m < k2; ++m) { // fp32 accumulation in rank order; one writer per slot per m
+        const int r = rank[(int64_t)i * KR + m];
+        const int cnt = vcnt[r];
+        const int *ix = vidx + (int64_t)r * vcap;
+        const uint16_t *vv = vval + (int64_t)r * vcap;
+        for (int a = lane; a < cnt; a += 64) {
+            const int c = ix[a];
+            const int slot = wpre[c >> 5] + __popc(mask[c >> 5] & ((1u << (c & 31)) - 1u));
+            acc[slot] = acc[slot] + mpreid_f16_to_f32(vv[a]);
+        }
+        __syncthreads();
+    }
+    extract_bits_sorted(mask, nw, ulist, lane);
+    __syncthreads();
+    const float k2f = (float)k2;
+    int out = 0;
+    for (int t0 = 0; t0 < nU; t0 += 64) {
+        const int t = t0 + lane;
+        uint16_t hv = 0;
+        if (t < nU) hv = mpreid_f32_to_f16(__fdiv_rn(acc[t], k2f));
+        const bool nz = (hv & 0x7fffu) != 0;
+        const unsigned long long mm = __ballot(nz);
+        if (nz) {
+            const int p = out + __popcll(mm & ((1ull << lane) - 1ull));
+            qidx[(int64_t)i * qcap + p] = ulist[t];
+            qval[(int64_t)i * qcap + p] = hv;
+        }
+        out += __popcll(mm);
+    }
+    if (lane == 0) qcnt[i] = out;
+}
+
+// ---------------------------------------------------------------------------------------------
+// inverted index (utils/reranking.py:80-82): CSC of V.  Order inside a column is irrelevant to
+// the result (each row occurs once per column), so the fill uses atomic cursors.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void csc_count_kernel(int64_t N, const int *__restrict__ qcnt,
+                                                        const int *__restrict__ qidx, int qcap,
+                                                        unsigned *__restrict__ ccnt) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const int cnt = qcnt[i];
+    for (int a = lane; a < cnt; a += 64) atomicAdd(&ccnt[qidx[i * qcap + a]], 1u);
+}
+
+// single-workgroup exclusive scan of ccnt[0..N) -> cptr[0..N]; also zeroes ccnt for reuse as cursor
+__global__ __launch_bounds__(1024) void csc_scan_kernel(int64_t N, unsigned *__restrict__ ccnt,
+                                                        long long *__restrict__ cptr) {
+    __shared__ long long part[1024];
+    const int tid = threadIdx.x;
+    const int64_t per = (N + 1023) / 1024;
+    const int64_t lo = (tid * per < N) ? tid * per : N, hi = (lo + per < N) ? lo + per : N;
+    long long s = 0;
+    for (int64_t c = lo; c < hi; ++c) s += ccnt[c];
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        long long run = 0;
+        for (int t = 0; t < 1024; ++t) {
+            const long long v = part[t];
+            part[t] = run;
+            run += v;
+        }
+        cptr[N] = run;
+    }
+    __syncthreads();
+    long long run = part[tid];
+    for (int64_t c = lo; c < hi; ++c) {
+        cptr[c] = run;
+        run += ccnt[c];
+        ccnt[c] = 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void csc_fill_kernel(int64_t N, const int *__restrict__ qcnt,
+                                                       const int *__restrict__ qidx,
+                                                       const uint16_t *__restrict__ qval, int qcap,
+                                                       const long long *__restrict__ cptr,
+                                                       unsigned *__restrict__ cursor, int *__restrict__ crow,
+                                                       uint16_t *__restrict__ cval) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const int cnt = qcnt[i];
+    for (int a = lane; a < cnt; a += 64) {
+        const int c = qidx[i * qcap + a];
+        const long long p = cptr[c] + (long long)atomicAdd(&cursor[c], 1u);
+        crow[p] = (int)i;
+        cval[p] = qval[i * qcap + a];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Jaccard min-sum with fp16 accumulation in ascending column order + final blend
+// (utils/reranking.py:84-100).  One 256-thread workgroup per query; t[] lives in LDS as fp16 bits,
+// r-space processed in chunks of rch entries so that any N fits.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void jaccard_kernel(int64_t N, int64_t nq, const float *__restrict__ MT, int64_t ld,
+                                                      const float *__restrict__ rowmax,
+                                                      const int *__restrict__ qcnt, const int *__restrict__ qidx,
+                                                      const uint16_t *__restrict__ qval, int qcap,
+                                                      const long long *__restrict__ cptr,
+                                                      const int *__restrict__ crow, const uint16_t *__restrict__ cval,
+                                                      int rch, uint16_t one_minus_lam_h, float lam32,
+                                                      float *__restrict__ out, int64_t ldo,
+                                                      unsigned long long *__restrict__ pair_counter) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t *t = (uint16_t *)smem;                                   // [rch]
+    long long *cp0 = (long long *)(smem + align_up((size_t)rch * 2, 16)); // [cnt]
+    int *clen = (int *)(cp0 + qcap);                                  // [cnt]
+    uint16_t *vi = (uint16_t *)(clen + qcap);                         // [cnt]
+    const int tid = threadIdx.x;
+    const int64_t i = blockIdx.x;
+    const int cnt = qcnt[i];
+    unsigned long long pairs = 0;
+    for (int a = tid; a < cnt; a += 256) {
+        const int c = qidx[i * qcap + a];
+        const long long p0 = cptr[c], p1 = cptr[c + 1];
+        cp0[a] = p0;
+        clen[a] = (int)(p1 - p0);
+        vi[a] = qval[i * qcap + a];
+        pairs += (unsigned long long)(p1 - p0);
+    }
+    if (pair_counter) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) pairs += __shfl_xor(pairs, off, 64);
+        if ((tid & 63) == 0 && pairs) atomicAdd(pair_counter, pairs);
+    }
+    const float mx = rowmax[i];
+    const float *row = MT + i * ld;
+    const uint16_t H1 = 0x3c00u, H2 = 0x4000u;
+    for (int64_t r0 = 0; r0 < N; r0 += rch) {
+        const int64_t r1 = (r0 + rch < N) ? r0 + rch : N;
+        for (int r = tid; r < rch; r += 256) t[r] = 0;
+        __syncthreads();
+        for (int a = 0; a < cnt; ++a) { // ascending column; rows of one column are distinct
+            const long long p0 = cp0[a];
+            const int len = clen[a];
+            const uint16_t vic = vi[a];
+            for (int e = tid; e < len; e += 256) {
+                const int r = crow[p0 + e];
+                if (r >= r0 && r < r1) {
+                    const uint16_t m = mpreid_h_min_nonneg(vic, cval[p0 + e]);
+                    t[r - r0] = mpreid_h_add(t[r - r0], m);
+                }
+            }
+            __syncthreads();
+        }
+        const int64_t jlo = (r0 > nq) ? r0 : nq;
+        for (int64_t j = jlo + tid; j < r1; j += 256) {
+            const uint16_t tv = t[j - r0];
+            const uint16_t den = mpreid_h_sub(H2, tv);
+            const uint16_t qt = mpreid_h_div(tv, den);
+            const uint16_t jac = mpreid_h_sub(H1, qt);
+            const uint16_t jl = mpreid_h_mul(jac, one_minus_lam_h);
+            const float o = __fdiv_rn(row[j], mx);
+            out[i * ldo + (j - nq)] = mpreid_f16_to_f32(jl) + o * lam32;
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host driver
+// ---------------------------------------------------------------------------------------------
+static uint16_t f64_to_f16_host(double d) {
+    // single rounding double -> half (numpy casts the Python float 1 - lambda straight to float16)
+    if (d != d) return 0x7e00u;
+    uint16_t sign = 0;
+    if (d < 0 || (d == 0 && 1.0 / d < 0)) {
+        sign = 0x8000u;
+        d = -d;
+    }
+    if (d >= 65520.0) return (uint16_t)(sign | 0x7c00u);
+    if (d == 0.0) return sign;
+    int e;
+    (void)frexp(d, &e);
+    const int ue = e - 1;
+    const double q = (ue < -14) ? ldexp(1.0, -24) : ldexp(1.0, ue - 10);
+    const double r = nearbyint(d / q) * q;
+    return (uint16_t)(sign | mpreid_f32_to_f16((float)r));
+}
+
+struct StageTimer {
+    bool on;
+    hipStream_t s;
+    std::vector<hipEvent_t> ev;
+    StageTimer(bool on_, hipStream_t s_) : on(on_), s(s_) {}
+    void mark() {
+        if (!on) return;
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        (void)hipEventRecord(e, s);
+        ev.push_back(e);
+    }
+    float ms(size_t a, size_t b) {
+        float m = 0.f;
+        if (on && b < ev.size()) (void)hipEventElapsedTime(&m, ev[a], ev[b]);
+        return m;
+    }
+    ~StageTimer() {
+        for (auto e : ev) (void)hipEventDestroy(e);
+    }
+};
+
+template <typename F>
+static int set_dyn_lds(F kernel, size_t bytes) {
+    if (bytes > 160 * 1024) {
+        mpreid_set_error("kernel needs %zu bytes of LDS (> 160 KiB)", bytes);
+        return MPREID_ERR_UNSUPPORTED;
+    }
+    if (bytes > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)bytes));
+    return MPREID_OK;
+}
+
+extern "C" int mpreid_rerank_f32(const float *q, const float *g, int64_t nq, int64_t ng, int d, int k1, int k2,
+                                 double lambda_value, const float *local, int only_local, float *out, int64_t ldo,
+                                 void *ws, size_t ws_bytes, mpreid_stream_t stream_, mpreid_rerank_stats *stats,
+                                 int timing) {
+    ARG_CHECK(q && g && out && nq > 0 && ng > 0 && d > 0 && k1 >= 0 && k2 >= 1 && ldo >= ng);
+    ARG_CHECK(!only_local || local);
+    const RerankLayout L = make_layout(nq, ng, d, k1, k2, local != nullptr);
+    const int64_t N = L.N;
+    ARG_CHECK(L.KR <= N);
+    if (L.KR > 256) {
+        mpreid_set_error("max(k1+1, k2) = %d > 256 is not supported", L.KR);
+        return MPREID_ERR_UNSUPPORTED;
+    }
+    if (N >= (1ll << 31) - 64) {
+        mpreid_set_error("N too large");
+        return MPREID_ERR_UNSUPPORTED;
+    }
+    if (!ws || ws_bytes < L.total) {
+        mpreid_set_error("rerank workspace too small: %zu < %zu", ws_bytes, L.total);
+        return MPREID_ERR_WORKSPACE;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    char *base = (char *)ws;
+    float *feat = (float *)(base + L.feat), *norms = (float *)(base + L.norms);
+    float *D = (float *)(base + L.D), *MT = (float *)(base + L.MT), *rowmax = (float *)(base + L.rowmax);
+    int *rank = (int *)(base + L.rank), *vcnt = (int *)(base + L.vcnt), *vidx = (int *)(base + L.vidx);
+    uint16_t *vval = (uint16_t *)(base + L.vval);
+    int *ucnt = (int *)(base + L.ucnt), *qcnt = (int *)(base + L.qcnt), *qidx = (int *)(base + L.qidx);
+    uint16_t *qval = (uint16_t *)(base + L.qval);
+    unsigned *ccnt = (unsigned *)(base + L.ccnt);
+    long long *cptr = (long long *)(base + L.cptr);
+    int *crow = (int *)(base + L.crow);
+    uint16_t *cval = (uint16_t *)(base + L.cval);
+    unsigned long long *counters = (unsigned long long *)(base + L.counters);
+    const int nw = (int)((N + 31) >> 5);
+
+    StageTimer tm(timing != 0, stream);
+    tm.mark(); // 0
+    // (1) original_dist
+    if (!only_local) {
+        HIP_TRY(hipMemcpyAsync(feat, q, (size_t)nq * d * 4, hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(feat + (size_t)nq * d, g, (size_t)ng * d * 4, hipMemcpyDeviceToDevice, stream));
+        int rc = mpreid_sqnorm_f32(feat, N, d, norms, stream);
+        if (rc) return rc;
+        rc = mpreid_distance_launch(feat, feat, N, N, d, norms, norms, D, L.ld, 0, stream);
+        if (rc) return rc;
+    }
+    if (local) {
+        const dim3 grid((unsigned)((N + 31) / 32), (unsigned)((N + 31) / 32));
+        hipLaunchKernelGGL(make_mt_kernel, grid, dim3(256), 0, stream, only_local ? (const float *)nullptr : D, L.ld,
+                           local, N, MT, L.ld);
+        LAUNCH_CHECK();
+    }
+    tm.mark(); // 1
+    // (2)+(3) row max and the first KR neighbours in (value, index) order
+    hipLaunchKernelGGL(rowmax_topk_kernel, dim3((unsigned)N), dim3(256), 0, stream, MT, L.ld, N, L.KR, rowmax, rank);
+    LAUNCH_CHECK();
+    tm.mark(); // 2
+    // (4)-(6) V rows
+    {
+        const size_t lds = (size_t)nw * 8 + (size_t)L.K * 8 + (size_t)L.vcap * 8;
+        int rc = set_dyn_lds(krecip_kernel, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(krecip_kernel, dim3((unsigned)N), dim3(64), lds, stream, MT, L.ld, N, rowmax, rank, L.K,
+                           L.KR, L.h, L.vcap, vcnt, vidx, vval);
+        LAUNCH_CHECK();
+    }
+    tm.mark(); // 3
+    // (7) query expansion
+    std::vector<int> host_cnt((size_t)N);
+    int64_t v_nnz = 0, q_nnz = 0;
+    int qcap = L.vcap;
+    const int *fcnt = vcnt, *fidx = vidx;
+    const uint16_t *fval = vval;
+    HIP_TRY(hipMemcpyAsync(host_cnt.data(), vcnt, (size_t)N * 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (int64_t i = 0; i < N; ++i) v_nnz += host_cnt[(size_t)i];
+    if (k2 != 1) {
+        {
+            const size_t lds = (size_t)nw * 4;
+            int rc = set_dyn_lds(qe_count_kernel, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL(qe_count_kernel, dim3((unsigned)N), dim3(64), lds, stream, N, rank, L.KR, k2, vcnt, vidx,
+                               L.vcap, ucnt);
+            LAUNCH_CHECK();
+        }
+        HIP_TRY(hipMemcpyAsync(host_cnt.data(), ucnt, (size_t)N * 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        int mxu = 1;
+        for (int64_t i = 0; i < N; ++i) mxu = std::max(mxu, host_cnt[(size_t)i]);
+        qcap = (int)std::min<int64_t>(L.qcap_bound, (int64_t)align_up((size_t)mxu, 8));
+        if (qcap < mxu) qcap = mxu;
+        {
+            const size_t lds = (size_t)nw * 8 + (size_t)qcap * 8;
+            int rc = set_dyn_lds(qe_fill_kernel, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL(qe_fill_kernel, dim3((unsigned)N), dim3(64), lds, stream, N, rank, L.KR, k2, vcnt, vidx,
+                               vval, L.vcap, qcap, qcnt, qidx, qval);
+            LAUNCH_CHECK();
+        }
+        fcnt = qcnt;
+        fidx = qidx;
+        fval = qval;
+    }
+    tm.mark(); // 4
+    // inverted index
+    HIP_TRY(hipMemsetAsync(ccnt, 0, (size_t)(N + 1) * 4, stream));
+    HIP_TRY(hipMemsetAsync(counters, 0, 64, stream));
+    hipLaunchKernelGGL(csc_count_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, N, fcnt, fidx, qcap,
+                       ccnt);
+    hipLaunchKernelGGL(csc_scan_kernel, dim3(1), dim3(1024), 0, stream, N, ccnt, cptr);
+    hipLaunchKernelGGL(csc_fill_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, N, fcnt, fidx, fval, qcap,
+                       cptr, ccnt, crow, cval);
+    LAUNCH_CHECK();
+    tm.mark(); // 5
+    // (8)-(11) Jaccard + blend
+    {
+        const uint16_t oml = f64_to_f16_host(1.0 - lambda_value);
+        const float lam32 = (float)lambda_value;
+        int rch = (int)std::min<int64_t>(N, 49152);
+        rch = (int)align_up((size_t)rch, 8);
+        const size_t lds = align_up((size_t)rch * 2, 16) + (size_t)qcap * (8 + 4 + 2) + 16;
+        int rc = set_dyn_lds(jaccard_kernel, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(jaccard_kernel, dim3((unsigned)nq), dim3(256), lds, stream, N, nq, MT, L.ld, rowmax, fcnt,
+                           fidx, fval, qcap, cptr, crow, cval, rch, oml, lam32, out, ldo, counters);
+        LAUNCH_CHECK();
+    }
+    tm.mark(); // 6
+    unsigned long long pairs = 0;
+    long long nnz_total = 0;
+    HIP_TRY(hipMemcpyAsync(&pairs, counters, 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(&nnz_total, cptr + N, 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    q_nnz = nnz_total;
+    if (stats) {
+        stats->n = N;
+        stats->k1 = k1;
+        stats->k2 = k2;
+        stats->half_k1 = L.h;
+        stats->v_cap = L.vcap;
+        stats->vqe_cap = qcap;
+        stats->v_nnz = v_nnz;
+        stats->vqe_nnz = q_nnz;
+        stats->jaccard_pairs = (int64_t)pairs;
+        stats->ms_gemm = tm.ms(0, 1);
+        stats->ms_topk = tm.ms(1, 2);
+        stats->ms_krecip = tm.ms(2, 3);
+        stats->ms_qe = tm.ms(3, 4);
+        stats->ms_csc = tm.ms(4, 5);
+        stats->ms_jaccard = tm.ms(5, 6);
+        stats->ms_total = tm.ms(0, 6);
+    }
+    return MPREID_OK;
+}
+
+extern "C" int mpreid_rerank_debug_copy(const void *ws, int64_t nq, int64_t ng, int d, int k1, int k2, int has_local,
+                                        int32_t *rank_out, int32_t *v_cnt, int32_t *vqe_cnt,
+                                        mpreid_stream_t stream_) {
+    ARG_CHECK(ws);
+    const RerankLayout L = make_layout(nq, ng, d, k1, k2, has_local);
+    hipStream_t stream = (hipStream_t)stream_;
+    const char *base = (const char *)ws;
+    if (rank_out)
+        HIP_TRY(hipMemcpy2DAsync(rank_out, (size_t)L.K * 4, base + L.rank, (size_t)L.KR * 4, (size_t)L.K * 4,
+                                 (size_t)L.N, hipMemcpyDeviceToHost, stream));
+    if (v_cnt) HIP_TRY(hipMemcpyAsync(v_cnt, base + L.vcnt, (size_t)L.N * 4, hipMemcpyDeviceToHost, stream));
+    if (vqe_cnt)
+        HIP_TRY(hipMemcpyAsync(vqe_cnt, base + (k2 != 1 ? L.qcnt : L.vcnt), (size_t)L.N * 4, hipMemcpyDeviceToHost,
+                               stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return MPREID_OK;
+}

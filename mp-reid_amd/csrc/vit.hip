@@ -1,0 +1,457 @@
+// vit.hip — CLIP ViT-B/16 image encoder forward for gfx950.
+//
+// Reference: model/clip/model.py:415-479 (VisionTransformer.forward), :278-281
+// (ResidualAttentionBlock), :150-156 (LayerNorm, fp32 statistics), :159-161 (QuickGELU);
+// model/make_model.py:81-115 (CLS of x12 and of x12 @ proj, eval BatchNorm necks, concat).
+//
+// Precision plan: residual stream, LayerNorm statistics, softmax and all accumulators fp32;
+// GEMM operands (LN outputs, Q/K/V, attention output, MLP hidden, weights) fp16 -> MFMA.
+//
+// HBM layout (workspace, M = B*L tokens, padded to 128 rows):
+//   patches fp16 [B*P pad][3*p*p]   im2col of the image, inner order (c, kh, kw)
+//   x       fp32 [M pad][W]         residual stream
+//   a       fp16 [M pad][W]         LN output, then attention output (GEMM A operands)
+//   qkv     fp16 [M pad][3W]        in_proj output, q | k | v column blocks, head h = cols [64h, 64h+64)
+//   hbuf    fp16 [M pad][4W]        MLP hidden after QuickGELU
+// Kernels: im2col (HBM), GEMM+epilogues (MFMA, gemm_f16.hip), LayerNorm (HBM), attention (MFMA +
+// LDS; L = 129 keys fit one workgroup), head (L2).
+#include "gemm_f16.h"
+
+// ---------------------------------------------------------------------------------------------
+// im2col: img [B][3][H][W] fp32 -> patches [MPpad][3*p*p] fp16; rows >= B*P are zero
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void im2col_kernel(const float *__restrict__ img, int B, int H, int Wd, int p,
+                                                     int stride, int h_res, int w_res, _Float16 *__restrict__ out,
+                                                     int mp_pad) {
+    const int Kp = 3 * p * p;
+    const int chunks = Kp / 8; // 8 consecutive kw per thread
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (int64_t)mp_pad * chunks) return;
+    const int m = (int)(gid / chunks), ch = (int)(gid % chunks);
+    const int P = h_res * w_res;
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    h8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (m < B * P) {
+        const int b = m / P, pi = m % P;
+        const int ph = pi / w_res, pw = pi % w_res;
+        const int k = ch * 8;
+        const int c = k / (p * p), kh = (k % (p * p)) / p, kw = k % p;
+        const float *src = img + (((int64_t)b * 3 + c) * H + (ph * stride + kh)) * Wd + pw * stride + kw;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (_Float16)src[j];
+    }
+    *reinterpret_cast<h8 *>(out + (int64_t)m * Kp + ch * 8) = o;
+}
+
+// x[b*L + 0][:] = class_embedding + pos[0] (+ cv_emb[b])      model/clip/model.py:419-422
+__global__ __launch_bounds__(256) void cls_token_kernel(const float *__restrict__ cls, const float *__restrict__ pos,
+                                                        const float *__restrict__ cv, int B, int L, int W,
+                                                        float *__restrict__ x) {
+    const int b = blockIdx.x;
+    for (int k = threadIdx.x; k < W; k += 256) {
+        float v = cls[k];
+        if (cv) v = v + cv[(int64_t)b * W + k];
+        x[(int64_t)b * L * W + k] = v + pos[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over the last dim (biased variance, eps 1e-5, fp32 stats); one wave per row.
+// OUT_F16: write fp16 (GEMM operand) else fp32 (may alias the input: ln_pre is in place).
+// ---------------------------------------------------------------------------------------------
+template <bool OUT_F16>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, int64_t rows, int W,
+                                                        const float *__restrict__ gamma,
+                                                        const float *__restrict__ beta, void *__restrict__ out,
+                                                        int64_t row_stride_in) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *xr = x + row * row_stride_in;
+    float4 v[4]; // W <= 1024; statically unrolled so that v[] stays in registers
+    bool act[4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        act[i] = (i * 256 + lane * 4) < W;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (act[i]) v[i] = *reinterpret_cast<const float4 *>(xr + i * 256 + lane * 4);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    const float mean = s / (float)W;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (act[i]) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+    const float rstd = 1.0f / __fsqrt_rn(q / (float)W + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (!act[i]) continue;
+        const int k = i * 256 + lane * 4;
+        const float4 gm = *reinterpret_cast<const float4 *>(gamma + k);
+        const float4 bt = *reinterpret_cast<const float4 *>(beta + k);
+        float4 y;
+        y.x = (v[i].x - mean) * rstd * gm.x + bt.x;
+        y.y = (v[i].y - mean) * rstd * gm.y + bt.y;
+        y.z = (v[i].z - mean) * rstd * gm.z + bt.z;
+        y.w = (v[i].w - mean) * rstd * gm.w + bt.w;
+        if (OUT_F16) {
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            h4 o = {(_Float16)y.x, (_Float16)y.y, (_Float16)y.z, (_Float16)y.w};
+            *reinterpret_cast<h4 *>(reinterpret_cast<_Float16 *>(out) + row * (int64_t)W + k) = o;
+        } else {
+            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(out) + row * (int64_t)W + k) = y;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// attention: softmax(q k^T / sqrt(64)) v per (image, head); L <= 16*KTP keys live in LDS.
+//
+// One workgroup per (image, head); each wave owns 16-query tiles.  Computed "key on the lane":
+//   S^T = K Q^T   (A = K rows from LDS, B = Q fragment straight from global)  -> C: col = query
+//   O^T = V^T P^T (A = V^T from LDS,   B = P^T = the S^T accumulators, converted in registers)
+// so the softmax reduction over keys is in-lane + 2 shuffles and P never touches LDS
+// (cdna_hip_programming.md §3 "An accumulator tile as the next MFMA's operand").
+// ---------------------------------------------------------------------------------------------
+typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+
+template <int KTP>
+__global__ __launch_bounds__(256) void attention_kernel(const _Float16 *__restrict__ qkv, int L, int W, int heads,
+                                                        _Float16 *__restrict__ out, int q_tiles) {
+    constexpr int KEYS = KTP * 16;
+    constexpr int VS = KEYS + 8; // halfs; VS*2 bytes = 16 * odd -> conflict-free ds_read_b64 of V^T
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *Ks = smem;                                             // [KEYS][128 B] swizzled
+    _Float16 *Vt = reinterpret_cast<_Float16 *>(smem + KEYS * 128);       // [64][VS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int64_t ld = 3 * (int64_t)W;
+    const _Float16 *base = qkv + (int64_t)b * L * ld + h * 64;
+
+    // ---- stage K (row-major, swizzled) ----
+    for (int idx = tid; idx < KEYS * 8; idx += blockDim.x) {
+        const int row = idx >> 3, c = idx & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < L) v = *reinterpret_cast<const uint4 *>(base + (int64_t)row * ld + W + c * 8);
+        *reinterpret_cast<uint4 *>(Ks + row * 128 + ((c ^ (row & 7)) << 4)) = v;
+    }
+    // ---- stage V transposed: Vt[d][key], two keys per 32-bit LDS write ----
+    for (int idx = tid; idx < KEYS * 4; idx += blockDim.x) {
+        const int kp = idx % (KEYS / 2), c = idx / (KEYS / 2); // lanes of a half-wave: distinct key pairs
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        h8 v0 = {0, 0, 0, 0, 0, 0, 0, 0}, v1 = v0;
+        if (2 * kp < L) v0 = *reinterpret_cast<const h8 *>(base + (int64_t)(2 * kp) * ld + 2 * W + c * 8);
+        if (2 * kp + 1 < L) v1 = *reinterpret_cast<const h8 *>(base + (int64_t)(2 * kp + 1) * ld + 2 * W + c * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            h2 pr = {v0[j], v1[j]};
+            *reinterpret_cast<h2 *>(Vt + (c * 8 + j) * VS + 2 * kp) = pr;
+        }
+    }
+    __syncthreads();
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const float scale_log2e = 0.125f * 1.44269504088896340736f;
+    const int nqt = (q_tiles > 0) ? q_tiles : (L + 15) / 16;
+    for (int qt = wave; qt < nqt; qt += nwaves) {
+        const int q = qt * 16 + fr;
+        // Q fragment as B operand: B[k = d][col = query]
+        f16x8 qf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            qf[ks] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (q < L) qf[ks] = *reinterpret_cast<const f16x8 *>(base + (int64_t)q * ld + ks * 32 + fq * 8);
+        }
+        f32x4 s[KTP];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kt = 0; kt < KTP; ++kt) {
+            s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (kt * 16 < L) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const f16x8 kf = *reinterpret_cast<const f16x8 *>(Ks + (kt * 16 + fr) * 128 +
+                                                                       (((ks * 4 + fq) ^ (lane & 7)) << 4));
+                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], s[kt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + fq * 4 + r;
+                if (key >= L) s[kt][r] = -3.0e38f;
+                mx = fmaxf(mx, s[kt][r]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KTP; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt * 16 + fq * 4 + r;
+                const float p = (key < L) ? exp2f((s[kt][r] - mx) * scale_log2e) : 0.f;
+                s[kt][r] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        // O^T = V^T P^T over 32-key steps; P^T fragment element j <-> key 32*s2 + 16*(j>>2) + 4*fq + (j&3)
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < KTP / 2; ++s2) {
+            if (s2 * 32 < L) {
+                f16x8 pf;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    pf[j] = (_Float16)s[2 * s2][j];
+                    pf[4 + j] = (_Float16)s[2 * s2 + 1][j];
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const _Float16 *vrow = Vt + (dt * 16 + fr) * VS + s2 * 32 + fq * 4;
+                    const h4_t lo = *reinterpret_cast<const h4_t *>(vrow);
+                    const h4_t hi = *reinterpret_cast<const h4_t *>(vrow + 16);
+                    const f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[dt], 0, 0, 0);
+                }
+            }
+        }
+        if (q < L) {
+            const float inv = 1.0f / sum;
+            _Float16 *orow = out + ((int64_t)b * L + q) * W + h * 64 + fq * 4;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                h4_t ov = {(_Float16)(o[dt][0] * inv), (_Float16)(o[dt][1] * inv), (_Float16)(o[dt][2] * inv),
+                           (_Float16)(o[dt][3] * inv)};
+                *reinterpret_cast<h4_t *>(orow + dt * 16) = ov;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// head: ln_post on the CLS row, CLS @ proj, optional eval-BN necks, concat -> [B][W + out_dim]
+// model/clip/model.py:471-474, model/make_model.py:98-115
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ x, int L, int W, int out_dim,
+                                                   const float *__restrict__ g, const float *__restrict__ bta,
+                                                   const float *__restrict__ proj, const float *__restrict__ bn_s,
+                                                   const float *__restrict__ bn_b, const float *__restrict__ bnp_s,
+                                                   const float *__restrict__ bnp_b, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *y = reinterpret_cast<float *>(smem); // [W]
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const float *xr = x + (int64_t)b * L * W;
+    float s = 0.f;
+    for (int k = tid; k < W; k += 256) s += xr[k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)W;
+    float q = 0.f;
+    for (int k = tid; k < W; k += 256) {
+        const float d = xr[k] - mean;
+        q += d * d;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+    if (lane == 0) red[4 + wave] = q;
+    __syncthreads();
+    const float rstd = 1.0f / __fsqrt_rn(((red[4] + red[5]) + (red[6] + red[7])) / (float)W + 1e-5f);
+    float *orow = out + (int64_t)b * (W + out_dim);
+    for (int k = tid; k < W; k += 256) {
+        const float v = (xr[k] - mean) * rstd * g[k] + bta[k];
+        y[k] = v;
+        orow[k] = bn_s ? fmaf(v, bn_s[k], bn_b[k]) : v;
+    }
+    __syncthreads();
+    for (int o = tid; o < out_dim; o += 256) {
+        float acc = 0.f;
+        for (int k = 0; k < W; ++k) acc = fmaf(y[k], proj[(int64_t)k * out_dim + o], acc);
+        orow[W + o] = bnp_s ? fmaf(acc, bnp_s[o], bnp_b[o]) : acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host driver
+// ---------------------------------------------------------------------------------------------
+struct VitLayout {
+    int L, P, M, Mpad, MPpad, Kp;
+    size_t patches, x, a, qkv, hbuf, total;
+};
+
+static VitLayout vit_layout(const mpreid_vit_cfg *c, int B) {
+    VitLayout v{};
+    v.P = c->h_res * c->w_res;
+    v.L = v.P + 1;
+    v.M = B * v.L;
+    v.Mpad = (int)align_up((size_t)v.M, GBM);
+    v.MPpad = (int)align_up((size_t)B * v.P, GBM);
+    v.Kp = 3 * c->patch * c->patch;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += align_up(bytes, 256);
+        return o;
+    };
+    const size_t W = (size_t)c->width;
+    v.patches = take((size_t)v.MPpad * v.Kp * 2);
+    v.x = take((size_t)v.Mpad * W * 4);
+    v.a = take((size_t)v.Mpad * W * 2);
+    v.qkv = take((size_t)v.Mpad * 3 * W * 2);
+    v.hbuf = take((size_t)v.Mpad * 4 * W * 2);
+    v.total = off;
+    return v;
+}
+
+static int vit_check_cfg(const mpreid_vit_cfg *c) {
+    ARG_CHECK(c != nullptr);
+    ARG_CHECK(c->width > 0 && c->heads > 0 && c->layers >= 0 && c->out_dim > 0);
+    if (c->width != c->heads * 64) {
+        mpreid_set_error("head dim must be 64 (width %d, heads %d)", c->width, c->heads);
+        return MPREID_ERR_UNSUPPORTED;
+    }
+    if (c->width % 128 != 0 || c->width > 1024 || (3 * c->patch * c->patch) % 64 != 0 || c->patch % 8 != 0) {
+        mpreid_set_error("unsupported ViT geometry (width %d, patch %d)", c->width, c->patch);
+        return MPREID_ERR_UNSUPPORTED;
+    }
+    ARG_CHECK(c->h_res == (c->img_h - c->patch) / c->stride + 1 && c->w_res == (c->img_w - c->patch) / c->stride + 1);
+    if (c->h_res * c->w_res + 1 > 256) {
+        mpreid_set_error("token count %d > 256 not supported by the LDS-resident attention kernel",
+                         c->h_res * c->w_res + 1);
+        return MPREID_ERR_UNSUPPORTED;
+    }
+    return MPREID_OK;
+}
+
+extern "C" size_t mpreid_vit_workspace_bytes(const mpreid_vit_cfg *cfg, int batch) {
+    if (!cfg || batch <= 0) return 0;
+    return vit_layout(cfg, batch).total;
+}
+
+template <int KTP>
+static int launch_attention(const _Float16 *qkv, int B, int L, int W, int heads, _Float16 *out, int q_tiles,
+                            hipStream_t stream) {
+    constexpr int KEYS = KTP * 16;
+    const size_t lds = (size_t)KEYS * 128 + (size_t)64 * (KEYS + 8) * 2;
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_kernel<KTP>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int nqt = (q_tiles > 0) ? q_tiles : (L + 15) / 16;
+    const int nw = (nqt % 3 == 0) ? 3 : (nqt < 4 ? nqt : 4);
+    hipLaunchKernelGGL(attention_kernel<KTP>, dim3((unsigned)(B * heads)), dim3(64 * nw), lds, stream, qkv, L, W, heads,
+                       out, q_tiles);
+    LAUNCH_CHECK();
+    return MPREID_OK;
+}
+
+static int attention_dispatch(const _Float16 *qkv, int B, int L, int W, int heads, _Float16 *out, int q_tiles,
+                              hipStream_t stream) {
+    const int kt = (L + 15) / 16;
+    if (kt <= 2) return launch_attention<2>(qkv, B, L, W, heads, out, q_tiles, stream);
+    if (kt <= 10) return launch_attention<10>(qkv, B, L, W, heads, out, q_tiles, stream);
+    if (kt <= 14) return launch_attention<14>(qkv, B, L, W, heads, out, q_tiles, stream);
+    return launch_attention<16>(qkv, B, L, W, heads, out, q_tiles, stream);
+}
+
+extern "C" int mpreid_vit_forward(const mpreid_vit_cfg *cfg, const mpreid_vit_weights *w, const float *img, int B,
+                                  const float *cv_emb, float *out, void *ws, size_t ws_bytes,
+                                  mpreid_stream_t stream_) {
+    int rc = vit_check_cfg(cfg);
+    if (rc) return rc;
+    ARG_CHECK(w && img && out && B > 0 && w->layers);
+    const VitLayout v = vit_layout(cfg, B);
+    if (!ws || ws_bytes < v.total) {
+        mpreid_set_error("vit workspace too small: %zu < %zu", ws_bytes, v.total);
+        return MPREID_ERR_WORKSPACE;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    const int W = cfg->width, L = v.L;
+    char *base = (char *)ws;
+    _Float16 *patches = (_Float16 *)(base + v.patches);
+    float *x = (float *)(base + v.x);
+    _Float16 *a = (_Float16 *)(base + v.a);
+    _Float16 *qkv = (_Float16 *)(base + v.qkv);
+    _Float16 *hbuf = (_Float16 *)(base + v.hbuf);
+
+    // patch embedding (conv1, no bias) + positional embedding; CLS row; ln_pre
+    {
+        const int64_t threads = (int64_t)v.MPpad * (v.Kp / 8);
+        hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, img, B,
+                           cfg->img_h, cfg->img_w, cfg->patch, cfg->stride, cfg->h_res, cfg->w_res, patches, v.MPpad);
+        LAUNCH_CHECK();
+        GemmArgs g{};
+        g.A = patches;
+        g.W = (const _Float16 *)w->conv_w;
+        g.M = v.MPpad;
+        g.N = W;
+        g.K = v.Kp;
+        g.out = x;
+        g.ldo = W;
+        g.aux = w->pos_emb;
+        g.m_valid = B * v.P;
+        g.P = v.P;
+        g.L = L;
+        rc = launch_gemm_f16(g, GE_PATCH, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(cls_token_kernel, dim3((unsigned)B), dim3(256), 0, stream, w->class_emb, w->pos_emb, cv_emb,
+                           B, L, W, x);
+        hipLaunchKernelGGL(layernorm_kernel<false>, dim3((unsigned)((v.M + 3) / 4)), dim3(256), 0, stream, x,
+                           (int64_t)v.M, W, w->ln_pre_g, w->ln_pre_b, (void *)x, (int64_t)W);
+        LAUNCH_CHECK();
+    }
+    for (int l = 0; l < cfg->layers; ++l) {
+        const mpreid_vit_layer &ly = w->layers[l];
+        GemmArgs g{};
+        // x = x + out_proj(attn(ln_1(x)))
+        hipLaunchKernelGGL(layernorm_kernel<true>, dim3((unsigned)((v.M + 3) / 4)), dim3(256), 0, stream, x,
+                           (int64_t)v.M, W, ly.ln1_g, ly.ln1_b, (void *)a, (int64_t)W);
+        LAUNCH_CHECK();
+        g = GemmArgs{};
+        g.A = a; g.W = (const _Float16 *)ly.in_proj_w; g.M = v.Mpad; g.N = 3 * W; g.K = W;
+        g.out = qkv; g.ldo = 3 * W; g.bias = ly.in_proj_b;
+        if ((rc = launch_gemm_f16(g, GE_BIAS_F16, stream))) return rc;
+        if ((rc = attention_dispatch(qkv, B, L, W, cfg->heads, a, 0, stream))) return rc;
+        g = GemmArgs{};
+        g.A = a; g.W = (const _Float16 *)ly.out_proj_w; g.M = v.Mpad; g.N = W; g.K = W;
+        g.out = x; g.ldo = W; g.bias = ly.out_proj_b;
+        if ((rc = launch_gemm_f16(g, GE_BIAS_RES, stream))) return rc;
+        // x = x + c_proj(quickgelu(c_fc(ln_2(x))))
+        hipLaunchKernelGGL(layernorm_kernel<true>, dim3((unsigned)((v.M + 3) / 4)), dim3(256), 0, stream, x,
+                           (int64_t)v.M, W, ly.ln2_g, ly.ln2_b, (void *)a, (int64_t)W);
+        LAUNCH_CHECK();
+        g = GemmArgs{};
+        g.A = a; g.W = (const _Float16 *)ly.fc_w; g.M = v.Mpad; g.N = 4 * W; g.K = W;
+        g.out = hbuf; g.ldo = 4 * W; g.bias = ly.fc_b;
+        if ((rc = launch_gemm_f16(g, GE_BIAS_GELU, stream))) return rc;
+        g = GemmArgs{};
+        g.A = hbuf; g.W = (const _Float16 *)ly.proj_w; g.M = v.Mpad; g.N = W; g.K = 4 * W;
+        g.out = x; g.ldo = W; g.bias = ly.proj_b;
+        if ((rc = launch_gemm_f16(g, GE_BIAS_RES, stream))) return rc;
+    }
+    const bool neck = cfg->neck_after != 0 && w->bn_scale && w->bn_proj_scale;
+    hipLaunchKernelGGL(head_kernel, dim3((unsigned)B), dim3(256), (size_t)W * 4, stream, x, L, W, cfg->out_dim,
+                       w->ln_post_g, w->ln_post_b, w->proj, neck ? w->bn_scale : nullptr, neck ? w->bn_shift : nullptr,
+                       neck ? w->bn_proj_scale : nullptr, neck ? w->bn_proj_shift : nullptr, out);
+    LAUNCH_CHECK();
+    return MPREID_OK;
+}

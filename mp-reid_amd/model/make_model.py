@@ -1,0 +1,119 @@
+"""Drop-in for the reference's ``model/make_model.py`` (eval path only): the CLIP ViT-B/16 image
+encoder + feature head of ``build_transformer``, executed by the HIP kernels of libmpreid_hip.so.
+
+Kept from the reference (model/make_model.py:81-133): ``make_model(cfg, num_class, camera_num, view_num)``
+returns an object with ``.load_param(path)``, ``.eval()``, ``.to(device)``, ``.state_dict()`` (same key
+layout as the reference's checkpoints: ``image_encoder.*``, ``bottleneck*``, ``classifier*``, ``cv_embed``)
+and ``__call__(x, label=None, cam_label=None, view_label=None) -> Tensor[B, 1280]``.
+
+Not kept on purpose: the constructor does not download the pretrained CLIP archive (the reference
+does, even at test time, model/make_model.py:137-139); weights are seeded random until
+``load_param`` is called.  Training-mode forward, the RN50 backbone and the text tower are out of
+scope.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from mpreid import ops as _ops
+from mpreid import synth as _synth
+
+
+def _put(root: nn.Module, dotted: str, tensor: torch.Tensor):
+    """register `tensor` as a parameter at a dotted state-dict path, creating containers on the way"""
+    parts = dotted.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, nn.Module())
+        mod = mod._modules[p]
+    mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+
+
+class build_transformer(nn.Module):
+    def __init__(self, num_classes, camera_num, view_num, cfg):
+        super().__init__()
+        self.model_name = cfg.MODEL.NAME
+        if self.model_name != 'ViT-B-16':
+            raise NotImplementedError("only MODEL.NAME == 'ViT-B-16' is on the accelerated path "
+                                      f"(got {self.model_name!r}; RN50 is listed as 'next' in SURVEY.md §8f)")
+        self.neck_feat = cfg.TEST.NECK_FEAT
+        self.in_planes, self.in_planes_proj = 768, 512
+        self.num_classes, self.camera_num, self.view_num = num_classes, camera_num, view_num
+        self.sie_coe = cfg.MODEL.SIE_COE
+        stride = cfg.MODEL.STRIDE_SIZE[0]
+        # the positional grid follows INPUT.SIZE_TRAIN, like upstream (it must equal SIZE_TEST)
+        self.h_resolution = int((cfg.INPUT.SIZE_TRAIN[0] - 16) // cfg.MODEL.STRIDE_SIZE[0] + 1)
+        self.w_resolution = int((cfg.INPUT.SIZE_TRAIN[1] - 16) // cfg.MODEL.STRIDE_SIZE[1] + 1)
+        self.img_hw = (int(cfg.INPUT.SIZE_TEST[0]), int(cfg.INPUT.SIZE_TEST[1]))
+        self.vit_cfg = dict(h_res=self.h_resolution, w_res=self.w_resolution, patch=16, stride=stride, width=768,
+                            layers=12, heads=12, out_dim=512)
+        seed = int(getattr(cfg.MODEL, "INIT_SEED", 7))
+        for k, v in _synth.vit_state_dict(self.vit_cfg, seed=seed).items():
+            _put(self, "image_encoder." + k, torch.from_numpy(v))
+        g = torch.Generator().manual_seed(seed)
+        _put(self, "classifier.weight", torch.randn(num_classes, self.in_planes, generator=g) * 0.001)
+        _put(self, "classifier_proj.weight", torch.randn(num_classes, self.in_planes_proj, generator=g) * 0.001)
+        for name, n in (("bottleneck", self.in_planes), ("bottleneck_proj", self.in_planes_proj)):
+            _put(self, name + ".weight", torch.ones(n))
+            _put(self, name + ".bias", torch.zeros(n))
+            bn = self._modules[name]
+            bn.register_buffer("running_mean", torch.zeros(n))
+            bn.register_buffer("running_var", torch.ones(n))
+            bn.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.sie_camera, self.sie_view = bool(cfg.MODEL.SIE_CAMERA), bool(cfg.MODEL.SIE_VIEW)
+        if self.sie_camera or self.sie_view:
+            rows = camera_num * view_num if (self.sie_camera and self.sie_view) else (
+                camera_num if self.sie_camera else view_num)
+            cv = torch.empty(rows, self.in_planes)
+            nn.init.trunc_normal_(cv, std=.02, generator=g)
+            self.cv_embed = nn.Parameter(cv, requires_grad=False)
+        self._encoder = None
+        self.eval()
+
+    # -- device encoder is (re)built lazily from the current parameters --------------------------
+    def _invalidate(self):
+        self._encoder = None
+
+    def _get_encoder(self):
+        if self._encoder is None:
+            sd = {k: v for k, v in self.state_dict().items() if k.startswith("image_encoder.")}
+            bn = None
+            if self.neck_feat == 'after':
+                bn = {n: (self._modules[n].weight, self._modules[n].bias, self._modules[n].running_mean,
+                          self._modules[n].running_var) for n in ("bottleneck", "bottleneck_proj")}
+            self._encoder = _ops.VitEncoder(self.vit_cfg, sd, self.img_hw, neck_after=(self.neck_feat == 'after'),
+                                            bn=bn)
+        return self._encoder
+
+    def forward(self, x, label=None, cam_label=None, view_label=None):
+        if self.training:
+            raise NotImplementedError("training-mode forward is out of scope; call .eval()")
+        cv_embed = None
+        if cam_label is not None and view_label is not None:
+            cv_embed = self.sie_coe * self.cv_embed[cam_label * self.view_num + view_label]
+        elif cam_label is not None:
+            cv_embed = self.sie_coe * self.cv_embed[cam_label]
+        elif view_label is not None:
+            cv_embed = self.sie_coe * self.cv_embed[view_label]
+        return self._get_encoder()(x, cv_embed)
+
+    def load_param(self, trained_path):
+        param_dict = torch.load(trained_path, map_location="cpu")
+        own = self.state_dict()
+        for name in param_dict:
+            own[name.replace('module.', '')].copy_(param_dict[name])
+        self._invalidate()
+        print('Loading pretrained model from {}'.format(trained_path))
+
+    def load_param_finetune(self, model_path):
+        self.load_param(model_path)
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._invalidate()
+        return r
+
+
+def make_model(cfg, num_class, camera_num, view_num):
+    return build_transformer(num_class, camera_num, view_num, cfg)

@@ -1,0 +1,118 @@
+"""ctypes binding of libmpreid_hip.so (include/mpreid.h).
+
+There is no CPU fallback: if the library is missing, or a compute entry point is called without a
+GPU, a RuntimeError is raised (SURVEY.md §8b "Errors").
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmpreid_hip.so")
+
+GEMM_F32_EXACT = 0
+GEMM_F16_FAST = 1
+
+#: every symbol include/mpreid.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "mpreid_version", "mpreid_last_error", "mpreid_device_count", "mpreid_device_info",
+    "mpreid_sqnorm_f32", "mpreid_l2_normalize_f32", "mpreid_distance_workspace_bytes",
+    "mpreid_euclidean_distance_f32", "mpreid_cosine_similarity_f32",
+    "mpreid_rerank_workspace_bytes", "mpreid_rerank_f32", "mpreid_rerank_debug_copy",
+    "mpreid_vit_workspace_bytes", "mpreid_vit_forward", "mpreid_gemm_f16_nt", "mpreid_cast_f32_to_f16",
+]
+
+
+class RerankStats(C.Structure):
+    _fields_ = [("n", C.c_int64), ("k1", C.c_int32), ("k2", C.c_int32), ("half_k1", C.c_int32),
+                ("v_cap", C.c_int32), ("vqe_cap", C.c_int32), ("v_nnz", C.c_int64), ("vqe_nnz", C.c_int64),
+                ("jaccard_pairs", C.c_int64), ("ms_gemm", C.c_float), ("ms_topk", C.c_float),
+                ("ms_krecip", C.c_float), ("ms_qe", C.c_float), ("ms_csc", C.c_float),
+                ("ms_jaccard", C.c_float), ("ms_total", C.c_float)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class VitCfg(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("img_h", "img_w", "patch", "stride", "h_res", "w_res", "width", "layers",
+                                         "heads", "out_dim", "neck_after", "cls_only_last")]
+
+
+class VitLayer(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "ln1_g", "ln1_b",
+                                          "ln2_g", "ln2_b", "fc_w", "fc_b", "proj_w", "proj_b")]
+
+
+class VitWeights(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("conv_w", "class_emb", "pos_emb", "ln_pre_g", "ln_pre_b", "ln_post_g",
+                                          "ln_post_b", "proj", "bn_scale", "bn_shift", "bn_proj_scale",
+                                          "bn_proj_shift")] + [("layers", C.POINTER(VitLayer))]
+
+
+_lib = None
+
+
+def load():
+    """Load the library and declare prototypes.  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python mp-reid_amd/mpreid/build.py` "
+            "(or __graft_entry__.build()).  There is no CPU fallback for the HIP path.")
+    L = C.CDLL(LIB_PATH)
+    vp, i64, i32, f32, f64, sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_double, C.c_size_t
+    L.mpreid_version.restype = i32
+    L.mpreid_last_error.restype = C.c_char_p
+    L.mpreid_device_count.restype = i32
+    L.mpreid_device_info.restype = i32
+    L.mpreid_device_info.argtypes = [C.c_char_p, i32, C.POINTER(i32), C.POINTER(sz)]
+    L.mpreid_sqnorm_f32.restype = i32
+    L.mpreid_sqnorm_f32.argtypes = [vp, i64, i32, vp, vp]
+    L.mpreid_l2_normalize_f32.restype = i32
+    L.mpreid_l2_normalize_f32.argtypes = [vp, i64, i32, f32, vp, vp]
+    L.mpreid_distance_workspace_bytes.restype = sz
+    L.mpreid_distance_workspace_bytes.argtypes = [i64, i64, i32, i32]
+    for f in (L.mpreid_euclidean_distance_f32, L.mpreid_cosine_similarity_f32):
+        f.restype = i32
+        f.argtypes = [vp, vp, i64, i64, i32, vp, i64, i32, vp, sz, vp]
+    L.mpreid_rerank_workspace_bytes.restype = sz
+    L.mpreid_rerank_workspace_bytes.argtypes = [i64, i64, i32, i32, i32, i32]
+    L.mpreid_rerank_f32.restype = i32
+    L.mpreid_rerank_f32.argtypes = [vp, vp, i64, i64, i32, i32, i32, f64, vp, i32, vp, i64, vp, sz, vp,
+                                    C.POINTER(RerankStats), i32]
+    L.mpreid_rerank_debug_copy.restype = i32
+    L.mpreid_rerank_debug_copy.argtypes = [vp, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp]
+    L.mpreid_vit_workspace_bytes.restype = sz
+    L.mpreid_vit_workspace_bytes.argtypes = [C.POINTER(VitCfg), i32]
+    L.mpreid_vit_forward.restype = i32
+    L.mpreid_vit_forward.argtypes = [C.POINTER(VitCfg), C.POINTER(VitWeights), vp, i32, vp, vp, vp, sz, vp]
+    L.mpreid_gemm_f16_nt.restype = i32
+    L.mpreid_gemm_f16_nt.argtypes = [vp, vp, vp, i64, i64, i64, vp]
+    L.mpreid_cast_f32_to_f16.restype = i32
+    L.mpreid_cast_f32_to_f16.argtypes = [vp, vp, i64, vp]
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().mpreid_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def require_gpu():
+    """The compute entry points need a HIP device; fail loudly instead of falling back."""
+    import torch
+    load()
+    if not torch.cuda.is_available():
+        raise RuntimeError("mpreid HIP path needs an MI355X (no HIP device visible); there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

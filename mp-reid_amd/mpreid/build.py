@@ -1,0 +1,70 @@
+"""Build libmpreid_hip.so (the C-ABI library of include/mpreid.h) with hipcc for gfx950.
+
+In-tree build: objects under mp-reid_amd/csrc/_obj/, library at mp-reid_amd/mpreid/libmpreid_hip.so
+(git-ignored, travels to the GPU box with the gpurun snapshot).  hipcc cross-compiles without a GPU.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(HERE), "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(HERE, "libmpreid_hip.so")
+SOURCES = ["api.cpp", "distance.hip", "rerank.hip", "gemm_f16.hip", "vit.hip"]
+# -ffp-contract=off: the rounding sequence of the re-ranking path is part of the contract
+# (include/mpreid_numerics.h); fused multiply-adds are written as explicit fmaf().
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-Wall", "-Wno-unused-function", "-x", "hip"]
+
+
+def _deps(src):
+    d = [os.path.join(CSRC, src), os.path.join(CSRC, "common.h")]
+    inc = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include")
+    d += [os.path.join(inc, f) for f in os.listdir(inc)]
+    d += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h") or f.endswith(".hpp")]
+    return d
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    jobs = []
+    objs = []
+    for src in SOURCES:
+        if not os.path.exists(os.path.join(CSRC, src)):
+            raise FileNotFoundError(src)
+        obj = os.path.join(OBJ, src.rsplit(".", 1)[0] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, _deps(src)):
+            jobs.append([hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        return r.stderr
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        for warn in ex.map(run, jobs):
+            if verbose and warn:
+                print(warn, file=sys.stderr)
+    if force or jobs or _stale(LIB, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,236 @@
+"""Tensor-level host API over the C ABI (torch is plumbing here: device memory + streams).
+
+Everything in this module runs on the current HIP device through libmpreid_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import GEMM_F16_FAST, GEMM_F32_EXACT  # noqa: F401  (re-exported)
+
+_ws_cache: Dict[tuple, torch.Tensor] = {}
+
+
+def _workspace(tag: str, nbytes: int, device) -> torch.Tensor:
+    """Grow-only cached byte buffer per (device, tag); the caller owns nothing."""
+    key = (str(device), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            del _ws_cache[key]
+            del buf
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def release_workspaces():
+    _ws_cache.clear()
+
+
+def _dev_f32(t, device) -> torch.Tensor:
+    if isinstance(t, np.ndarray):
+        t = torch.from_numpy(t)
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def l2_normalize(x: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
+    """utils/metrics.py:112-114 — F.normalize(feats, dim=1, p=2)."""
+    dev = _lib.require_gpu()
+    x = _dev_f32(x, dev)
+    out = torch.empty_like(x)
+    if x.shape[0]:
+        _lib.check(_lib.load().mpreid_l2_normalize_f32(_ptr(x), x.shape[0], x.shape[1], eps, _ptr(out),
+                                                       _lib.stream_ptr()), "mpreid_l2_normalize_f32")
+    return out
+
+
+def sqnorm(x: torch.Tensor) -> torch.Tensor:
+    dev = _lib.require_gpu()
+    x = _dev_f32(x, dev)
+    out = torch.empty(x.shape[0], dtype=torch.float32, device=dev)
+    if x.shape[0]:
+        _lib.check(_lib.load().mpreid_sqnorm_f32(_ptr(x), x.shape[0], x.shape[1], _ptr(out), _lib.stream_ptr()),
+                   "mpreid_sqnorm_f32")
+    return out
+
+
+def _distance(fn_name: str, q, g, mode: int, out: Optional[torch.Tensor], col_offset: int) -> torch.Tensor:
+    dev = _lib.require_gpu()
+    L = _lib.load()
+    q, g = _dev_f32(q, dev), _dev_f32(g, dev)
+    assert q.dim() == 2 and g.dim() == 2 and q.shape[1] == g.shape[1], (q.shape, g.shape)
+    nq, ng, d = q.shape[0], g.shape[0], q.shape[1]
+    if out is None:
+        out = torch.empty((nq, ng), dtype=torch.float32, device=dev)
+        col_offset = 0
+    assert out.is_contiguous() and out.dtype == torch.float32 and out.shape[0] == nq
+    ldo = out.shape[1]
+    assert col_offset + ng <= ldo
+    if nq == 0 or ng == 0:
+        return out
+    wsb = L.mpreid_distance_workspace_bytes(nq, ng, d, mode)
+    ws = _workspace("distance", wsb, dev)
+    optr = C.c_void_p(out.data_ptr() + 4 * col_offset)
+    _lib.check(getattr(L, fn_name)(_ptr(q), _ptr(g), nq, ng, d, optr, ldo, mode, _ptr(ws), ws.numel(),
+                                   _lib.stream_ptr()), fn_name)
+    return out
+
+
+def euclidean_distance(q, g, mode: int = GEMM_F32_EXACT, out: Optional[torch.Tensor] = None,
+                       col_offset: int = 0) -> torch.Tensor:
+    """utils/metrics.py:7-13 on the GPU; returns a device tensor [nq, ng] (squared L2)."""
+    return _distance("mpreid_euclidean_distance_f32", q, g, mode, out, col_offset)
+
+
+def cosine_similarity(q, g, mode: int = GEMM_F32_EXACT, out: Optional[torch.Tensor] = None,
+                      col_offset: int = 0) -> torch.Tensor:
+    """utils/metrics.py:15-25 on the GPU; returns a device tensor [nq, ng] (arccos of the cosine)."""
+    return _distance("mpreid_cosine_similarity_f32", q, g, mode, out, col_offset)
+
+
+def re_ranking(q, g, k1: int, k2: int, lambda_value: float, local_distmat=None, only_local: bool = False,
+               timing: bool = False, debug: bool = False):
+    """utils/reranking.py:29-100 on the GPU.  Returns (device tensor [nq, ng] fp32, stats dict)
+    and, with debug=True, additionally (initial_rank[:, :k1+1], nnz(V) per row, nnz(V_qe) per row)."""
+    dev = _lib.require_gpu()
+    L = _lib.load()
+    q, g = _dev_f32(q, dev), _dev_f32(g, dev)
+    nq, ng, d = q.shape[0], g.shape[0], q.shape[1]
+    N = nq + ng
+    loc = None
+    if local_distmat is not None:
+        loc = _dev_f32(local_distmat, dev)
+        assert tuple(loc.shape) == (N, N)
+    wsb = L.mpreid_rerank_workspace_bytes(nq, ng, d, int(k1), int(k2), int(loc is not None))
+    ws = _workspace("rerank", wsb, dev)
+    out = torch.empty((nq, ng), dtype=torch.float32, device=dev)
+    st = _lib.RerankStats()
+    _lib.check(L.mpreid_rerank_f32(_ptr(q), _ptr(g), nq, ng, d, int(k1), int(k2), float(lambda_value), _ptr(loc),
+                                   int(bool(only_local)), _ptr(out), ng, _ptr(ws), ws.numel(), _lib.stream_ptr(),
+                                   C.byref(st), int(bool(timing))), "mpreid_rerank_f32")
+    stats = st.as_dict()
+    if not debug:
+        return out, stats
+    rank = np.empty((N, k1 + 1), np.int32)
+    vc = np.empty(N, np.int32)
+    vq = np.empty(N, np.int32)
+    _lib.check(L.mpreid_rerank_debug_copy(_ptr(ws), nq, ng, d, int(k1), int(k2), int(loc is not None),
+                                          C.c_void_p(rank.ctypes.data), C.c_void_p(vc.ctypes.data),
+                                          C.c_void_p(vq.ctypes.data), _lib.stream_ptr()), "mpreid_rerank_debug_copy")
+    return out, stats, rank, vc, vq
+
+
+def gemm_f16_nt(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """C[M,N] fp32 = A[M,K] fp16 x B[N,K]^T fp16 (M, N multiples of 128, K of 64)."""
+    dev = _lib.require_gpu()
+    assert a.dtype == torch.float16 and b.dtype == torch.float16 and a.is_contiguous() and b.is_contiguous()
+    m, k = a.shape
+    n = b.shape[0]
+    c = torch.empty((m, n), dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().mpreid_gemm_f16_nt(_ptr(a), _ptr(b), _ptr(c), m, n, k, _lib.stream_ptr()),
+               "mpreid_gemm_f16_nt")
+    return c
+
+
+# ----------------------------------------------------------------------------------------------
+# ViT image encoder
+# ----------------------------------------------------------------------------------------------
+class VitEncoder:
+    """Device-resident CLIP ViT image encoder + feature head.
+
+    cfg keys: h_res, w_res, patch, stride, width, layers, heads, out_dim (mpreid.synth.VIT_B16 layout).
+    state_dict: CLIP VisionTransformer key names (optionally prefixed 'image_encoder.'), numpy or torch.
+    bn: optional dict(bottleneck=(weight, bias, running_mean, running_var), bottleneck_proj=(...)).
+    """
+
+    def __init__(self, cfg: dict, state_dict: dict, img_hw, neck_after: bool = False, bn: Optional[dict] = None,
+                 device=None):
+        self.device = device or _lib.require_gpu()
+        self.cfg = dict(cfg)
+        self.img_hw = tuple(img_hw)
+        dev = self.device
+
+        def get(name):
+            for k in (name, "image_encoder." + name):
+                if k in state_dict:
+                    v = state_dict[k]
+                    return torch.from_numpy(np.ascontiguousarray(v)) if isinstance(v, np.ndarray) else v.detach()
+            raise KeyError(name)
+
+        def f32(name):
+            return get(name).to(device=dev, dtype=torch.float32).contiguous()
+
+        def f16(name, shape=None):
+            t = get(name).to(device=dev, dtype=torch.float32)
+            if shape is not None:
+                t = t.reshape(shape)
+            return t.to(torch.float16).contiguous()
+
+        w = cfg["width"]
+        self._keep = []  # owns every device tensor referenced by the C structs
+        keep = self._keep.append
+        self.c_cfg = _lib.VitCfg(self.img_hw[0], self.img_hw[1], cfg["patch"], cfg["stride"], cfg["h_res"],
+                                 cfg["w_res"], w, cfg["layers"], cfg["heads"], cfg["out_dim"], int(bool(neck_after)), 0)
+        layers = (_lib.VitLayer * max(cfg["layers"], 1))()
+        for i in range(cfg["layers"]):
+            b = f"transformer.resblocks.{i}"
+            t = dict(in_proj_w=f16(b + ".attn.in_proj_weight"), in_proj_b=f32(b + ".attn.in_proj_bias"),
+                     out_proj_w=f16(b + ".attn.out_proj.weight"), out_proj_b=f32(b + ".attn.out_proj.bias"),
+                     ln1_g=f32(b + ".ln_1.weight"), ln1_b=f32(b + ".ln_1.bias"),
+                     ln2_g=f32(b + ".ln_2.weight"), ln2_b=f32(b + ".ln_2.bias"),
+                     fc_w=f16(b + ".mlp.c_fc.weight"), fc_b=f32(b + ".mlp.c_fc.bias"),
+                     proj_w=f16(b + ".mlp.c_proj.weight"), proj_b=f32(b + ".mlp.c_proj.bias"))
+            for k, v in t.items():
+                keep(v)
+                setattr(layers[i], k, v.data_ptr())
+        self._layers = layers
+        top = dict(conv_w=f16("conv1.weight", (w, -1)), class_emb=f32("class_embedding"),
+                   pos_emb=f32("positional_embedding"), ln_pre_g=f32("ln_pre.weight"), ln_pre_b=f32("ln_pre.bias"),
+                   ln_post_g=f32("ln_post.weight"), ln_post_b=f32("ln_post.bias"), proj=f32("proj"))
+        L = cfg["h_res"] * cfg["w_res"] + 1
+        assert tuple(top["pos_emb"].shape) == (L, w), (top["pos_emb"].shape, L, w)
+        self.c_w = _lib.VitWeights()
+        for k, v in top.items():
+            keep(v)
+            setattr(self.c_w, k, v.data_ptr())
+        if bn is not None:
+            for name, (sk, bk) in (("bottleneck", ("bn_scale", "bn_shift")),
+                                   ("bottleneck_proj", ("bn_proj_scale", "bn_proj_shift"))):
+                wt, bs, mu, var = (torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a).to(
+                    device=dev, dtype=torch.float32) for a in bn[name])
+                scale = (wt / torch.sqrt(var + 1e-5)).contiguous()
+                shift = (bs - mu * scale).contiguous()
+                keep(scale), keep(shift)
+                setattr(self.c_w, sk, scale.data_ptr())
+                setattr(self.c_w, bk, shift.data_ptr())
+        self.c_w.layers = C.cast(layers, C.POINTER(_lib.VitLayer))
+        self.feat_dim = w + cfg["out_dim"]
+
+    @torch.no_grad()
+    def forward(self, img: torch.Tensor, cv_emb: Optional[torch.Tensor] = None) -> torch.Tensor:
+        L = _lib.load()
+        img = _dev_f32(img, self.device)
+        B = img.shape[0]
+        assert tuple(img.shape[1:]) == (3,) + self.img_hw, img.shape
+        cv = None
+        if cv_emb is not None:
+            cv = _dev_f32(cv_emb, self.device)
+            assert tuple(cv.shape) == (B, self.cfg["width"])
+        out = torch.empty((B, self.feat_dim), dtype=torch.float32, device=self.device)
+        wsb = L.mpreid_vit_workspace_bytes(C.byref(self.c_cfg), B)
+        ws = _workspace("vit", wsb, self.device)
+        _lib.check(L.mpreid_vit_forward(C.byref(self.c_cfg), C.byref(self.c_w), _ptr(img), B, _ptr(cv), _ptr(out),
+                                        _ptr(ws), ws.numel(), _lib.stream_ptr()), "mpreid_vit_forward")
+        return out
+
+    __call__ = forward

@@ -1,0 +1,106 @@
+"""Drop-in for the reference's ``utils/metrics.py``: distance matrices, CMC/mAP and the
+``R1_mAP_eval`` accumulator, with the heavy steps on the MI355X (libmpreid_hip.so).
+
+Signatures kept (reference utils/metrics.py): euclidean_distance(qf, gf) :7, cosine_similarity(qf, gf) :15,
+eval_func(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50) :28,
+R1_mAP_eval(num_query, max_rank=50, feat_norm=True, reranking=False) with reset/update/compute :91-134.
+
+Differences that are deliberate and invisible to callers:
+  * update() keeps a device-resident copy of each feature batch instead of ``feat.cpu()``; the
+    whole of compute() except eval_func's ranking statistics runs on the GPU.
+  * ties in eval_func's ranking are broken by ascending gallery index (the reference's
+    np.argsort is unstable, so it has no defined order on ties).
+"""
+import numpy as np
+import torch
+
+from mpreid import ops as _ops
+from utils.reranking import re_ranking, re_ranking_device
+
+
+def _as_tensor(x):
+    return torch.from_numpy(x) if isinstance(x, np.ndarray) else x
+
+
+def euclidean_distance(qf, gf):
+    """Squared Euclidean distance |q|^2 + |g|^2 - 2 q.g  ->  np.float32 [m, n]."""
+    return _ops.euclidean_distance(_as_tensor(qf), _as_tensor(gf)).cpu().numpy()
+
+
+def cosine_similarity(qf, gf):
+    """arccos of the clipped cosine  ->  np.float32 [m, n]."""
+    return _ops.cosine_similarity(_as_tensor(qf), _as_tensor(gf)).cpu().numpy()
+
+
+def eval_func(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50):
+    """Market-1501 style CMC and mAP exactly as the reference computes them: gallery samples that
+    share pid AND camera with the query are NOT removed (that filter is disabled upstream), so the
+    camera ids are accepted and unused.  Host-side, vectorised over queries."""
+    distmat = np.asarray(distmat)
+    q_pids = np.asarray(q_pids)
+    g_pids = np.asarray(g_pids)
+    num_q, num_g = distmat.shape
+    if num_g < max_rank:
+        max_rank = num_g
+        print("Note: number of gallery samples is quite small, got {}".format(num_g))
+    order = np.argsort(distmat, axis=1, kind="stable")
+    hit = (g_pids[order] == q_pids[:, None])
+    valid = hit.any(axis=1)
+    num_valid_q = float(valid.sum())
+    assert num_valid_q > 0, "Error: all query identities do not appear in gallery"
+    hit = hit[valid]
+    running = np.cumsum(hit, axis=1)
+    # CMC: 1 from the first correct match on
+    cmc_rows = (running[:, :max_rank] > 0).astype(np.float32)
+    all_cmc = cmc_rows.sum(0) / num_valid_q
+    # AP = mean over relevant ranks k of (hits up to k) / k
+    ranks = np.arange(1, num_g + 1) * 1.0
+    prec_at_hit = (running / ranks) * hit
+    all_AP = prec_at_hit.sum(axis=1) / hit.sum(axis=1)
+    mAP = np.mean(all_AP)
+    return all_cmc, mAP
+
+
+class R1_mAP_eval():
+    def __init__(self, num_query, max_rank=50, feat_norm=True, reranking=False):
+        super(R1_mAP_eval, self).__init__()
+        self.num_query = num_query
+        self.max_rank = max_rank
+        self.feat_norm = feat_norm      # used as a truth value, like upstream ('yes' and 'no' both normalise)
+        self.reranking = reranking
+        self.distance_mode = _ops.GEMM_F32_EXACT
+        self.last_rerank_stats = None
+
+    def reset(self):
+        self.feats = []
+        self.pids = []
+        self.camids = []
+
+    def update(self, output):  # called once for each batch
+        feat, pid, camid = output
+        dev = _ops._lib.require_gpu()
+        # own a device-resident fp32 copy: the caller may reuse its buffer
+        self.feats.append(feat.detach().to(device=dev, dtype=torch.float32, copy=True))
+        self.pids.extend(np.asarray(pid))
+        self.camids.extend(np.asarray(camid))
+
+    def compute(self):  # called after each epoch
+        feats = torch.cat(self.feats, dim=0)
+        if self.feat_norm:
+            print("The test feature is normalized")
+            feats = _ops.l2_normalize(feats)
+        qf = feats[:self.num_query]
+        gf = feats[self.num_query:]
+        q_pids = np.asarray(self.pids[:self.num_query])
+        q_camids = np.asarray(self.camids[:self.num_query])
+        g_pids = np.asarray(self.pids[self.num_query:])
+        g_camids = np.asarray(self.camids[self.num_query:])
+        if self.reranking:
+            print('=> Enter reranking')
+            dist, self.last_rerank_stats = re_ranking_device(qf, gf, k1=50, k2=15, lambda_value=0.3)
+        else:
+            print('=> Computing DistMat with euclidean_distance')
+            dist = _ops.euclidean_distance(qf, gf, mode=self.distance_mode)
+        distmat = dist.cpu().numpy()
+        cmc, mAP = eval_func(distmat, q_pids, g_pids, q_camids, g_camids)
+        return cmc, mAP, distmat, self.pids, self.camids, qf.cpu(), gf.cpu()

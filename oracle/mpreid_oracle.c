@@ -245,8 +245,9 @@ ORC_API int orc_rerank(const float *q, const float *g, long nq, long ng, int d, 
                        double lambda_value, const float *local, int only_local, float *out,
                        int *rank_out, int *v_cnt, int *vqe_cnt) {
     const long N = nq + ng;
-    const int K = k1 + 1;
-    if (K > N || k2 > N || k2 < 1) return -2;
+    const int K = k1 + 1;               /* neighbours used by the k-reciprocal tests          */
+    const int KR = K > k2 ? K : k2;     /* columns of initial_rank that are ever read (:48,:76) */
+    if (KR > N || k2 < 1) return -2;
     const int h = mpreid_half_k1(k1);
     const uint16_t one_minus_lam_h = orc_f64_to_f16(1.0 - lambda_value);
     const float lam32 = (float)lambda_value;
@@ -289,11 +290,12 @@ ORC_API int orc_rerank(const float *q, const float *g, long nq, long ng, int d, 
     free(orig);
 
     /* (3) initial_rank[:, :k1+1], utils/reranking.py:48 (ties -> ascending index) */
-    int *rank = (int *)malloc(sizeof(int) * (size_t)N * K);
+    int *rank = (int *)malloc(sizeof(int) * (size_t)N * KR);
     if (!rank) { free(colmax); free(O); return -1; }
 #pragma omp parallel for schedule(dynamic, 16)
-    for (long i = 0; i < N; i++) topk_row(O + i * N, N, K, rank + i * K);
-    if (rank_out) memcpy(rank_out, rank, sizeof(int) * (size_t)N * K);
+    for (long i = 0; i < N; i++) topk_row(O + i * N, N, KR, rank + i * KR);
+    if (rank_out)
+        for (long i = 0; i < N; i++) memcpy(rank_out + i * K, rank + i * KR, sizeof(int) * K);
 
     /* (4)-(6) k-reciprocal sets, expansion, V rows; utils/reranking.py:51-71 */
     sprow *V = (sprow *)calloc(N, sizeof(sprow));
@@ -305,18 +307,18 @@ ORC_API int orc_rerank(const float *q, const float *g, long nq, long ng, int d, 
         int *Rc = (int *)malloc(sizeof(int) * h);
         float *w = (float *)malloc(sizeof(float) * cap);
         int nR = 0, nE = 0;
-        const int *fwd = rank + i * K;
+        const int *fwd = rank + i * KR;
         for (int a = 0; a < K; a++) { /* k_reciprocal_index, in rank order */
-            const int *bwd = rank + (long)fwd[a] * K;
+            const int *bwd = rank + (long)fwd[a] * KR;
             for (int b = 0; b < K; b++) if (bwd[b] == (int)i) { R[nR++] = fwd[a]; break; }
         }
         for (int a = 0; a < nR; a++) E[nE++] = R[a];
         for (int a = 0; a < nR; a++) {
             const int cand = R[a];
-            const int *cf = rank + (long)cand * K; /* first h entries */
+            const int *cf = rank + (long)cand * KR; /* first h entries */
             int nRc = 0;
             for (int b = 0; b < h; b++) {
-                const int *cb = rank + (long)cf[b] * K;
+                const int *cb = rank + (long)cf[b] * KR;
                 for (int c = 0; c < h; c++) if (cb[c] == cand) { Rc[nRc++] = cf[b]; break; }
             }
             int inter = 0; /* len(np.intersect1d(Rc, R)) — both duplicate-free */
@@ -350,11 +352,11 @@ ORC_API int orc_rerank(const float *q, const float *g, long nq, long ng, int d, 
 #pragma omp parallel for schedule(dynamic, 16)
         for (long i = 0; i < N; i++) {
             int tot = 0;
-            for (int m = 0; m < k2; m++) tot += V[rank[i * K + m]].n;
+            for (int m = 0; m < k2; m++) tot += V[rank[i * KR + m]].n;
             int *ci = (int *)malloc(sizeof(int) * (tot ? tot : 1));
             int nc = 0;
             for (int m = 0; m < k2; m++) {
-                const sprow *r = &V[rank[i * K + m]];
+                const sprow *r = &V[rank[i * KR + m]];
                 memcpy(ci + nc, r->idx, sizeof(int) * r->n);
                 nc += r->n;
             }
@@ -364,7 +366,7 @@ ORC_API int orc_rerank(const float *q, const float *g, long nq, long ng, int d, 
             nc = u;
             float *acc = (float *)calloc(nc ? nc : 1, sizeof(float));
             for (int m = 0; m < k2; m++) { /* fp32 sum in rank order */
-                const sprow *r = &V[rank[i * K + m]];
+                const sprow *r = &V[rank[i * KR + m]];
                 int p = 0;
                 for (int a = 0; a < r->n; a++) {
                     while (ci[p] != r->idx[a]) p++;

@@ -1,0 +1,66 @@
+"""CPU-side checks of the C ABI: the library loads, exports every symbol include/mpreid.h declares,
+and the product path fails loudly (no CPU fallback) when there is no GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from mpreid import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "mpreid.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mpreid_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.load()
+    declared = _declared()
+    assert declared == sorted(_lib.SYMBOLS), (declared, sorted(_lib.SYMBOLS))
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.mpreid_version() >= 100
+
+
+def test_workspace_queries_need_no_gpu():
+    L = _lib.load()
+    assert L.mpreid_distance_workspace_bytes(100, 200, 64, 0) >= 300 * 4
+    n = 19281
+    b = L.mpreid_rerank_workspace_bytes(3368, 15913, 1280, 50, 15, 0)
+    assert b > 4 * n * n
+    cfg = _lib.VitCfg(256, 128, 16, 16, 16, 8, 768, 12, 12, 512, 0, 0)
+    assert L.mpreid_vit_workspace_bytes(ctypes.byref(cfg), 64) > 64 * 129 * 768 * 4
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_product_path_fails_loudly_without_gpu():
+    from utils import metrics, reranking
+    q = torch.randn(4, 8)
+    with pytest.raises(RuntimeError):
+        metrics.euclidean_distance(q, q)
+    with pytest.raises(RuntimeError):
+        reranking.re_ranking(q, q, 2, 1, 0.3)
+    ev = metrics.R1_mAP_eval(2)
+    ev.reset()
+    with pytest.raises(RuntimeError):
+        ev.update((q, (0, 1, 0, 1), (0, 0, 1, 1)))
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under mp-reid_amd/ may reference it."""
+    bad = []
+    pkg = os.path.join(ROOT, "mp-reid_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(dp, f), errors="replace").read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "mpreid_oracle" in txt.replace(
+                        "oracle/mpreid_oracle.c", ""):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad

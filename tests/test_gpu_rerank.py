@@ -1,0 +1,140 @@
+"""GPU parity: k-reciprocal re-ranking through the C ABI.
+
+Bar: BIT-EXACT against the oracle (outputs, neighbour table, nnz of V / V_qe), and against the
+reference's golden outputs with the documented tolerance frac(|d|>1e-5) <= 1e-4, max <= 5e-4."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from mpreid import ops as o
+    return o
+
+
+def _check_vs_oracle(ops, f, nq, k1, k2, lam, local=None, only_local=False):
+    q, g = torch.from_numpy(f[:nq]), torch.from_numpy(f[nq:])
+    got, st, rank, vc, vq = ops.re_ranking(q, g, k1, k2, lam, local_distmat=local, only_local=only_local, debug=True)
+    want, orank, ovc, ovq = orc.re_ranking(f[:nq], f[nq:], k1, k2, lam, local_distmat=local, only_local=only_local,
+                                           debug=True)
+    assert np.array_equal(rank, orank), "initial_rank differs"
+    assert np.array_equal(vc, ovc), "nnz(V) differs"
+    assert np.array_equal(vq, ovq), "nnz(V_qe) differs"
+    got = got.cpu().numpy()
+    assert got.dtype == np.float32 and got.shape == want.shape
+    assert np.array_equal(got, want), np.abs(got - want).max()
+    assert st["v_nnz"] == int(ovc.sum()) and st["vqe_nnz"] == int(ovq.sum())
+    return got
+
+
+@pytest.mark.parametrize("case", ["50_15_0.3", "20_6_0.3", "5_1_0.3", "20_6_0.0", "20_6_1.0", "7_3_0.5", "10_1_0.3"])
+def test_rerank_golden_cases(ops, golden, case):
+    g = golden("rerank.npz")
+    k1, k2, lam = case.split("_")
+    nq = int(g["nq"])
+    got = _check_vs_oracle(ops, g["feat"], nq, int(k1), int(k2), float(lam))
+    d = np.abs(got - g[f"rr_{case}"])
+    assert (d > 1e-5).mean() <= 1e-4 and d.max() <= 5e-4, ((d > 1e-5).mean(), d.max())
+
+
+def test_rerank_local_distmat(ops, golden):
+    g = golden("rerank.npz")
+    nq = int(g["nq"])
+    local = g["local"].astype(np.float32)
+    got = _check_vs_oracle(ops, g["feat"], nq, 20, 6, 0.3, local=local)
+    d = np.abs(got - g["rr_local_20_6_0.3"])
+    assert (d > 1e-5).mean() <= 1e-4 and d.max() <= 5e-4
+    got = _check_vs_oracle(ops, g["feat"], nq, 20, 6, 0.3, local=local, only_local=True)
+    d = np.abs(got - g["rr_onlylocal_20_6_0.3"])
+    assert (d > 1e-5).mean() <= 1e-4 and d.max() <= 5e-4
+
+
+def test_rerank_dropin_signature(ops, golden):
+    from utils.reranking import re_ranking
+    g = golden("rerank.npz")
+    nq = int(g["nq"])
+    f = torch.from_numpy(g["feat"])
+    out = re_ranking(f[:nq], f[nq:], 20, 6, 0.3)
+    assert isinstance(out, np.ndarray) and out.dtype == np.float32 and out.shape == (nq, f.shape[0] - nq)
+    assert np.array_equal(out, orc.re_ranking(g["feat"][:nq], g["feat"][nq:], 20, 6, 0.3))
+    out2 = re_ranking(f[:nq].cuda(), f[nq:].cuda(), 20, 6, 0.3)   # device tensors are accepted too
+    assert np.array_equal(out, out2)
+
+
+@pytest.mark.parametrize("n,nq,d,k1,k2,sigma", [(3000, 600, 768, 50, 15, 3.0), (2500, 1, 128, 20, 6, 2.0),
+                                                 (1200, 1199, 64, 50, 15, 1.0), (700, 100, 1280, 30, 40, 3.5),
+                                                 (64, 10, 32, 5, 2, 1.0), (2000, 300, 256, 126, 10, 2.5)])
+def test_rerank_seeded_bit_exact(ops, n, nq, d, k1, k2, sigma):
+    from mpreid import synth
+    f, _ = synth.clustered_features(n, d, sigma, seed=n + k1, per_id=20)
+    _check_vs_oracle(ops, f, nq, k1, k2, 0.3)
+
+
+def test_rerank_with_exact_ties(ops):
+    """duplicated images give exactly tied distances: the (value, index) tie-break must agree"""
+    from mpreid import synth
+    f, _ = synth.clustered_features(600, 64, 2.0, seed=77, per_id=10)
+    f[100:160] = f[40:100]       # 60 exact duplicates
+    f[300:310] = f[0]            # 10 copies of one row
+    _check_vs_oracle(ops, f, 120, 20, 6, 0.3)
+    _check_vs_oracle(ops, f, 120, 50, 15, 0.3)
+    # all rows identical: every distance ties
+    same = np.tile(f[:1], (80, 1))
+    _check_vs_oracle(ops, same, 16, 10, 3, 0.3)
+
+
+def test_r1_map_eval_vs_reference(golden):
+    from utils.metrics import R1_mAP_eval
+    g = golden("r1_map_eval.npz")
+    nq = int(g["nq"])
+    raw, pid, cam = g["raw"], g["pid"], g["cam"]
+    for rr in (False, True):
+        for fn in (True, False):
+            ev = R1_mAP_eval(nq, max_rank=50, feat_norm=fn, reranking=rr)
+            ev.reset()
+            for s in range(0, raw.shape[0], 64):
+                ev.update((torch.from_numpy(raw[s:s + 64]).cuda(), tuple(int(x) for x in pid[s:s + 64]),
+                           tuple(int(x) for x in cam[s:s + 64])))
+            cmc, mAP, distmat, pids, camids, qf, gf = ev.compute()
+            tag = f"rr{int(rr)}_fn{int(fn)}"
+            assert abs(mAP - float(g[f"mAP_{tag}"])) < 1e-4, tag
+            assert np.abs(cmc - g[f"cmc_{tag}"]).max() < 1e-4, tag
+            assert distmat.dtype == np.float32 and qf.shape[0] == nq and len(pids) == raw.shape[0]
+            want = g[f"distmat_{tag}"]
+            scale = max(1.0, float(np.abs(want).max()))
+            dd = np.abs(distmat - want) / scale
+            if rr:
+                assert (dd > 1e-5).mean() <= 1e-4 and dd.max() <= 5e-4, (tag, (dd > 1e-5).mean(), dd.max())
+            else:
+                assert dd.max() < 1e-5, (tag, dd.max())
+
+
+def test_rerank_market_scale_properties(ops):
+    """N = 19 281 (Market-1501 shape): size-independent properties instead of the oracle.
+    lambda = 1 reduces the result to the normalised original distance; results do not depend on
+    how often / in which order the call is made (idempotence); mAP improves over the plain ranking."""
+    from mpreid import synth
+    from utils.metrics import eval_func
+    N, nq = 19281, 3368
+    f, pid = synth.clustered_features(N, 768, 3.0, seed=1234)
+    ft = torch.from_numpy(f).cuda()
+    q, g = ft[:nq], ft[nq:]
+    r1, st = ops.re_ranking(q, g, 50, 15, 1.0, timing=True)
+    d_full = ops.euclidean_distance(ft[:nq], ft)          # rows of the N x N problem
+    colmax = ops.euclidean_distance(ft, ft[:nq]).max(dim=0).values  # max over column i of D
+    want = (d_full / colmax[:, None])[:, nq:] * np.float32(1.0)
+    assert torch.equal(r1, want)
+    ra, st = ops.re_ranking(q, g, 50, 15, 0.3, timing=True)
+    rb, _ = ops.re_ranking(q, g, 50, 15, 0.3)
+    assert torch.equal(ra, rb)
+    assert st["vqe_nnz"] > st["v_nnz"] > N * 10 and st["jaccard_pairs"] > 0
+    d_plain = ops.euclidean_distance(q, g).cpu().numpy()
+    _, map_plain = eval_func(d_plain, pid[:nq], pid[nq:], None, None)
+    _, map_rr = eval_func(ra.cpu().numpy(), pid[:nq], pid[nq:], None, None)
+    assert map_rr > map_plain
+    print("rerank stats", st, "mAP plain/rr", map_plain, map_rr)
