@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py — MP-ReID evaluation hot path on MI355X: ViT-B/16 encode of query+gallery -> L2-normalise
+-> euclidean distance matrix (BASELINE.json configs[1], Market-1501 shape, no re-rank).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full pass: encode every resident synthetic image (3368 queries + 15913 gallery per
+GPU shard) in batches, normalise, all-gather the query features (N > 1), compute this rank's
+[3368, 15913] distance block.  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE
+JSON line (contract in the task statement) with `roofline` (dominant kernel, hipEvents on the launch
+stream inside the timed region) and `cpu_baseline` (the CPU oracle on a bounded sample, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "mp-reid_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+NQ, NG, H, W = 3368, 15913, 256, 128          # Market-1501 test split (datasets/market1501.py:24), vit_base.yml
+GFLOP_PER_IMG = 22.68                           # SURVEY.md §8d (full 12th block, CLS-only proj)
+PEAK_F16_TFLOPS = 2500.0                        # MI355X_MICROARCH.md: dense fp16/bf16 MFMA
+PEAK_F32_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256, help="images per encoder call (reference yml: 64)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--cpu-images", type=int, default=24)
+    ap.add_argument("--small", action="store_true", help="debug: 1/16 of the workload")
+    return ap.parse_args()
+
+
+def make_images(n, seed, device, chunk=1024):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = torch.empty((n, 3, H, W), dtype=torch.float32, device=device)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        out[s:e] = torch.randn((e - s, 3, H, W), generator=g, device=device).clamp_(-1.0, 1.0)
+    return out
+
+
+def cpu_baseline(n_img):
+    """CPU oracle (kind 'port') on a bounded sample of the same workload, all host cores."""
+    from mpreid import synth
+    from oracle import oracle as orc
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = synth.vit_state_dict(synth.VIT_B16, seed=7)
+    imgs = synth.synthetic_images(n_img, H, W, seed=1)
+    orc.vit_features(sd, synth.VIT_B16, imgs[:2])  # warm
+    t0 = time.perf_counter()
+    orc.vit_features(sd, synth.VIT_B16, imgs)
+    t_enc = time.perf_counter() - t0
+    f, _ = synth.clustered_features(NQ + 1024, 1280, 3.5, seed=2)
+    orc.euclidean_distance(f[:64], f[NQ:])
+    t0 = time.perf_counter()
+    orc.euclidean_distance(f[:NQ], f[NQ:])
+    t_dist = time.perf_counter() - t0
+    total = (NQ + NG) / n_img * t_enc + NG / 1024.0 * t_dist
+    return {"value": round((NQ + NG) / total, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle ViT-B/16 fp32 (torch CPU) on {n_img} images: {t_enc:.2f} s; oracle euclid "
+                      f"{NQ}x1024x1280: {t_dist:.2f} s; extrapolated linearly to {NQ}+{NG} images",
+            "encode_images_per_s": round(n_img / t_enc, 3)}
+
+
+def extras(ops, dev):
+    """secondary figures named by BASELINE.json's metric: 20k x 20k feat-GEMM and re-rank (one run each)"""
+    from mpreid import synth
+    out = {}
+    f, _ = synth.clustered_features(20000, 768, 3.0, seed=1234)
+    ft = torch.from_numpy(f).to(dev)
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    buf = torch.empty((20000, 20000), dtype=torch.float32, device=dev)
+    flop = 2.0 * 20000 * 20000 * 768
+    ms = timed(lambda: ops.euclidean_distance(ft, ft, mode=ops.GEMM_F16_FAST, out=buf), 5)
+    out["feat_gemm_20kx20k_d768_fp16_ms"] = round(ms, 4)
+    out["feat_gemm_20kx20k_d768_fp16_tflops"] = round(flop / ms / 1e9, 1)
+    out["feat_gemm_20kx20k_d768_fp16_frac_of_peak"] = round(flop / ms / 1e9 / PEAK_F16_TFLOPS, 4)
+    ms = timed(lambda: ops.euclidean_distance(ft, ft, mode=ops.GEMM_F32_EXACT, out=buf), 3)
+    out["feat_gemm_20kx20k_d768_fp32exact_ms"] = round(ms, 4)
+    out["feat_gemm_20kx20k_d768_fp32exact_tflops"] = round(flop / ms / 1e9, 1)
+    del buf
+    ops.re_ranking(ft[:4000], ft[4000:], 50, 15, 0.3)
+    _, st = ops.re_ranking(ft[:4000], ft[4000:], 50, 15, 0.3, timing=True)
+    out["rerank_N20000_nq4000_d768_k50_15_ms"] = round(st["ms_total"], 3)
+    out["rerank_stages_ms"] = {k[3:]: round(v, 3) for k, v in st.items() if k.startswith("ms_") and k != "ms_total"}
+    out["rerank_nnz"] = {"v": st["v_nnz"], "vqe": st["vqe_nnz"], "jaccard_pairs": st["jaccard_pairs"]}
+    return out
+
+
+def main():
+    a = parse()
+    from mpreid import _lib, distributed as D, ops, synth
+    import torch.distributed as dist
+
+    rank, world, local = D.init_from_env()
+    assert world == a.gpus or world == 1 and a.gpus == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    L = _lib.load()
+
+    nq, ng = (NQ // 16, NG // 16) if a.small else (NQ, NG)
+    q_lo, q_hi = D.shard_range(nq, rank, world)
+    nq_local = q_hi - q_lo
+    n_local = nq_local + ng
+    enc = ops.VitEncoder(synth.VIT_B16, synth.vit_state_dict(synth.VIT_B16, seed=7), (H, W))
+    imgs = make_images(n_local, 1234 + rank, dev)
+    feats = torch.empty((n_local, enc.feat_dim), dtype=torch.float32, device=dev)
+    block = torch.empty((nq, ng), dtype=torch.float32, device=dev)
+
+    def step():
+        for s in range(0, n_local, a.batch):
+            e = min(n_local, s + a.batch)
+            enc(imgs[s:e], out=feats[s:e])
+        fn = ops.l2_normalize(feats)
+        qf = D.all_gather_rows(fn[:nq_local], nq)   # RCCL all-gather of the query features (N > 1)
+        ops.euclidean_distance(qf, fn[nq_local:], out=block)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    L.mpreid_profile_reset()
+    L.mpreid_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    L.mpreid_profile_enable(0)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(block).all()
+
+    if rank == 0:
+        total_images = (nq + world * ng) * a.steps
+        ents = (_lib.ProfileEntry * 16)()
+        n_ent = L.mpreid_profile_query(ents, 16)
+        classes = []
+        for i in range(min(n_ent, 16)):
+            e = ents[i]
+            avg_ms = e.total_ms / max(e.launches, 1)
+            classes.append({"kernel": f"gemm_f16_kernel<{_lib.GEMM_EPILOGUE_NAMES.get(e.epilogue, e.epilogue)}>",
+                            "M": e.m, "N": e.n, "K": e.k, "launches": e.launches, "avg_ms": round(avg_ms, 4),
+                            "total_ms": round(e.total_ms, 2),
+                            "tflops": round(e.flops_per_launch / avg_ms / 1e9, 1) if avg_ms > 0 else None})
+        top = classes[0] if classes else None
+        roof = None
+        if top:
+            roof = {"bound": "mfma", "kernel": top["kernel"], "shape": [top["M"], top["N"], top["K"]],
+                    "achieved": top["tflops"], "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(top["tflops"] / PEAK_F16_TFLOPS, 4), "traffic": None,
+                    "avg_launch_ms": top["avg_ms"], "launches": top["launches"],
+                    "all_gemm_tflops": round(sum(c["tflops"] * c["total_ms"] for c in classes) /
+                                             max(sum(c["total_ms"] for c in classes), 1e-9), 1),
+                    "gemm_share_of_step": round(sum(c["total_ms"] for c in classes) / (dt * 1e3), 3)}
+        res = {
+            "metric": "gallery images/s encode + distmat+rerank ms, 20k×20k; mAP/Rank-1 parity",
+            "value": round(total_images / dt, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16 MFMA operands, f32 accumulate/residual; distmat f32",
+            "data": "synthetic",
+            "config": {"workload": "Market-1501 shape on MI355X (BASELINE configs[1]): ViT-B/16 encode of "
+                                   f"{nq} query + {ng} gallery 3x256x128 images per GPU shard (seeded random init), "
+                                   "L2-normalise, all-gather query features, euclidean distmat "
+                                   f"[{nq} x {ng}] per GPU (exact fp32 MFMA), no re-rank",
+                       "images_per_step": nq + world * ng, "encoder_batch": a.batch,
+                       "sharding": f"gallery rows over {world} GPU(s), queries 1/{world} each + all-gather"},
+            "encode_tflops_algorithmic": round(total_images * GFLOP_PER_IMG / dt / 1e3, 1),
+            "roofline": roof, "gemm_classes": classes,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(a.cpu_images)
+        if world == 1 and not a.no_extras and not a.small:
+            torch.cuda.empty_cache()
+            res["extras"] = extras(ops, dev)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -140,6 +140,21 @@ int mpreid_gemm_f16_nt(const void *a_dev, const void *b_dev, float *c_dev, int64
 /* fp32 -> fp16 (RNE) conversion of a flat array */
 int mpreid_cast_f32_to_f16(const float *x_dev, void *y_dev, int64_t n, mpreid_stream_t stream);
 
+/* ---- measurement hooks (bench.py roofline leg) --------------------------------------------- */
+typedef struct {
+    int32_t epilogue;        /* GemmEpi id of the fp16 GEMM class */
+    int32_t n, k;            /* GEMM N and K */
+    int64_t m;               /* GEMM M of the last launch in the class */
+    int64_t launches;        /* launches recorded while profiling was enabled */
+    double total_ms;         /* sum of per-launch durations (hipEvents on the launch stream) */
+    double flops_per_launch; /* 2*M*N*K */
+} mpreid_profile_entry;
+/* While enabled, every fp16 GEMM launch is bracketed by two hipEvents on its stream. */
+int mpreid_profile_enable(int on);
+int mpreid_profile_reset(void);
+/* Synchronises the recorded events; entries sorted by total time, returns the class count. */
+int mpreid_profile_query(mpreid_profile_entry *out, int cap);
+
 #ifdef __cplusplus
 }
 #endif

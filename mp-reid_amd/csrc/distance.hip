@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float *__restrict__ x
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= n) return;
     float s = row_sqnorm(x + row * (int64_t)d, d, lane);
-    if (mode == 1) s = __fsqrt_rn(s);
+    if (mode == 1) s = sqrtf(s);
     if (lane == 0) out[row] = s;
 }
 
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void l2_normalize_kernel(const float *__restri
     if (row >= n) return;
     const float *xr = x + row * (int64_t)d;
     float *orow = out + row * (int64_t)d;
-    const float nrm = __fsqrt_rn(row_sqnorm(xr, d, lane));
+    const float nrm = sqrtf(row_sqnorm(xr, d, lane)); // sqrtf = correctly rounded expansion; __fsqrt_rn is the bare v_sqrt_f32
     const float den = nrm > eps ? nrm : eps;
     for (int k = lane; k < d; k += 64) orow[k] = __fdiv_rn(xr[k], den);
 }

@@ -1,4 +1,6 @@
 // gemm_f16.hip — see gemm_f16.h for the design.  Roofline: MFMA fp16 (2.5 PFLOP/s dense peak).
+#include <algorithm>
+
 #include "gemm_f16.h"
 
 typedef __attribute__((address_space(3))) void lds_ptr_t;
@@ -150,6 +152,70 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// optional per-launch event timing (bench.py's roofline leg): hipEvents recorded on the launch
+// stream around every GEMM launch while enabled, aggregated per (epilogue, N, K) class.
+// ---------------------------------------------------------------------------------------------
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+namespace {
+struct ProfClass {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    double flops_per_launch = 0.0;
+    int64_t m = 0;
+};
+bool g_prof_on = false;
+std::mutex g_prof_mu;
+std::map<std::tuple<int, int, int>, ProfClass> g_prof;
+} // namespace
+
+extern "C" int mpreid_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return MPREID_OK;
+}
+
+extern "C" int mpreid_profile_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto &kv : g_prof)
+        for (auto &e : kv.second.ev) {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
+    g_prof.clear();
+    return MPREID_OK;
+}
+
+// Fills up to `cap` entries, sorted by total time descending; returns the number of classes.
+extern "C" int mpreid_profile_query(mpreid_profile_entry *out, int cap) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    std::vector<mpreid_profile_entry> v;
+    for (auto &kv : g_prof) {
+        mpreid_profile_entry e{};
+        e.epilogue = std::get<0>(kv.first);
+        e.n = std::get<1>(kv.first);
+        e.k = std::get<2>(kv.first);
+        e.m = kv.second.m;
+        e.launches = (int64_t)kv.second.ev.size();
+        e.flops_per_launch = kv.second.flops_per_launch;
+        double tot = 0.0;
+        for (auto &p : kv.second.ev) {
+            if (hipEventSynchronize(p.second) != hipSuccess) continue;
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) tot += ms;
+        }
+        e.total_ms = tot;
+        v.push_back(e);
+    }
+    std::sort(v.begin(), v.end(), [](const mpreid_profile_entry &a, const mpreid_profile_entry &b) {
+        return a.total_ms > b.total_ms;
+    });
+    for (int i = 0; i < (int)v.size() && i < cap; ++i) out[i] = v[i];
+    return (int)v.size();
+}
+
 template <int EPI>
 static int launch_one(const GemmArgs &a, hipStream_t stream) {
     static bool attr_set = false;
@@ -159,9 +225,23 @@ static int launch_one(const GemmArgs &a, hipStream_t stream) {
         attr_set = true;
     }
     const int tiles_m = a.M / GBM, tiles_n = a.N / GBN;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (g_prof_on) {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, stream));
+    }
     hipLaunchKernelGGL(gemm_f16_kernel<EPI>, dim3((unsigned)tiles_m * (unsigned)tiles_n), dim3(256), G_LDS_BYTES, stream,
                        a, tiles_m, tiles_n);
     LAUNCH_CHECK();
+    if (e0) {
+        HIP_TRY(hipEventRecord(e1, stream));
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        ProfClass &pc = g_prof[std::make_tuple(EPI, a.N, a.K)];
+        pc.ev.emplace_back(e0, e1);
+        pc.m = a.M;
+        pc.flops_per_launch = 2.0 * (double)a.M * (double)a.N * (double)a.K;
+    }
     return MPREID_OK;
 }
 

@@ -21,6 +21,7 @@ SYMBOLS = [
     "mpreid_euclidean_distance_f32", "mpreid_cosine_similarity_f32",
     "mpreid_rerank_workspace_bytes", "mpreid_rerank_f32", "mpreid_rerank_debug_copy",
     "mpreid_vit_workspace_bytes", "mpreid_vit_forward", "mpreid_gemm_f16_nt", "mpreid_cast_f32_to_f16",
+    "mpreid_profile_enable", "mpreid_profile_reset", "mpreid_profile_query",
 ]
 
 
@@ -50,6 +51,14 @@ class VitWeights(C.Structure):
                                           "ln_post_b", "proj", "bn_scale", "bn_shift", "bn_proj_scale",
                                           "bn_proj_shift")] + [("layers", C.POINTER(VitLayer))]
 
+
+class ProfileEntry(C.Structure):
+    _fields_ = [("epilogue", C.c_int32), ("n", C.c_int32), ("k", C.c_int32), ("m", C.c_int64),
+                ("launches", C.c_int64), ("total_ms", C.c_double), ("flops_per_launch", C.c_double)]
+
+
+GEMM_EPILOGUE_NAMES = {0: "f32", 1: "qkv_bias_f16", 2: "bias_residual", 3: "fc_bias_quickgelu", 4: "patch_embed",
+                       5: "euclid", 6: "cosine"}
 
 _lib = None
 
@@ -94,6 +103,11 @@ def load():
     L.mpreid_gemm_f16_nt.argtypes = [vp, vp, vp, i64, i64, i64, vp]
     L.mpreid_cast_f32_to_f16.restype = i32
     L.mpreid_cast_f32_to_f16.argtypes = [vp, vp, i64, vp]
+    L.mpreid_profile_enable.restype = i32
+    L.mpreid_profile_enable.argtypes = [i32]
+    L.mpreid_profile_reset.restype = i32
+    L.mpreid_profile_query.restype = i32
+    L.mpreid_profile_query.argtypes = [C.POINTER(ProfileEntry), i32]
     _lib = L
     return L
 

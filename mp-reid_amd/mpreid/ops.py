@@ -217,7 +217,8 @@ class VitEncoder:
         self.feat_dim = w + cfg["out_dim"]
 
     @torch.no_grad()
-    def forward(self, img: torch.Tensor, cv_emb: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward(self, img: torch.Tensor, cv_emb: Optional[torch.Tensor] = None,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
         L = _lib.load()
         img = _dev_f32(img, self.device)
         B = img.shape[0]
@@ -226,7 +227,9 @@ class VitEncoder:
         if cv_emb is not None:
             cv = _dev_f32(cv_emb, self.device)
             assert tuple(cv.shape) == (B, self.cfg["width"])
-        out = torch.empty((B, self.feat_dim), dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty((B, self.feat_dim), dtype=torch.float32, device=self.device)
+        assert out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (B, self.feat_dim)
         wsb = L.mpreid_vit_workspace_bytes(C.byref(self.c_cfg), B)
         ws = _workspace("vit", wsb, self.device)
         _lib.check(L.mpreid_vit_forward(C.byref(self.c_cfg), C.byref(self.c_w), _ptr(img), B, _ptr(cv), _ptr(out),
