@@ -144,10 +144,10 @@ int mpreid_cast_f32_to_f16(const float *x_dev, void *y_dev, int64_t n, mpreid_st
 typedef struct {
     int32_t epilogue;        /* GemmEpi id of the fp16 GEMM class */
     int32_t n, k;            /* GEMM N and K */
-    int64_t m;               /* GEMM M of the last launch in the class */
+    int64_t m;               /* largest GEMM M launched in the class */
     int64_t launches;        /* launches recorded while profiling was enabled */
     double total_ms;         /* sum of per-launch durations (hipEvents on the launch stream) */
-    double flops_per_launch; /* 2*M*N*K */
+    double flops_total;      /* sum over the recorded launches of 2*M*N*K */
 } mpreid_profile_entry;
 /* While enabled, every fp16 GEMM launch is bracketed by two hipEvents on its stream. */
 int mpreid_profile_enable(int on);

@@ -163,8 +163,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
 namespace {
 struct ProfClass {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
-    double flops_per_launch = 0.0;
-    int64_t m = 0;
+    double flops_total = 0.0;
+    int64_t m = 0; // largest M seen in the class
 };
 bool g_prof_on = false;
 std::mutex g_prof_mu;
@@ -199,7 +199,7 @@ extern "C" int mpreid_profile_query(mpreid_profile_entry *out, int cap) {
         e.k = std::get<2>(kv.first);
         e.m = kv.second.m;
         e.launches = (int64_t)kv.second.ev.size();
-        e.flops_per_launch = kv.second.flops_per_launch;
+        e.flops_total = kv.second.flops_total;
         double tot = 0.0;
         for (auto &p : kv.second.ev) {
             if (hipEventSynchronize(p.second) != hipSuccess) continue;
@@ -239,8 +239,8 @@ static int launch_one(const GemmArgs &a, hipStream_t stream) {
         std::lock_guard<std::mutex> lk(g_prof_mu);
         ProfClass &pc = g_prof[std::make_tuple(EPI, a.N, a.K)];
         pc.ev.emplace_back(e0, e1);
-        pc.m = a.M;
-        pc.flops_per_launch = 2.0 * (double)a.M * (double)a.N * (double)a.K;
+        pc.m = std::max<int64_t>(pc.m, a.M);
+        pc.flops_total += 2.0 * (double)a.M * (double)a.N * (double)a.K;
     }
     return MPREID_OK;
 }

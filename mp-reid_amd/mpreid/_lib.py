@@ -54,7 +54,7 @@ class VitWeights(C.Structure):
 
 class ProfileEntry(C.Structure):
     _fields_ = [("epilogue", C.c_int32), ("n", C.c_int32), ("k", C.c_int32), ("m", C.c_int64),
-                ("launches", C.c_int64), ("total_ms", C.c_double), ("flops_per_launch", C.c_double)]
+                ("launches", C.c_int64), ("total_ms", C.c_double), ("flops_total", C.c_double)]
 
 
 GEMM_EPILOGUE_NAMES = {0: "f32", 1: "qkv_bias_f16", 2: "bias_residual", 3: "fc_bias_quickgelu", 4: "patch_embed",
