@@ -137,6 +137,10 @@ int mpreid_vit_forward(const mpreid_vit_cfg *cfg, const mpreid_vit_weights *w, c
  * C[M][N] (fp32) = A[M][K] (fp16) x B[N][K]^T (fp16).  M, N multiples of 128... see DESIGN.md. */
 int mpreid_gemm_f16_nt(const void *a_dev, const void *b_dev, float *c_dev, int64_t m, int64_t n, int64_t k,
                        mpreid_stream_t stream);
+/* same GEMM with a fused epilogue: 0 = fp32 out, 1 = +bias -> fp16, 2 = out(fp32) += acc + bias,
+ * 3 = QuickGELU(acc + bias) -> fp16.  Used by the unit tests and tools/gemm_bench.py. */
+int mpreid_gemm_f16_nt_ex(const void *a_dev, const void *b_dev, void *out_dev, const float *bias_dev, int64_t m,
+                          int64_t n, int64_t k, int epilogue, mpreid_stream_t stream);
 /* fp32 -> fp16 (RNE) conversion of a flat array */
 int mpreid_cast_f32_to_f16(const float *x_dev, void *y_dev, int64_t n, mpreid_stream_t stream);
 

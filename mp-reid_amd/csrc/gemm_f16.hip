@@ -1,5 +1,6 @@
 // gemm_f16.hip — see gemm_f16.h for the design.  Roofline: MFMA fp16 (2.5 PFLOP/s dense peak).
 #include <algorithm>
+#include <cstdlib>
 
 #include "gemm_f16.h"
 
@@ -13,7 +14,8 @@ __device__ __forceinline__ void dma16(const void *gsrc, unsigned char *lds_dst_w
 
 __device__ __forceinline__ float quick_gelu(float h) {
     // model/clip/model.py:159-161  x * sigmoid(1.702 x)
-    return h / (1.0f + __expf(-1.702f * h));
+    // v_exp + v_rcp (1 ulp) instead of the ~15-instruction IEEE divide: the result is rounded to fp16
+    return h * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.44269504088896340736f * h));
 }
 
 template <int EPI>
@@ -112,33 +114,107 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
             const uint4 v = *reinterpret_cast<const uint4 *>(wreg + lr * 72 + ch * 8);
             *reinterpret_cast<uint4 *>(out + (int64_t)(m0 + wm * 64 + lr) * g.ldo + n0 + wn * 64 + ch * 8) = v;
         }
+    } else if constexpr (EPI == GE_BIAS_RES || EPI == GE_EUCLID || EPI == GE_F32) {
+        // fp32 outputs: transpose each wave's 64x64 accumulator block through LDS in two 32-row
+        // halves so that global accesses are whole 256-byte row pieces (16 B per lane when aligned)
+        __syncthreads();
+        float *wreg = reinterpret_cast<float *>(smem) + wave * (32 * 68);
+        float *outp = reinterpret_cast<float *>(g.out);
+        const bool vec_ok = (g.ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(outp) & 15) == 0);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        wreg[(ii * 16 + fq * 4 + r) * 68 + j * 16 + frow] = acc[half * 2 + ii][j][r];
+            __syncthreads();
+            const int mbase = m0 + wm * 64 + half * 32, nbase = n0 + wn * 64;
+            if (vec_ok) {
+                const int c4 = (lane & 15) * 4;
+                float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), bn4 = bias4;
+                if (EPI == GE_BIAS_RES) bias4 = *reinterpret_cast<const float4 *>(g.bias + nbase + c4);
+                if (EPI == GE_EUCLID) {
+                    bn4.x = (nbase + c4 + 0 < g.n_valid) ? g.aux2[nbase + c4 + 0] : 0.f;
+                    bn4.y = (nbase + c4 + 1 < g.n_valid) ? g.aux2[nbase + c4 + 1] : 0.f;
+                    bn4.z = (nbase + c4 + 2 < g.n_valid) ? g.aux2[nbase + c4 + 2] : 0.f;
+                    bn4.w = (nbase + c4 + 3 < g.n_valid) ? g.aux2[nbase + c4 + 3] : 0.f;
+                }
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int lr = it * 4 + (lane >> 4);
+                    const int m = mbase + lr;
+                    const float4 a = *reinterpret_cast<const float4 *>(wreg + lr * 68 + c4);
+                    float *dst = outp + (int64_t)m * g.ldo + nbase + c4;
+                    if (EPI == GE_F32) {
+                        *reinterpret_cast<float4 *>(dst) = a;
+                    } else if (EPI == GE_BIAS_RES) {
+                        float4 x = *reinterpret_cast<const float4 *>(dst);
+                        x.x = x.x + (a.x + bias4.x);
+                        x.y = x.y + (a.y + bias4.y);
+                        x.z = x.z + (a.z + bias4.z);
+                        x.w = x.w + (a.w + bias4.w);
+                        *reinterpret_cast<float4 *>(dst) = x;
+                    } else { // GE_EUCLID
+                        if (m < g.m_valid) {
+                            const float am = g.aux[m];
+                            float4 o;
+                            o.x = fmaf(-2.0f, a.x, am + bn4.x);
+                            o.y = fmaf(-2.0f, a.y, am + bn4.y);
+                            o.z = fmaf(-2.0f, a.z, am + bn4.z);
+                            o.w = fmaf(-2.0f, a.w, am + bn4.w);
+                            if (nbase + c4 + 3 < g.n_valid) {
+                                *reinterpret_cast<float4 *>(dst) = o;
+                            } else {
+                                if (nbase + c4 + 0 < g.n_valid) dst[0] = o.x;
+                                if (nbase + c4 + 1 < g.n_valid) dst[1] = o.y;
+                                if (nbase + c4 + 2 < g.n_valid) dst[2] = o.z;
+                            }
+                        }
+                    }
+                }
+            } else {
+                // unaligned rows (e.g. ng = 15913): one full 256-byte row per wave instruction
+                const int n = nbase + lane;
+                float bias = 0.f, bnv = 0.f;
+                if (EPI == GE_BIAS_RES) bias = g.bias[n];
+                if (EPI == GE_EUCLID) bnv = (n < g.n_valid) ? g.aux2[n] : 0.f;
+#pragma unroll 4
+                for (int lr = 0; lr < 32; ++lr) {
+                    const int m = mbase + lr;
+                    const float a = wreg[lr * 68 + lane];
+                    float *dst = outp + (int64_t)m * g.ldo + n;
+                    if (EPI == GE_F32) {
+                        *dst = a;
+                    } else if (EPI == GE_BIAS_RES) {
+                        *dst = *dst + (a + bias);
+                    } else if (m < g.m_valid && n < g.n_valid) {
+                        *dst = fmaf(-2.0f, a, g.aux[m] + bnv);
+                    }
+                }
+            }
+            __syncthreads();
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wn * 64 + j * 16 + frow;
-            float bias = 0.f, bnv = 0.f;
-            if (EPI == GE_BIAS_RES) bias = g.bias[n];
-            if (EPI == GE_EUCLID || EPI == GE_COSINE) bnv = (n < g.n_valid) ? g.aux2[n] : 0.f;
+            float bnv = 0.f;
+            if (EPI == GE_COSINE) bnv = (n < g.n_valid) ? g.aux2[n] : 0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + wm * 64 + i * 16 + fq * 4 + r;
                     const float a = acc[i][j][r];
-                    if (EPI == GE_F32) {
-                        reinterpret_cast<float *>(g.out)[(int64_t)m * g.ldo + n] = a;
-                    } else if (EPI == GE_BIAS_RES) {
-                        float *x = reinterpret_cast<float *>(g.out) + (int64_t)m * g.ldo + n;
-                        *x = *x + (a + bias);
-                    } else if (EPI == GE_PATCH) {
+                    if (EPI == GE_PATCH) {
                         if (m < g.m_valid) {
                             const int b = m / g.P, p = m - b * g.P;
                             reinterpret_cast<float *>(g.out)[((int64_t)b * g.L + 1 + p) * g.ldo + n] =
                                 a + g.aux[(int64_t)(1 + p) * g.N + n];
                         }
-                    } else if (EPI == GE_EUCLID) {
-                        if (m < g.m_valid && n < g.n_valid)
-                            reinterpret_cast<float *>(g.out)[(int64_t)m * g.ldo + n] = fmaf(-2.0f, a, g.aux[m] + bnv);
                     } else if (EPI == GE_COSINE) {
                         if (m < g.m_valid && n < g.n_valid) {
                             float c = a * __fdiv_rn(1.0f, g.aux[m] * bnv);
@@ -148,6 +224,253 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
                         }
                     }
                 }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// "big" kernel: 256 x 256 tile, 8 waves (2 x 4, 128 x 64 per wave), K consumed in 32-wide stages
+// held in a 4-slot LDS ring (4 x 32 KB).  LDS-DMA runs 2-3 stages ahead and is never drained inside
+// the loop: counted s_waitcnt vmcnt(4) + raw s_barrier per stage (cdna_hip_programming.md §5
+// "Pipelining across barriers").  MFMA operand fragments are double-buffered in registers, so the
+// ds_read_b128 of stage t+1 are issued before the 32 MFMAs of stage t.  One workgroup per CU.
+//
+// LDS stage image: A part [256 rows][64 B], then B part [256 rows][64 B]; one DMA instruction
+// writes 16 rows x 64 B.  Bank swizzle for 64-byte rows read by ds_read_b128 (four non-contiguous
+// 16-lane groups): 16-byte chunk index ^= 3 * ((row >> 3) & 1) -- conflict-free for all groups;
+// applied to the DMA source address and to the read address (rule 21).
+// ---------------------------------------------------------------------------------------------
+constexpr int BBM = 256, BBN = 256, BBK = 32, B_NSTAGE = 4;
+constexpr int B_PART_BYTES = BBM * BBK * 2;          // 16 KB
+constexpr int B_STAGE_BYTES = 2 * B_PART_BYTES;      // 32 KB
+constexpr int B_LDS_BYTES = B_NSTAGE * B_STAGE_BYTES; // 128 KB
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int tm, tn;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, 8, tm, tn);
+    const int m0 = tm * BBM, n0 = tn * BBN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int K = g.K;
+
+    // ---- DMA: wave w moves rows [32w, 32w+32) of the A part and of the B part of every stage ----
+    const int drow = lane >> 2;                                     // row inside a 16-row DMA piece
+    const int dchunk = (lane & 3) ^ (((drow >> 3) & 1) * 3);        // source chunk for LDS slot lane&3
+    const _Float16 *a_src = g.A + (int64_t)(m0 + wave * 32 + drow) * K + dchunk * 8;
+    const _Float16 *b_src = g.W + (int64_t)(n0 + wave * 32 + drow) * K + dchunk * 8;
+    auto dma_stage = [&](int st) {
+        unsigned char *abase = smem + (st & (B_NSTAGE - 1)) * B_STAGE_BYTES + wave * 2048;
+        unsigned char *bbase = abase + B_PART_BYTES;
+        const int koff = st * BBK;
+        dma16(a_src + koff, abase);
+        dma16(a_src + (int64_t)16 * K + koff, abase + 1024);
+        dma16(b_src + koff, bbase);
+        dma16(b_src + (int64_t)16 * K + koff, bbase + 1024);
+    };
+
+    // ---- fragment addresses ----
+    const int frow = lane & 15, fq = lane >> 4;
+    const int fsw = (fq ^ (((lane >> 3) & 1) * 3)) << 4;
+    const int a_off = (wr * 128 + frow) * 64 + fsw;                 // + i * 1024
+    const int b_off = B_PART_BYTES + (wc * 64 + frow) * 64 + fsw;   // + j * 1024
+    auto load_frags = [&](int st, f16x8 (&fa)[8], f16x8 (&fb)[4]) {
+        const unsigned char *sb = smem + (st & (B_NSTAGE - 1)) * B_STAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const f16x8 *>(sb + b_off + j * 1024);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const f16x8 *>(sb + a_off + i * 1024);
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nst = K / BBK; // even (K is a multiple of 64)
+    dma_stage(0);
+    if (1 < nst) dma_stage(1);
+    if (2 < nst) dma_stage(2);
+    if (nst > 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+
+    f16x8 fa0[8], fb0[4], fa1[8], fb1[4];
+    load_frags(0, fa0, fb0);
+
+    // one pipeline step: stage t is in (fa, fb); make stage t+1 visible, start the DMA of stage t+3
+    // into the slot stage t-1 used, fetch the fragments of stage t+1, then 32 MFMAs on stage t
+    auto mfma32 = [&](f16x8 (&fa)[8], f16x8 (&fb)[4]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    };
+    // steady state (no conditions, one basic block): the 4 DMA pieces and the 12 fragment reads are
+    // spread between the MFMAs (1 DMA + 3 ds_read per 8 MFMA) so that the CU's load path works
+    // beside the matrix pipe instead of in a burst after the barrier
+    auto step_steady = [&](int t, f16x8 (&fa)[8], f16x8 (&fb)[4], f16x8 (&na)[8], f16x8 (&nb)[4]) {
+        asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        unsigned char *dbase = smem + ((t + 3) & (B_NSTAGE - 1)) * B_STAGE_BYTES + wave * 2048;
+        const unsigned char *sb = smem + ((t + 1) & (B_NSTAGE - 1)) * B_STAGE_BYTES;
+        const int koff = (t + 3) * BBK;
+#define MPREID_FRAG_B(j) nb[j] = *reinterpret_cast<const f16x8 *>(sb + b_off + (j) * 1024)
+#define MPREID_FRAG_A(i) na[i] = *reinterpret_cast<const f16x8 *>(sb + a_off + (i) * 1024)
+#define MPREID_MFMA_ROWS(i0)                                                                             \
+    _Pragma("unroll") for (int ii = (i0); ii < (i0) + 2; ++ii) _Pragma("unroll") for (int j = 0; j < 4; ++j) \
+        acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[ii], fb[j], acc[ii][j], 0, 0, 0)
+        // group 0
+        dma16(a_src + koff, dbase);
+        MPREID_FRAG_B(0); MPREID_FRAG_B(1); MPREID_FRAG_B(2);
+        MPREID_MFMA_ROWS(0);
+        __builtin_amdgcn_sched_barrier(0);
+        // group 1
+        dma16(a_src + (int64_t)16 * K + koff, dbase + 1024);
+        MPREID_FRAG_B(3); MPREID_FRAG_A(0); MPREID_FRAG_A(1);
+        MPREID_MFMA_ROWS(2);
+        __builtin_amdgcn_sched_barrier(0);
+        // group 2
+        dma16(b_src + koff, dbase + B_PART_BYTES);
+        MPREID_FRAG_A(2); MPREID_FRAG_A(3); MPREID_FRAG_A(4);
+        MPREID_MFMA_ROWS(4);
+        __builtin_amdgcn_sched_barrier(0);
+        // group 3
+        dma16(b_src + (int64_t)16 * K + koff, dbase + B_PART_BYTES + 1024);
+        MPREID_FRAG_A(5); MPREID_FRAG_A(6); MPREID_FRAG_A(7);
+        MPREID_MFMA_ROWS(6);
+        __builtin_amdgcn_sched_barrier(0);
+#undef MPREID_FRAG_A
+#undef MPREID_FRAG_B
+#undef MPREID_MFMA_ROWS
+    };
+    auto step_tail = [&](int t, f16x8 (&fa)[8], f16x8 (&fb)[4], f16x8 (&na)[8], f16x8 (&nb)[4]) {
+        if (t + 1 < nst) {
+            if (t + 2 < nst) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (t + 3 < nst) dma_stage(t + 3);
+            load_frags(t + 1, na, nb);
+        }
+        mfma32(fa, fb);
+    };
+    int t = 0;
+    for (; t + 4 < nst; t += 2) {
+        step_steady(t, fa0, fb0, fa1, fb1);
+        step_steady(t + 1, fa1, fb1, fa0, fb0);
+    }
+    for (; t < nst; t += 2) {
+        step_tail(t, fa0, fb0, fa1, fb1);
+        step_tail(t + 1, fa1, fb1, fa0, fb0);
+    }
+
+    // ---- epilogue (LDS is free after this barrier) ----
+    __syncthreads();
+    if constexpr (EPI == GE_BIAS_F16 || EPI == GE_BIAS_GELU) {
+        _Float16 *wreg = reinterpret_cast<_Float16 *>(smem) + wave * (64 * 72);
+        _Float16 *out = reinterpret_cast<_Float16 *>(g.out);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float bias = g.bias[n0 + wc * 64 + j * 16 + frow];
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[half * 4 + ii][j][r] + bias;
+                        if (EPI == GE_BIAS_GELU) v = quick_gelu(v);
+                        wreg[(ii * 16 + fq * 4 + r) * 72 + j * 16 + frow] = (_Float16)v;
+                    }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int lr = it * 8 + (lane >> 3), ch = lane & 7;
+                const uint4 v = *reinterpret_cast<const uint4 *>(wreg + lr * 72 + ch * 8);
+                *reinterpret_cast<uint4 *>(out + (int64_t)(m0 + wr * 128 + half * 64 + lr) * g.ldo + n0 + wc * 64 +
+                                           ch * 8) = v;
+            }
+            __syncthreads();
+        }
+    } else {
+        float *wreg = reinterpret_cast<float *>(smem) + wave * (32 * 68);
+        float *outp = reinterpret_cast<float *>(g.out);
+        const bool vec_ok = (g.ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(outp) & 15) == 0);
+        const int nbase = n0 + wc * 64;
+#pragma unroll
+        for (int part = 0; part < 4; ++part) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        wreg[(ii * 16 + fq * 4 + r) * 68 + j * 16 + frow] = acc[part * 2 + ii][j][r];
+            __syncthreads();
+            const int mbase = m0 + wr * 128 + part * 32;
+            if (vec_ok) {
+                const int c4 = (lane & 15) * 4;
+                float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), bn4 = bias4;
+                if (EPI == GE_BIAS_RES) bias4 = *reinterpret_cast<const float4 *>(g.bias + nbase + c4);
+                if (EPI == GE_EUCLID) {
+                    bn4.x = (nbase + c4 + 0 < g.n_valid) ? g.aux2[nbase + c4 + 0] : 0.f;
+                    bn4.y = (nbase + c4 + 1 < g.n_valid) ? g.aux2[nbase + c4 + 1] : 0.f;
+                    bn4.z = (nbase + c4 + 2 < g.n_valid) ? g.aux2[nbase + c4 + 2] : 0.f;
+                    bn4.w = (nbase + c4 + 3 < g.n_valid) ? g.aux2[nbase + c4 + 3] : 0.f;
+                }
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int lr = it * 4 + (lane >> 4);
+                    const int m = mbase + lr;
+                    const float4 a = *reinterpret_cast<const float4 *>(wreg + lr * 68 + c4);
+                    float *dst = outp + (int64_t)m * g.ldo + nbase + c4;
+                    if (EPI == GE_F32) {
+                        *reinterpret_cast<float4 *>(dst) = a;
+                    } else if (EPI == GE_BIAS_RES) {
+                        float4 x = *reinterpret_cast<const float4 *>(dst);
+                        x.x = x.x + (a.x + bias4.x);
+                        x.y = x.y + (a.y + bias4.y);
+                        x.z = x.z + (a.z + bias4.z);
+                        x.w = x.w + (a.w + bias4.w);
+                        *reinterpret_cast<float4 *>(dst) = x;
+                    } else if (m < g.m_valid) { // GE_EUCLID
+                        const float am = g.aux[m];
+                        float4 o;
+                        o.x = fmaf(-2.0f, a.x, am + bn4.x);
+                        o.y = fmaf(-2.0f, a.y, am + bn4.y);
+                        o.z = fmaf(-2.0f, a.z, am + bn4.z);
+                        o.w = fmaf(-2.0f, a.w, am + bn4.w);
+                        if (nbase + c4 + 3 < g.n_valid) {
+                            *reinterpret_cast<float4 *>(dst) = o;
+                        } else {
+                            if (nbase + c4 + 0 < g.n_valid) dst[0] = o.x;
+                            if (nbase + c4 + 1 < g.n_valid) dst[1] = o.y;
+                            if (nbase + c4 + 2 < g.n_valid) dst[2] = o.z;
+                        }
+                    }
+                }
+            } else {
+                const int n = nbase + lane;
+                float bias = 0.f, bnv = 0.f;
+                if (EPI == GE_BIAS_RES) bias = g.bias[n];
+                if (EPI == GE_EUCLID) bnv = (n < g.n_valid) ? g.aux2[n] : 0.f;
+#pragma unroll 4
+                for (int lr = 0; lr < 32; ++lr) {
+                    const int m = mbase + lr;
+                    const float a = wreg[lr * 68 + lane];
+                    float *dst = outp + (int64_t)m * g.ldo + n;
+                    if (EPI == GE_F32) {
+                        *dst = a;
+                    } else if (EPI == GE_BIAS_RES) {
+                        *dst = *dst + (a + bias);
+                    } else if (m < g.m_valid && n < g.n_valid) {
+                        *dst = fmaf(-2.0f, a, g.aux[m] + bnv);
+                    }
+                }
+            }
+            __syncthreads();
         }
     }
 }
@@ -167,6 +490,16 @@ struct ProfClass {
     int64_t m = 0; // largest M seen in the class
 };
 bool g_prof_on = false;
+// MPREID_GEMM_BIG: 0 = never use the 256x256 kernel, 1 = when the grid fills the chip (default),
+// 2 = whenever the shape is divisible (tests)
+int big_mode() {
+    static int mode = -1;
+    if (mode < 0) {
+        const char *e = getenv("MPREID_GEMM_BIG");
+        mode = e ? atoi(e) : 1;
+    }
+    return mode;
+}
 std::mutex g_prof_mu;
 std::map<std::tuple<int, int, int>, ProfClass> g_prof;
 } // namespace
@@ -224,15 +557,33 @@ static int launch_one(const GemmArgs &a, hipStream_t stream) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES));
         attr_set = true;
     }
-    const int tiles_m = a.M / GBM, tiles_n = a.N / GBN;
+    constexpr bool HAS_BIG = (EPI == GE_F32 || EPI == GE_BIAS_F16 || EPI == GE_BIAS_RES || EPI == GE_BIAS_GELU ||
+                              EPI == GE_EUCLID);
+    const int bm = big_mode();
+    const bool use_big = HAS_BIG && bm > 0 && (a.M % BBM == 0) && (a.N % BBN == 0) &&
+                         (bm >= 2 || (int64_t)(a.M / BBM) * (a.N / BBN) >= 128);
+    static bool big_attr_set = false;
+    if (HAS_BIG && !big_attr_set) {
+        if constexpr (HAS_BIG)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_big_kernel<EPI>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES));
+        big_attr_set = true;
+    }
+    const int tiles_m = use_big ? a.M / BBM : a.M / GBM, tiles_n = use_big ? a.N / BBN : a.N / GBN;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (g_prof_on) {
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, stream));
     }
-    hipLaunchKernelGGL(gemm_f16_kernel<EPI>, dim3((unsigned)tiles_m * (unsigned)tiles_n), dim3(256), G_LDS_BYTES, stream,
-                       a, tiles_m, tiles_n);
+    if (use_big) {
+        if constexpr (HAS_BIG)
+            hipLaunchKernelGGL(gemm_f16_big_kernel<EPI>, dim3((unsigned)tiles_m * (unsigned)tiles_n), dim3(512),
+                               B_LDS_BYTES, stream, a, tiles_m, tiles_n);
+    } else {
+        hipLaunchKernelGGL(gemm_f16_kernel<EPI>, dim3((unsigned)tiles_m * (unsigned)tiles_n), dim3(256), G_LDS_BYTES,
+                           stream, a, tiles_m, tiles_n);
+    }
     LAUNCH_CHECK();
     if (e0) {
         HIP_TRY(hipEventRecord(e1, stream));
@@ -315,9 +666,26 @@ extern "C" int mpreid_gemm_f16_nt(const void *a, const void *b, float *c, int64_
     return launch_gemm_f16(g, GE_F32, (hipStream_t)stream);
 }
 
+// GEMM with a selectable fused epilogue (0 f32, 1 +bias->f16, 2 +bias+residual (out fp32, in place),
+// 3 +bias,QuickGELU->f16): unit tests and the GEMM micro-benchmark (tools/gemm_bench.py).
+extern "C" int mpreid_gemm_f16_nt_ex(const void *a, const void *b, void *out, const float *bias, int64_t m, int64_t n,
+                                     int64_t k, int epilogue, mpreid_stream_t stream) {
+    ARG_CHECK(a && b && out && epilogue >= 0 && epilogue <= 3 && (epilogue == 0 || bias));
+    GemmArgs g{};
+    g.A = (const _Float16 *)a;
+    g.W = (const _Float16 *)b;
+    g.M = (int)m;
+    g.N = (int)n;
+    g.K = (int)k;
+    g.out = out;
+    g.ldo = n;
+    g.bias = bias;
+    return launch_gemm_f16(g, epilogue, (hipStream_t)stream);
+}
+
 size_t mpreid_distance_f16_ws_bytes(int64_t nq, int64_t ng, int d) {
     const size_t dp = align_up((size_t)d, GBK);
-    return align_up(align_up((size_t)nq, GBM) * dp * 2, 256) + align_up(align_up((size_t)ng, GBN) * dp * 2, 256);
+    return align_up(align_up((size_t)nq, 256) * dp * 2, 256) + align_up(align_up((size_t)ng, 256) * dp * 2, 256);
 }
 
 int mpreid_distance_f16_fast(const float *q, const float *g, int64_t nq, int64_t ng, int d, const float *qn,
@@ -328,7 +696,7 @@ int mpreid_distance_f16_fast(const float *q, const float *g, int64_t nq, int64_t
         return MPREID_ERR_WORKSPACE;
     }
     const int dp = (int)align_up((size_t)d, GBK);
-    const int64_t mp = (int64_t)align_up((size_t)nq, GBM), np = (int64_t)align_up((size_t)ng, GBN);
+    const int64_t mp = (int64_t)align_up((size_t)nq, BBM), np = (int64_t)align_up((size_t)ng, BBN);
     _Float16 *qh = (_Float16 *)ws;
     _Float16 *gh = (_Float16 *)((char *)ws + align_up((size_t)mp * dp * 2, 256));
     hipLaunchKernelGGL(cast_pad_kernel, dim3((unsigned)mp), dim3(256), 0, stream, q, nq, d, qh, mp, dp);

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
 
 template <int KTP>
-__global__ __launch_bounds__(256) void attention_kernel(const _Float16 *__restrict__ qkv, int L, int W, int heads,
+__global__ __launch_bounds__(KTP <= 10 ? 64 * KTP : 512) void attention_kernel(const _Float16 *__restrict__ qkv, int L, int W, int heads,
                                                         _Float16 *__restrict__ out, int q_tiles) {
     constexpr int KEYS = KTP * 16;
     constexpr int VS = KEYS + 8; // halfs; VS*2 bytes = 16 * odd -> conflict-free ds_read_b64 of V^T
@@ -136,6 +136,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const _Float16 *__restri
     const int b = blockIdx.x / heads, h = blockIdx.x % heads;
     const int64_t ld = 3 * (int64_t)W;
     const _Float16 *base = qkv + (int64_t)b * L * ld + h * 64;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nqt = (q_tiles > 0) ? q_tiles : (L + 15) / 16;
+
+    // Q fragment of this wave's first query tile (B operand: B[k = d][col = query]) is requested
+    // before the K/V staging so that its latency overlaps the staging traffic
+    f16x8 qf[2];
+    {
+        const int q = wave * 16 + fr;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            qf[ks] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (wave < nqt && q < L) qf[ks] = *reinterpret_cast<const f16x8 *>(base + (int64_t)q * ld + ks * 32 + fq * 8);
+        }
+    }
 
     // ---- stage K (row-major, swizzled) ----
     for (int idx = tid; idx < KEYS * 8; idx += blockDim.x) {
@@ -160,17 +174,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const _Float16 *__restri
     }
     __syncthreads();
 
-    const int fr = lane & 15, fq = lane >> 4;
     const float scale_log2e = 0.125f * 1.44269504088896340736f;
-    const int nqt = (q_tiles > 0) ? q_tiles : (L + 15) / 16;
     for (int qt = wave; qt < nqt; qt += nwaves) {
         const int q = qt * 16 + fr;
-        // Q fragment as B operand: B[k = d][col = query]
-        f16x8 qf[2];
+        if (qt != wave) { // later tiles of this wave (only when there are more tiles than waves)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            qf[ks] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (q < L) qf[ks] = *reinterpret_cast<const f16x8 *>(base + (int64_t)q * ld + ks * 32 + fq * 8);
+            for (int ks = 0; ks < 2; ++ks) {
+                qf[ks] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (q < L) qf[ks] = *reinterpret_cast<const f16x8 *>(base + (int64_t)q * ld + ks * 32 + fq * 8);
+            }
         }
         f32x4 s[KTP];
         float mx = -3.0e38f;
@@ -200,7 +212,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const _Float16 *__restri
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = kt * 16 + fq * 4 + r;
-                const float p = (key < L) ? exp2f((s[kt][r] - mx) * scale_log2e) : 0.f;
+                const float p = (key < L) ? __builtin_amdgcn_exp2f((s[kt][r] - mx) * scale_log2e) : 0.f;
                 s[kt][r] = p;
                 sum += p;
             }
@@ -246,45 +258,73 @@ __global__ __launch_bounds__(256) void attention_kernel(const _Float16 *__restri
 // head: ln_post on the CLS row, CLS @ proj, optional eval-BN necks, concat -> [B][W + out_dim]
 // model/clip/model.py:471-474, model/make_model.py:98-115
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ x, int L, int W, int out_dim,
-                                                   const float *__restrict__ g, const float *__restrict__ bta,
-                                                   const float *__restrict__ proj, const float *__restrict__ bn_s,
-                                                   const float *__restrict__ bn_b, const float *__restrict__ bnp_s,
-                                                   const float *__restrict__ bnp_b, float *__restrict__ out) {
+constexpr int HEAD_IMGS = 8;
+// x_cls: CLS rows, row b at x + b*row_stride.  One workgroup normalises HEAD_IMGS rows into LDS and
+// then streams proj once for all of them (proj is read B/8 times instead of B times).
+__global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ x, int64_t row_stride, int B, int W,
+                                                   int out_dim, const float *__restrict__ g,
+                                                   const float *__restrict__ bta, const float *__restrict__ proj,
+                                                   const float *__restrict__ bn_s, const float *__restrict__ bn_b,
+                                                   const float *__restrict__ bnp_s, const float *__restrict__ bnp_b,
+                                                   float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *y = reinterpret_cast<float *>(smem); // [W]
-    __shared__ float red[8];
+    float *y = reinterpret_cast<float *>(smem); // [HEAD_IMGS][W]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x;
-    const float *xr = x + (int64_t)b * L * W;
-    float s = 0.f;
-    for (int k = tid; k < W; k += 256) s += xr[k];
+    const int b0 = blockIdx.x * HEAD_IMGS;
+    // LayerNorm (ln_post) of each CLS row: one wave per row, two rows per wave
+    for (int i = wave; i < HEAD_IMGS; i += 4) {
+        const int b = b0 + i;
+        if (b >= B) {
+            for (int k = lane; k < W; k += 64) y[i * W + k] = 0.f;
+            continue;
+        }
+        const float *xr = x + (int64_t)b * row_stride;
+        float s = 0.f;
+        for (int k = lane; k < W; k += 64) s += xr[k];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (lane == 0) red[wave] = s;
-    __syncthreads();
-    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)W;
-    float q = 0.f;
-    for (int k = tid; k < W; k += 256) {
-        const float d = xr[k] - mean;
-        q += d * d;
-    }
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        const float mean = s / (float)W;
+        float q = 0.f;
+        for (int k = lane; k < W; k += 64) {
+            const float d = xr[k] - mean;
+            q += d * d;
+        }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
-    if (lane == 0) red[4 + wave] = q;
-    __syncthreads();
-    const float rstd = 1.0f / __fsqrt_rn(((red[4] + red[5]) + (red[6] + red[7])) / (float)W + 1e-5f);
-    float *orow = out + (int64_t)b * (W + out_dim);
-    for (int k = tid; k < W; k += 256) {
-        const float v = (xr[k] - mean) * rstd * g[k] + bta[k];
-        y[k] = v;
-        orow[k] = bn_s ? fmaf(v, bn_s[k], bn_b[k]) : v;
+        for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+        const float rstd = 1.0f / sqrtf(q / (float)W + 1e-5f);
+        float *orow = out + (int64_t)b * (W + out_dim);
+        for (int k = lane; k < W; k += 64) {
+            const float v = (xr[k] - mean) * rstd * g[k] + bta[k];
+            y[i * W + k] = v;
+            orow[k] = bn_s ? fmaf(v, bn_s[k], bn_b[k]) : v;
+        }
     }
     __syncthreads();
     for (int o = tid; o < out_dim; o += 256) {
-        float acc = 0.f;
-        for (int k = 0; k < W; ++k) acc = fmaf(y[k], proj[(int64_t)k * out_dim + o], acc);
-        orow[W + o] = bnp_s ? fmaf(acc, bnp_s[o], bnp_b[o]) : acc;
+        float acc[HEAD_IMGS];
+#pragma unroll
+        for (int i = 0; i < HEAD_IMGS; ++i) acc[i] = 0.f;
+        for (int k = 0; k < W; ++k) {
+            const float pw = proj[(int64_t)k * out_dim + o];
+#pragma unroll
+            for (int i = 0; i < HEAD_IMGS; ++i) acc[i] = fmaf(y[i * W + k], pw, acc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < HEAD_IMGS; ++i) {
+            const int b = b0 + i;
+            if (b < B) out[(int64_t)b * (W + out_dim) + W + o] = bnp_s ? fmaf(acc[i], bnp_s[o], bnp_b[o]) : acc[i];
+        }
+    }
+}
+
+// CLS rows of the residual stream / attention output -> compact [Bpad][W] buffers (last block only)
+__global__ __launch_bounds__(256) void gather_cls_kernel(const float *__restrict__ x, const _Float16 *__restrict__ a,
+                                                         int B, int L, int W, float *__restrict__ x_cls,
+                                                         _Float16 *__restrict__ a_cls) {
+    const int b = blockIdx.x;
+    for (int k = threadIdx.x; k < W; k += 256) {
+        x_cls[(int64_t)b * W + k] = x[(int64_t)b * L * W + k];
+        a_cls[(int64_t)b * W + k] = a[(int64_t)b * L * W + k];
     }
 }
 
@@ -292,8 +332,8 @@ __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ x, 
 // host driver
 // ---------------------------------------------------------------------------------------------
 struct VitLayout {
-    int L, P, M, Mpad, MPpad, Kp;
-    size_t patches, x, a, qkv, hbuf, total;
+    int L, P, M, Mpad, MPpad, Kp, Bpad;
+    size_t patches, x, a, qkv, hbuf, x_cls, a_cls, h_cls, total;
 };
 
 static VitLayout vit_layout(const mpreid_vit_cfg *c, int B) {
@@ -301,8 +341,8 @@ static VitLayout vit_layout(const mpreid_vit_cfg *c, int B) {
     v.P = c->h_res * c->w_res;
     v.L = v.P + 1;
     v.M = B * v.L;
-    v.Mpad = (int)align_up((size_t)v.M, GBM);
-    v.MPpad = (int)align_up((size_t)B * v.P, GBM);
+    v.Mpad = (int)align_up((size_t)v.M, 256);   // 256-row tiles of the big GEMM kernel
+    v.MPpad = (int)align_up((size_t)B * v.P, 256);
     v.Kp = 3 * c->patch * c->patch;
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -316,6 +356,10 @@ static VitLayout vit_layout(const mpreid_vit_cfg *c, int B) {
     v.a = take((size_t)v.Mpad * W * 2);
     v.qkv = take((size_t)v.Mpad * 3 * W * 2);
     v.hbuf = take((size_t)v.Mpad * 4 * W * 2);
+    v.Bpad = (int)align_up((size_t)B, GBM);
+    v.x_cls = take((size_t)v.Bpad * W * 4);
+    v.a_cls = take((size_t)v.Bpad * W * 2);
+    v.h_cls = take((size_t)v.Bpad * 4 * W * 2);
     v.total = off;
     return v;
 }
@@ -357,7 +401,8 @@ static int launch_attention(const _Float16 *qkv, int B, int L, int W, int heads,
         attr_set = true;
     }
     const int nqt = (q_tiles > 0) ? q_tiles : (L + 15) / 16;
-    const int nw = (nqt % 3 == 0) ? 3 : (nqt < 4 ? nqt : 4);
+    const int maxw = (KTP <= 10) ? KTP : 8;     // one wave per 16-query tile when the block can hold them
+    const int nw = nqt < maxw ? nqt : maxw;
     hipLaunchKernelGGL(attention_kernel<KTP>, dim3((unsigned)(B * heads)), dim3(64 * nw), lds, stream, qkv, L, W, heads,
                        out, q_tiles);
     LAUNCH_CHECK();
@@ -392,6 +437,10 @@ extern "C" int mpreid_vit_forward(const mpreid_vit_cfg *cfg, const mpreid_vit_we
     _Float16 *a = (_Float16 *)(base + v.a);
     _Float16 *qkv = (_Float16 *)(base + v.qkv);
     _Float16 *hbuf = (_Float16 *)(base + v.hbuf);
+    float *x_cls = (float *)(base + v.x_cls);
+    _Float16 *a_cls = (_Float16 *)(base + v.a_cls);
+    _Float16 *h_cls = (_Float16 *)(base + v.h_cls);
+    const bool cls_last = cfg->cls_only_last != 0 && cfg->layers > 0;
 
     // patch embedding (conv1, no bias) + positional embedding; CLS row; ln_pre
     {
@@ -421,6 +470,7 @@ extern "C" int mpreid_vit_forward(const mpreid_vit_cfg *cfg, const mpreid_vit_we
     }
     for (int l = 0; l < cfg->layers; ++l) {
         const mpreid_vit_layer &ly = w->layers[l];
+        const bool tail = cls_last && (l == cfg->layers - 1);
         GemmArgs g{};
         // x = x + out_proj(attn(ln_1(x)))
         hipLaunchKernelGGL(layernorm_kernel<true>, dim3((unsigned)((v.M + 3) / 4)), dim3(256), 0, stream, x,
@@ -430,28 +480,40 @@ extern "C" int mpreid_vit_forward(const mpreid_vit_cfg *cfg, const mpreid_vit_we
         g.A = a; g.W = (const _Float16 *)ly.in_proj_w; g.M = v.Mpad; g.N = 3 * W; g.K = W;
         g.out = qkv; g.ldo = 3 * W; g.bias = ly.in_proj_b;
         if ((rc = launch_gemm_f16(g, GE_BIAS_F16, stream))) return rc;
-        if ((rc = attention_dispatch(qkv, B, L, W, cfg->heads, a, 0, stream))) return rc;
+        // in the last block only the CLS row reaches the output (model/make_model.py:98-100): the
+        // attention runs the first query tile only and everything after it runs on the B CLS rows.
+        if ((rc = attention_dispatch(qkv, B, L, W, cfg->heads, a, tail ? 1 : 0, stream))) return rc;
+        float *xr = x;
+        _Float16 *ar = a, *hr = hbuf;
+        int rows = v.M, rows_pad = v.Mpad;
+        if (tail) {
+            hipLaunchKernelGGL(gather_cls_kernel, dim3((unsigned)B), dim3(256), 0, stream, x, a, B, L, W, x_cls, a_cls);
+            LAUNCH_CHECK();
+            xr = x_cls; ar = a_cls; hr = h_cls; rows = B; rows_pad = v.Bpad;
+        }
         g = GemmArgs{};
-        g.A = a; g.W = (const _Float16 *)ly.out_proj_w; g.M = v.Mpad; g.N = W; g.K = W;
-        g.out = x; g.ldo = W; g.bias = ly.out_proj_b;
+        g.A = ar; g.W = (const _Float16 *)ly.out_proj_w; g.M = rows_pad; g.N = W; g.K = W;
+        g.out = xr; g.ldo = W; g.bias = ly.out_proj_b;
         if ((rc = launch_gemm_f16(g, GE_BIAS_RES, stream))) return rc;
         // x = x + c_proj(quickgelu(c_fc(ln_2(x))))
-        hipLaunchKernelGGL(layernorm_kernel<true>, dim3((unsigned)((v.M + 3) / 4)), dim3(256), 0, stream, x,
-                           (int64_t)v.M, W, ly.ln2_g, ly.ln2_b, (void *)a, (int64_t)W);
+        hipLaunchKernelGGL(layernorm_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, xr,
+                           (int64_t)rows, W, ly.ln2_g, ly.ln2_b, (void *)ar, (int64_t)W);
         LAUNCH_CHECK();
         g = GemmArgs{};
-        g.A = a; g.W = (const _Float16 *)ly.fc_w; g.M = v.Mpad; g.N = 4 * W; g.K = W;
-        g.out = hbuf; g.ldo = 4 * W; g.bias = ly.fc_b;
+        g.A = ar; g.W = (const _Float16 *)ly.fc_w; g.M = rows_pad; g.N = 4 * W; g.K = W;
+        g.out = hr; g.ldo = 4 * W; g.bias = ly.fc_b;
         if ((rc = launch_gemm_f16(g, GE_BIAS_GELU, stream))) return rc;
         g = GemmArgs{};
-        g.A = hbuf; g.W = (const _Float16 *)ly.proj_w; g.M = v.Mpad; g.N = W; g.K = 4 * W;
-        g.out = x; g.ldo = W; g.bias = ly.proj_b;
+        g.A = hr; g.W = (const _Float16 *)ly.proj_w; g.M = rows_pad; g.N = W; g.K = 4 * W;
+        g.out = xr; g.ldo = W; g.bias = ly.proj_b;
         if ((rc = launch_gemm_f16(g, GE_BIAS_RES, stream))) return rc;
     }
     const bool neck = cfg->neck_after != 0 && w->bn_scale && w->bn_proj_scale;
-    hipLaunchKernelGGL(head_kernel, dim3((unsigned)B), dim3(256), (size_t)W * 4, stream, x, L, W, cfg->out_dim,
-                       w->ln_post_g, w->ln_post_b, w->proj, neck ? w->bn_scale : nullptr, neck ? w->bn_shift : nullptr,
-                       neck ? w->bn_proj_scale : nullptr, neck ? w->bn_proj_shift : nullptr, out);
+    hipLaunchKernelGGL(head_kernel, dim3((unsigned)((B + HEAD_IMGS - 1) / HEAD_IMGS)), dim3(256),
+                       (size_t)HEAD_IMGS * W * 4, stream, cls_last ? x_cls : x, cls_last ? (int64_t)W : (int64_t)L * W, B, W,
+                       cfg->out_dim, w->ln_post_g, w->ln_post_b, w->proj, neck ? w->bn_scale : nullptr,
+                       neck ? w->bn_shift : nullptr, neck ? w->bn_proj_scale : nullptr,
+                       neck ? w->bn_proj_shift : nullptr, out);
     LAUNCH_CHECK();
     return MPREID_OK;
 }

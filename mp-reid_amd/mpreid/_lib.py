@@ -20,8 +20,8 @@ SYMBOLS = [
     "mpreid_sqnorm_f32", "mpreid_l2_normalize_f32", "mpreid_distance_workspace_bytes",
     "mpreid_euclidean_distance_f32", "mpreid_cosine_similarity_f32",
     "mpreid_rerank_workspace_bytes", "mpreid_rerank_f32", "mpreid_rerank_debug_copy",
-    "mpreid_vit_workspace_bytes", "mpreid_vit_forward", "mpreid_gemm_f16_nt", "mpreid_cast_f32_to_f16",
-    "mpreid_profile_enable", "mpreid_profile_reset", "mpreid_profile_query",
+    "mpreid_vit_workspace_bytes", "mpreid_vit_forward", "mpreid_gemm_f16_nt", "mpreid_gemm_f16_nt_ex",
+    "mpreid_cast_f32_to_f16", "mpreid_profile_enable", "mpreid_profile_reset", "mpreid_profile_query",
 ]
 
 
@@ -101,6 +101,8 @@ def load():
     L.mpreid_vit_forward.argtypes = [C.POINTER(VitCfg), C.POINTER(VitWeights), vp, i32, vp, vp, vp, sz, vp]
     L.mpreid_gemm_f16_nt.restype = i32
     L.mpreid_gemm_f16_nt.argtypes = [vp, vp, vp, i64, i64, i64, vp]
+    L.mpreid_gemm_f16_nt_ex.restype = i32
+    L.mpreid_gemm_f16_nt_ex.argtypes = [vp, vp, vp, vp, i64, i64, i64, i32, vp]
     L.mpreid_cast_f32_to_f16.restype = i32
     L.mpreid_cast_f32_to_f16.argtypes = [vp, vp, i64, vp]
     L.mpreid_profile_enable.restype = i32

@@ -154,8 +154,9 @@ class VitEncoder:
     """
 
     def __init__(self, cfg: dict, state_dict: dict, img_hw, neck_after: bool = False, bn: Optional[dict] = None,
-                 device=None):
+                 device=None, cls_only_last: bool = True, ws_tag: str = "vit"):
         self.device = device or _lib.require_gpu()
+        self.ws_tag = ws_tag   # encoders that run concurrently on different streams need distinct workspaces
         self.cfg = dict(cfg)
         self.img_hw = tuple(img_hw)
         dev = self.device
@@ -180,7 +181,8 @@ class VitEncoder:
         self._keep = []  # owns every device tensor referenced by the C structs
         keep = self._keep.append
         self.c_cfg = _lib.VitCfg(self.img_hw[0], self.img_hw[1], cfg["patch"], cfg["stride"], cfg["h_res"],
-                                 cfg["w_res"], w, cfg["layers"], cfg["heads"], cfg["out_dim"], int(bool(neck_after)), 0)
+                                 cfg["w_res"], w, cfg["layers"], cfg["heads"], cfg["out_dim"], int(bool(neck_after)),
+                                 int(bool(cls_only_last)))
         layers = (_lib.VitLayer * max(cfg["layers"], 1))()
         for i in range(cfg["layers"]):
             b = f"transformer.resblocks.{i}"
@@ -231,9 +233,16 @@ class VitEncoder:
             out = torch.empty((B, self.feat_dim), dtype=torch.float32, device=self.device)
         assert out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (B, self.feat_dim)
         wsb = L.mpreid_vit_workspace_bytes(C.byref(self.c_cfg), B)
-        ws = _workspace("vit", wsb, self.device)
+        ws = _workspace(self.ws_tag, wsb, self.device)
         _lib.check(L.mpreid_vit_forward(C.byref(self.c_cfg), C.byref(self.c_w), _ptr(img), B, _ptr(cv), _ptr(out),
                                         _ptr(ws), ws.numel(), _lib.stream_ptr()), "mpreid_vit_forward")
         return out
 
     __call__ = forward
+
+    def clone_for_stream(self, ws_tag: str) -> "VitEncoder":
+        """a second handle on the same device weights with its own workspace (for a second HIP stream)"""
+        import copy
+        other = copy.copy(self)
+        other.ws_tag = ws_tag
+        return other

@@ -109,6 +109,29 @@ def test_gemm_f16_exact_integers(ops):
     assert np.array_equal(c, a @ b.T)
 
 
+@pytest.mark.parametrize("m,n,k", [(256, 256, 64), (512, 768, 192), (1024, 512, 768), (256, 1024, 3072)])
+def test_gemm_f16_big_kernel_exact_integers(m, n, k):
+    """the 256x256 ring-pipelined kernel (forced with MPREID_GEMM_BIG=2 in a child process)"""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent(f"""
+        import sys, numpy as np, torch
+        sys.path[:0] = [{root!r}, {root!r} + "/mp-reid_amd"]
+        from mpreid import ops
+        rng = np.random.default_rng(1)
+        a = rng.integers(-4, 5, size=({m}, {k})).astype(np.float32)
+        b = rng.integers(-4, 5, size=({n}, {k})).astype(np.float32)
+        b[:, 0] += np.arange({n}) % 3
+        for rep in range(3):
+            c = ops.gemm_f16_nt(torch.from_numpy(a).half().cuda(), torch.from_numpy(b).half().cuda()).cpu().numpy()
+            assert np.array_equal(c, a @ b.T), np.abs(c - a @ b.T).max()
+        print("ok")
+    """)
+    env = dict(os.environ, MPREID_GEMM_BIG="2")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_full_size_properties(ops):
     """Market-1501 shape (3368 x 15913 x 1280): size-independent checks instead of the oracle."""
     from mpreid import synth

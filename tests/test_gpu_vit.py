@@ -81,3 +81,14 @@ def test_vit_bn_neck_vs_oracle():
     enc = _encoder(SMALL, sd, (64, 32), neck_after=True, bn=bn)
     want = orc.vit_features(sd, SMALL, imgs, bn=bn, neck_feat="after")
     _close(enc(torch.from_numpy(imgs)).cpu().numpy(), want)
+
+
+def test_vit_cls_only_last_block_is_bit_identical():
+    """the last block restricted to the CLS row (the only row the output uses) must not change a bit"""
+    from mpreid import synth
+    big = synth.VIT_B16
+    sd = synth.vit_state_dict(big, seed=7, std=0.02, ln_jitter=0.05)
+    imgs = torch.from_numpy(synth.synthetic_images(9, 256, 128, seed=5))
+    full = _encoder(big, sd, (256, 128), cls_only_last=False)(imgs).cpu().numpy()
+    tail = _encoder(big, sd, (256, 128), cls_only_last=True)(imgs).cpu().numpy()
+    assert np.array_equal(full, tail)
