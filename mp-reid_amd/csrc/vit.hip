@@ -15,6 +15,8 @@
 //   hbuf    fp16 [M pad][4W]        MLP hidden after QuickGELU
 // Kernels: im2col (HBM), GEMM+epilogues (MFMA, gemm_f16.hip), LayerNorm (HBM), attention (MFMA +
 // LDS; L = 129 keys fit one workgroup), head (L2).
+#include <cstdlib>
+
 #include "gemm_f16.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -124,134 +126,201 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 // ---------------------------------------------------------------------------------------------
 typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
 
-template <int KTP>
-__global__ __launch_bounds__(KTP <= 10 ? 64 * KTP : 512) void attention_kernel(const _Float16 *__restrict__ qkv, int L, int W, int heads,
-                                                        _Float16 *__restrict__ out, int q_tiles) {
+// K / V prefetch registers are NAMED scalars (k0..k4, v0..v4) expanded by macros: as arrays they were kept
+// in scratch memory by hipcc, doubling the memory traffic of the kernel.
+// thread -> (row, 16-byte chunk), 8 lanes per 128-byte row, so every wave instruction covers 8 whole cache
+// lines.  Rows past L are clamped (always a valid address): a guarded load would put every load in its own
+// branch with a vmcnt(0) behind it; clamped copies are harmless because keys >= L are masked before softmax.
+#define ATT_FOR_EACH_ITER(X) X(0) X(1) X(2) X(3) X(4)
+#define ATT_DECL(i) uint4 k##i = make_uint4(0, 0, 0, 0), v##i = k##i;
+#define ATT_LOAD(i)                                                                                  \
+    if constexpr (K_ITERS > i) {                                                                     \
+        const int idx_ = tid + i * NT;                                                               \
+        const int row_ = idx_ >> 3, c_ = idx_ & 7;                                                   \
+        const int rc_ = row_ < L ? row_ : L - 1;                                                     \
+        k##i = *reinterpret_cast<const uint4 *>(pbase_ + (int64_t)rc_ * ld + W + c_ * 8);           \
+        v##i = *reinterpret_cast<const uint4 *>(pbase_ + (int64_t)rc_ * ld + 2 * W + c_ * 8);       \
+    }
+#define ATT_STORE(i)                                                                                 \
+    if constexpr (K_ITERS > i) {                                                                     \
+        const int idx_ = tid + i * NT;                                                               \
+        const int row_ = idx_ >> 3, c_ = idx_ & 7;                                                   \
+        if (idx_ < KEYS * 8) {                                                                       \
+            *reinterpret_cast<uint4 *>(Ks + row_ * 128 + ((c_ ^ (row_ & 7)) << 4)) = k##i;           \
+            *reinterpret_cast<uint4 *>(Vs + row_ * 128 + ((c_ ^ (((row_ >> 1) & 3) << 1)) << 4)) = v##i; \
+        }                                                                                            \
+    }
+#define ATT_PREFETCH(pr)                                                                             \
+    {                                                                                                \
+        const int pb_ = (pr) / heads, ph_ = (pr) - pb_ * heads;                                      \
+        const _Float16 *pbase_ = qkv + (int64_t)pb_ * L * ld + ph_ * 64;                             \
+        ATT_FOR_EACH_ITER(ATT_LOAD)                                                                  \
+    }
+
+typedef short att_s4 __attribute__((__vector_size__(4 * sizeof(short))));
+typedef __attribute__((address_space(3))) att_s4 att_lds_s4;
+
+// Persistent form: a workgroup walks (image, head) pairs pair = blockIdx.x, + gridDim.x, ...  The
+// K / V / Q data of the NEXT pair are requested into registers before the current pair is computed
+// from LDS, so HBM loads stay in flight during the MFMA/softmax phase (the non-persistent form kept
+// loads in flight only about half of the time: 2.5 TB/s).
+template <int KTP, int NW, bool EXACT>
+__global__ __launch_bounds__(64 * NW, (NW == 8 && KTP <= 10) ? 4 : 2) void attention_kernel(const _Float16 *__restrict__ qkv, int L, int W, int heads,
+                                                               _Float16 *__restrict__ out, int q_tiles,
+                                                               int total_pairs, int dbg) {
     constexpr int KEYS = KTP * 16;
-    constexpr int VS = KEYS + 8; // halfs; VS*2 bytes = 16 * odd -> conflict-free ds_read_b64 of V^T
+    constexpr int NT = 64 * NW;
+    constexpr int K_ITERS = (KEYS * 8 + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char *Ks = smem;                                             // [KEYS][128 B] swizzled
-    _Float16 *Vt = reinterpret_cast<_Float16 *>(smem + KEYS * 128);       // [64][VS]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
-    const int64_t ld = 3 * (int64_t)W;
-    const _Float16 *base = qkv + (int64_t)b * L * ld + h * 64;
+    // K  [KEYS][128 B], 16-byte chunk ^= row & 7           (ds_read_b128 of A fragments, conflict free)
+    // V  [KEYS][128 B], 16-byte chunk ^= ((row>>1)&3) << 1 (ds_read_b64_tr_b16 of 4-key x 16-d blocks, conflict free)
+    unsigned char *Ks = smem;
+    unsigned char *Vs = smem + KEYS * 128;
+    constexpr int OS = 72;                                                // halfs per row of an O patch (144 B)
+    _Float16 *Ot = reinterpret_cast<_Float16 *>(smem + 2 * KEYS * 128);   // [NW][16][OS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
+    const int64_t ld = 3 * (int64_t)W;
     const int nqt = (q_tiles > 0) ? q_tiles : (L + 15) / 16;
-
-    // Q fragment of this wave's first query tile (B operand: B[k = d][col = query]) is requested
-    // before the K/V staging so that its latency overlaps the staging traffic
-    f16x8 qf[2];
-    {
-        const int q = wave * 16 + fr;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            qf[ks] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (wave < nqt && q < L) qf[ks] = *reinterpret_cast<const f16x8 *>(base + (int64_t)q * ld + ks * 32 + fq * 8);
-        }
-    }
-
-    // ---- stage K (row-major, swizzled) ----
-    for (int idx = tid; idx < KEYS * 8; idx += blockDim.x) {
-        const int row = idx >> 3, c = idx & 7;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (row < L) v = *reinterpret_cast<const uint4 *>(base + (int64_t)row * ld + W + c * 8);
-        *reinterpret_cast<uint4 *>(Ks + row * 128 + ((c ^ (row & 7)) << 4)) = v;
-    }
-    // ---- stage V transposed: Vt[d][key], two keys per 32-bit LDS write ----
-    for (int idx = tid; idx < KEYS * 4; idx += blockDim.x) {
-        const int kp = idx % (KEYS / 2), c = idx / (KEYS / 2); // lanes of a half-wave: distinct key pairs
-        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-        h8 v0 = {0, 0, 0, 0, 0, 0, 0, 0}, v1 = v0;
-        if (2 * kp < L) v0 = *reinterpret_cast<const h8 *>(base + (int64_t)(2 * kp) * ld + 2 * W + c * 8);
-        if (2 * kp + 1 < L) v1 = *reinterpret_cast<const h8 *>(base + (int64_t)(2 * kp + 1) * ld + 2 * W + c * 8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-            h2 pr = {v0[j], v1[j]};
-            *reinterpret_cast<h2 *>(Vt + (c * 8 + j) * VS + 2 * kp) = pr;
-        }
-    }
-    __syncthreads();
-
     const float scale_log2e = 0.125f * 1.44269504088896340736f;
-    for (int qt = wave; qt < nqt; qt += nwaves) {
-        const int q = qt * 16 + fr;
-        if (qt != wave) { // later tiles of this wave (only when there are more tiles than waves)
+
+    static_assert(K_ITERS <= 5, "extend ATT_FOR_EACH_ITER");
+    ATT_FOR_EACH_ITER(ATT_DECL)
+
+    int pair = blockIdx.x;
+    if (pair >= total_pairs) return;
+    if (!(dbg & 1)) ATT_PREFETCH(pair)
+    for (; pair < total_pairs; pair += gridDim.x) {
+        const int b = pair / heads, h = pair - b * heads;
+        const _Float16 *base = qkv + (int64_t)b * L * ld + h * 64;
+        __syncthreads(); // every wave is done reading the previous pair from LDS
+        // ---- registers -> LDS (rows >= L hold a clamped, finite copy of row L-1: masked before the softmax) ----
+        ATT_FOR_EACH_ITER(ATT_STORE)
+        f16x8 qf[2];
+        {   // Q fragment (B operand: B[k = d][col = query]) of this wave's first tile, requested before the
+            // barrier; rows past L are clamped and only feed discarded output columns
+            const int q = wave * 16 + fr;
+            const int qc = q < L ? q : L - 1;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                qf[ks] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                if (q < L) qf[ks] = *reinterpret_cast<const f16x8 *>(base + (int64_t)q * ld + ks * 32 + fq * 8);
-            }
+            for (int ks = 0; ks < 2; ++ks)
+                qf[ks] = *reinterpret_cast<const f16x8 *>(base + (int64_t)qc * ld + ks * 32 + fq * 8);
         }
+        __syncthreads();
+        {   // unconditional (a clamped pair index on the last trip): keeps the register arrays out of scratch
+            const int nxt = pair + (int)gridDim.x < total_pairs ? pair + (int)gridDim.x : pair;
+            if (!(dbg & 1)) ATT_PREFETCH(nxt)
+        }
+
+        for (int qt = wave; qt < ((dbg & 2) ? 0 : nqt); qt += NW) {
+            const int q = qt * 16 + fr;
+            if (qt != wave) { // later tiles of this wave (only when there are more tiles than waves)
+                const int qc = q < L ? q : L - 1;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    qf[ks] = *reinterpret_cast<const f16x8 *>(base + (int64_t)qc * ld + ks * 32 + fq * 8);
+            }
+        // S^T tiles, branch free.  EXACT: KTP is the even round-up of ceil(L/16), so tiles 0..KTP-3
+        // hold only valid keys and only the last two can contain keys >= L (K rows past L are zero in
+        // LDS; their scores are forced to -huge).  !EXACT (KTP larger than needed): mask every tile.
         f32x4 s[KTP];
         float mx = -3.0e38f;
 #pragma unroll
         for (int kt = 0; kt < KTP; ++kt) {
             s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (kt * 16 < L) {
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const f16x8 kf = *reinterpret_cast<const f16x8 *>(Ks + (kt * 16 + fr) * 128 +
-                                                                       (((ks * 4 + fq) ^ (lane & 7)) << 4));
-                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], s[kt], 0, 0, 0);
-                }
+            for (int ks = 0; ks < 2; ++ks) {
+                const f16x8 kf = *reinterpret_cast<const f16x8 *>(Ks + (kt * 16 + fr) * 128 +
+                                                                   (((ks * 4 + fq) ^ (lane & 7)) << 4));
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], s[kt], 0, 0, 0);
             }
+            // keep at most two tiles' worth of K fragments in flight (bounds the register live ranges
+            // so that two workgroups fit a CU)
+            if (kt & 1) __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kt * 16 + fq * 4 + r;
-                if (key >= L) s[kt][r] = -3.0e38f;
-                mx = fmaxf(mx, s[kt][r]);
+        for (int kt = 0; kt < KTP; ++kt) {
+            if (!EXACT || kt >= KTP - 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kt * 16 + fq * 4 + r >= L) s[kt][r] = -3.0e38f;
             }
+            mx = fmaxf(mx, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        // p = exp2(s*c - mx*c): one fma + one v_exp per element; masked entries give exp2(-huge) = 0
+        const float nmx = -mx * scale_log2e;
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < KTP; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int key = kt * 16 + fq * 4 + r;
-                const float p = (key < L) ? __builtin_amdgcn_exp2f((s[kt][r] - mx) * scale_log2e) : 0.f;
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], scale_log2e, nmx));
                 s[kt][r] = p;
                 sum += p;
             }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
         // O^T = V^T P^T over 32-key steps; P^T fragment element j <-> key 32*s2 + 16*(j>>2) + 4*fq + (j&3)
+        // (V^T columns past L are zero in LDS and their P is 0, so every step runs unconditionally)
         f32x4 o[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s2 = 0; s2 < KTP / 2; ++s2) {
-            if (s2 * 32 < L) {
-                f16x8 pf;
+            f16x8 pf;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    pf[j] = (_Float16)s[2 * s2][j];
-                    pf[4 + j] = (_Float16)s[2 * s2 + 1][j];
-                }
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const _Float16 *vrow = Vt + (dt * 16 + fr) * VS + s2 * 32 + fq * 4;
-                    const h4_t lo = *reinterpret_cast<const h4_t *>(vrow);
-                    const h4_t hi = *reinterpret_cast<const h4_t *>(vrow + 16);
-                    const f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[dt], 0, 0, 0);
-                }
+            for (int j = 0; j < 4; ++j) {
+                pf[j] = (_Float16)s[2 * s2][j];
+                pf[4 + j] = (_Float16)s[2 * s2 + 1][j];
             }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                // A operand = V^T: lane (d = dt*16 + fr, key group fq) needs keys 32*s2 + 4*fq + {0..3} and + 16.
+                // One ds_read_b64_tr_b16 hands lane i of a 16-lane group column i of a 4-row x 16-column block;
+                // lane 4q+p of the group supplies the address of row q, columns 4p..4p+3.
+                const int trq = fr >> 2, trp = fr & 3;
+                const int row0 = s2 * 32 + fq * 4 + trq;
+                const int chunk = dt * 2 + (trp >> 1);
+                const unsigned char *a0 = Vs + row0 * 128 + ((chunk ^ (((row0 >> 1) & 3) << 1)) << 4) + (trp & 1) * 8;
+                const int row1 = row0 + 16;
+                const unsigned char *a1 = Vs + row1 * 128 + ((chunk ^ (((row1 >> 1) & 3) << 1)) << 4) + (trp & 1) * 8;
+                const att_s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((att_lds_s4 *)a0);
+                const att_s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((att_lds_s4 *)a1);
+                typedef short s8_t __attribute__((ext_vector_type(8)));
+                const s8_t vs8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const f16x8 vf = __builtin_bit_cast(f16x8, vs8);
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, o[dt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (q < L) {
+        // O^T accumulators hold 4 consecutive d for one query per lane.  Writing them straight out would be
+        // 8-byte stores touching 16 partial lines per instruction (store-issue-bound); instead the wave's
+        // 16 x 64 tile goes through its private LDS patch and leaves as whole 128-byte rows, 16 B per lane.
+        {
             const float inv = 1.0f / sum;
-            _Float16 *orow = out + ((int64_t)b * L + q) * W + h * 64 + fq * 4;
+            _Float16 *ot = Ot + wave * (16 * OS);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 h4_t ov = {(_Float16)(o[dt][0] * inv), (_Float16)(o[dt][1] * inv), (_Float16)(o[dt][2] * inv),
                            (_Float16)(o[dt][3] * inv)};
-                *reinterpret_cast<h4_t *>(orow + dt * 16) = ov;
+                *reinterpret_cast<h4_t *>(ot + fr * OS + dt * 16 + fq * 4) = ov;
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int row = it * 8 + (lane >> 3), ch = lane & 7;
+                const uint4 v = *reinterpret_cast<const uint4 *>(ot + row * OS + ch * 8);
+                const int qrow = qt * 16 + row;
+                if (qrow < L && !(dbg & 4))
+                    *reinterpret_cast<uint4 *>(out + ((int64_t)b * L + qrow) * W + h * 64 + ch * 8) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-    }
+        } // query tiles
+    }     // (image, head) pairs
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -259,61 +328,67 @@ __global__ __launch_bounds__(KTP <= 10 ? 64 * KTP : 512) void attention_kernel(c
 // model/clip/model.py:471-474, model/make_model.py:98-115
 // ---------------------------------------------------------------------------------------------
 constexpr int HEAD_IMGS = 8;
-// x_cls: CLS rows, row b at x + b*row_stride.  One workgroup normalises HEAD_IMGS rows into LDS and
-// then streams proj once for all of them (proj is read B/8 times instead of B times).
-__global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ x, int64_t row_stride, int B, int W,
-                                                   int out_dim, const float *__restrict__ g,
-                                                   const float *__restrict__ bta, const float *__restrict__ proj,
-                                                   const float *__restrict__ bn_s, const float *__restrict__ bn_b,
-                                                   const float *__restrict__ bnp_s, const float *__restrict__ bnp_b,
-                                                   float *__restrict__ out) {
+// ln_post of the CLS rows (one wave per row): y[b][:] (fp32, for the projection) and out[b][0:W]
+__global__ __launch_bounds__(256) void cls_ln_kernel(const float *__restrict__ x, int64_t row_stride, int B, int W,
+                                                     int out_dim, const float *__restrict__ g,
+                                                     const float *__restrict__ bta, const float *__restrict__ bn_s,
+                                                     const float *__restrict__ bn_b, float *__restrict__ y,
+                                                     float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float *xr = x + (int64_t)b * row_stride;
+    float s = 0.f;
+    for (int k = lane; k < W; k += 64) s += xr[k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    const float mean = s / (float)W;
+    float q = 0.f;
+    for (int k = lane; k < W; k += 64) {
+        const float d = xr[k] - mean;
+        q += d * d;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+    const float rstd = 1.0f / sqrtf(q / (float)W + 1e-5f);
+    float *orow = out + (int64_t)b * (W + out_dim);
+    for (int k = lane; k < W; k += 64) {
+        const float v = (xr[k] - mean) * rstd * g[k] + bta[k];
+        y[(int64_t)b * W + k] = v;
+        orow[k] = bn_s ? fmaf(v, bn_s[k], bn_b[k]) : v;
+    }
+}
+
+// out[b][W + o] = sum_k y[b][k] * proj[k][o]  (fp32, k ascending).  grid = (ceil(B/8), ceil(out_dim/256));
+// 8 rows of y sit in LDS, every thread owns one output column for those 8 images.
+__global__ __launch_bounds__(256) void cls_proj_kernel(const float *__restrict__ y, int B, int W, int out_dim,
+                                                       const float *__restrict__ proj,
+                                                       const float *__restrict__ bnp_s,
+                                                       const float *__restrict__ bnp_b, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *y = reinterpret_cast<float *>(smem); // [HEAD_IMGS][W]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *ys = reinterpret_cast<float *>(smem); // [HEAD_IMGS][W]
+    const int tid = threadIdx.x;
     const int b0 = blockIdx.x * HEAD_IMGS;
-    // LayerNorm (ln_post) of each CLS row: one wave per row, two rows per wave
-    for (int i = wave; i < HEAD_IMGS; i += 4) {
-        const int b = b0 + i;
-        if (b >= B) {
-            for (int k = lane; k < W; k += 64) y[i * W + k] = 0.f;
-            continue;
-        }
-        const float *xr = x + (int64_t)b * row_stride;
-        float s = 0.f;
-        for (int k = lane; k < W; k += 64) s += xr[k];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-        const float mean = s / (float)W;
-        float q = 0.f;
-        for (int k = lane; k < W; k += 64) {
-            const float d = xr[k] - mean;
-            q += d * d;
-        }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
-        const float rstd = 1.0f / sqrtf(q / (float)W + 1e-5f);
-        float *orow = out + (int64_t)b * (W + out_dim);
-        for (int k = lane; k < W; k += 64) {
-            const float v = (xr[k] - mean) * rstd * g[k] + bta[k];
-            y[i * W + k] = v;
-            orow[k] = bn_s ? fmaf(v, bn_s[k], bn_b[k]) : v;
-        }
+    for (int idx = tid; idx < HEAD_IMGS * W; idx += 256) {
+        const int i = idx / W, k = idx - i * W;
+        ys[idx] = (b0 + i < B) ? y[(int64_t)(b0 + i) * W + k] : 0.f;
     }
     __syncthreads();
-    for (int o = tid; o < out_dim; o += 256) {
-        float acc[HEAD_IMGS];
+    const int o = blockIdx.y * 256 + tid;
+    if (o >= out_dim) return;
+    float acc[HEAD_IMGS];
 #pragma unroll
-        for (int i = 0; i < HEAD_IMGS; ++i) acc[i] = 0.f;
-        for (int k = 0; k < W; ++k) {
-            const float pw = proj[(int64_t)k * out_dim + o];
+    for (int i = 0; i < HEAD_IMGS; ++i) acc[i] = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < W; ++k) {
+        const float pw = proj[(int64_t)k * out_dim + o];
 #pragma unroll
-            for (int i = 0; i < HEAD_IMGS; ++i) acc[i] = fmaf(y[i * W + k], pw, acc[i]);
-        }
+        for (int i = 0; i < HEAD_IMGS; ++i) acc[i] = fmaf(ys[i * W + k], pw, acc[i]);
+    }
 #pragma unroll
-        for (int i = 0; i < HEAD_IMGS; ++i) {
-            const int b = b0 + i;
-            if (b < B) out[(int64_t)b * (W + out_dim) + W + o] = bnp_s ? fmaf(acc[i], bnp_s[o], bnp_b[o]) : acc[i];
-        }
+    for (int i = 0; i < HEAD_IMGS; ++i) {
+        const int b = b0 + i;
+        if (b < B) out[(int64_t)b * (W + out_dim) + W + o] = bnp_s ? fmaf(acc[i], bnp_s[o], bnp_b[o]) : acc[i];
     }
 }
 
@@ -333,7 +408,7 @@ __global__ __launch_bounds__(256) void gather_cls_kernel(const float *__restrict
 // ---------------------------------------------------------------------------------------------
 struct VitLayout {
     int L, P, M, Mpad, MPpad, Kp, Bpad;
-    size_t patches, x, a, qkv, hbuf, x_cls, a_cls, h_cls, total;
+    size_t patches, x, a, qkv, hbuf, x_cls, a_cls, h_cls, y_cls, total;
 };
 
 static VitLayout vit_layout(const mpreid_vit_cfg *c, int B) {
@@ -360,6 +435,7 @@ static VitLayout vit_layout(const mpreid_vit_cfg *c, int B) {
     v.x_cls = take((size_t)v.Bpad * W * 4);
     v.a_cls = take((size_t)v.Bpad * W * 2);
     v.h_cls = take((size_t)v.Bpad * 4 * W * 2);
+    v.y_cls = take((size_t)v.Bpad * W * 4);
     v.total = off;
     return v;
 }
@@ -389,33 +465,61 @@ extern "C" size_t mpreid_vit_workspace_bytes(const mpreid_vit_cfg *cfg, int batc
     return vit_layout(cfg, batch).total;
 }
 
-template <int KTP>
+template <int KTP, int NW, bool EXACT>
 static int launch_attention(const _Float16 *qkv, int B, int L, int W, int heads, _Float16 *out, int q_tiles,
                             hipStream_t stream) {
     constexpr int KEYS = KTP * 16;
-    const size_t lds = (size_t)KEYS * 128 + (size_t)64 * (KEYS + 8) * 2;
+    const size_t lds = (size_t)2 * KEYS * 128 + (size_t)NW * 16 * 72 * 2;
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_kernel<KTP>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_kernel<KTP, NW, EXACT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    const int nqt = (q_tiles > 0) ? q_tiles : (L + 15) / 16;
-    const int maxw = (KTP <= 10) ? KTP : 8;     // one wave per 16-query tile when the block can hold them
-    const int nw = nqt < maxw ? nqt : maxw;
-    hipLaunchKernelGGL(attention_kernel<KTP>, dim3((unsigned)(B * heads)), dim3(64 * nw), lds, stream, qkv, L, W, heads,
-                       out, q_tiles);
+    // persistent grid: as many workgroups as fit the chip at once (LDS and the 4-waves/SIMD register
+    // bound), each walking pairs with stride gridDim
+    static int blocks_per_cu = 0;
+    if (blocks_per_cu == 0) {
+        int occ = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(attention_kernel<KTP, NW, EXACT>),
+                                                            64 * NW, lds));
+        blocks_per_cu = occ > 0 ? occ : 1;
+        if (getenv("MPREID_DEBUG"))
+            fprintf(stderr, "[mpreid] attention<%d,%d>: %d workgroups/CU by the occupancy API (lds %zu B, %d threads)\n", KTP,
+                    NW, occ, lds, 64 * NW);
+    }
+    int dev = 0, cus = 256;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int total = B * heads;
+    int grid = cus * blocks_per_cu;
+    if (grid > total) grid = total;
+    hipLaunchKernelGGL((attention_kernel<KTP, NW, EXACT>), dim3((unsigned)grid), dim3(64 * NW), lds, stream, qkv, L, W,
+                       heads, out, q_tiles, total, getenv("MPREID_ATT_DBG") ? atoi(getenv("MPREID_ATT_DBG")) : 0);
     LAUNCH_CHECK();
     return MPREID_OK;
 }
 
+// waves per workgroup: one per 16-query tile when the block can hold them; at least 4 so that the
+// K/V staging of a CLS-only call (one query tile) is still spread over 256 threads
 static int attention_dispatch(const _Float16 *qkv, int B, int L, int W, int heads, _Float16 *out, int q_tiles,
                               hipStream_t stream) {
     const int kt = (L + 15) / 16;
-    if (kt <= 2) return launch_attention<2>(qkv, B, L, W, heads, out, q_tiles, stream);
-    if (kt <= 10) return launch_attention<10>(qkv, B, L, W, heads, out, q_tiles, stream);
-    if (kt <= 14) return launch_attention<14>(qkv, B, L, W, heads, out, q_tiles, stream);
-    return launch_attention<16>(qkv, B, L, W, heads, out, q_tiles, stream);
+    const int nqt = (q_tiles > 0) ? q_tiles : kt;
+    if (kt <= 2) return launch_attention<2, 2, true>(qkv, B, L, W, heads, out, q_tiles, stream);
+    if (kt <= 10) {
+        const bool exact = kt >= 9;
+        if (nqt > 4) // 8 waves: two workgroups per CU under the 4-waves/SIMD register bound (wave 0 takes tile 8 too)
+            return exact ? launch_attention<10, 8, true>(qkv, B, L, W, heads, out, q_tiles, stream)
+                         : launch_attention<10, 8, false>(qkv, B, L, W, heads, out, q_tiles, stream);
+        return exact ? launch_attention<10, 4, true>(qkv, B, L, W, heads, out, q_tiles, stream)
+                     : launch_attention<10, 4, false>(qkv, B, L, W, heads, out, q_tiles, stream);
+    }
+    if (kt <= 14)
+        return kt >= 13 ? launch_attention<14, 8, true>(qkv, B, L, W, heads, out, q_tiles, stream)
+                        : launch_attention<14, 8, false>(qkv, B, L, W, heads, out, q_tiles, stream);
+    return kt >= 15 ? launch_attention<16, 8, true>(qkv, B, L, W, heads, out, q_tiles, stream)
+                    : launch_attention<16, 8, false>(qkv, B, L, W, heads, out, q_tiles, stream);
 }
 
 extern "C" int mpreid_vit_forward(const mpreid_vit_cfg *cfg, const mpreid_vit_weights *w, const float *img, int B,
@@ -440,6 +544,7 @@ extern "C" int mpreid_vit_forward(const mpreid_vit_cfg *cfg, const mpreid_vit_we
     float *x_cls = (float *)(base + v.x_cls);
     _Float16 *a_cls = (_Float16 *)(base + v.a_cls);
     _Float16 *h_cls = (_Float16 *)(base + v.h_cls);
+    float *y_cls = (float *)(base + v.y_cls);
     const bool cls_last = cfg->cls_only_last != 0 && cfg->layers > 0;
 
     // patch embedding (conv1, no bias) + positional embedding; CLS row; ln_pre
@@ -509,11 +614,12 @@ extern "C" int mpreid_vit_forward(const mpreid_vit_cfg *cfg, const mpreid_vit_we
         if ((rc = launch_gemm_f16(g, GE_BIAS_RES, stream))) return rc;
     }
     const bool neck = cfg->neck_after != 0 && w->bn_scale && w->bn_proj_scale;
-    hipLaunchKernelGGL(head_kernel, dim3((unsigned)((B + HEAD_IMGS - 1) / HEAD_IMGS)), dim3(256),
-                       (size_t)HEAD_IMGS * W * 4, stream, cls_last ? x_cls : x, cls_last ? (int64_t)W : (int64_t)L * W, B, W,
-                       cfg->out_dim, w->ln_post_g, w->ln_post_b, w->proj, neck ? w->bn_scale : nullptr,
-                       neck ? w->bn_shift : nullptr, neck ? w->bn_proj_scale : nullptr,
-                       neck ? w->bn_proj_shift : nullptr, out);
+    hipLaunchKernelGGL(cls_ln_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, cls_last ? x_cls : x,
+                       cls_last ? (int64_t)W : (int64_t)L * W, B, W, cfg->out_dim, w->ln_post_g, w->ln_post_b,
+                       neck ? w->bn_scale : nullptr, neck ? w->bn_shift : nullptr, y_cls, out);
+    hipLaunchKernelGGL(cls_proj_kernel, dim3((unsigned)((B + HEAD_IMGS - 1) / HEAD_IMGS), (unsigned)((cfg->out_dim + 255) / 256)),
+                       dim3(256), (size_t)HEAD_IMGS * W * 4, stream, y_cls, B, W, cfg->out_dim, w->proj,
+                       neck ? w->bn_proj_scale : nullptr, neck ? w->bn_proj_shift : nullptr, out);
     LAUNCH_CHECK();
     return MPREID_OK;
 }

@@ -21,6 +21,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Wall", "-Wno-unused-function", "-x", "hip"]
 
 
+# The encoder is a floating-point kernel with a stated tolerance: assuming finite values there removes the
+# NaN-canonicalising v_max before every fmaxf.  (distance.hip / rerank.hip keep strict IEEE semantics.)
+EXTRA_FLAGS = {"vit.hip": ["-ffinite-math-only", "-fno-signed-zeros"]}
+
+
 def _deps(src):
     d = [os.path.join(CSRC, src), os.path.join(CSRC, "common.h")]
     inc = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include")
@@ -46,8 +51,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise FileNotFoundError(src)
         obj = os.path.join(OBJ, src.rsplit(".", 1)[0] + ".o")
         objs.append(obj)
-        if force or _stale(obj, _deps(src)):
-            jobs.append([hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj])
+        if force or _stale(obj, _deps(src) + [os.path.abspath(__file__)]):
+            jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj])
 
     def run(cmd):
         if verbose:
