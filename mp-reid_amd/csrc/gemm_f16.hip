@@ -243,24 +243,39 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
 constexpr int BBM = 256, BBN = 256, BBK = 32, B_NSTAGE = 4;
 constexpr int B_PART_BYTES = BBM * BBK * 2;          // 16 KB
 constexpr int B_STAGE_BYTES = 2 * B_PART_BYTES;      // 32 KB
-constexpr int B_LDS_BYTES = B_NSTAGE * B_STAGE_BYTES; // 128 KB
+constexpr int B_LDS_BYTES = B_NSTAGE * B_STAGE_BYTES; // 128 KB ring
+constexpr int B_LDS_TOTAL = B_LDS_BYTES + 8 * 4096;   // + 32 KB of epilogue patches = the CU's whole 160 KB
 
-template <int EPI>
+// DBG (timing-only ablation builds, never used by the product path): 1 no DMA in the steady loop,
+// 2 no MFMA, 4 no fragment reads in the steady loop, 8 no epilogue
+template <int EPI, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int tm, tn;
-    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, 8, tm, tn);
-    const int m0 = tm * BBM, n0 = tn * BBN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int K = g.K;
+    const int nst = K / BBK; // even (K is a multiple of 64)
+
+    // PERSISTENT: gridDim.x workgroups (one per CU) walk the tiles with stride gridDim.x.  The workgroups
+    // of one XCD (blockIdx % 8) take neighbouring tiles of every sweep (private-L2 locality only).
+    const int ntiles = tiles_m * tiles_n;
+    const int nb = (int)gridDim.x;
+    const int slot = (nb % 8 == 0) ? (int)(blockIdx.x & 7) * (nb >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
 
     // ---- DMA: wave w moves rows [32w, 32w+32) of the A part and of the B part of every stage ----
     const int drow = lane >> 2;                                     // row inside a 16-row DMA piece
     const int dchunk = (lane & 3) ^ (((drow >> 3) & 1) * 3);        // source chunk for LDS slot lane&3
-    const _Float16 *a_src = g.A + (int64_t)(m0 + wave * 32 + drow) * K + dchunk * 8;
-    const _Float16 *b_src = g.W + (int64_t)(n0 + wave * 32 + drow) * K + dchunk * 8;
+    const _Float16 *a_src = nullptr, *b_src = nullptr;
+    int m0 = 0, n0 = 0;
+    auto set_tile = [&](int tile) {
+        int tm, tn;
+        tile_coords((unsigned)tile, tiles_m, tiles_n, 8, tm, tn);
+        m0 = tm * BBM;
+        n0 = tn * BBN;
+        a_src = g.A + (int64_t)(m0 + wave * 32 + drow) * K + dchunk * 8;
+        b_src = g.W + (int64_t)(n0 + wave * 32 + drow) * K + dchunk * 8;
+    };
     auto dma_stage = [&](int st) {
         unsigned char *abase = smem + (st & (B_NSTAGE - 1)) * B_STAGE_BYTES + wave * 2048;
         unsigned char *bbase = abase + B_PART_BYTES;
@@ -269,6 +284,11 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
         dma16(a_src + (int64_t)16 * K + koff, abase + 1024);
         dma16(b_src + koff, bbase);
         dma16(b_src + (int64_t)16 * K + koff, bbase + 1024);
+    };
+    auto dma_prologue = [&]() {
+        dma_stage(0);
+        if (1 < nst) dma_stage(1);
+        if (2 < nst) dma_stage(2);
     };
 
     // ---- fragment addresses ----
@@ -284,16 +304,19 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
         for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const f16x8 *>(sb + a_off + i * 1024);
     };
 
+    int tile = slot;
+    if (tile >= ntiles) return;
+    set_tile(tile);
+    dma_prologue();
+    for (;;) {
     f32x4 acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nst = K / BBK; // even (K is a multiple of 64)
-    dma_stage(0);
-    if (1 < nst) dma_stage(1);
-    if (2 < nst) dma_stage(2);
+    // stage 0 of this tile has landed everywhere (its DMA was issued before the previous tile's last
+    // stores drained, or at kernel start); in-order vmcnt also retires every older store
     if (nst > 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
 
@@ -320,26 +343,30 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
 #define MPREID_FRAG_B(j) nb[j] = *reinterpret_cast<const f16x8 *>(sb + b_off + (j) * 1024)
 #define MPREID_FRAG_A(i) na[i] = *reinterpret_cast<const f16x8 *>(sb + a_off + (i) * 1024)
 #define MPREID_MFMA_ROWS(i0)                                                                             \
-    _Pragma("unroll") for (int ii = (i0); ii < (i0) + 2; ++ii) _Pragma("unroll") for (int j = 0; j < 4; ++j) \
-        acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[ii], fb[j], acc[ii][j], 0, 0, 0)
+    _Pragma("unroll") for (int ii = (i0); ii < (i0) + 2; ++ii) _Pragma("unroll") for (int j = 0; j < 4; ++j) { \
+        if constexpr (!(DBG & 2))                                                                        \
+            acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[ii], fb[j], acc[ii][j], 0, 0, 0);       \
+        else                                                                                             \
+            asm volatile("" ::"v"(fa[ii]), "v"(fb[j]));                                                  \
+    }
         // group 0
-        dma16(a_src + koff, dbase);
-        MPREID_FRAG_B(0); MPREID_FRAG_B(1); MPREID_FRAG_B(2);
+        if constexpr (!(DBG & 1)) dma16(a_src + koff, dbase);
+        if constexpr (!(DBG & 4)) { MPREID_FRAG_B(0); MPREID_FRAG_B(1); MPREID_FRAG_B(2); }
         MPREID_MFMA_ROWS(0);
         __builtin_amdgcn_sched_barrier(0);
         // group 1
-        dma16(a_src + (int64_t)16 * K + koff, dbase + 1024);
-        MPREID_FRAG_B(3); MPREID_FRAG_A(0); MPREID_FRAG_A(1);
+        if constexpr (!(DBG & 1)) dma16(a_src + (int64_t)16 * K + koff, dbase + 1024);
+        if constexpr (!(DBG & 4)) { MPREID_FRAG_B(3); MPREID_FRAG_A(0); MPREID_FRAG_A(1); }
         MPREID_MFMA_ROWS(2);
         __builtin_amdgcn_sched_barrier(0);
         // group 2
-        dma16(b_src + koff, dbase + B_PART_BYTES);
-        MPREID_FRAG_A(2); MPREID_FRAG_A(3); MPREID_FRAG_A(4);
+        if constexpr (!(DBG & 1)) dma16(b_src + koff, dbase + B_PART_BYTES);
+        if constexpr (!(DBG & 4)) { MPREID_FRAG_A(2); MPREID_FRAG_A(3); MPREID_FRAG_A(4); }
         MPREID_MFMA_ROWS(4);
         __builtin_amdgcn_sched_barrier(0);
         // group 3
-        dma16(b_src + (int64_t)16 * K + koff, dbase + B_PART_BYTES + 1024);
-        MPREID_FRAG_A(5); MPREID_FRAG_A(6); MPREID_FRAG_A(7);
+        if constexpr (!(DBG & 1)) dma16(b_src + (int64_t)16 * K + koff, dbase + B_PART_BYTES + 1024);
+        if constexpr (!(DBG & 4)) { MPREID_FRAG_A(5); MPREID_FRAG_A(6); MPREID_FRAG_A(7); }
         MPREID_MFMA_ROWS(6);
         __builtin_amdgcn_sched_barrier(0);
 #undef MPREID_FRAG_A
@@ -365,66 +392,85 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
         step_tail(t + 1, fa1, fb1, fa0, fb0);
     }
 
-    // ---- epilogue (LDS is free after this barrier) ----
+    // ---- epilogue.  The accumulators leave through wave-private patches in the 32 KB of LDS above the
+    // ring, so the ring itself is free for the next tile's first stages as soon as every wave has passed
+    // this barrier ----
     __syncthreads();
-    if constexpr (EPI == GE_BIAS_F16 || EPI == GE_BIAS_GELU) {
-        _Float16 *wreg = reinterpret_cast<_Float16 *>(smem) + wave * (64 * 72);
+    const int cur_m0 = m0, cur_n0 = n0;
+    const int next_tile = tile + nb;
+    unsigned char *patch = smem + B_LDS_BYTES;
+    if constexpr (DBG & 8) {
+        // keep EVERY accumulator live (rule 17: a skipped consumer lets the compiler delete the MFMAs too)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+    } else if constexpr (EPI == GE_BIAS_F16 || EPI == GE_BIAS_GELU) {
+        // one 16-row MFMA tile row per pass: patch [16][72] halfs (2304 B) -> two 16-byte row pieces per lane
+        _Float16 *wreg = reinterpret_cast<_Float16 *>(patch + wave * 4096);
         _Float16 *out = reinterpret_cast<_Float16 *>(g.out);
+        float bias[4];
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int j = 0; j < 4; ++j) bias[j] = g.bias[cur_n0 + wc * 64 + j * 16 + frow];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float bias = g.bias[n0 + wc * 64 + j * 16 + frow];
+        for (int i = 0; i < 8; ++i) {
 #pragma unroll
-                for (int ii = 0; ii < 4; ++ii)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = acc[half * 4 + ii][j][r] + bias;
-                        if (EPI == GE_BIAS_GELU) v = quick_gelu(v);
-                        wreg[(ii * 16 + fq * 4 + r) * 72 + j * 16 + frow] = (_Float16)v;
-                    }
-            }
-            __syncthreads();
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[i][j][r] + bias[j];
+                    if (EPI == GE_BIAS_GELU) v = quick_gelu(v);
+                    wreg[(fq * 4 + r) * 72 + j * 16 + frow] = (_Float16)v;
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
+            for (int it = 0; it < 2; ++it) {
                 const int lr = it * 8 + (lane >> 3), ch = lane & 7;
                 const uint4 v = *reinterpret_cast<const uint4 *>(wreg + lr * 72 + ch * 8);
-                *reinterpret_cast<uint4 *>(out + (int64_t)(m0 + wr * 128 + half * 64 + lr) * g.ldo + n0 + wc * 64 +
+                *reinterpret_cast<uint4 *>(out + (int64_t)(cur_m0 + wr * 128 + i * 16 + lr) * g.ldo + cur_n0 + wc * 64 +
                                            ch * 8) = v;
             }
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
         }
     } else {
-        float *wreg = reinterpret_cast<float *>(smem) + wave * (32 * 68);
+        // fp32 outputs: patch [16][64] floats (4 KB) per pass
+        float *wreg = reinterpret_cast<float *>(patch + wave * 4096);
         float *outp = reinterpret_cast<float *>(g.out);
         const bool vec_ok = (g.ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(outp) & 15) == 0);
-        const int nbase = n0 + wc * 64;
+        const int nbase = cur_n0 + wc * 64;
+        const int c4 = (lane & 15) * 4;
+        float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), bn4 = bias4;
+        float bias1 = 0.f, bnv1 = 0.f;
+        if (vec_ok) {
+            if (EPI == GE_BIAS_RES) bias4 = *reinterpret_cast<const float4 *>(g.bias + nbase + c4);
+            if (EPI == GE_EUCLID) {
+                bn4.x = (nbase + c4 + 0 < g.n_valid) ? g.aux2[nbase + c4 + 0] : 0.f;
+                bn4.y = (nbase + c4 + 1 < g.n_valid) ? g.aux2[nbase + c4 + 1] : 0.f;
+                bn4.z = (nbase + c4 + 2 < g.n_valid) ? g.aux2[nbase + c4 + 2] : 0.f;
+                bn4.w = (nbase + c4 + 3 < g.n_valid) ? g.aux2[nbase + c4 + 3] : 0.f;
+            }
+        } else {
+            if (EPI == GE_BIAS_RES) bias1 = g.bias[nbase + lane];
+            if (EPI == GE_EUCLID) bnv1 = (nbase + lane < g.n_valid) ? g.aux2[nbase + lane] : 0.f;
+        }
 #pragma unroll
-        for (int part = 0; part < 4; ++part) {
+        for (int i = 0; i < 8; ++i) {
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        wreg[(ii * 16 + fq * 4 + r) * 68 + j * 16 + frow] = acc[part * 2 + ii][j][r];
-            __syncthreads();
-            const int mbase = m0 + wr * 128 + part * 32;
+                for (int r = 0; r < 4; ++r) wreg[(fq * 4 + r) * 64 + j * 16 + frow] = acc[i][j][r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int mbase = cur_m0 + wr * 128 + i * 16;
             if (vec_ok) {
-                const int c4 = (lane & 15) * 4;
-                float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), bn4 = bias4;
-                if (EPI == GE_BIAS_RES) bias4 = *reinterpret_cast<const float4 *>(g.bias + nbase + c4);
-                if (EPI == GE_EUCLID) {
-                    bn4.x = (nbase + c4 + 0 < g.n_valid) ? g.aux2[nbase + c4 + 0] : 0.f;
-                    bn4.y = (nbase + c4 + 1 < g.n_valid) ? g.aux2[nbase + c4 + 1] : 0.f;
-                    bn4.z = (nbase + c4 + 2 < g.n_valid) ? g.aux2[nbase + c4 + 2] : 0.f;
-                    bn4.w = (nbase + c4 + 3 < g.n_valid) ? g.aux2[nbase + c4 + 3] : 0.f;
-                }
 #pragma unroll
-                for (int it = 0; it < 8; ++it) {
+                for (int it = 0; it < 4; ++it) {
                     const int lr = it * 4 + (lane >> 4);
                     const int m = mbase + lr;
-                    const float4 a = *reinterpret_cast<const float4 *>(wreg + lr * 68 + c4);
+                    const float4 a = *reinterpret_cast<const float4 *>(wreg + lr * 64 + c4);
                     float *dst = outp + (int64_t)m * g.ldo + nbase + c4;
                     if (EPI == GE_F32) {
                         *reinterpret_cast<float4 *>(dst) = a;
@@ -453,24 +499,187 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
                 }
             } else {
                 const int n = nbase + lane;
-                float bias = 0.f, bnv = 0.f;
-                if (EPI == GE_BIAS_RES) bias = g.bias[n];
-                if (EPI == GE_EUCLID) bnv = (n < g.n_valid) ? g.aux2[n] : 0.f;
 #pragma unroll 4
-                for (int lr = 0; lr < 32; ++lr) {
+                for (int lr = 0; lr < 16; ++lr) {
                     const int m = mbase + lr;
-                    const float a = wreg[lr * 68 + lane];
+                    const float a = wreg[lr * 64 + lane];
                     float *dst = outp + (int64_t)m * g.ldo + n;
                     if (EPI == GE_F32) {
                         *dst = a;
                     } else if (EPI == GE_BIAS_RES) {
-                        *dst = *dst + (a + bias);
+                        *dst = *dst + (a + bias1);
                     } else if (m < g.m_valid && n < g.n_valid) {
-                        *dst = fmaf(-2.0f, a, g.aux[m] + bnv);
+                        *dst = fmaf(-2.0f, a, g.aux[m] + bnv1);
                     }
                 }
             }
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // next tile: its first three DMA stages go out right behind this tile's stores (the ring was released by
+    // the barrier above), so their cold latency overlaps the store drain
+    tile = next_tile;
+    if (tile >= ntiles) break;
+    set_tile(tile);
+    dma_prologue();
+    } // tiles
+}
+
+// ---------------------------------------------------------------------------------------------
+// "p2" kernel: PERSISTENT, two independent 4-wave workgroups per CU.
+//   tile 256 (M) x 128 (N), waves 2 x 2 (128 x 64 per wave, same fragment code as the big kernel),
+//   K in 32-wide stages, 3-slot LDS ring per workgroup (3 x 24 KB = 72 KB -> two workgroups per CU),
+//   LDS-DMA two stages ahead, counted vmcnt + raw s_barrier, one barrier per 32 MFMAs.
+// Why: the ablation of the one-workgroup-per-CU kernel (tools/gemm_bench.py, MPREID_GEMM_DBG) showed
+// its MFMA loop near the clock-limited ceiling while ~45 % of the time went to phases in which the
+// matrix pipe idles: workgroup dispatch + cold prologue (52 us of 260 on the QKV shape) and the
+// epilogue, which is simply the HBM time of the output (50-63 us).  Two workgroups per CU that walk
+// tiles out of phase (odd workgroups start half a tile late) put one's epilogue/prologue beside the
+// other's MFMA loop.
+// ---------------------------------------------------------------------------------------------
+constexpr int PBM = 256, PBN = 128, PBK = 32, P_NSTAGE = 3;
+constexpr int P_A_BYTES = PBM * PBK * 2;                 // 16 KB
+constexpr int P_B_BYTES = PBN * PBK * 2;                 // 8 KB
+constexpr int P_STAGE_BYTES = P_A_BYTES + P_B_BYTES;     // 24 KB
+constexpr int P_LDS_BYTES = P_NSTAGE * P_STAGE_BYTES;    // 72 KB
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_f16_p2_kernel(GemmArgs g, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int K = g.K;
+    const int nst = K / PBK;
+    const int ntiles = tiles_m * tiles_n;
+    const int nb = (int)gridDim.x;
+    // logical tile order: the workgroups of one XCD (blockIdx % 8) take neighbouring tiles of every sweep
+    const int per_xcd = nb >> 3;
+    const int slot = (nb % 8 == 0) ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+
+    // odd workgroups start half a main loop late (once), so that the two workgroups of a CU alternate
+    // between the MFMA loop and the memory-bound epilogue / prologue
+    if (blockIdx.x & 8) {
+        const int naps = nst * 6; // ~ half of nst stages x ~800 cycles, in units of s_sleep 1 (64 cycles)
+        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(1);
+    }
+
+    // DMA geometry: one piece = 16 rows x 64 B.  A part: 16 pieces, wave w takes 4w..4w+3; B part: 8 pieces,
+    // wave w takes 2w, 2w+1.
+    const int drow = lane >> 2;
+    const int dchunk = (lane & 3) ^ (((drow >> 3) & 1) * 3);
+    const int frow = lane & 15, fq = lane >> 4;
+    const int fsw = (fq ^ (((lane >> 3) & 1) * 3)) << 4;
+    const int a_off = (wr * 128 + frow) * 64 + fsw;                // + i * 1024
+    const int b_off = P_A_BYTES + (wc * 64 + frow) * 64 + fsw;     // + j * 1024
+
+    for (int tile = slot; tile < ntiles; tile += nb) {
+        int tm, tn;
+        tile_coords((unsigned)tile, tiles_m, tiles_n, 8, tm, tn);
+        const int m0 = tm * PBM, n0 = tn * PBN;
+        const _Float16 *a_src = g.A + (int64_t)(m0 + wave * 64 + drow) * K + dchunk * 8;
+        const _Float16 *b_src = g.W + (int64_t)(n0 + wave * 32 + drow) * K + dchunk * 8;
+        auto dma_stage = [&](int st) {
+            unsigned char *sb = smem + (st % P_NSTAGE) * P_STAGE_BYTES;
+            const int koff = st * PBK;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dma16(a_src + (int64_t)t * 16 * K + koff, sb + wave * 4096 + t * 1024);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                dma16(b_src + (int64_t)t * 16 * K + koff, sb + P_A_BYTES + wave * 2048 + t * 1024);
+        };
+
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        __syncthreads(); // previous tile's epilogue is done with the LDS (also drains its stores)
+        dma_stage(0);
+        if (nst > 1) dma_stage(1);
+        for (int t = 0; t < nst; ++t) {
+            // stage t landed everywhere (stage t+1 may stay in flight); slot (t+2)%3 = slot of stage t-1 is free
+            if (t + 1 < nst) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (t + 2 < nst) dma_stage(t + 2);
+            const unsigned char *sb = smem + (t % P_NSTAGE) * P_STAGE_BYTES;
+            f16x8 fa[8], fb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const f16x8 *>(sb + b_off + j * 1024);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const f16x8 *>(sb + a_off + i * 1024);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+
+        // ---- epilogue (through LDS patches private to each wave) ----
+        __syncthreads();
+        if constexpr (EPI == GE_BIAS_F16 || EPI == GE_BIAS_GELU) {
+            _Float16 *wreg = reinterpret_cast<_Float16 *>(smem) + wave * (64 * 72);
+            _Float16 *out = reinterpret_cast<_Float16 *>(g.out);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float bias = g.bias[n0 + wc * 64 + j * 16 + frow];
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float v = acc[half * 4 + ii][j][r] + bias;
+                            if (EPI == GE_BIAS_GELU) v = quick_gelu(v);
+                            wreg[(ii * 16 + fq * 4 + r) * 72 + j * 16 + frow] = (_Float16)v;
+                        }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int lr = it * 8 + (lane >> 3), ch = lane & 7;
+                    const uint4 v = *reinterpret_cast<const uint4 *>(wreg + lr * 72 + ch * 8);
+                    *reinterpret_cast<uint4 *>(out + (int64_t)(m0 + wr * 128 + half * 64 + lr) * g.ldo + n0 + wc * 64 +
+                                               ch * 8) = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else { // GE_BIAS_RES (fp32 read-modify-write, ldo % 4 == 0 checked by the launcher)
+            float *wreg = reinterpret_cast<float *>(smem) + wave * (32 * 68);
+            float *outp = reinterpret_cast<float *>(g.out);
+            const int nbase = n0 + wc * 64;
+            const int c4 = (lane & 15) * 4;
+            const float4 bias4 = *reinterpret_cast<const float4 *>(g.bias + nbase + c4);
+#pragma unroll
+            for (int part = 0; part < 4; ++part) {
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            wreg[(ii * 16 + fq * 4 + r) * 68 + j * 16 + frow] = acc[part * 2 + ii][j][r];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int mbase = m0 + wr * 128 + part * 32;
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int lr = it * 4 + (lane >> 4);
+                    const float4 a = *reinterpret_cast<const float4 *>(wreg + lr * 68 + c4);
+                    float *dst = outp + (int64_t)(mbase + lr) * g.ldo + nbase + c4;
+                    float4 x = *reinterpret_cast<const float4 *>(dst);
+                    x.x = x.x + (a.x + bias4.x);
+                    x.y = x.y + (a.y + bias4.y);
+                    x.z = x.z + (a.z + bias4.z);
+                    x.w = x.w + (a.w + bias4.w);
+                    *reinterpret_cast<float4 *>(dst) = x;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
         }
     }
 }
@@ -566,8 +775,46 @@ static int launch_one(const GemmArgs &a, hipStream_t stream) {
     if (HAS_BIG && !big_attr_set) {
         if constexpr (HAS_BIG)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_big_kernel<EPI>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_BYTES));
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_TOTAL));
         big_attr_set = true;
+    }
+    // MPREID_GEMM_BIG=3: persistent two-workgroups-per-CU kernel (bias->f16, GELU, residual epilogues)
+    constexpr bool HAS_P2 = (EPI == GE_BIAS_F16 || EPI == GE_BIAS_RES || EPI == GE_BIAS_GELU);
+    const bool use_p2 = HAS_P2 && bm == 3 && (a.M % PBM == 0) && (a.N % PBN == 0) && (a.ldo % 4 == 0) &&
+                        ((int64_t)(a.M / PBM) * (a.N / PBN) >= 512);
+    if (use_p2) {
+        if constexpr (HAS_P2) {
+            static bool p2_attr = false;
+            static int p2_grid = 512;
+            if (!p2_attr) {
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_p2_kernel<EPI>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES));
+                int dev = 0, cus = 256;
+                HIP_TRY(hipGetDevice(&dev));
+                HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+                p2_grid = 2 * cus;
+                p2_attr = true;
+            }
+            const int ptm = a.M / PBM, ptn = a.N / PBN;
+            hipEvent_t pe0 = nullptr, pe1 = nullptr;
+            if (g_prof_on) {
+                HIP_TRY(hipEventCreate(&pe0));
+                HIP_TRY(hipEventCreate(&pe1));
+                HIP_TRY(hipEventRecord(pe0, stream));
+            }
+            hipLaunchKernelGGL(gemm_f16_p2_kernel<EPI>, dim3((unsigned)p2_grid), dim3(256), P_LDS_BYTES, stream, a, ptm,
+                               ptn);
+            LAUNCH_CHECK();
+            if (pe0) {
+                HIP_TRY(hipEventRecord(pe1, stream));
+                std::lock_guard<std::mutex> lk(g_prof_mu);
+                ProfClass &pc = g_prof[std::make_tuple(EPI, a.N, a.K)];
+                pc.ev.emplace_back(pe0, pe1);
+                pc.m = std::max<int64_t>(pc.m, a.M);
+                pc.flops_total += 2.0 * (double)a.M * (double)a.N * (double)a.K;
+            }
+            return MPREID_OK;
+        }
     }
     const int tiles_m = use_big ? a.M / BBM : a.M / GBM, tiles_n = use_big ? a.N / BBN : a.N / GBN;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -577,9 +824,40 @@ static int launch_one(const GemmArgs &a, hipStream_t stream) {
         HIP_TRY(hipEventRecord(e0, stream));
     }
     if (use_big) {
-        if constexpr (HAS_BIG)
-            hipLaunchKernelGGL(gemm_f16_big_kernel<EPI>, dim3((unsigned)tiles_m * (unsigned)tiles_n), dim3(512),
-                               B_LDS_BYTES, stream, a, tiles_m, tiles_n);
+        if constexpr (HAS_BIG) {
+            static const int dbg = getenv("MPREID_GEMM_DBG") ? atoi(getenv("MPREID_GEMM_DBG")) : 0;
+            // persistent: one workgroup per CU (the kernel owns the CU's whole LDS), each walking tiles
+            static int big_cus = 0;
+            if (big_cus == 0) {
+                int dev = 0;
+                HIP_TRY(hipGetDevice(&dev));
+                HIP_TRY(hipDeviceGetAttribute(&big_cus, hipDeviceAttributeMultiprocessorCount, dev));
+            }
+            const unsigned total_tiles = (unsigned)tiles_m * (unsigned)tiles_n;
+            const dim3 grid(total_tiles < (unsigned)big_cus ? total_tiles : (unsigned)big_cus);
+            if constexpr (EPI == GE_BIAS_F16) {
+#define MPREID_DBG_CASE(D)                                                                                  \
+    case D: {                                                                                               \
+        static bool once = false;                                                                           \
+        if (!once) {                                                                                        \
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_big_kernel<EPI, D>),        \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_TOTAL));          \
+            once = true;                                                                                    \
+        }                                                                                                   \
+        hipLaunchKernelGGL((gemm_f16_big_kernel<EPI, D>), grid, dim3(512), B_LDS_TOTAL, stream, a, tiles_m, tiles_n); \
+        break;                                                                                              \
+    }
+                switch (dbg) {
+                    MPREID_DBG_CASE(1) MPREID_DBG_CASE(2) MPREID_DBG_CASE(3) MPREID_DBG_CASE(4) MPREID_DBG_CASE(5)
+                    MPREID_DBG_CASE(7) MPREID_DBG_CASE(8) MPREID_DBG_CASE(9) MPREID_DBG_CASE(15)
+                default:
+                    hipLaunchKernelGGL(gemm_f16_big_kernel<EPI>, grid, dim3(512), B_LDS_TOTAL, stream, a, tiles_m, tiles_n);
+                }
+#undef MPREID_DBG_CASE
+            } else {
+                hipLaunchKernelGGL(gemm_f16_big_kernel<EPI>, grid, dim3(512), B_LDS_TOTAL, stream, a, tiles_m, tiles_n);
+            }
+        }
     } else {
         hipLaunchKernelGGL(gemm_f16_kernel<EPI>, dim3((unsigned)tiles_m * (unsigned)tiles_n), dim3(256), G_LDS_BYTES,
                            stream, a, tiles_m, tiles_n);
