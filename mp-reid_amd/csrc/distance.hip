@@ -74,17 +74,31 @@ __device__ __forceinline__ float4 load_k4(const float *__restrict__ base, int64_
     return v;
 }
 
-template <int EPI>
+// SYM: A == B (all-pairs distance of one feature set).  D is bit-symmetric (same k-ascending chain for
+// (i,j) and (j,i), commutative norm sum), so only tiles with tn >= tm are computed; off-diagonal tiles
+// are also written mirrored, transposed through LDS so that the mirrored rows leave as 128-byte pieces.
+template <int EPI, bool SYM>
 __global__ __launch_bounds__(256) void gemm_f32_exact_kernel(const float *__restrict__ A, const float *__restrict__ B,
                                                              int64_t M, int64_t N, int K,
                                                              const float *__restrict__ an,
                                                              const float *__restrict__ bn, float *__restrict__ C,
                                                              int64_t ldc, int tiles_m, int tiles_n, int vec_ok) {
-    __shared__ float As[2][XBK][XLD];
-    __shared__ float Bs[2][XBK][XLD];
+    __shared__ float Sm[2][2][XBK][XLD]; // one object: A stages, then B stages (33,792 B, reused by the mirror)
+    float (&As)[2][XBK][XLD] = Sm[0];
+    float (&Bs)[2][XBK][XLD] = Sm[1];
 
     int tm, tn;
-    tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, 8, tm, tn);
+    if (SYM) {
+        // upper triangle enumerated column by column: id = tn*(tn+1)/2 + tm, tm <= tn
+        const unsigned id = blockIdx.x;
+        int c = (int)((__fsqrt_rn(8.0f * (float)id + 1.0f) - 1.0f) * 0.5f);
+        while ((unsigned)(c + 1) * (unsigned)(c + 2) / 2u <= id) ++c;
+        while ((unsigned)c * (unsigned)(c + 1) / 2u > id) --c;
+        tn = c;
+        tm = (int)(id - (unsigned)c * (unsigned)(c + 1) / 2u);
+    } else {
+        tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, 8, tm, tn);
+    }
     const int64_t m0 = (int64_t)tm * XBM, n0 = (int64_t)tn * XBN;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -173,7 +187,36 @@ __global__ __launch_bounds__(256) void gemm_f32_exact_kernel(const float *__rest
                     v = acosf(c);
                 }
                 C[row * ldc + col] = v;
+                if (SYM) acc[i][j][r] = v; // keep the finished value for the mirrored write
             }
+        }
+    }
+    if (SYM && tm != tn) {
+        // mirrored tile: C[col][row] = C[row][col].  Each wave transposes its 64 x 64 block in two halves of
+        // 32 rows through a private [64 cols][33] LDS patch (the staging buffers are free now).
+        __syncthreads();
+        static_assert(sizeof(Sm) >= 4 * 64 * 33 * sizeof(float), "mirror patches must fit the staging buffers");
+        float *patch = &Sm[0][0][0][0] + wave * (64 * 33); // 4 x 8448 B
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    patch[(j * 32 + li) * 33 + (r & 3) + 8 * (r >> 2) + 4 * lh] = acc[i][j][r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // lanes 0..31 -> 32 consecutive original rows (= mirrored columns), lanes 32..63 the next column
+            const int64_t mrow0 = m0 + wm * 64 + i * 32;
+#pragma unroll 4
+            for (int cc = 0; cc < 64; cc += 2) {
+                const int cidx = cc + lh;
+                const int64_t col = n0 + wn * 64 + cidx; // original column = mirrored row
+                const int64_t row = mrow0 + li;          // original row = mirrored column
+                if (col < N && row < M) C[col * ldc + row] = patch[cidx * 33 + li];
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -217,12 +260,17 @@ int mpreid_distance_launch(const float *q, const float *g, int64_t nq, int64_t n
     const int tiles_m = (int)((nq + XBM - 1) / XBM), tiles_n = (int)((ng + XBN - 1) / XBN);
     const int vec_ok = (d % 4 == 0) && (((uintptr_t)q | (uintptr_t)g) % 16 == 0);
     const dim3 grid((unsigned)tiles_m * (unsigned)tiles_n);
-    if (epi == EPI_EUCLID)
-        hipLaunchKernelGGL(gemm_f32_exact_kernel<EPI_EUCLID>, grid, dim3(256), 0, stream, q, g, nq, ng, d, qn, gn, out,
-                           ldo, tiles_m, tiles_n, vec_ok);
+    if (epi == EPI_EUCLID && q == g && nq == ng && qn == gn) {
+        // all-pairs distance of one set: upper-triangular tiles + mirrored writes
+        const dim3 tri((unsigned)tiles_m * (unsigned)(tiles_m + 1) / 2u);
+        hipLaunchKernelGGL((gemm_f32_exact_kernel<EPI_EUCLID, true>), tri, dim3(256), 0, stream, q, g, nq, ng, d, qn, gn,
+                           out, ldo, tiles_m, tiles_n, vec_ok);
+    } else if (epi == EPI_EUCLID)
+        hipLaunchKernelGGL((gemm_f32_exact_kernel<EPI_EUCLID, false>), grid, dim3(256), 0, stream, q, g, nq, ng, d, qn,
+                           gn, out, ldo, tiles_m, tiles_n, vec_ok);
     else
-        hipLaunchKernelGGL(gemm_f32_exact_kernel<EPI_COSINE>, grid, dim3(256), 0, stream, q, g, nq, ng, d, qn, gn, out,
-                           ldo, tiles_m, tiles_n, vec_ok);
+        hipLaunchKernelGGL((gemm_f32_exact_kernel<EPI_COSINE, false>), grid, dim3(256), 0, stream, q, g, nq, ng, d, qn,
+                           gn, out, ldo, tiles_m, tiles_n, vec_ok);
     LAUNCH_CHECK();
     return MPREID_OK;
 }

@@ -614,7 +614,8 @@ __global__ __launch_bounds__(256) void csc_fill_kernel(int64_t N, const int *__r
 // (utils/reranking.py:84-100).  One 256-thread workgroup per query; t[] lives in LDS as fp16 bits,
 // r-space processed in chunks of rch entries so that any N fits.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void jaccard_kernel(int64_t N, int64_t nq, const float *__restrict__ MT, int64_t ld,
+constexpr int JT = 512; // threads per query workgroup
+__global__ __launch_bounds__(JT) void jaccard_kernel(int64_t N, int64_t nq, const float *__restrict__ MT, int64_t ld,
                                                       const float *__restrict__ rowmax,
                                                       const int *__restrict__ qcnt, const int *__restrict__ qidx,
                                                       const uint16_t *__restrict__ qval, int qcap,
@@ -632,7 +633,7 @@ __global__ __launch_bounds__(256) void jaccard_kernel(int64_t N, int64_t nq, con
     const int64_t i = blockIdx.x;
     const int cnt = qcnt[i];
     unsigned long long pairs = 0;
-    for (int a = tid; a < cnt; a += 256) {
+    for (int a = tid; a < cnt; a += JT) {
         const int c = qidx[i * qcap + a];
         const long long p0 = cptr[c], p1 = cptr[c + 1];
         cp0[a] = p0;
@@ -650,23 +651,63 @@ __global__ __launch_bounds__(256) void jaccard_kernel(int64_t N, int64_t nq, con
     const uint16_t H1 = 0x3c00u, H2 = 0x4000u;
     for (int64_t r0 = 0; r0 < N; r0 += rch) {
         const int64_t r1 = (r0 + rch < N) ? r0 + rch : N;
-        for (int r = tid; r < rch; r += 256) t[r] = 0;
+        for (int r = tid; r < rch; r += JT) t[r] = 0;
         __syncthreads();
-        for (int a = 0; a < cnt; ++a) { // ascending column; rows of one column are distinct
+        // ascending column; rows of one column are distinct, so the threads of a column never collide and
+        // one barrier per column keeps the fp16 accumulation order of the reference.  The (row, value)
+        // pairs of column a+1 are requested into registers before column a is applied, so the L2/HBM
+        // latency of the gathers is paid once per pipeline fill instead of once per column.
+        constexpr int NPF = 2; // entries per thread held in registers (columns up to 1024 entries)
+        int pr[NPF];
+        uint16_t pv[NPF];
+        auto fetch = [&](int a) {
             const long long p0 = cp0[a];
             const int len = clen[a];
+#pragma unroll
+            for (int i = 0; i < NPF; ++i) {
+                const int e = tid + i * JT;
+                pr[i] = -1;
+                pv[i] = 0;
+                if (e < len) {
+                    pr[i] = crow[p0 + e];
+                    pv[i] = cval[p0 + e];
+                }
+            }
+        };
+        if (cnt > 0) fetch(0);
+        for (int a = 0; a < cnt; ++a) {
+            int cr[NPF];
+            uint16_t cv[NPF];
+#pragma unroll
+            for (int i = 0; i < NPF; ++i) {
+                cr[i] = pr[i];
+                cv[i] = pv[i];
+            }
+            if (a + 1 < cnt) fetch(a + 1);
             const uint16_t vic = vi[a];
-            for (int e = tid; e < len; e += 256) {
-                const int r = crow[p0 + e];
-                if (r >= r0 && r < r1) {
-                    const uint16_t m = mpreid_h_min_nonneg(vic, cval[p0 + e]);
+#pragma unroll
+            for (int i = 0; i < NPF; ++i) {
+                const int r = cr[i];
+                if (r >= r0 && r < r1) { // r == -1 (no entry) fails r >= r0
+                    const uint16_t m = mpreid_h_min_nonneg(vic, cv[i]);
                     t[r - r0] = mpreid_h_add(t[r - r0], m);
+                }
+            }
+            const int len = clen[a];
+            if (len > NPF * JT) { // rare long column: the tail is gathered directly
+                const long long p0 = cp0[a];
+                for (int e = tid + NPF * JT; e < len; e += JT) {
+                    const int r = crow[p0 + e];
+                    if (r >= r0 && r < r1) {
+                        const uint16_t m = mpreid_h_min_nonneg(vic, cval[p0 + e]);
+                        t[r - r0] = mpreid_h_add(t[r - r0], m);
+                    }
                 }
             }
             __syncthreads();
         }
         const int64_t jlo = (r0 > nq) ? r0 : nq;
-        for (int64_t j = jlo + tid; j < r1; j += 256) {
+        for (int64_t j = jlo + tid; j < r1; j += JT) {
             const uint16_t tv = t[j - r0];
             const uint16_t den = mpreid_h_sub(H2, tv);
             const uint16_t qt = mpreid_h_div(tv, den);
@@ -858,7 +899,7 @@ extern "C" int mpreid_rerank_f32(const float *q, const float *g, int64_t nq, int
         const size_t lds = align_up((size_t)rch * 2, 16) + (size_t)qcap * (8 + 4 + 2) + 16;
         int rc = set_dyn_lds(jaccard_kernel, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(jaccard_kernel, dim3((unsigned)nq), dim3(256), lds, stream, N, nq, MT, L.ld, rowmax, fcnt,
+        hipLaunchKernelGGL(jaccard_kernel, dim3((unsigned)nq), dim3(JT), lds, stream, N, nq, MT, L.ld, rowmax, fcnt,
                            fidx, fval, qcap, cptr, crow, cval, rch, oml, lam32, out, ldo, counters);
         LAUNCH_CHECK();
     }
