@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=24)
     ap.add_argument("--small", action="store_true", help="debug: 1/16 of the workload")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the encoder batches alternate on (HBM-bound phases of one batch overlap "
                          "MFMA phases of the other)")
     return ap.parse_args()
@@ -209,11 +209,21 @@ def main():
                             "tflops": round(e.flops_total / e.total_ms / 1e9, 1) if e.total_ms > 0 else None})
         top = classes[0] if classes else None
         roof = None
+        traffic = None
+        try:  # HBM bytes per launch of the dominant kernel: committed rocprofv3 PMC passes (profiles/)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_gemm_pmc_traffic.json")))
+            e0 = ents[0]
+            key = f"{_lib.GEMM_EPILOGUE_NAMES.get(e0.epilogue)}:{e0.n}:{e0.k}"
+            traffic = tj["classes"].get(key, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
         if top:
             roof = {"bound": "mfma", "kernel": top["kernel"], "shape": [top["M"], top["N"], top["K"]],
                     "achieved": top["tflops"], "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                     "algorithmic_gflop_per_launch": top["gflop_per_launch"],
-                    "frac": round(top["tflops"] / PEAK_F16_TFLOPS, 4), "traffic": None,
+                    "frac": round(top["tflops"] / PEAK_F16_TFLOPS, 4), "traffic": traffic,
+                    "traffic_source": "profiles/r01_gemm_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate "
+                                      "passes), bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, same kernel and shape at M=65536",
                     "avg_launch_ms": top["avg_ms"], "launches": top["launches"],
                     "measured": "hipEvents around every launch, on the launch stream, " +
                                 ("inside the timed region" if instrument_live else

@@ -257,11 +257,24 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
     const int K = g.K;
     const int nst = K / BBK; // even (K is a multiple of 64)
 
-    // PERSISTENT: gridDim.x workgroups (one per CU) walk the tiles with stride gridDim.x.  The workgroups
-    // of one XCD (blockIdx % 8) take neighbouring tiles of every sweep (private-L2 locality only).
+    // PERSISTENT: gridDim.x workgroups (one per CU) walk the tiles.  L2 is private to an XCD, so each XCD
+    // (blockIdx % 8 under round-robin dispatch; locality only, never correctness) OWNS whole groups of 8
+    // tile rows and sweeps all their tile columns back to back: the group's A panel (8 x 256 rows) stays in
+    // that XCD's L2 while the weight panels stream past it.  (The plain strided walk re-fetched A 4x: 442 MB
+    // FETCH_SIZE vs 105 MB algorithmic on the FC1 shape.)
     const int ntiles = tiles_m * tiles_n;
     const int nb = (int)gridDim.x;
-    const int slot = (nb % 8 == 0) ? (int)(blockIdx.x & 7) * (nb >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const bool owned = (tiles_m % 8 == 0) && (nb % 8 == 0);
+    const int xcd = (int)(blockIdx.x & 7), per_xcd = nb >> 3, per_group = 8 * tiles_n, ngroups = tiles_m >> 3;
+    int pos = owned ? (int)(blockIdx.x >> 3) : (int)blockIdx.x; // position in this XCD's (or the global) tile list
+    const int pos_step = owned ? per_xcd : nb;
+    auto tile_at = [&](int p) -> int { // -1 when the list is exhausted
+        if (!owned) return p < ntiles ? p : -1;
+        const int grp = xcd + 8 * (p / per_group);
+        if (grp >= ngroups) return -1;
+        const int within = p % per_group;
+        return (grp * 8 + (within & 7)) * tiles_n + (within >> 3); // row-major tile id
+    };
 
     // ---- DMA: wave w moves rows [32w, 32w+32) of the A part and of the B part of every stage ----
     const int drow = lane >> 2;                                     // row inside a 16-row DMA piece
@@ -270,7 +283,12 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
     int m0 = 0, n0 = 0;
     auto set_tile = [&](int tile) {
         int tm, tn;
-        tile_coords((unsigned)tile, tiles_m, tiles_n, 8, tm, tn);
+        if (owned) {
+            tm = tile / tiles_n;
+            tn = tile - tm * tiles_n;
+        } else {
+            tile_coords((unsigned)tile, tiles_m, tiles_n, 8, tm, tn);
+        }
         m0 = tm * BBM;
         n0 = tn * BBN;
         a_src = g.A + (int64_t)(m0 + wave * 32 + drow) * K + dchunk * 8;
@@ -304,8 +322,8 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
         for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const f16x8 *>(sb + a_off + i * 1024);
     };
 
-    int tile = slot;
-    if (tile >= ntiles) return;
+    int tile = tile_at(pos);
+    if (tile < 0) return;
     set_tile(tile);
     dma_prologue();
     for (;;) {
@@ -397,7 +415,8 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
     // this barrier ----
     __syncthreads();
     const int cur_m0 = m0, cur_n0 = n0;
-    const int next_tile = tile + nb;
+    pos += pos_step;
+    const int next_tile = tile_at(pos);
     unsigned char *patch = smem + B_LDS_BYTES;
     if constexpr (DBG & 8) {
         // keep EVERY accumulator live (rule 17: a skipped consumer lets the compiler delete the MFMAs too)
@@ -519,7 +538,7 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
     // next tile: its first three DMA stages go out right behind this tile's stores (the ring was released by
     // the barrier above), so their cold latency overlaps the store drain
     tile = next_tile;
-    if (tile >= ntiles) break;
+    if (tile < 0) break;
     set_tile(tile);
     dma_prologue();
     } // tiles
