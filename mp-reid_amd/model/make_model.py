@@ -90,12 +90,14 @@ class build_transformer(nn.Module):
         if self.training:
             raise NotImplementedError("training-mode forward is out of scope; call .eval()")
         cv_embed = None
-        if cam_label is not None and view_label is not None:
-            cv_embed = self.sie_coe * self.cv_embed[cam_label * self.view_num + view_label]
-        elif cam_label is not None:
-            cv_embed = self.sie_coe * self.cv_embed[cam_label]
-        elif view_label is not None:
-            cv_embed = self.sie_coe * self.cv_embed[view_label]
+        if cam_label is not None or view_label is not None:
+            # SIE: index = cam * view_num + view | cam | view (reference model/make_model.py:89-96); the table may
+            # live on the CPU (the module was not .to("cuda")-ed) while the labels are on the GPU
+            if cam_label is not None and view_label is not None:
+                idx = cam_label * self.view_num + view_label
+            else:
+                idx = cam_label if cam_label is not None else view_label
+            cv_embed = self.sie_coe * self.cv_embed[idx.to(self.cv_embed.device)]
         return self._get_encoder()(x, cv_embed)
 
     def load_param(self, trained_path):
