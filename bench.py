@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=24)
     ap.add_argument("--small", action="store_true", help="debug: 1/16 of the workload")
+    ap.add_argument("--rerank", action="store_true",
+                    help="also run k-reciprocal re-ranking (k1=50, k2=15, lambda=0.3) in every step "
+                         "(BASELINE configs[2] stand-in; rows sharded over the ranks when N > 1)")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the encoder batches alternate on (HBM-bound phases of one batch overlap "
                          "MFMA phases of the other)")
@@ -160,6 +163,10 @@ def main():
         fn = ops.l2_normalize(feats)
         qf = D.all_gather_rows(fn[:nq_local], nq)   # RCCL all-gather of the query features (N > 1)
         ops.euclidean_distance(qf, fn[nq_local:], out=block)
+        if a.rerank:
+            gf_all = D.all_gather_rows(fn[nq_local:], world * ng) if world > 1 else fn[nq_local:]
+            rr = D.re_ranking_sharded(qf, gf_all, 50, 15, 0.3)   # this rank's final_dist[q_lo:q_hi, nq:]
+            assert rr.shape[1] == world * ng
 
     def fence():
         torch.cuda.synchronize()

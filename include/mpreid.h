@@ -93,6 +93,41 @@ int mpreid_rerank_debug_copy(const void *ws_dev, int64_t nq, int64_t ng, int d, 
                              int32_t *rank_out_host, int32_t *v_cnt_host, int32_t *vqe_cnt_host,
                              mpreid_stream_t stream);
 
+/* ---- row-sharded re-ranking: the same kernels, phase by phase over a row range ------------
+ * Rows [r_lo, r_lo+rows) of the N x N problem belong to the calling rank; between the phases the caller
+ * all-gathers (RCCL) the rank table, the sparse V rows and the sparse V_qe rows.  mpreid/distributed.py
+ * (re_ranking_sharded) is the driver; results do not depend on the number of ranks. */
+/* phase 1: D rows + row maxima (+ first kr neighbours when rank_local != NULL); norms_all = mpreid_sqnorm_f32 */
+int mpreid_rr_dist_rows(const float *feat_all_dev, const float *norms_all_dev, int64_t n, int d, int64_t r_lo,
+                        int64_t rows, float *d_local_dev, int64_t ld, float *rowmax_local_dev,
+                        int32_t *rank_local_dev, int kr, mpreid_stream_t stream);
+/* ELL row capacity of V before query expansion: min(N, (k1+1)*(1+half_k1)) */
+int mpreid_rr_vcap(int64_t n, int k1);
+/* phase 2: V rows (ELL, row stride mpreid_rr_vcap) of the local rows from the global rank table [N][kr] */
+int mpreid_rr_krecip(const float *d_local_dev, int64_t ld, int64_t n, const float *rowmax_local_dev,
+                     const int32_t *rank_all_dev, int k1, int kr, int64_t r_lo, int64_t rows, int32_t *vcnt_dev,
+                     int32_t *vidx_dev, uint16_t *vval_dev, mpreid_stream_t stream);
+/* re-stride ELL rows (for the all-gather: common width = global max count) */
+int mpreid_rr_pack_rows(const int32_t *cnt_dev, const int32_t *idx_dev, const uint16_t *val_dev, int64_t rows,
+                        int src_stride, int dst_stride, int32_t *idx_out_dev, uint16_t *val_out_dev,
+                        mpreid_stream_t stream);
+/* phase 3: local query expansion of the local rows from the global V (row stride vstride) */
+int mpreid_rr_qe_count(int64_t n, const int32_t *rank_all_dev, int kr, int k2, int64_t r_lo, int64_t rows,
+                       const int32_t *vcnt_all_dev, const int32_t *vidx_all_dev, int vstride,
+                       int32_t *ucnt_local_dev, mpreid_stream_t stream);
+int mpreid_rr_qe_fill(int64_t n, const int32_t *rank_all_dev, int kr, int k2, int64_t r_lo, int64_t rows,
+                      const int32_t *vcnt_all_dev, const int32_t *vidx_all_dev, const uint16_t *vval_all_dev,
+                      int vstride, int qcap, int32_t *qcnt_local_dev, int32_t *qidx_local_dev,
+                      uint16_t *qval_local_dev, mpreid_stream_t stream);
+/* phase 4: inverted index of the global V_qe + Jaccard / blend for query rows [q_lo, q_lo+qrows);
+ * out [qrows][ldo] = final_dist[q_lo : q_lo+qrows, nq:].  Scratch: ccnt [N+1] u32, cptr [N+1] i64,
+ * crow / cval [sum of qcnt_all]. */
+int mpreid_rr_jaccard(int64_t n, int64_t nq, int64_t q_lo, int64_t qrows, const float *d_q_dev, int64_t ld,
+                      const float *rowmax_q_dev, const int32_t *qcnt_all_dev, const int32_t *qidx_all_dev,
+                      const uint16_t *qval_all_dev, int qstride, double lambda_value, uint32_t *ccnt_dev,
+                      long long *cptr_dev, int32_t *crow_dev, uint16_t *cval_dev, float *out_dev, int64_t ldo,
+                      mpreid_stream_t stream);
+
 /* ---- CLIP ViT-B/16 image encoder, model/clip/model.py:415-479 + model/make_model.py:81-115 -- */
 typedef struct {
     int32_t img_h, img_w;   /* INPUT.SIZE_TEST */

@@ -346,10 +346,12 @@ __device__ __forceinline__ int extract_bits_sorted(const unsigned *mask, int nw,
     return base;
 }
 
+// MT / rowmax / vcnt / vidx / vval are indexed by the LOCAL row (blockIdx.x); `rank` is the global table and
+// row0 the global index of local row 0 (0 on a single GPU; the rank's first row when rows are sharded).
 __global__ __launch_bounds__(64) void krecip_kernel(const float *__restrict__ MT, int64_t ld, int64_t N,
                                                     const float *__restrict__ rowmax, const int *__restrict__ rank,
                                                     int K, int KR, int h, int vcap, int *__restrict__ vcnt,
-                                                    int *__restrict__ vidx, uint16_t *__restrict__ vval) {
+                                                    int *__restrict__ vidx, uint16_t *__restrict__ vval, int row0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nw = (int)((N + 31) >> 5);
     unsigned *Rmask = (unsigned *)smem;
@@ -359,7 +361,8 @@ __global__ __launch_bounds__(64) void krecip_kernel(const float *__restrict__ MT
     int *Elist = R + K;
     float *wbuf = (float *)(Elist + vcap);
     const int lane = threadIdx.x;
-    const int i = blockIdx.x;
+    const int li = blockIdx.x;      // local row
+    const int i = row0 + li;        // global row
 
     for (int w = lane; w < nw; w += 64) {
         Rmask[w] = 0u;
@@ -424,8 +427,8 @@ __global__ __launch_bounds__(64) void krecip_kernel(const float *__restrict__ MT
     // np.unique(expansion index) == set bits of Emask in ascending order
     const int nE = extract_bits_sorted(Emask, nw, Elist, lane);
     __syncthreads();
-    const float mx = rowmax[i];
-    const float *row = MT + (int64_t)i * ld;
+    const float mx = rowmax[li];
+    const float *row = MT + (int64_t)li * ld;
     for (int t = lane; t < nE; t += 64) wbuf[t] = mpreid_expf(-__fdiv_rn(row[Elist[t]], mx));
     __syncthreads();
     const float s = wave_pairwise_sum(wbuf, nE, lane);
@@ -439,26 +442,28 @@ __global__ __launch_bounds__(64) void krecip_kernel(const float *__restrict__ MT
         const unsigned long long m = __ballot(nz);
         if (nz) {
             const int p = out + __popcll(m & ((1ull << lane) - 1ull));
-            vidx[(int64_t)i * vcap + p] = Elist[t];
-            vval[(int64_t)i * vcap + p] = hv;
+            vidx[(int64_t)li * vcap + p] = Elist[t];
+            vval[(int64_t)li * vcap + p] = hv;
         }
         out += __popcll(m);
     }
-    if (lane == 0) vcnt[i] = out;
+    if (lane == 0) vcnt[li] = out;
 }
 
 // ---------------------------------------------------------------------------------------------
 // local query expansion (utils/reranking.py:73-78): V_qe[i] = fp16( sum_{m<k2} V[rank[i][m]] / k2 )
 // fp32 sum in rank order, true divide by fp32(k2).  One wave per row.
 // ---------------------------------------------------------------------------------------------
+// V (vcnt/vidx/vval, row stride vcap) is global; ucnt / qcnt / qidx / qval are indexed by the local row
 __global__ __launch_bounds__(64) void qe_count_kernel(int64_t N, const int *__restrict__ rank, int KR, int k2,
                                                       const int *__restrict__ vcnt, const int *__restrict__ vidx,
-                                                      int vcap, int *__restrict__ ucnt) {
+                                                      int vcap, int *__restrict__ ucnt, int row0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned *mask = (unsigned *)smem;
     const int nw = (int)((N + 31) >> 5);
     const int lane = threadIdx.x;
-    const int i = blockIdx.x;
+    const int li = blockIdx.x;
+    const int i = row0 + li;
     for (int w = lane; w < nw; w += 64) mask[w] = 0u;
     __syncthreads();
     for (int m = 0; m < k2; ++m) {
@@ -475,14 +480,14 @@ __global__ __launch_bounds__(64) void qe_count_kernel(int64_t N, const int *__re
     for (int w = lane; w < nw; w += 64) tot += __popc(mask[w]);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) tot += __shfl_xor(tot, off, 64);
-    if (lane == 0) ucnt[i] = tot;
+    if (lane == 0) ucnt[li] = tot;
 }
 
 __global__ __launch_bounds__(64) void qe_fill_kernel(int64_t N, const int *__restrict__ rank, int KR, int k2,
                                                      const int *__restrict__ vcnt, const int *__restrict__ vidx,
                                                      const uint16_t *__restrict__ vval, int vcap, int qcap,
                                                      int *__restrict__ qcnt, int *__restrict__ qidx,
-                                                     uint16_t *__restrict__ qval) {
+                                                     uint16_t *__restrict__ qval, int row0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nw = (int)((N + 31) >> 5);
     unsigned *mask = (unsigned *)smem;
@@ -490,7 +495,8 @@ __global__ __launch_bounds__(64) void qe_fill_kernel(int64_t N, const int *__res
     float *acc = (float *)(wpre + nw);
     int *ulist = (int *)(acc + qcap);
     const int lane = threadIdx.x;
-    const int i = blockIdx.x;
+    const int li = blockIdx.x;
+    const int i = row0 + li;
     for (int w = lane; w < nw; w += 64) mask[w] = 0u;
     for (int t = lane; t < qcap; t += 64) acc[t] = 0.0f;
     __syncthreads();
@@ -540,12 +546,12 @@ __global__ __launch_bounds__(64) void qe_fill_kernel(int64_t N, const int *__res
         const unsigned long long mm = __ballot(nz);
         if (nz) {
             const int p = out + __popcll(mm & ((1ull << lane) - 1ull));
-            qidx[(int64_t)i * qcap + p] = ulist[t];
-            qval[(int64_t)i * qcap + p] = hv;
+            qidx[(int64_t)li * qcap + p] = ulist[t];
+            qval[(int64_t)li * qcap + p] = hv;
         }
         out += __popcll(mm);
     }
-    if (lane == 0) qcnt[i] = out;
+    if (lane == 0) qcnt[li] = out;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -623,22 +629,23 @@ __global__ __launch_bounds__(JT) void jaccard_kernel(int64_t N, int64_t nq, cons
                                                       const int *__restrict__ crow, const uint16_t *__restrict__ cval,
                                                       int rch, uint16_t one_minus_lam_h, float lam32,
                                                       float *__restrict__ out, int64_t ldo,
-                                                      unsigned long long *__restrict__ pair_counter) {
+                                                      unsigned long long *__restrict__ pair_counter, int q0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t *t = (uint16_t *)smem;                                   // [rch]
     long long *cp0 = (long long *)(smem + align_up((size_t)rch * 2, 16)); // [cnt]
     int *clen = (int *)(cp0 + qcap);                                  // [cnt]
     uint16_t *vi = (uint16_t *)(clen + qcap);                         // [cnt]
     const int tid = threadIdx.x;
-    const int64_t i = blockIdx.x;
-    const int cnt = qcnt[i];
+    const int64_t i = blockIdx.x;              // local query row: MT / rowmax / out are indexed by it
+    const int64_t ig = (int64_t)q0 + i;        // global row: the sparse V rows are indexed by it
+    const int cnt = qcnt[ig];
     unsigned long long pairs = 0;
     for (int a = tid; a < cnt; a += JT) {
-        const int c = qidx[i * qcap + a];
+        const int c = qidx[ig * qcap + a];
         const long long p0 = cptr[c], p1 = cptr[c + 1];
         cp0[a] = p0;
         clen[a] = (int)(p1 - p0);
-        vi[a] = qval[i * qcap + a];
+        vi[a] = qval[ig * qcap + a];
         pairs += (unsigned long long)(p1 - p0);
     }
     if (pair_counter) {
@@ -839,7 +846,7 @@ extern "C" int mpreid_rerank_f32(const float *q, const float *g, int64_t nq, int
         int rc = set_dyn_lds(krecip_kernel, lds);
         if (rc) return rc;
         hipLaunchKernelGGL(krecip_kernel, dim3((unsigned)N), dim3(64), lds, stream, MT, L.ld, N, rowmax, rank, L.K,
-                           L.KR, L.h, L.vcap, vcnt, vidx, vval);
+                           L.KR, L.h, L.vcap, vcnt, vidx, vval, 0);
         LAUNCH_CHECK();
     }
     tm.mark(); // 3
@@ -858,7 +865,7 @@ extern "C" int mpreid_rerank_f32(const float *q, const float *g, int64_t nq, int
             int rc = set_dyn_lds(qe_count_kernel, lds);
             if (rc) return rc;
             hipLaunchKernelGGL(qe_count_kernel, dim3((unsigned)N), dim3(64), lds, stream, N, rank, L.KR, k2, vcnt, vidx,
-                               L.vcap, ucnt);
+                               L.vcap, ucnt, 0);
             LAUNCH_CHECK();
         }
         HIP_TRY(hipMemcpyAsync(host_cnt.data(), ucnt, (size_t)N * 4, hipMemcpyDeviceToHost, stream));
@@ -872,7 +879,7 @@ extern "C" int mpreid_rerank_f32(const float *q, const float *g, int64_t nq, int
             int rc = set_dyn_lds(qe_fill_kernel, lds);
             if (rc) return rc;
             hipLaunchKernelGGL(qe_fill_kernel, dim3((unsigned)N), dim3(64), lds, stream, N, rank, L.KR, k2, vcnt, vidx,
-                               vval, L.vcap, qcap, qcnt, qidx, qval);
+                               vval, L.vcap, qcap, qcnt, qidx, qval, 0);
             LAUNCH_CHECK();
         }
         fcnt = qcnt;
@@ -900,7 +907,7 @@ extern "C" int mpreid_rerank_f32(const float *q, const float *g, int64_t nq, int
         int rc = set_dyn_lds(jaccard_kernel, lds);
         if (rc) return rc;
         hipLaunchKernelGGL(jaccard_kernel, dim3((unsigned)nq), dim3(JT), lds, stream, N, nq, MT, L.ld, rowmax, fcnt,
-                           fidx, fval, qcap, cptr, crow, cval, rch, oml, lam32, out, ldo, counters);
+                           fidx, fval, qcap, cptr, crow, cval, rch, oml, lam32, out, ldo, counters, 0);
         LAUNCH_CHECK();
     }
     tm.mark(); // 6
@@ -946,5 +953,156 @@ extern "C" int mpreid_rerank_debug_copy(const void *ws, int64_t nq, int64_t ng, 
         HIP_TRY(hipMemcpyAsync(vqe_cnt, base + (k2 != 1 ? L.qcnt : L.vcnt), (size_t)L.N * 4, hipMemcpyDeviceToHost,
                                stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    return MPREID_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row-sharded re-ranking: the same kernels driven phase by phase over a row range
+// [r_lo, r_lo + rows) of the N x N problem.  Between the phases the caller all-gathers the rank table, the
+// sparse V rows and the sparse V_qe rows (mpreid/distributed.py: RCCL through torch.distributed).  No
+// floating-point reduction crosses ranks and every row is computed by exactly the same instruction
+// sequence as on one GPU, so the result does not depend on the number of ranks.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rowmax_kernel(const float *__restrict__ M, int64_t ld, int64_t N,
+                                                     float *__restrict__ rowmax) {
+    __shared__ float s_red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *row = M + (int64_t)blockIdx.x * ld;
+    float mx = -3.402823466e+38f;
+    for (int j = tid; j < (int)N; j += 256) mx = fmaxf(mx, row[j]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if (lane == 0) s_red[wave] = mx;
+    __syncthreads();
+    if (tid == 0) rowmax[blockIdx.x] = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+}
+
+// copy ELL rows from row stride `ss` to row stride `ds` (ds >= max count); entries past the count are zeroed
+__global__ __launch_bounds__(256) void pack_rows_kernel(const int *__restrict__ cnt, const int *__restrict__ idx,
+                                                        const uint16_t *__restrict__ val, int64_t rows, int ss, int ds,
+                                                        int *__restrict__ idx_out, uint16_t *__restrict__ val_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int c = cnt[r];
+    for (int a = lane; a < ds; a += 64) {
+        idx_out[r * ds + a] = a < c ? idx[r * ss + a] : 0;
+        val_out[r * ds + a] = a < c ? val[r * ss + a] : (uint16_t)0;
+    }
+}
+
+// phase 1: rows [r_lo, r_lo+rows) of D = |f_i|^2 + |f_j|^2 - 2 f_i.f_j  (norms_all from mpreid_sqnorm_f32),
+// their row maxima and (if rank_local != NULL) their first KR neighbours.  D_local [rows][ld], ld >= N.
+extern "C" int mpreid_rr_dist_rows(const float *feat_all, const float *norms_all, int64_t n, int d, int64_t r_lo,
+                                   int64_t rows, float *d_local, int64_t ld, float *rowmax_local, int32_t *rank_local,
+                                   int kr, mpreid_stream_t stream_) {
+    ARG_CHECK(feat_all && norms_all && d_local && rowmax_local && n > 0 && d > 0 && rows > 0 && r_lo >= 0 &&
+              r_lo + rows <= n && ld >= n);
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = mpreid_distance_launch(feat_all + r_lo * (int64_t)d, feat_all, rows, n, d, norms_all + r_lo, norms_all,
+                                    d_local, ld, 0, stream);
+    if (rc) return rc;
+    if (rank_local) {
+        ARG_CHECK(kr >= 1 && kr <= 256 && kr <= n);
+        hipLaunchKernelGGL(rowmax_topk_kernel, dim3((unsigned)rows), dim3(256), 0, stream, d_local, ld, n, kr,
+                           rowmax_local, rank_local);
+    } else {
+        hipLaunchKernelGGL(rowmax_kernel, dim3((unsigned)rows), dim3(256), 0, stream, d_local, ld, n, rowmax_local);
+    }
+    LAUNCH_CHECK();
+    return MPREID_OK;
+}
+
+// phase 2: V rows of the local row range from the GLOBAL rank table; ELL with row stride vcap =
+// min(N, (k1+1)*(1+half_k1)) (mpreid_rr_vcap)
+extern "C" int mpreid_rr_vcap(int64_t n, int k1) {
+    const int64_t cap = (int64_t)(k1 + 1) * (1 + mpreid_half_k1(k1));
+    return (int)(cap < n ? cap : n);
+}
+
+extern "C" int mpreid_rr_krecip(const float *d_local, int64_t ld, int64_t n, const float *rowmax_local,
+                                const int32_t *rank_all, int k1, int kr, int64_t r_lo, int64_t rows, int32_t *vcnt,
+                                int32_t *vidx, uint16_t *vval, mpreid_stream_t stream_) {
+    ARG_CHECK(d_local && rowmax_local && rank_all && vcnt && vidx && vval && rows > 0 && kr >= k1 + 1);
+    const int K = k1 + 1, h = mpreid_half_k1(k1), vcap = mpreid_rr_vcap(n, k1);
+    const int nw = (int)((n + 31) >> 5);
+    const size_t lds = (size_t)nw * 8 + (size_t)K * 8 + (size_t)vcap * 8;
+    int rc = set_dyn_lds(krecip_kernel, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(krecip_kernel, dim3((unsigned)rows), dim3(64), lds, (hipStream_t)stream_, d_local, ld, n,
+                       rowmax_local, rank_all, K, kr, h, vcap, vcnt, vidx, vval, (int)r_lo);
+    LAUNCH_CHECK();
+    return MPREID_OK;
+}
+
+extern "C" int mpreid_rr_pack_rows(const int32_t *cnt, const int32_t *idx, const uint16_t *val, int64_t rows,
+                                   int src_stride, int dst_stride, int32_t *idx_out, uint16_t *val_out,
+                                   mpreid_stream_t stream_) {
+    ARG_CHECK(cnt && idx && val && idx_out && val_out && rows > 0 && src_stride > 0 && dst_stride > 0);
+    hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, cnt, idx,
+                       val, rows, src_stride, dst_stride, idx_out, val_out);
+    LAUNCH_CHECK();
+    return MPREID_OK;
+}
+
+// phase 3: query expansion of the local rows from the GLOBAL V (row stride vstride).  Two steps: union sizes
+// (ucnt_local), then the fill with row stride qcap >= max union size.
+extern "C" int mpreid_rr_qe_count(int64_t n, const int32_t *rank_all, int kr, int k2, int64_t r_lo, int64_t rows,
+                                  const int32_t *vcnt_all, const int32_t *vidx_all, int vstride, int32_t *ucnt_local,
+                                  mpreid_stream_t stream_) {
+    ARG_CHECK(rank_all && vcnt_all && vidx_all && ucnt_local && rows > 0 && k2 >= 1 && kr >= k2);
+    const size_t lds = (size_t)((n + 31) >> 5) * 4;
+    int rc = set_dyn_lds(qe_count_kernel, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(qe_count_kernel, dim3((unsigned)rows), dim3(64), lds, (hipStream_t)stream_, n, rank_all, kr, k2,
+                       vcnt_all, vidx_all, vstride, ucnt_local, (int)r_lo);
+    LAUNCH_CHECK();
+    return MPREID_OK;
+}
+
+extern "C" int mpreid_rr_qe_fill(int64_t n, const int32_t *rank_all, int kr, int k2, int64_t r_lo, int64_t rows,
+                                 const int32_t *vcnt_all, const int32_t *vidx_all, const uint16_t *vval_all, int vstride,
+                                 int qcap, int32_t *qcnt_local, int32_t *qidx_local, uint16_t *qval_local,
+                                 mpreid_stream_t stream_) {
+    ARG_CHECK(rank_all && vcnt_all && vidx_all && vval_all && qcnt_local && qidx_local && qval_local && rows > 0 &&
+              qcap > 0);
+    const size_t lds = (size_t)((n + 31) >> 5) * 8 + (size_t)qcap * 8;
+    int rc = set_dyn_lds(qe_fill_kernel, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(qe_fill_kernel, dim3((unsigned)rows), dim3(64), lds, (hipStream_t)stream_, n, rank_all, kr, k2,
+                       vcnt_all, vidx_all, vval_all, vstride, qcap, qcnt_local, qidx_local, qval_local, (int)r_lo);
+    LAUNCH_CHECK();
+    return MPREID_OK;
+}
+
+// phase 4: inverted index of the GLOBAL V_qe (row stride qstride) + Jaccard / blend for the query rows
+// [q_lo, q_lo + qrows): d_q [qrows][ld] and rowmax_q from mpreid_rr_dist_rows on that range.
+// Scratch: ccnt [N+1] u32, cptr [N+1] i64, crow [nnz] i32, cval [nnz] u16 (nnz = sum of qcnt_all).
+extern "C" int mpreid_rr_jaccard(int64_t n, int64_t nq, int64_t q_lo, int64_t qrows, const float *d_q, int64_t ld,
+                                 const float *rowmax_q, const int32_t *qcnt_all, const int32_t *qidx_all,
+                                 const uint16_t *qval_all, int qstride, double lambda_value, uint32_t *ccnt,
+                                 long long *cptr, int32_t *crow, uint16_t *cval, float *out, int64_t ldo,
+                                 mpreid_stream_t stream_) {
+    ARG_CHECK(d_q && rowmax_q && qcnt_all && qidx_all && qval_all && ccnt && cptr && crow && cval && out && qrows > 0 &&
+              q_lo >= 0 && q_lo + qrows <= nq && ldo >= n - nq);
+    hipStream_t stream = (hipStream_t)stream_;
+    HIP_TRY(hipMemsetAsync(ccnt, 0, (size_t)(n + 1) * 4, stream));
+    hipLaunchKernelGGL(csc_count_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, n, qcnt_all, qidx_all,
+                       qstride, ccnt);
+    hipLaunchKernelGGL(csc_scan_kernel, dim3(1), dim3(1024), 0, stream, n, ccnt, cptr);
+    hipLaunchKernelGGL(csc_fill_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, n, qcnt_all, qidx_all,
+                       qval_all, qstride, cptr, ccnt, crow, cval);
+    LAUNCH_CHECK();
+    const uint16_t oml = f64_to_f16_host(1.0 - lambda_value);
+    const float lam32 = (float)lambda_value;
+    int rch = (int)std::min<int64_t>(n, 49152);
+    rch = (int)align_up((size_t)rch, 8);
+    const size_t lds = align_up((size_t)rch * 2, 16) + (size_t)qstride * (8 + 4 + 2) + 16;
+    int rc = set_dyn_lds(jaccard_kernel, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(jaccard_kernel, dim3((unsigned)qrows), dim3(JT), lds, stream, n, nq, d_q, ld, rowmax_q, qcnt_all,
+                       qidx_all, qval_all, qstride, cptr, crow, cval, rch, oml, lam32, out, ldo,
+                       (unsigned long long *)nullptr, (int)q_lo);
+    LAUNCH_CHECK();
     return MPREID_OK;
 }

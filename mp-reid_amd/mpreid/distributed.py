@@ -72,3 +72,192 @@ def gather_column_blocks_to_host(block: torch.Tensor, dst: int = 0):
     parts = [None] * dist.get_world_size() if dist.get_rank() == dst else None
     dist.gather_object(host, parts, dst=dst)
     return np.concatenate(parts, axis=1) if parts is not None else None
+
+
+# ----------------------------------------------------------------------------------------------
+# Row-sharded k-reciprocal re-ranking (SURVEY.md §8e, row "Re-rank")
+#
+#   phase 1  rows [r_lo, r_hi) of D = all-pairs distance, row maxima, first max(k1+1, k2) neighbours
+#            -> ALL-GATHER rank table [N][KR] int32
+#   phase 2  k-reciprocal expansion -> sparse V rows of the local rows
+#            -> ALL-GATHER V (ELL rows re-strided to the global max count)
+#   phase 3  local query expansion of the local rows (skipped when k2 == 1)
+#            -> ALL-GATHER V_qe
+#   phase 4  queries sharded nq/P: distance rows of the local queries, inverted index of V_qe, Jaccard + blend
+#            -> each rank owns final_dist[q_lo:q_hi, nq:]; row blocks are concatenated on the host
+#
+# Every row is produced by the same instruction sequence as in the single-GPU call and no floating-point
+# reduction crosses ranks, so the result is bit-identical for any number of ranks
+# (tests/test_gpu_rerank.py::test_sharded_rerank_is_rank_count_independent).
+# ----------------------------------------------------------------------------------------------
+def _rr_ptr(t):
+    import ctypes as C
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+class _RerankShard:
+    """state of one (real or virtual) rank"""
+
+    def __init__(self, feat_all, norms_all, nq, k1, k2, lam, rank, world):
+        from . import _lib
+        self.L = _lib.load()
+        self.lib = _lib
+        self.feat, self.norms = feat_all, norms_all
+        self.N, self.d = feat_all.shape
+        self.nq, self.k1, self.k2, self.lam = nq, k1, k2, lam
+        self.KR = max(k1 + 1, k2)
+        self.r_lo, self.r_hi = shard_range(self.N, rank, world)
+        self.q_lo, self.q_hi = shard_range(nq, rank, world)
+        self.rows = self.r_hi - self.r_lo
+        self.ld = (self.N + 63) // 64 * 64
+        self.dev = feat_all.device
+        self.vcap = self.L.mpreid_rr_vcap(self.N, k1)
+
+    def phase1(self):
+        t, dev = torch, self.dev
+        self.D = t.empty((max(self.rows, 1), self.ld), dtype=t.float32, device=dev)
+        self.rowmax = t.empty(max(self.rows, 1), dtype=t.float32, device=dev)
+        rank_local = t.empty((self.rows, self.KR), dtype=t.int32, device=dev)
+        if self.rows:
+            self.lib.check(self.L.mpreid_rr_dist_rows(_rr_ptr(self.feat), _rr_ptr(self.norms), self.N, self.d, self.r_lo,
+                                                      self.rows, _rr_ptr(self.D), self.ld, _rr_ptr(self.rowmax),
+                                                      _rr_ptr(rank_local), self.KR, self.lib.stream_ptr()),
+                           "mpreid_rr_dist_rows")
+        return rank_local
+
+    def phase2(self, rank_all):
+        t, dev = torch, self.dev
+        self.rank_all = rank_all
+        self.vcnt = t.zeros(self.rows, dtype=t.int32, device=dev)
+        self.vidx = t.empty((max(self.rows, 1), self.vcap), dtype=t.int32, device=dev)
+        self.vval = t.empty((max(self.rows, 1), self.vcap), dtype=t.int16, device=dev)
+        if self.rows:
+            self.lib.check(self.L.mpreid_rr_krecip(_rr_ptr(self.D), self.ld, self.N, _rr_ptr(self.rowmax),
+                                                   _rr_ptr(rank_all), self.k1, self.KR, self.r_lo, self.rows,
+                                                   _rr_ptr(self.vcnt), _rr_ptr(self.vidx), _rr_ptr(self.vval),
+                                                   self.lib.stream_ptr()), "mpreid_rr_krecip")
+        return int(self.vcnt.max().item()) if self.rows else 0
+
+    def _pack(self, cnt, idx, val, width):
+        t = torch
+        oi = t.empty((self.rows, width), dtype=t.int32, device=self.dev)
+        ov = t.empty((self.rows, width), dtype=t.int16, device=self.dev)
+        if self.rows:
+            self.lib.check(self.L.mpreid_rr_pack_rows(_rr_ptr(cnt), _rr_ptr(idx), _rr_ptr(val), self.rows, idx.shape[1],
+                                                      width, _rr_ptr(oi), _rr_ptr(ov), self.lib.stream_ptr()),
+                           "mpreid_rr_pack_rows")
+        return oi, ov
+
+    def pack_v(self, width):
+        return (self.vcnt,) + self._pack(self.vcnt, self.vidx, self.vval, width)
+
+    def phase3_count(self, vcnt_all, vidx_all, vval_all):
+        t = torch
+        self.V = (vcnt_all, vidx_all, vval_all)
+        self.ucnt = t.zeros(self.rows, dtype=t.int32, device=self.dev)
+        if self.rows:
+            self.lib.check(self.L.mpreid_rr_qe_count(self.N, _rr_ptr(self.rank_all), self.KR, self.k2, self.r_lo, self.rows,
+                                                     _rr_ptr(vcnt_all), _rr_ptr(vidx_all), vidx_all.shape[1],
+                                                     _rr_ptr(self.ucnt), self.lib.stream_ptr()), "mpreid_rr_qe_count")
+        return int(self.ucnt.max().item()) if self.rows else 0
+
+    def phase3_fill(self, qcap):
+        t = torch
+        vcnt_all, vidx_all, vval_all = self.V
+        qcnt = t.zeros(self.rows, dtype=t.int32, device=self.dev)
+        qidx = t.zeros((self.rows, qcap), dtype=t.int32, device=self.dev)
+        qval = t.zeros((self.rows, qcap), dtype=t.int16, device=self.dev)
+        if self.rows:
+            self.lib.check(self.L.mpreid_rr_qe_fill(self.N, _rr_ptr(self.rank_all), self.KR, self.k2, self.r_lo, self.rows,
+                                                    _rr_ptr(vcnt_all), _rr_ptr(vidx_all), _rr_ptr(vval_all),
+                                                    vidx_all.shape[1], qcap, _rr_ptr(qcnt), _rr_ptr(qidx), _rr_ptr(qval),
+                                                    self.lib.stream_ptr()), "mpreid_rr_qe_fill")
+        return qcnt, qidx, qval
+
+    def phase4(self, qcnt_all, qidx_all, qval_all):
+        t, dev = torch, self.dev
+        qrows = self.q_hi - self.q_lo
+        ng = self.N - self.nq
+        out = t.empty((qrows, ng), dtype=t.float32, device=dev)
+        if qrows == 0:
+            return out
+        del self.D  # the row block of phase 1 is no longer needed
+        dq = t.empty((qrows, self.ld), dtype=t.float32, device=dev)
+        rmq = t.empty(qrows, dtype=t.float32, device=dev)
+        self.lib.check(self.L.mpreid_rr_dist_rows(_rr_ptr(self.feat), _rr_ptr(self.norms), self.N, self.d, self.q_lo, qrows,
+                                                  _rr_ptr(dq), self.ld, _rr_ptr(rmq), None, 0, self.lib.stream_ptr()),
+                       "mpreid_rr_dist_rows")
+        nnz = int(qcnt_all.sum().item())
+        ccnt = t.empty(self.N + 1, dtype=t.int32, device=dev)
+        cptr = t.empty(self.N + 1, dtype=t.int64, device=dev)
+        crow = t.empty(max(nnz, 1), dtype=t.int32, device=dev)
+        cval = t.empty(max(nnz, 1), dtype=t.int16, device=dev)
+        self.lib.check(self.L.mpreid_rr_jaccard(self.N, self.nq, self.q_lo, qrows, _rr_ptr(dq), self.ld, _rr_ptr(rmq),
+                                                _rr_ptr(qcnt_all), _rr_ptr(qidx_all), _rr_ptr(qval_all),
+                                                qidx_all.shape[1], float(self.lam), _rr_ptr(ccnt), _rr_ptr(cptr),
+                                                _rr_ptr(crow), _rr_ptr(cval), _rr_ptr(out), ng, self.lib.stream_ptr()),
+                       "mpreid_rr_jaccard")
+        return out
+
+
+def _rr_prepare(qf, gf):
+    from . import ops
+    dev = ops._lib.require_gpu()
+    feat = torch.cat([ops._dev_f32(qf, dev), ops._dev_f32(gf, dev)], dim=0).contiguous()
+    return feat, ops.sqnorm(feat)
+
+
+def re_ranking_sharded(qf_all, gf_all, k1, k2, lambda_value):
+    """Re-ranking with the rows of the N x N problem sharded over the ranks of the default process group
+    (every rank passes the full, all-gathered query and gallery features).  Returns this rank's
+    final_dist[q_lo:q_hi, nq:] block on the GPU; use gather_row_blocks_to_host() for the full matrix."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    feat, norms = _rr_prepare(qf_all, gf_all)
+    N, nq = feat.shape[0], qf_all.shape[0]
+    sh = _RerankShard(feat, norms, nq, int(k1), int(k2), float(lambda_value), rank, world)
+
+    def gmax(v):
+        if world == 1:
+            return v
+        tt = torch.tensor([v], dtype=torch.int64, device=feat.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return int(tt.item())
+
+    rank_all = all_gather_rows(sh.phase1(), N)
+    w = max(gmax(sh.phase2(rank_all)), 1)
+    vc, vi, vv = sh.pack_v(w)
+    vc, vi, vv = all_gather_rows(vc, N), all_gather_rows(vi, N), all_gather_rows(vv, N)
+    if k2 != 1:
+        qcap = max(gmax(sh.phase3_count(vc, vi, vv)), 1)
+        qc, qi, qv = sh.phase3_fill(qcap)
+        vc, vi, vv = all_gather_rows(qc, N), all_gather_rows(qi, N), all_gather_rows(qv, N)
+    return sh.phase4(vc, vi, vv)
+
+
+def re_ranking_virtual(qf_all, gf_all, k1, k2, lambda_value, world):
+    """The same phases for `world` VIRTUAL ranks executed one after the other on the current GPU (no process
+    group): the all-gathers become concatenations.  Used to test rank-count independence on one GPU."""
+    feat, norms = _rr_prepare(qf_all, gf_all)
+    nq = qf_all.shape[0]
+    shards = [_RerankShard(feat, norms, nq, int(k1), int(k2), float(lambda_value), r, world) for r in range(world)]
+    rank_all = torch.cat([s.phase1() for s in shards], dim=0)
+    w = max(max(s.phase2(rank_all) for s in shards), 1)
+    packs = [s.pack_v(w) for s in shards]
+    vc, vi, vv = (torch.cat([p[i] for p in packs], dim=0) for i in range(3))
+    if k2 != 1:
+        qcap = max(max(s.phase3_count(vc, vi, vv) for s in shards), 1)
+        fills = [s.phase3_fill(qcap) for s in shards]
+        vc, vi, vv = (torch.cat([f[i] for f in fills], dim=0) for i in range(3))
+    return torch.cat([s.phase4(vc, vi, vv) for s in shards], dim=0)
+
+
+def gather_row_blocks_to_host(block: torch.Tensor, dst: int = 0):
+    """host-side concatenation of per-rank ROW blocks (sharded re-ranking)"""
+    import numpy as np
+    host = block.cpu().numpy()
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return host
+    parts = [None] * dist.get_world_size() if dist.get_rank() == dst else None
+    dist.gather_object(host, parts, dst=dst)
+    return np.concatenate(parts, axis=0) if parts is not None else None

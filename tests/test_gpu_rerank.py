@@ -139,3 +139,20 @@ def test_rerank_market_scale_properties(ops):
     _, map_rr = eval_func(ra.cpu().numpy(), pid[:nq], pid[nq:], None, None)
     assert map_rr > map_plain
     print("rerank stats", st, "mAP plain/rr", map_plain, map_rr)
+
+
+@pytest.mark.parametrize("n,nq,d,k1,k2,world", [(1500, 300, 256, 50, 15, 1), (1500, 300, 256, 50, 15, 3),
+                                                 (1500, 300, 256, 50, 15, 8), (900, 7, 64, 20, 6, 4),
+                                                 (700, 100, 128, 10, 1, 5), (640, 90, 96, 30, 40, 2)])
+def test_sharded_rerank_is_rank_count_independent(ops, n, nq, d, k1, k2, world):
+    """row-sharded phases (virtual ranks on one GPU) == single-call result == oracle, bit for bit"""
+    from mpreid import distributed as D, synth
+    f, _ = synth.clustered_features(n, d, 2.5, seed=n + world, per_id=20)
+    q, g = torch.from_numpy(f[:nq]).cuda(), torch.from_numpy(f[nq:]).cuda()
+    single, _ = ops.re_ranking(q, g, k1, k2, 0.3)
+    sharded = D.re_ranking_virtual(q, g, k1, k2, 0.3, world)
+    assert torch.equal(single, sharded)
+    assert np.array_equal(sharded.cpu().numpy(), orc.re_ranking(f[:nq], f[nq:], k1, k2, 0.3))
+    if world == 1:
+        real = D.re_ranking_sharded(q, g, k1, k2, 0.3)   # the torch.distributed driver with no process group
+        assert torch.equal(real, single)
