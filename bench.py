@@ -129,6 +129,7 @@ def main():
 
     rank, world, local = D.init_from_env()
     assert world == a.gpus or world == 1 and a.gpus == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    local = local % max(torch.cuda.device_count(), 1)   # (debug) more ranks than GPUs share devices
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     L = _lib.load()
@@ -197,7 +198,7 @@ def main():
         L.mpreid_profile_enable(0)
         nstreams, side[:], encs[:] = saved[0], saved[1], saved[2]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert torch.isfinite(block).all()
@@ -249,7 +250,9 @@ def main():
             "config": {"workload": "Market-1501 shape on MI355X (BASELINE configs[1]): ViT-B/16 encode of "
                                    f"{nq} query + {ng} gallery 3x256x128 images per GPU shard (seeded random init), "
                                    "L2-normalise, all-gather query features, euclidean distmat "
-                                   f"[{nq} x {ng}] per GPU (exact fp32 MFMA), no re-rank",
+                                   f"[{nq} x {ng}] per GPU (exact fp32 MFMA), " +
+                                   ("plus k-reciprocal re-ranking (k1=50, k2=15, lambda=0.3) of all queries against the "
+                                    "whole gallery, rows sharded over the GPUs" if a.rerank else "no re-rank"),
                        "images_per_step": nq + world * ng, "encoder_batch": a.batch, "encoder_streams": nstreams,
                        "sharding": f"gallery rows over {world} GPU(s), queries 1/{world} each + all-gather"},
             "encode_tflops_algorithmic": round(total_images * GFLOP_PER_IMG / dt / 1e3, 1),

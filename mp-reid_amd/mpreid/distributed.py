@@ -26,7 +26,8 @@ def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # MPREID_DIST_BACKEND=gloo: debugging aid (several ranks sharing one GPU, CPU-staged collectives)
+            backend = os.environ.get("MPREID_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)
@@ -49,14 +50,22 @@ def all_gather_rows(x: torch.Tensor, n_total: int) -> torch.Tensor:
     Ragged shards are padded to the largest one for the collective and trimmed afterwards."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return x
+    if x.dtype == torch.int16:   # fp16 bit patterns: neither NCCL/RCCL nor gloo has a 16-bit integer type
+        x2 = x.contiguous().view(torch.uint8)
+        return all_gather_rows(x2, n_total).view(torch.int16)
     world = dist.get_world_size()
     sizes = shard_sizes(n_total, world)
     mx = max(sizes)
     assert x.shape[0] == sizes[dist.get_rank()], (x.shape, sizes)
     pad = torch.zeros((mx,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
     pad[: x.shape[0]] = x
-    out = torch.empty((world * mx,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-    dist.all_gather_into_tensor(out, pad)
+    if dist.get_backend() == "gloo" and x.is_cuda:   # debug backend: stage through the host
+        host = [torch.empty(pad.shape, dtype=pad.dtype) for _ in range(world)]
+        dist.all_gather(host, pad.cpu())
+        out = torch.cat(host, dim=0).to(x.device)
+    else:
+        out = torch.empty((world * mx,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, pad)
     if all(s == mx for s in sizes):
         return out
     return torch.cat([out[r * mx: r * mx + sizes[r]] for r in range(world)], dim=0)
