@@ -93,6 +93,16 @@ int mpreid_rerank_debug_copy(const void *ws_dev, int64_t nq, int64_t ng, int d, 
                              int32_t *rank_out_host, int32_t *v_cnt_host, int32_t *vqe_cnt_host,
                              mpreid_stream_t stream);
 
+/* ---- eval_func ranking, utils/metrics.py:28-88 ---------------------------------------------------------
+ * For every query: the 0-based positions, in the ascending (distance, gallery index) order of its row, of the
+ * gallery items whose pid equals the query's pid (what the reference reads off np.argsort + matches).
+ * pos_out [nq][rcap] int32 ascending, padded with -1; cnt_out [nq] = number of relevant items, or -1 when a
+ * query has more than min(rcap, 2048) of them (the caller ranks that row on the host).  CMC / AP are finished
+ * on the host from the positions (float64, numpy's summation order): mp-reid_amd/utils/metrics.py. */
+int mpreid_eval_rank_positions(const float *dist_dev, int64_t ld, int nq, int ng, const int64_t *q_pids_dev,
+                               const int64_t *g_pids_dev, int rcap, int32_t *pos_out_dev, int32_t *cnt_out_dev,
+                               mpreid_stream_t stream);
+
 /* ---- row-sharded re-ranking: the same kernels, phase by phase over a row range ------------
  * Rows [r_lo, r_lo+rows) of the N x N problem belong to the calling rank; between the phases the caller
  * all-gathers (RCCL) the rank table, the sparse V rows and the sparse V_qe rows.  mpreid/distributed.py

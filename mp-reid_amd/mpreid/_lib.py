@@ -20,7 +20,7 @@ SYMBOLS = [
     "mpreid_sqnorm_f32", "mpreid_l2_normalize_f32", "mpreid_distance_workspace_bytes",
     "mpreid_euclidean_distance_f32", "mpreid_cosine_similarity_f32",
     "mpreid_rerank_workspace_bytes", "mpreid_rerank_f32", "mpreid_rerank_debug_copy",
-    "mpreid_rr_dist_rows", "mpreid_rr_vcap", "mpreid_rr_krecip", "mpreid_rr_pack_rows", "mpreid_rr_qe_count",
+    "mpreid_eval_rank_positions", "mpreid_rr_dist_rows", "mpreid_rr_vcap", "mpreid_rr_krecip", "mpreid_rr_pack_rows", "mpreid_rr_qe_count",
     "mpreid_rr_qe_fill", "mpreid_rr_jaccard",
     "mpreid_vit_workspace_bytes", "mpreid_vit_forward", "mpreid_gemm_f16_nt", "mpreid_gemm_f16_nt_ex",
     "mpreid_cast_f32_to_f16", "mpreid_profile_enable", "mpreid_profile_reset", "mpreid_profile_query",
@@ -97,6 +97,8 @@ def load():
                                     C.POINTER(RerankStats), i32]
     L.mpreid_rerank_debug_copy.restype = i32
     L.mpreid_rerank_debug_copy.argtypes = [vp, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp]
+    L.mpreid_eval_rank_positions.restype = i32
+    L.mpreid_eval_rank_positions.argtypes = [vp, i64, i32, i32, vp, vp, i32, vp, vp, vp]
     L.mpreid_rr_dist_rows.restype = i32
     L.mpreid_rr_dist_rows.argtypes = [vp, vp, i64, i32, i64, i64, vp, i64, vp, vp, i32, vp]
     L.mpreid_rr_vcap.restype = i32

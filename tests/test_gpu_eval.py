@@ -1,0 +1,65 @@
+"""GPU parity of the ranking behind eval_func (utils/metrics.py:28-88) through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_eval_func_device_vs_reference_golden(golden):
+    from utils.metrics import eval_func, eval_func_device
+    g = golden("eval_func.npz")
+    d = golden("distance.npz")["euclid"]
+    dt = torch.from_numpy(d).cuda()
+    cmc, mAP = eval_func_device(dt, g["q_pid"], g["g_pid"], g["q_cam"], g["g_cam"])
+    assert cmc.dtype == np.float32 and np.array_equal(cmc, g["cmc"])
+    assert abs(mAP - float(g["mAP"])) < 1e-12
+    cmc, mAP = eval_func_device(dt[:, :30].contiguous(), g["q_pid"], g["g_pid"][:30], g["q_cam"], g["g_cam"][:30])
+    assert cmc.shape == g["cmc_small"].shape and np.array_equal(cmc, g["cmc_small"])
+    assert abs(mAP - float(g["mAP_small"])) < 1e-12
+    # non-contiguous rows (a column block of a wider matrix) are accepted through the leading dimension
+    cmc2, mAP2 = eval_func_device(dt[:, :200], g["q_pid"], g["g_pid"][:200])
+    cmc3, mAP3 = eval_func(d[:, :200], g["q_pid"], g["g_pid"][:200], None, None)
+    assert np.array_equal(cmc2, cmc3) and abs(mAP2 - mAP3) < 1e-12
+
+
+@pytest.mark.parametrize("nq,ng,nid,ties", [(50, 400, 20, False), (300, 5000, 100, False), (64, 3000, 3, False),
+                                            (40, 600, 10, True), (10, 4100, 1, False)])
+def test_eval_func_device_vs_host_and_oracle(nq, ng, nid, ties):
+    from utils.metrics import eval_func, eval_func_device
+    rng = np.random.default_rng(nq + ng)
+    d = rng.random((nq, ng)).astype(np.float32)
+    if ties:
+        d = np.round(d * 8) / 8          # many exact ties: order must follow the gallery index
+    q_pid = rng.integers(0, nid, nq)
+    g_pid = rng.integers(0, nid, ng)
+    q_pid[0] = 10_000                    # a query without any match is skipped
+    cmc_h, map_h = eval_func(d, q_pid, g_pid, None, None)
+    cmc_d, map_d = eval_func_device(torch.from_numpy(d).cuda(), q_pid, g_pid)
+    cmc_o, map_o = orc.eval_func(d, q_pid, g_pid)
+    assert np.array_equal(cmc_d, cmc_h) and np.array_equal(cmc_d, cmc_o)
+    assert abs(map_d - map_h) < 1e-12 and abs(map_d - map_o) < 1e-12
+
+
+def test_eval_func_device_all_queries_unmatched():
+    from utils.metrics import eval_func_device
+    d = torch.rand((4, 60), device="cuda")
+    with pytest.raises(AssertionError, match="all query identities do not appear in gallery"):
+        eval_func_device(d, np.array([100, 101, 102, 103]), np.arange(60) % 7)
+
+
+def test_eval_func_device_market_scale():
+    """3368 x 15913: positions agree with a host argsort on sampled rows; mAP equals the host value"""
+    from mpreid import ops, synth
+    from utils.metrics import eval_func, eval_func_device
+    f, pid = synth.clustered_features(19281, 256, 3.0, seed=1234)
+    ft = torch.from_numpy(f).cuda()
+    d = ops.euclidean_distance(ft[:3368], ft[3368:])
+    cmc_d, map_d = eval_func_device(d, pid[:3368], pid[3368:])
+    rows = np.arange(0, 3368, 7)
+    cmc_h, map_h = eval_func(d[torch.from_numpy(rows).cuda()].cpu().numpy(), pid[:3368][rows], pid[3368:], None, None)
+    cmc_s, map_s = eval_func_device(d[torch.from_numpy(rows).cuda()].contiguous(), pid[:3368][rows], pid[3368:])
+    assert np.array_equal(cmc_s, cmc_h) and abs(map_s - map_h) < 1e-12
+    assert 0.0 < map_d <= 1.0 and cmc_d[0] <= cmc_d[-1] <= 1.0
