@@ -70,6 +70,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64; it must be in the process BEFORE this library is dlopen-ed so that the
+    # dynamic linker resolves our dependency to the same runtime.  Loaded the other way round the process holds
+    # two HIP runtimes and the second one reports "no ROCm-capable device".
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python mp-reid_amd/mpreid/build.py` "
