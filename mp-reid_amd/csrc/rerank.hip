@@ -39,9 +39,11 @@ static RerankLayout make_layout(int64_t nq, int64_t ng, int d, int k1, int k2, i
     RerankLayout L{};
     L.N = nq + ng;
     L.ld = (int64_t)align_up((size_t)L.N, 64);
-    L.K = k1 + 1;
-    L.KR = std::max(k1 + 1, k2);
-    L.h = mpreid_half_k1(k1);
+    // numpy slicing clamps the neighbour lists when N is smaller than k1+1 / k1/2+1 / k2 (utils/reranking.py:53-54,
+    // 60-62,76); np.mean then averages over min(k2, N) rows
+    L.K = (int)std::min<int64_t>(k1 + 1, L.N);
+    L.KR = std::max(L.K, (int)std::min<int64_t>(k2, L.N));
+    L.h = (int)std::min<int64_t>(mpreid_half_k1(k1), L.N);
     int64_t cap = (int64_t)L.K * (1 + L.h);
     L.vcap = (int)std::min<int64_t>(cap, L.N);
     L.qcap_bound = std::min<int64_t>(L.N, (int64_t)std::max(k2, 1) * L.vcap);
@@ -1024,6 +1026,7 @@ extern "C" int mpreid_rerank_f32(const float *q, const float *g, int64_t nq, int
     // (7) query expansion
     std::vector<int> host_cnt((size_t)N);
     int64_t v_nnz = 0, q_nnz = 0;
+    const int k2e = (int)std::min<int64_t>(k2, N); // rows the query expansion really averages (numpy clamps the slice)
     int qcap = L.vcap;
     const int *fcnt = vcnt, *fidx = vidx;
     const uint16_t *fval = vval;
@@ -1035,7 +1038,7 @@ extern "C" int mpreid_rerank_f32(const float *q, const float *g, int64_t nq, int
             const size_t lds = (size_t)nw * 4;
             int rc = set_dyn_lds(qe_count_kernel, lds);
             if (rc) return rc;
-            hipLaunchKernelGGL(qe_count_kernel, dim3((unsigned)N), dim3(64), lds, stream, N, rank, L.KR, k2, vcnt, vidx,
+            hipLaunchKernelGGL(qe_count_kernel, dim3((unsigned)N), dim3(64), lds, stream, N, rank, L.KR, k2e, vcnt, vidx,
                                L.vcap, ucnt, 0);
             LAUNCH_CHECK();
         }
@@ -1049,7 +1052,7 @@ extern "C" int mpreid_rerank_f32(const float *q, const float *g, int64_t nq, int
             const size_t lds = (size_t)nw * 8 + (size_t)qcap * 8;
             int rc = set_dyn_lds(qe_fill_kernel, lds);
             if (rc) return rc;
-            hipLaunchKernelGGL(qe_fill_kernel, dim3((unsigned)N), dim3(64), lds, stream, N, rank, L.KR, k2, vcnt, vidx,
+            hipLaunchKernelGGL(qe_fill_kernel, dim3((unsigned)N), dim3(64), lds, stream, N, rank, L.KR, k2e, vcnt, vidx,
                                vval, L.vcap, qcap, qcnt, qidx, qval, 0);
             LAUNCH_CHECK();
         }
@@ -1116,9 +1119,11 @@ extern "C" int mpreid_rerank_debug_copy(const void *ws, int64_t nq, int64_t ng, 
     const RerankLayout L = make_layout(nq, ng, d, k1, k2, has_local);
     hipStream_t stream = (hipStream_t)stream_;
     const char *base = (const char *)ws;
-    if (rank_out)
-        HIP_TRY(hipMemcpy2DAsync(rank_out, (size_t)L.K * 4, base + L.rank, (size_t)L.KR * 4, (size_t)L.K * 4,
+    if (rank_out) { // [N][k1+1]; columns past min(k1+1, N) are -1
+        for (int64_t t = 0; t < L.N * (int64_t)(k1 + 1); ++t) rank_out[t] = -1;
+        HIP_TRY(hipMemcpy2DAsync(rank_out, (size_t)(k1 + 1) * 4, base + L.rank, (size_t)L.KR * 4, (size_t)L.K * 4,
                                  (size_t)L.N, hipMemcpyDeviceToHost, stream));
+    }
     if (v_cnt) HIP_TRY(hipMemcpyAsync(v_cnt, base + L.vcnt, (size_t)L.N * 4, hipMemcpyDeviceToHost, stream));
     if (vqe_cnt)
         HIP_TRY(hipMemcpyAsync(vqe_cnt, base + (k2 != 1 ? L.qcnt : L.vcnt), (size_t)L.N * 4, hipMemcpyDeviceToHost,
@@ -1187,15 +1192,17 @@ extern "C" int mpreid_rr_dist_rows(const float *feat_all, const float *norms_all
 // phase 2: V rows of the local row range from the GLOBAL rank table; ELL with row stride vcap =
 // min(N, (k1+1)*(1+half_k1)) (mpreid_rr_vcap)
 extern "C" int mpreid_rr_vcap(int64_t n, int k1) {
-    const int64_t cap = (int64_t)(k1 + 1) * (1 + mpreid_half_k1(k1));
+    const int64_t K = std::min<int64_t>(k1 + 1, n), h = std::min<int64_t>(mpreid_half_k1(k1), n);
+    const int64_t cap = K * (1 + h);
     return (int)(cap < n ? cap : n);
 }
 
 extern "C" int mpreid_rr_krecip(const float *d_local, int64_t ld, int64_t n, const float *rowmax_local,
                                 const int32_t *rank_all, int k1, int kr, int64_t r_lo, int64_t rows, int32_t *vcnt,
                                 int32_t *vidx, uint16_t *vval, mpreid_stream_t stream_) {
-    ARG_CHECK(d_local && rowmax_local && rank_all && vcnt && vidx && vval && rows > 0 && kr >= k1 + 1);
-    const int K = k1 + 1, h = mpreid_half_k1(k1), vcap = mpreid_rr_vcap(n, k1);
+    const int K = (int)std::min<int64_t>(k1 + 1, n), h = (int)std::min<int64_t>(mpreid_half_k1(k1), n);
+    const int vcap = mpreid_rr_vcap(n, k1);
+    ARG_CHECK(d_local && rowmax_local && rank_all && vcnt && vidx && vval && rows > 0 && kr >= K);
     const int nw = (int)((n + 31) >> 5);
     const size_t lds = (size_t)nw * 8 + (size_t)K * 8 + (size_t)vcap * 8;
     int rc = set_dyn_lds(krecip_kernel, lds);

@@ -113,8 +113,9 @@ class _RerankShard:
         self.lib = _lib
         self.feat, self.norms = feat_all, norms_all
         self.N, self.d = feat_all.shape
-        self.nq, self.k1, self.k2, self.lam = nq, k1, k2, lam
-        self.KR = max(k1 + 1, k2)
+        self.nq, self.k1, self.lam = nq, k1, lam
+        self.k2 = min(k2, self.N)   # numpy clamps initial_rank[i, :k2]; np.mean averages the clamped row count
+        self.KR = max(min(k1 + 1, self.N), self.k2)
         self.r_lo, self.r_hi = shard_range(self.N, rank, world)
         self.q_lo, self.q_hi = shard_range(nq, rank, world)
         self.rows = self.r_hi - self.r_lo

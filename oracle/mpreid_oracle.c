@@ -245,10 +245,15 @@ ORC_API int orc_rerank(const float *q, const float *g, long nq, long ng, int d, 
                        double lambda_value, const float *local, int only_local, float *out,
                        int *rank_out, int *v_cnt, int *vqe_cnt) {
     const long N = nq + ng;
-    const int K = k1 + 1;               /* neighbours used by the k-reciprocal tests          */
-    const int KR = K > k2 ? K : k2;     /* columns of initial_rank that are ever read (:48,:76) */
-    if (KR > N || k2 < 1) return -2;
-    const int h = mpreid_half_k1(k1);
+    /* numpy slicing clamps: initial_rank[i, :k1+1] has min(k1+1, N) entries, [:k1/2+1] min(.., N), and
+     * np.mean(V[initial_rank[i, :k2]], axis=0) averages over min(k2, N) rows (pinned by rerank_small.npz) */
+    if (k2 < 1 || k1 < 0 || N < 1) return -2;
+    const int k2_orig = k2;
+    if (k2 > N) k2 = (int)N;
+    const int K = (k1 + 1 < N) ? k1 + 1 : (int)N; /* neighbours used by the k-reciprocal tests          */
+    const int KR = K > k2 ? K : k2;               /* columns of initial_rank that are ever read (:48,:76) */
+    int h = mpreid_half_k1(k1);
+    if (h > N) h = (int)N;
     const uint16_t one_minus_lam_h = orc_f64_to_f16(1.0 - lambda_value);
     const float lam32 = (float)lambda_value;
     int rc = 0;
@@ -294,8 +299,11 @@ ORC_API int orc_rerank(const float *q, const float *g, long nq, long ng, int d, 
     if (!rank) { free(colmax); free(O); return -1; }
 #pragma omp parallel for schedule(dynamic, 16)
     for (long i = 0; i < N; i++) topk_row(O + i * N, N, KR, rank + i * KR);
-    if (rank_out)
-        for (long i = 0; i < N; i++) memcpy(rank_out + i * K, rank + i * KR, sizeof(int) * K);
+    if (rank_out) /* [N][k1+1]; columns past min(k1+1, N) are -1 */
+        for (long i = 0; i < N; i++) {
+            for (int c = 0; c < k1 + 1; c++) rank_out[i * (k1 + 1) + c] = -1;
+            memcpy(rank_out + i * (k1 + 1), rank + i * KR, sizeof(int) * K);
+        }
 
     /* (4)-(6) k-reciprocal sets, expansion, V rows; utils/reranking.py:51-71 */
     sprow *V = (sprow *)calloc(N, sizeof(sprow));
@@ -346,7 +354,7 @@ ORC_API int orc_rerank(const float *q, const float *g, long nq, long ng, int d, 
     }
 
     /* (7) local query expansion, utils/reranking.py:73-78 */
-    if (k2 != 1) {
+    if (k2_orig != 1) {
         sprow *Vq = (sprow *)calloc(N, sizeof(sprow));
         const float k2f = (float)k2;
 #pragma omp parallel for schedule(dynamic, 16)

@@ -157,6 +157,20 @@ def gen_rerank():
     save("r1_map_eval.npz", **e2e)
 
 
+def gen_rerank_small():
+    """N smaller than k1+1 / k2: numpy slicing clamps the neighbour lists and np.mean divides by the clamped
+    row count (utils/reranking.py:53-54,60-62,76) - behaviour the build has to follow, pinned here."""
+    out = {}
+    for tag, (N, nq, D, seed) in {"a": (30, 6, 32, 3), "b": (12, 3, 16, 4), "c": (52, 10, 24, 5)}.items():
+        feat, pid = synth.clustered_features(N, D, sigma=1.5, seed=seed, per_id=5)
+        q, g = torch.from_numpy(feat[:nq]), torch.from_numpy(feat[nq:])
+        out[f"feat_{tag}"] = feat
+        out[f"nq_{tag}"] = nq
+        for k1, k2, lam in [(50, 15, 0.3), (20, 6, 0.3), (60, 40, 0.5)]:
+            out[f"rr_{tag}_{k1}_{k2}_{lam}"] = ref_reranking.re_ranking(q, g, k1, k2, lam)
+    save("rerank_small.npz", **out)
+
+
 # --------------------------------------------------------------------------------------------
 # (4) VisionTransformer
 # --------------------------------------------------------------------------------------------
@@ -204,5 +218,7 @@ if __name__ == "__main__":
         gen_distance()
     if "rerank" in which:
         gen_rerank()
+    if "rerank_small" in which:
+        gen_rerank_small()
     if "vit" in which:
         gen_vit()

@@ -156,3 +156,20 @@ def test_sharded_rerank_is_rank_count_independent(ops, n, nq, d, k1, k2, world):
     if world == 1:
         real = D.re_ranking_sharded(q, g, k1, k2, 0.3)   # the torch.distributed driver with no process group
         assert torch.equal(real, single)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_rerank_small_n_clamped_like_reference(ops, golden, tag):
+    """N < k1+1 / N < k2 (the reference's slices clamp): HIP == oracle bit for bit, both within tolerance of the
+    reference's golden; the sharded driver agrees too"""
+    from mpreid import distributed as D
+    g = golden("rerank_small.npz")
+    nq = int(g[f"nq_{tag}"])
+    feat = g[f"feat_{tag}"]
+    for k1, k2, lam in [(50, 15, 0.3), (20, 6, 0.3), (60, 40, 0.5)]:
+        got = _check_vs_oracle(ops, feat, nq, k1, k2, lam)
+        want = g[f"rr_{tag}_{k1}_{k2}_{lam}"]
+        d = np.abs(got - want)
+        assert d.max() <= 5e-4 and (d > 1e-5).mean() <= 0.01
+        q, ga = torch.from_numpy(feat[:nq]).cuda(), torch.from_numpy(feat[nq:]).cuda()
+        assert np.array_equal(D.re_ranking_virtual(q, ga, k1, k2, lam, 3).cpu().numpy(), got)

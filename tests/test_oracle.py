@@ -156,3 +156,16 @@ def test_vit_oracle_vs_reference(golden):
     sd12 = synth.vit_state_dict(s12, seed=8, std=0.02, ln_jitter=0.05)
     f = orc.vit_features(sd12, s12, imgs[:1])
     assert np.abs(f - g["b16_s12_feat"][:1]).max() < 5e-5
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_rerank_small_n_vs_reference(golden, tag):
+    """N < k1+1 and N < k2: the reference's numpy slices clamp; pinned by rerank_small.npz"""
+    g = golden("rerank_small.npz")
+    nq = int(g[f"nq_{tag}"])
+    feat = g[f"feat_{tag}"]
+    for k1, k2, lam in [(50, 15, 0.3), (20, 6, 0.3), (60, 40, 0.5)]:
+        got = orc.re_ranking(feat[:nq], feat[nq:], k1, k2, lam)
+        want = g[f"rr_{tag}_{k1}_{k2}_{lam}"]
+        d = np.abs(got - want)
+        assert d.max() <= 5e-4 and (d > 1e-5).mean() <= 0.01, (tag, k1, k2, d.max(), (d > 1e-5).mean())
