@@ -178,6 +178,13 @@ int mpreid_vit_forward(const mpreid_vit_cfg *cfg, const mpreid_vit_weights *w, c
                        const float *cv_emb_dev, float *out_dev, void *ws_dev, size_t ws_bytes,
                        mpreid_stream_t stream);
 
+/* same, from uint8 images [B][img_h][img_w][3] (HWC, after Resize): ToTensor (x/255) and Normalize
+ * ((x - pixel_mean)/pixel_std, host arrays of 3 floats: INPUT.PIXEL_MEAN / PIXEL_STD) of the reference's
+ * val_transforms (datasets/make_dataloader.py:57-61) are fused into the patch gather; 4x fewer input bytes. */
+int mpreid_vit_forward_u8(const mpreid_vit_cfg *cfg, const mpreid_vit_weights *w, const uint8_t *img_hwc_dev,
+                          const float *pixel_mean3, const float *pixel_std3, int batch, const float *cv_emb_dev,
+                          float *out_dev, void *ws_dev, size_t ws_bytes, mpreid_stream_t stream);
+
 /* fp16 GEMM used by the encoder, exposed for the roofline bench and unit tests:
  * C[M][N] (fp32) = A[M][K] (fp16) x B[N][K]^T (fp16).  M, N multiples of 128... see DESIGN.md. */
 int mpreid_gemm_f16_nt(const void *a_dev, const void *b_dev, float *c_dev, int64_t m, int64_t n, int64_t k,

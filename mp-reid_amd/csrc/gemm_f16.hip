@@ -561,6 +561,9 @@ constexpr int P_A_BYTES = PBM * PBK * 2;                 // 16 KB
 constexpr int P_B_BYTES = PBN * PBK * 2;                 // 8 KB
 constexpr int P_STAGE_BYTES = P_A_BYTES + P_B_BYTES;     // 24 KB
 constexpr int P_LDS_BYTES = P_NSTAGE * P_STAGE_BYTES;    // 72 KB
+#ifndef P2_NAPS_PER_STAGE
+#define P2_NAPS_PER_STAGE 2 // ~1000 cycles per stage = about half of a stage pair's time
+#endif
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_f16_p2_kernel(GemmArgs g, int tiles_m, int tiles_n) {
@@ -578,9 +581,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_p2_kernel(GemmArgs g, int til
 
     // odd workgroups start half a main loop late (once), so that the two workgroups of a CU alternate
     // between the MFMA loop and the memory-bound epilogue / prologue
-    if (blockIdx.x & 8) {
-        const int naps = nst * 6; // ~ half of nst stages x ~800 cycles, in units of s_sleep 1 (64 cycles)
-        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(1);
+    // (the second workgroup of a CU is, in practice, the one dispatched in the second half of the grid)
+    if ((int)blockIdx.x >= (nb >> 1)) {
+        const int naps = nst * P2_NAPS_PER_STAGE; // units of s_sleep 8 (~512 cycles)
+        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(8);
     }
 
     // DMA geometry: one piece = 16 rows x 64 B.  A part: 16 pieces, wave w takes 4w..4w+3; B part: 8 pieces,

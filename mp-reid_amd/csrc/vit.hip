@@ -45,6 +45,34 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float *__restrict__ i
     *reinterpret_cast<h8 *>(out + (int64_t)m * Kp + ch * 8) = o;
 }
 
+// uint8 variant: img [B][H][W][3] (HWC, what PIL / cv2 hand over after Resize).  ToTensor (x / 255) and
+// Normalize ((x - mean) / std) of the reference's val_transforms (datasets/make_dataloader.py:57-61) are applied
+// while gathering, in fp32, before the fp16 rounding -- the same values the fp32 entry point receives.
+__global__ __launch_bounds__(256) void im2col_u8_kernel(const unsigned char *__restrict__ img, int B, int H, int Wd, int p,
+                                                        int stride, int h_res, int w_res, float m0, float m1, float m2,
+                                                        float s0, float s1, float s2, _Float16 *__restrict__ out,
+                                                        int mp_pad) {
+    const int Kp = 3 * p * p;
+    const int chunks = Kp / 8;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (int64_t)mp_pad * chunks) return;
+    const int m = (int)(gid / chunks), ch = (int)(gid % chunks);
+    const int P = h_res * w_res;
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    h8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (m < B * P) {
+        const int b = m / P, pi = m % P;
+        const int ph = pi / w_res, pw = pi % w_res;
+        const int k = ch * 8;
+        const int c = k / (p * p), kh = (k % (p * p)) / p, kw = k % p;
+        const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+        const unsigned char *src = img + (((int64_t)b * H + (ph * stride + kh)) * Wd + pw * stride + kw) * 3 + c;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (_Float16)__fdiv_rn(__fdiv_rn((float)src[j * 3], 255.0f) - mean, sd);
+    }
+    *reinterpret_cast<h8 *>(out + (int64_t)m * Kp + ch * 8) = o;
+}
+
 // x[b*L + 0][:] = class_embedding + pos[0] (+ cv_emb[b])      model/clip/model.py:419-422
 __global__ __launch_bounds__(256) void cls_token_kernel(const float *__restrict__ cls, const float *__restrict__ pos,
                                                         const float *__restrict__ cv, int B, int L, int W,
@@ -522,12 +550,12 @@ static int attention_dispatch(const _Float16 *qkv, int B, int L, int W, int head
                     : launch_attention<16, 8, false>(qkv, B, L, W, heads, out, q_tiles, stream);
 }
 
-extern "C" int mpreid_vit_forward(const mpreid_vit_cfg *cfg, const mpreid_vit_weights *w, const float *img, int B,
-                                  const float *cv_emb, float *out, void *ws, size_t ws_bytes,
-                                  mpreid_stream_t stream_) {
+static int vit_forward_impl(const mpreid_vit_cfg *cfg, const mpreid_vit_weights *w, const float *img,
+                            const unsigned char *img_u8, const float *mean3, const float *std3, int B,
+                            const float *cv_emb, float *out, void *ws, size_t ws_bytes, mpreid_stream_t stream_) {
     int rc = vit_check_cfg(cfg);
     if (rc) return rc;
-    ARG_CHECK(w && img && out && B > 0 && w->layers);
+    ARG_CHECK(w && (img || img_u8) && out && B > 0 && w->layers);
     const VitLayout v = vit_layout(cfg, B);
     if (!ws || ws_bytes < v.total) {
         mpreid_set_error("vit workspace too small: %zu < %zu", ws_bytes, v.total);
@@ -550,8 +578,13 @@ extern "C" int mpreid_vit_forward(const mpreid_vit_cfg *cfg, const mpreid_vit_we
     // patch embedding (conv1, no bias) + positional embedding; CLS row; ln_pre
     {
         const int64_t threads = (int64_t)v.MPpad * (v.Kp / 8);
-        hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, img, B,
-                           cfg->img_h, cfg->img_w, cfg->patch, cfg->stride, cfg->h_res, cfg->w_res, patches, v.MPpad);
+        if (img_u8)
+            hipLaunchKernelGGL(im2col_u8_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, img_u8, B,
+                               cfg->img_h, cfg->img_w, cfg->patch, cfg->stride, cfg->h_res, cfg->w_res, mean3[0], mean3[1],
+                               mean3[2], std3[0], std3[1], std3[2], patches, v.MPpad);
+        else
+            hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, img, B,
+                               cfg->img_h, cfg->img_w, cfg->patch, cfg->stride, cfg->h_res, cfg->w_res, patches, v.MPpad);
         LAUNCH_CHECK();
         GemmArgs g{};
         g.A = patches;
@@ -622,4 +655,17 @@ extern "C" int mpreid_vit_forward(const mpreid_vit_cfg *cfg, const mpreid_vit_we
                        neck ? w->bn_proj_scale : nullptr, neck ? w->bn_proj_shift : nullptr, out);
     LAUNCH_CHECK();
     return MPREID_OK;
+}
+
+extern "C" int mpreid_vit_forward(const mpreid_vit_cfg *cfg, const mpreid_vit_weights *w, const float *img, int B,
+                                  const float *cv_emb, float *out, void *ws, size_t ws_bytes, mpreid_stream_t stream) {
+    ARG_CHECK(img);
+    return vit_forward_impl(cfg, w, img, nullptr, nullptr, nullptr, B, cv_emb, out, ws, ws_bytes, stream);
+}
+
+extern "C" int mpreid_vit_forward_u8(const mpreid_vit_cfg *cfg, const mpreid_vit_weights *w, const uint8_t *img_hwc,
+                                     const float *pixel_mean3, const float *pixel_std3, int B, const float *cv_emb,
+                                     float *out, void *ws, size_t ws_bytes, mpreid_stream_t stream) {
+    ARG_CHECK(img_hwc && pixel_mean3 && pixel_std3);
+    return vit_forward_impl(cfg, w, nullptr, img_hwc, pixel_mean3, pixel_std3, B, cv_emb, out, ws, ws_bytes, stream);
 }

@@ -22,7 +22,7 @@ SYMBOLS = [
     "mpreid_rerank_workspace_bytes", "mpreid_rerank_f32", "mpreid_rerank_debug_copy",
     "mpreid_eval_rank_positions", "mpreid_rr_dist_rows", "mpreid_rr_vcap", "mpreid_rr_krecip", "mpreid_rr_pack_rows", "mpreid_rr_qe_count",
     "mpreid_rr_qe_fill", "mpreid_rr_jaccard",
-    "mpreid_vit_workspace_bytes", "mpreid_vit_forward", "mpreid_gemm_f16_nt", "mpreid_gemm_f16_nt_ex",
+    "mpreid_vit_workspace_bytes", "mpreid_vit_forward", "mpreid_vit_forward_u8", "mpreid_gemm_f16_nt", "mpreid_gemm_f16_nt_ex",
     "mpreid_cast_f32_to_f16", "mpreid_profile_enable", "mpreid_profile_reset", "mpreid_profile_query",
 ]
 
@@ -121,6 +121,9 @@ def load():
     L.mpreid_vit_workspace_bytes.argtypes = [C.POINTER(VitCfg), i32]
     L.mpreid_vit_forward.restype = i32
     L.mpreid_vit_forward.argtypes = [C.POINTER(VitCfg), C.POINTER(VitWeights), vp, i32, vp, vp, vp, sz, vp]
+    L.mpreid_vit_forward_u8.restype = i32
+    L.mpreid_vit_forward_u8.argtypes = [C.POINTER(VitCfg), C.POINTER(VitWeights), vp, C.POINTER(C.c_float),
+                                        C.POINTER(C.c_float), i32, vp, vp, vp, sz, vp]
     L.mpreid_gemm_f16_nt.restype = i32
     L.mpreid_gemm_f16_nt.argtypes = [vp, vp, vp, i64, i64, i64, vp]
     L.mpreid_gemm_f16_nt_ex.restype = i32

@@ -240,6 +240,25 @@ class VitEncoder:
 
     __call__ = forward
 
+    @torch.no_grad()
+    def forward_u8(self, img_hwc: torch.Tensor, pixel_mean=(0.5, 0.5, 0.5), pixel_std=(0.5, 0.5, 0.5),
+                   cv_emb: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """uint8 images [B, H, W, 3] (after Resize); ToTensor + Normalize run inside the patch-gather kernel."""
+        L = _lib.load()
+        img = img_hwc.detach().to(device=self.device, dtype=torch.uint8).contiguous()
+        B = img.shape[0]
+        assert tuple(img.shape[1:]) == self.img_hw + (3,), img.shape
+        cv = None if cv_emb is None else _dev_f32(cv_emb, self.device)
+        if out is None:
+            out = torch.empty((B, self.feat_dim), dtype=torch.float32, device=self.device)
+        mean = (C.c_float * 3)(*[float(x) for x in pixel_mean])
+        std = (C.c_float * 3)(*[float(x) for x in pixel_std])
+        wsb = L.mpreid_vit_workspace_bytes(C.byref(self.c_cfg), B)
+        ws = _workspace(self.ws_tag, wsb, self.device)
+        _lib.check(L.mpreid_vit_forward_u8(C.byref(self.c_cfg), C.byref(self.c_w), _ptr(img), mean, std, B, _ptr(cv),
+                                           _ptr(out), _ptr(ws), ws.numel(), _lib.stream_ptr()), "mpreid_vit_forward_u8")
+        return out
+
     def clone_for_stream(self, ws_tag: str) -> "VitEncoder":
         """a second handle on the same device weights with its own workspace (for a second HIP stream)"""
         import copy

@@ -92,3 +92,18 @@ def test_vit_cls_only_last_block_is_bit_identical():
     full = _encoder(big, sd, (256, 128), cls_only_last=False)(imgs).cpu().numpy()
     tail = _encoder(big, sd, (256, 128), cls_only_last=True)(imgs).cpu().numpy()
     assert np.array_equal(full, tail)
+
+
+def test_vit_uint8_input_matches_float_path():
+    """uint8 HWC images + fused ToTensor/Normalize == the fp32 entry point fed with the transformed tensor"""
+    from mpreid import synth
+    rng = np.random.default_rng(0)
+    sd = synth.vit_state_dict(SMALL, seed=7, std=0.05, ln_jitter=0.1)
+    enc = _encoder(SMALL, sd, (64, 32))
+    u8 = rng.integers(0, 256, size=(5, 64, 32, 3), dtype=np.uint8)
+    mean, std = (0.5, 0.4, 0.45), (0.5, 0.25, 0.3)
+    x = torch.from_numpy(u8).permute(0, 3, 1, 2).float().div(255.0)     # ToTensor
+    x = (x - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)  # Normalize
+    want = enc(x).cpu().numpy()
+    got = enc.forward_u8(torch.from_numpy(u8), mean, std).cpu().numpy()
+    assert np.array_equal(got, want)
