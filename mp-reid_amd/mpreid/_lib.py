@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmpreid_hip.so")
+#: MPREID_LIB points at another build of the same library (kernel A/B runs); there is no other fallback
+LIB_PATH = os.environ.get("MPREID_LIB") or os.path.join(_HERE, "libmpreid_hip.so")
 
 GEMM_F32_EXACT = 0
 GEMM_F16_FAST = 1

@@ -107,3 +107,34 @@ def test_vit_uint8_input_matches_float_path():
     want = enc(x).cpu().numpy()
     got = enc.forward_u8(torch.from_numpy(u8), mean, std).cpu().numpy()
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("name,n,k,epi", [("qkv", 2304, 768, 1), ("out", 768, 768, 2), ("fc1", 3072, 768, 3),
+                                            ("fc2", 768, 3072, 2), ("f32", 768, 768, 0)])
+def test_gemm_kernels_agree_bitwise(name, n, k, epi):
+    """The dispatcher picks the 128x128 or the persistent 256x256 kernel by tile count, so the same image goes
+    through either depending on the batch it arrives in: both must give the same bits for every epilogue."""
+    import ctypes as C
+    from mpreid import _lib
+    L = _lib.load()
+    dev = _lib.require_gpu()
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    mb, ms = 16384, 256       # 64 x (n/256) >= 128 big tiles -> persistent kernel; 2 x (n/128) tiles -> small kernel
+    a = (torch.rand((mb, k), generator=gen) * 2 - 1).half().to(dev)
+    w = ((torch.rand((n, k), generator=gen) * 2 - 1) * 0.05).half().to(dev)
+    bias = torch.randn(n, generator=gen).to(dev)
+    dt = torch.float16 if epi in (1, 3) else torch.float32
+    init = torch.randn((mb, n), generator=gen).to(dt).to(dev)
+    ob, osm = init.clone(), init[:ms].clone()
+    for x, o in ((a, ob), (a[:ms].contiguous(), osm)):
+        _lib.check(L.mpreid_gemm_f16_nt_ex(C.c_void_p(x.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(o.data_ptr()),
+                                           C.c_void_p(bias.data_ptr()), x.shape[0], n, k, epi, _lib.stream_ptr()), name)
+    torch.cuda.synchronize()
+    assert torch.equal(ob[:ms], osm)
+    ref = a[:ms].float() @ w.float().T
+    if epi in (1, 3):
+        ref = ref + bias
+        ref = ref * torch.sigmoid(1.702 * ref) if epi == 3 else ref
+    elif epi == 2:
+        ref = init[:ms].float() + (ref + bias)
+    assert torch.allclose(osm.float(), ref, rtol=2e-3, atol=2e-3)
