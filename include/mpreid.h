@@ -185,6 +185,35 @@ int mpreid_vit_forward_u8(const mpreid_vit_cfg *cfg, const mpreid_vit_weights *w
                           const float *pixel_mean3, const float *pixel_std3, int batch, const float *cv_emb_dev,
                           float *out_dev, void *ws_dev, size_t ws_bytes, mpreid_stream_t stream);
 
+/* Test-time-augmentation views of the reference's Uni-Prompt evaluation ("option A",
+ * processor/processor_uniprompt_stage2.py:605-633), applied while the patches are gathered instead of
+ * materialising a transformed [B,3,H,W] tensor per view. */
+#define MPREID_VIEW_ORIGINAL 0
+#define MPREID_VIEW_FLIP 1        /* torch.flip(img, [3]) */
+#define MPREID_VIEW_PSEUDO_IR 2   /* img.mean(dim=1, keepdim=True).repeat(1, 3, 1, 1) */
+#define MPREID_VIEW_PSEUDO_RGB 3  /* img[:, 0:1].repeat(1, 3, 1, 1) */
+/* mpreid_vit_forward / mpreid_vit_forward_u8 on one view: exactly one of img_f32_dev ([B][3][H][W], already
+ * normalised) and img_hwc_u8_dev ([B][H][W][3] + pixel_mean3 / pixel_std3 host arrays) is non-NULL. */
+int mpreid_vit_forward_view(const mpreid_vit_cfg *cfg, const mpreid_vit_weights *w, const float *img_f32_dev,
+                            const uint8_t *img_hwc_u8_dev, const float *pixel_mean3, const float *pixel_std3, int view,
+                            int batch, const float *cv_emb_dev, float *out_dev, void *ws_dev, size_t ws_bytes,
+                            mpreid_stream_t stream);
+/* processor/processor_uniprompt_stage2.py:636-640: out[rows][dim] = mean over the views of
+ * feats[n_views][rows][dim] (sequential sum in view order, true division), then F.normalize(p=2, dim=1,
+ * eps=1e-12) when normalize != 0. */
+int mpreid_tta_mean_f32(const float *feats_dev, int n_views, int64_t rows, int dim, int normalize, float *out_dev,
+                        mpreid_stream_t stream);
+
+/* T.Resize(cfg.INPUT.SIZE_TEST) of val_transforms (datasets/make_dataloader.py:57-58) for a ragged batch of decoded
+ * uint8 RGB images: bit-exact with PIL.Image.resize((out_w, out_h), BILINEAR) (Pillow 8-bit two-pass resample,
+ * which is what torchvision's Resize calls for PIL inputs).  Image b is src_dev[offsets_dev[b] ...] as [h][w][3]
+ * with (h, w) = hw_dev[2b], hw_dev[2b+1]; max_in_h >= every h.  dst_dev is [batch][out_h][out_w][3], the input
+ * layout of mpreid_vit_forward_u8. */
+size_t mpreid_resize_workspace_bytes(int batch, int max_in_h, int out_w);
+int mpreid_resize_bilinear_u8(const uint8_t *src_dev, const int64_t *offsets_dev, const int32_t *hw_dev, int batch,
+                              int max_in_h, int out_h, int out_w, uint8_t *dst_dev, void *ws_dev, size_t ws_bytes,
+                              mpreid_stream_t stream);
+
 /* fp16 GEMM used by the encoder, exposed for the roofline bench and unit tests:
  * C[M][N] (fp32) = A[M][K] (fp16) x B[N][K]^T (fp16).  M, N multiples of 128... see DESIGN.md. */
 int mpreid_gemm_f16_nt(const void *a_dev, const void *b_dev, float *c_dev, int64_t m, int64_t n, int64_t k,

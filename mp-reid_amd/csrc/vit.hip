@@ -21,7 +21,13 @@
 
 // ---------------------------------------------------------------------------------------------
 // im2col: img [B][3][H][W] fp32 -> patches [MPpad][3*p*p] fp16; rows >= B*P are zero
+//
+// VIEW = the test-time-augmentation views of processor/processor_uniprompt_stage2.py:605-633, applied while
+// gathering (the reference materialises each view as a new [B,3,H,W] tensor and runs the model on it):
+//   0 original   1 torch.flip(img, [3]) (mirror in W)   2 pseudo-IR: img.mean(dim=1) in all 3 channels
+//   3 pseudo-RGB: channel 0 in all 3 channels
 // ---------------------------------------------------------------------------------------------
+template <int VIEW>
 __global__ __launch_bounds__(256) void im2col_kernel(const float *__restrict__ img, int B, int H, int Wd, int p,
                                                      int stride, int h_res, int w_res, _Float16 *__restrict__ out,
                                                      int mp_pad) {
@@ -38,16 +44,27 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float *__restrict__ i
         const int ph = pi / w_res, pw = pi % w_res;
         const int k = ch * 8;
         const int c = k / (p * p), kh = (k % (p * p)) / p, kw = k % p;
-        const float *src = img + (((int64_t)b * 3 + c) * H + (ph * stride + kh)) * Wd + pw * stride + kw;
+        const int64_t plane = (int64_t)H * Wd;
+        const int csrc = (VIEW == 2 || VIEW == 3) ? 0 : c;
+        const float *row = img + ((int64_t)b * 3 + csrc) * plane + (int64_t)(ph * stride + kh) * Wd;
+        const int x0 = pw * stride + kw;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (_Float16)src[j];
+        for (int j = 0; j < 8; ++j) {
+            const int x = (VIEW == 1) ? (Wd - 1 - (x0 + j)) : (x0 + j);
+            float v = row[x];
+            // torch mean over the channel dim: ((c0 + c1) + c2) / 3
+            if (VIEW == 2) v = __fdiv_rn((v + row[plane + x]) + row[2 * plane + x], 3.0f);
+            o[j] = (_Float16)v;
+        }
     }
     *reinterpret_cast<h8 *>(out + (int64_t)m * Kp + ch * 8) = o;
 }
 
 // uint8 variant: img [B][H][W][3] (HWC, what PIL / cv2 hand over after Resize).  ToTensor (x / 255) and
 // Normalize ((x - mean) / std) of the reference's val_transforms (datasets/make_dataloader.py:57-61) are applied
-// while gathering, in fp32, before the fp16 rounding -- the same values the fp32 entry point receives.
+// while gathering, in fp32, before the fp16 rounding -- the same values the fp32 entry point receives.  The views
+// act on the normalised values, as in the reference.
+template <int VIEW>
 __global__ __launch_bounds__(256) void im2col_u8_kernel(const unsigned char *__restrict__ img, int B, int H, int Wd, int p,
                                                         int stride, int h_res, int w_res, float m0, float m1, float m2,
                                                         float s0, float s1, float s2, _Float16 *__restrict__ out,
@@ -65,10 +82,21 @@ __global__ __launch_bounds__(256) void im2col_u8_kernel(const unsigned char *__r
         const int ph = pi / w_res, pw = pi % w_res;
         const int k = ch * 8;
         const int c = k / (p * p), kh = (k % (p * p)) / p, kw = k % p;
-        const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
-        const unsigned char *src = img + (((int64_t)b * H + (ph * stride + kh)) * Wd + pw * stride + kw) * 3 + c;
+        const int csrc = (VIEW == 2 || VIEW == 3) ? 0 : c;
+        const float mean = csrc == 0 ? m0 : (csrc == 1 ? m1 : m2), sd = csrc == 0 ? s0 : (csrc == 1 ? s1 : s2);
+        const unsigned char *row = img + ((int64_t)b * H + (ph * stride + kh)) * Wd * 3;
+        const int x0 = pw * stride + kw;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (_Float16)__fdiv_rn(__fdiv_rn((float)src[j * 3], 255.0f) - mean, sd);
+        for (int j = 0; j < 8; ++j) {
+            const int x = (VIEW == 1) ? (Wd - 1 - (x0 + j)) : (x0 + j);
+            float v = __fdiv_rn(__fdiv_rn((float)row[x * 3 + csrc], 255.0f) - mean, sd);
+            if (VIEW == 2) {
+                const float v1 = __fdiv_rn(__fdiv_rn((float)row[x * 3 + 1], 255.0f) - m1, s1);
+                const float v2 = __fdiv_rn(__fdiv_rn((float)row[x * 3 + 2], 255.0f) - m2, s2);
+                v = __fdiv_rn((v + v1) + v2, 3.0f);
+            }
+            o[j] = (_Float16)v;
+        }
     }
     *reinterpret_cast<h8 *>(out + (int64_t)m * Kp + ch * 8) = o;
 }
@@ -551,11 +579,11 @@ static int attention_dispatch(const _Float16 *qkv, int B, int L, int W, int head
 }
 
 static int vit_forward_impl(const mpreid_vit_cfg *cfg, const mpreid_vit_weights *w, const float *img,
-                            const unsigned char *img_u8, const float *mean3, const float *std3, int B,
+                            const unsigned char *img_u8, const float *mean3, const float *std3, int view, int B,
                             const float *cv_emb, float *out, void *ws, size_t ws_bytes, mpreid_stream_t stream_) {
     int rc = vit_check_cfg(cfg);
     if (rc) return rc;
-    ARG_CHECK(w && (img || img_u8) && out && B > 0 && w->layers);
+    ARG_CHECK(w && (img || img_u8) && out && B > 0 && w->layers && view >= 0 && view <= 3);
     const VitLayout v = vit_layout(cfg, B);
     if (!ws || ws_bytes < v.total) {
         mpreid_set_error("vit workspace too small: %zu < %zu", ws_bytes, v.total);
@@ -578,13 +606,21 @@ static int vit_forward_impl(const mpreid_vit_cfg *cfg, const mpreid_vit_weights 
     // patch embedding (conv1, no bias) + positional embedding; CLS row; ln_pre
     {
         const int64_t threads = (int64_t)v.MPpad * (v.Kp / 8);
-        if (img_u8)
-            hipLaunchKernelGGL(im2col_u8_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, img_u8, B,
-                               cfg->img_h, cfg->img_w, cfg->patch, cfg->stride, cfg->h_res, cfg->w_res, mean3[0], mean3[1],
-                               mean3[2], std3[0], std3[1], std3[2], patches, v.MPpad);
-        else
-            hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, img, B,
-                               cfg->img_h, cfg->img_w, cfg->patch, cfg->stride, cfg->h_res, cfg->w_res, patches, v.MPpad);
+        const dim3 grid((unsigned)((threads + 255) / 256));
+#define MPREID_IM2COL(V)                                                                                               \
+    case V:                                                                                                            \
+        if (img_u8)                                                                                                    \
+            hipLaunchKernelGGL(im2col_u8_kernel<V>, grid, dim3(256), 0, stream, img_u8, B, cfg->img_h, cfg->img_w,     \
+                               cfg->patch, cfg->stride, cfg->h_res, cfg->w_res, mean3[0], mean3[1], mean3[2], std3[0], \
+                               std3[1], std3[2], patches, v.MPpad);                                                    \
+        else                                                                                                           \
+            hipLaunchKernelGGL(im2col_kernel<V>, grid, dim3(256), 0, stream, img, B, cfg->img_h, cfg->img_w,           \
+                               cfg->patch, cfg->stride, cfg->h_res, cfg->w_res, patches, v.MPpad);                     \
+        break;
+        switch (view) {
+            MPREID_IM2COL(0) MPREID_IM2COL(1) MPREID_IM2COL(2) MPREID_IM2COL(3)
+        }
+#undef MPREID_IM2COL
         LAUNCH_CHECK();
         GemmArgs g{};
         g.A = patches;
@@ -660,12 +696,22 @@ static int vit_forward_impl(const mpreid_vit_cfg *cfg, const mpreid_vit_weights 
 extern "C" int mpreid_vit_forward(const mpreid_vit_cfg *cfg, const mpreid_vit_weights *w, const float *img, int B,
                                   const float *cv_emb, float *out, void *ws, size_t ws_bytes, mpreid_stream_t stream) {
     ARG_CHECK(img);
-    return vit_forward_impl(cfg, w, img, nullptr, nullptr, nullptr, B, cv_emb, out, ws, ws_bytes, stream);
+    return vit_forward_impl(cfg, w, img, nullptr, nullptr, nullptr, 0, B, cv_emb, out, ws, ws_bytes, stream);
 }
 
 extern "C" int mpreid_vit_forward_u8(const mpreid_vit_cfg *cfg, const mpreid_vit_weights *w, const uint8_t *img_hwc,
                                      const float *pixel_mean3, const float *pixel_std3, int B, const float *cv_emb,
                                      float *out, void *ws, size_t ws_bytes, mpreid_stream_t stream) {
     ARG_CHECK(img_hwc && pixel_mean3 && pixel_std3);
-    return vit_forward_impl(cfg, w, nullptr, img_hwc, pixel_mean3, pixel_std3, B, cv_emb, out, ws, ws_bytes, stream);
+    return vit_forward_impl(cfg, w, nullptr, img_hwc, pixel_mean3, pixel_std3, 0, B, cv_emb, out, ws, ws_bytes, stream);
+}
+
+extern "C" int mpreid_vit_forward_view(const mpreid_vit_cfg *cfg, const mpreid_vit_weights *w, const float *img_f32,
+                                       const uint8_t *img_hwc_u8, const float *pixel_mean3, const float *pixel_std3,
+                                       int view, int B, const float *cv_emb, float *out, void *ws, size_t ws_bytes,
+                                       mpreid_stream_t stream) {
+    ARG_CHECK((img_f32 != nullptr) != (img_hwc_u8 != nullptr));
+    ARG_CHECK(!img_hwc_u8 || (pixel_mean3 && pixel_std3));
+    return vit_forward_impl(cfg, w, img_f32, img_hwc_u8, pixel_mean3, pixel_std3, view, B, cv_emb, out, ws, ws_bytes,
+                            stream);
 }

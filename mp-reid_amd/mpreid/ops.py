@@ -142,6 +142,50 @@ def gemm_f16_nt(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return c
 
 
+VIEW_ORIGINAL, VIEW_FLIP, VIEW_PSEUDO_IR, VIEW_PSEUDO_RGB = 0, 1, 2, 3
+
+
+def tta_mean(feats: torch.Tensor, normalize: bool = True) -> torch.Tensor:
+    """feats [n_views, rows, dim] fp32 -> [rows, dim]: torch.stack(feat_list).mean(0) (+ F.normalize)."""
+    dev = _lib.require_gpu()
+    f = _dev_f32(feats, dev)
+    assert f.dim() == 3
+    out = torch.empty(f.shape[1:], dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().mpreid_tta_mean_f32(_ptr(f), f.shape[0], f.shape[1], f.shape[2], int(bool(normalize)), _ptr(out),
+                                               _lib.stream_ptr()), "mpreid_tta_mean_f32")
+    return out
+
+
+def resize_bilinear_u8(images, out_hw) -> torch.Tensor:
+    """T.Resize(cfg.INPUT.SIZE_TEST) of val_transforms (datasets/make_dataloader.py:57-58) on the GPU, bit-exact with
+    PIL.Image.resize(BILINEAR): images = sequence of uint8 [h, w, 3] arrays / tensors of any sizes (decoded RGB);
+    returns uint8 [B, out_h, out_w, 3] on the device -- the input of VitEncoder.forward_u8.  One H2D copy of the packed
+    bytes (pinned staging), two kernels."""
+    dev = _lib.require_gpu()
+    L = _lib.load()
+    arrs = [np.ascontiguousarray(im.cpu().numpy() if isinstance(im, torch.Tensor) else im, dtype=np.uint8) for im in images]
+    B = len(arrs)
+    assert B > 0 and all(a.ndim == 3 and a.shape[2] == 3 for a in arrs)
+    hw = np.array([a.shape[:2] for a in arrs], dtype=np.int32)
+    sizes = hw[:, 0].astype(np.int64) * hw[:, 1] * 3
+    offsets = np.zeros(B, np.int64)
+    offsets[1:] = np.cumsum(sizes)[:-1]
+    packed = torch.empty(int(sizes.sum()), dtype=torch.uint8).pin_memory()
+    pk = packed.numpy()
+    for a, o, n in zip(arrs, offsets, sizes):
+        pk[o:o + n] = a.reshape(-1)
+    src = packed.to(dev, non_blocking=True)
+    offs_d = torch.from_numpy(offsets).to(dev)
+    hw_d = torch.from_numpy(hw).to(dev)
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    max_h = int(hw[:, 0].max())
+    dst = torch.empty((B, oh, ow, 3), dtype=torch.uint8, device=dev)
+    ws = _workspace("resize", L.mpreid_resize_workspace_bytes(B, max_h, ow), dev)
+    _lib.check(L.mpreid_resize_bilinear_u8(_ptr(src), _ptr(offs_d), _ptr(hw_d), B, max_h, oh, ow, _ptr(dst), _ptr(ws),
+                                           ws.numel(), _lib.stream_ptr()), "mpreid_resize_bilinear_u8")
+    return dst
+
+
 # ----------------------------------------------------------------------------------------------
 # ViT image encoder
 # ----------------------------------------------------------------------------------------------
@@ -258,6 +302,45 @@ class VitEncoder:
         _lib.check(L.mpreid_vit_forward_u8(C.byref(self.c_cfg), C.byref(self.c_w), _ptr(img), mean, std, B, _ptr(cv),
                                            _ptr(out), _ptr(ws), ws.numel(), _lib.stream_ptr()), "mpreid_vit_forward_u8")
         return out
+
+    @torch.no_grad()
+    def forward_view(self, img: torch.Tensor, view: int, cv_emb: Optional[torch.Tensor] = None,
+                     pixel_mean=(0.5, 0.5, 0.5), pixel_std=(0.5, 0.5, 0.5),
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """One test-time-augmentation view (VIEW_ORIGINAL / VIEW_FLIP / VIEW_PSEUDO_IR / VIEW_PSEUDO_RGB) of a batch:
+        img is either fp32 [B,3,H,W] (already normalised) or uint8 [B,H,W,3].  The view transform of
+        processor/processor_uniprompt_stage2.py:605-633 happens inside the patch gather."""
+        L = _lib.load()
+        u8 = img.dtype == torch.uint8
+        if u8:
+            img = img.detach().to(device=self.device).contiguous()
+            assert tuple(img.shape[1:]) == self.img_hw + (3,), img.shape
+        else:
+            img = _dev_f32(img, self.device)
+            assert tuple(img.shape[1:]) == (3,) + self.img_hw, img.shape
+        B = img.shape[0]
+        cv = None if cv_emb is None else _dev_f32(cv_emb, self.device)
+        if out is None:
+            out = torch.empty((B, self.feat_dim), dtype=torch.float32, device=self.device)
+        assert out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (B, self.feat_dim)
+        mean = (C.c_float * 3)(*[float(x) for x in pixel_mean])
+        std = (C.c_float * 3)(*[float(x) for x in pixel_std])
+        ws = _workspace(self.ws_tag, L.mpreid_vit_workspace_bytes(C.byref(self.c_cfg), B), self.device)
+        _lib.check(L.mpreid_vit_forward_view(C.byref(self.c_cfg), C.byref(self.c_w), None if u8 else _ptr(img),
+                                             _ptr(img) if u8 else None, mean, std, int(view), B, _ptr(cv), _ptr(out),
+                                             _ptr(ws), ws.numel(), _lib.stream_ptr()), "mpreid_vit_forward_view")
+        return out
+
+    @torch.no_grad()
+    def forward_tta(self, img: torch.Tensor, cv_emb: Optional[torch.Tensor] = None, views=(0, 1, 2, 3),
+                    normalize: bool = True, pixel_mean=(0.5, 0.5, 0.5), pixel_std=(0.5, 0.5, 0.5)) -> torch.Tensor:
+        """processor/processor_uniprompt_stage2.py:598-640: features of the views, averaged, then L2-normalised when
+        TEST.FEAT_NORM is set."""
+        B = img.shape[0]
+        feats = torch.empty((len(views), B, self.feat_dim), dtype=torch.float32, device=self.device)
+        for i, v in enumerate(views):
+            self.forward_view(img, v, cv_emb, pixel_mean, pixel_std, out=feats[i])
+        return tta_mean(feats, normalize)
 
     def clone_for_stream(self, ws_tag: str) -> "VitEncoder":
         """a second handle on the same device weights with its own workspace (for a second HIP stream)"""

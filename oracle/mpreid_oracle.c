@@ -486,3 +486,97 @@ ORC_API long orc_eval_func(const float *dist, const int64_t *q_pid, const int64_
     free(cmc_sum); free(aps); free(row); free(tmp);
     return nvalid;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* val_transforms' T.Resize (datasets/make_dataloader.py:57-58) on a PIL image.               */
+/* ------------------------------------------------------------------------------------------ */
+/* torchvision 0.19.1 (requirements.txt:171) hands a PIL image to Image.resize(size[::-1], BILINEAR); the
+ * arithmetic is Pillow's (pinned 10.4.0, requirements.txt:122; NOT vendored under /root/reference), file
+ * src/libImaging/Resample.c, 8-bit path.  Published algorithm, restated:
+ *   precompute_coeffs: scale = in/out; filterscale = max(scale, 1); support = 1.0 * filterscale (triangle
+ *     filter); for output xx: center = (xx + 0.5) * scale; xmin = max((int)(center - support + 0.5), 0);
+ *     xmax = min((int)(center + support + 0.5), in) - xmin; w[x] = tri((x + xmin - center + 0.5) / filterscale)
+ *     normalised by their sum, all in double;
+ *   normalize_coeffs_8bpc: k = (int)(0.5 + w * 2^22)   (weights of the triangle filter are never negative);
+ *   pass: acc = 2^21 + sum pixel * k  (int32);  out = clip8(acc >> 22);
+ *   horizontal pass first into an 8-bit image, then the vertical pass over it.
+ * Pinned by tests/golden/resize.npz (made with the Pillow in this image, 12.2.0 -- same Resample.c arithmetic).
+ * Images are HWC uint8, 3 channels. */
+#define ORC_RS_BITS 22
+static inline double orc_rs_tri(double x) {
+    if (x < 0.0) x = -x;
+    return x < 1.0 ? 1.0 - x : 0.0;
+}
+/* bounds and (on request) the x-th fixed-point coefficient of output position xx */
+static inline void orc_rs_bounds(int in_size, int out_size, int xx, int *xmin_o, int *xcnt_o, double *center_o,
+                                 double *ss_o, double *ww_o) {
+    double scale = (double)((float)in_size - 0.0f) / out_size, filterscale = scale;
+    if (filterscale < 1.0) filterscale = 1.0;
+    const double support = 1.0 * filterscale;
+    const double center = 0.0 + (xx + 0.5) * scale;
+    const double ss = 1.0 / filterscale;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    double ww = 0.0;
+    for (int x = 0; x < xmax; ++x) ww += orc_rs_tri((x + xmin - center + 0.5) * ss);
+    *xmin_o = xmin;
+    *xcnt_o = xmax;
+    *center_o = center;
+    *ss_o = ss;
+    *ww_o = ww;
+}
+static inline int32_t orc_rs_coeff(int x, int xmin, double center, double ss, double ww) {
+    double w = orc_rs_tri((x + xmin - center + 0.5) * ss);
+    if (ww != 0.0) w /= ww;
+    return (int32_t)(0.5 + w * (double)(1 << ORC_RS_BITS));
+}
+static inline uint8_t orc_rs_clip8(int32_t acc) {
+    const int32_t v = acc >> ORC_RS_BITS; /* arithmetic shift, as the lookup table index in Resample.c */
+    return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+/* src [in_h][in_w][3] -> dst [out_h][out_w][3]; tmp [in_h][out_w][3] caller-provided */
+ORC_API void orc_resize_bilinear_u8(const uint8_t *src, int in_h, int in_w, uint8_t *dst, int out_h, int out_w,
+                                    uint8_t *tmp) {
+    for (int xx = 0; xx < out_w; ++xx) {
+        int xmin, xcnt;
+        double center, ss, ww;
+        orc_rs_bounds(in_w, out_w, xx, &xmin, &xcnt, &center, &ss, &ww);
+        for (int y = 0; y < in_h; ++y) {
+            int32_t a0 = 1 << (ORC_RS_BITS - 1), a1 = a0, a2 = a0;
+            for (int x = 0; x < xcnt; ++x) {
+                const int32_t k = orc_rs_coeff(x, xmin, center, ss, ww);
+                const uint8_t *p = src + ((size_t)y * in_w + xmin + x) * 3;
+                a0 += p[0] * k;
+                a1 += p[1] * k;
+                a2 += p[2] * k;
+            }
+            uint8_t *o = tmp + ((size_t)y * out_w + xx) * 3;
+            o[0] = orc_rs_clip8(a0);
+            o[1] = orc_rs_clip8(a1);
+            o[2] = orc_rs_clip8(a2);
+        }
+    }
+    for (int yy = 0; yy < out_h; ++yy) {
+        int ymin, ycnt;
+        double center, ss, ww;
+        orc_rs_bounds(in_h, out_h, yy, &ymin, &ycnt, &center, &ss, &ww);
+        for (int xx = 0; xx < out_w; ++xx) {
+            int32_t a0 = 1 << (ORC_RS_BITS - 1), a1 = a0, a2 = a0;
+            for (int y = 0; y < ycnt; ++y) {
+                const int32_t k = orc_rs_coeff(y, ymin, center, ss, ww);
+                const uint8_t *p = tmp + ((size_t)(ymin + y) * out_w + xx) * 3;
+                a0 += p[0] * k;
+                a1 += p[1] * k;
+                a2 += p[2] * k;
+            }
+            uint8_t *o = dst + ((size_t)yy * out_w + xx) * 3;
+            o[0] = orc_rs_clip8(a0);
+            o[1] = orc_rs_clip8(a1);
+            o[2] = orc_rs_clip8(a2);
+        }
+    }
+}

@@ -212,6 +212,64 @@ def gen_vit():
     save("vit.npz", **out)
 
 
+def gen_resize():
+    """T.Resize of val_transforms (datasets/make_dataloader.py:57-58): torchvision hands the PIL image to
+    Image.resize(size[::-1], BILINEAR).  torchvision is not installed here; the Pillow call it makes is.  Ragged
+    uint8 inputs -> (out_h, out_w) outputs; a TTA golden for the four views of
+    processor/processor_uniprompt_stage2.py:605-633 rides along (tensor ops only, computed with torch)."""
+    from PIL import Image
+    import PIL
+    rng = np.random.default_rng(77)
+    cases = [((128, 64), (256, 128)),    # Market-1501 native size -> SIZE_TEST, 2x up
+             ((64, 32), (64, 32)),       # already the target size (Image.resize returns a copy)
+             ((301, 97), (256, 128)),    # down in h, up in w, odd sizes
+             ((259, 107), (128, 48)),    # > 2x down (wider filter support: 5 taps)
+             ((40, 33), (64, 32)),       # small, ~1x in w
+             ((1, 1), (8, 4)),           # degenerate
+             ((200, 50), (32, 16))]      # 6.25x / 3.1x down
+    out = {"n": np.int64(len(cases)), "pillow_version": np.array(PIL.__version__)}
+    for i, ((h, w), (oh, ow)) in enumerate(cases):
+        # smooth-ish + noise so that clipping at 0/255 and all rounding branches occur
+        base = rng.integers(0, 256, ((h + 7) // 8, (w + 7) // 8, 3)).astype(np.float32)
+        img = np.kron(base, np.ones((8, 8, 1), np.float32))[:h, :w]
+        img = np.clip(img + rng.normal(0, 40, img.shape), 0, 255).astype(np.uint8)
+        res = np.asarray(Image.fromarray(img, "RGB").resize((ow, oh), Image.BILINEAR))
+        out[f"in{i}"] = img
+        out[f"out{i}"] = res
+    save("resize.npz", **out)
+
+
+def gen_tta():
+    """TTA "option A" of the Uni-Prompt evaluation (processor/processor_uniprompt_stage2.py:598-640): the four views
+    are built with the reference's own tensor expressions, encoded by the reference VisionTransformer, averaged
+    with torch.stack(...).mean(0) and normalised with F.normalize."""
+    import torch.nn.functional as F
+    out = {}
+    small = dict(h_res=4, w_res=2, patch=16, stride=16, width=128, layers=2, heads=2, out_dim=64)
+    sd = synth.vit_state_dict(small, seed=7, std=0.05, ln_jitter=0.1)
+    for tag, imgs in (("f32", synth.synthetic_images(5, 64, 32, seed=21)),):
+        img = torch.from_numpy(imgs)
+        views = [img, torch.flip(img, [3]), img.mean(dim=1, keepdim=True).repeat(1, 3, 1, 1),
+                 img[:, 0:1, :, :].repeat(1, 3, 1, 1)]
+        feats = [torch.from_numpy(run_vit(small, sd, v.contiguous().numpy())[0]) for v in views]
+        out[f"{tag}_views"] = torch.stack(feats, 0).numpy()
+        agg = torch.stack(feats, dim=0).mean(dim=0)
+        out[f"{tag}_mean"] = agg.numpy()
+        out[f"{tag}_mean_norm"] = F.normalize(agg, p=2, dim=1).numpy()
+    # uint8 HWC input through ToTensor + Normalize(mean, std) first (datasets/make_dataloader.py:59-60)
+    rng = np.random.default_rng(5)
+    u8 = rng.integers(0, 256, (4, 64, 32, 3), dtype=np.uint8)
+    mean, std = np.array([0.5, 0.4, 0.45], np.float32), np.array([0.5, 0.25, 0.3], np.float32)
+    t = torch.from_numpy(u8).permute(0, 3, 1, 2).to(torch.float32).div(255)
+    t = (t - torch.from_numpy(mean)[None, :, None, None]) / torch.from_numpy(std)[None, :, None, None]
+    views = [t, torch.flip(t, [3]), t.mean(dim=1, keepdim=True).repeat(1, 3, 1, 1), t[:, 0:1].repeat(1, 3, 1, 1)]
+    feats = [torch.from_numpy(run_vit(small, sd, v.contiguous().numpy())[0]) for v in views]
+    out["u8_img"], out["u8_mean"], out["u8_std"] = u8, mean, std
+    out["u8_views"] = torch.stack(feats, 0).numpy()
+    out["u8_mean_norm"] = F.normalize(torch.stack(feats, 0).mean(0), p=2, dim=1).numpy()
+    save("tta.npz", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["distance", "rerank", "vit"]
     if "distance" in which:
@@ -222,3 +280,7 @@ if __name__ == "__main__":
         gen_rerank_small()
     if "vit" in which:
         gen_vit()
+    if "resize" in which:
+        gen_resize()
+    if "tta" in which:
+        gen_tta()

@@ -169,3 +169,13 @@ def test_rerank_small_n_vs_reference(golden, tag):
         want = g[f"rr_{tag}_{k1}_{k2}_{lam}"]
         d = np.abs(got - want)
         assert d.max() <= 5e-4 and (d > 1e-5).mean() <= 0.01, (tag, k1, k2, d.max(), (d > 1e-5).mean())
+
+
+def test_resize_oracle_matches_pillow_goldens(golden):
+    """orc_resize_bilinear_u8 (restated Pillow 8-bit two-pass BILINEAR resample, what T.Resize applies to a PIL
+    image) against outputs of PIL.Image.resize itself: bit-exact on ragged up/down/identity/degenerate cases."""
+    g = golden("resize.npz")
+    for i in range(int(g["n"])):
+        want = g[f"out{i}"]
+        got = orc.resize_bilinear_u8(g[f"in{i}"], want.shape[0], want.shape[1])
+        assert np.array_equal(got, want), i
