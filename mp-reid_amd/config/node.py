@@ -73,10 +73,15 @@ def make_defaults():
                   "DIST_TRAIN": False, "INIT_SEED": 7},
         "INPUT": {"SIZE_TRAIN": [256, 128], "SIZE_TEST": [256, 128], "PIXEL_MEAN": [0.5, 0.5, 0.5],
                   "PIXEL_STD": [0.5, 0.5, 0.5]},
-        "DATASETS": {"NAMES": "synthetic", "ROOT_DIR": "", "SYNTH_QUERY": 3368, "SYNTH_GALLERY": 15913,
-                     "SYNTH_IDS": 751, "SYNTH_SEED": 1234},
+        "DATASETS": {"NAMES": "synthetic", "ROOT_DIR": "", "EXP_SETTING": "", "SYNTH_QUERY": 3368,
+                     "SYNTH_GALLERY": 15913, "SYNTH_IDS": 751, "SYNTH_SEED": 1234,
+                     # SYNTH_RAW: the loader hands over DECODED uint8 images of ragged sizes (what PIL gives before
+                     # val_transforms) and Resize + ToTensor + Normalize run on the GPU
+                     "SYNTH_RAW": False},
         "DATALOADER": {"NUM_WORKERS": 0},
         "TEST": {"IMS_PER_BATCH": 64, "RE_RANKING": False, "WEIGHT": "", "NECK_FEAT": "before", "FEAT_NORM": "yes",
-                 "DIST_MAT": "dist_mat.npy", "EVAL": False},
+                 "DIST_MAT": "dist_mat.npy", "EVAL": False,
+                 # Uni-Prompt evaluation (reference config/defaults.py:331-344)
+                 "TTA_ENABLED": False, "TTPT": {"ENABLED": False, "LR": 0.001, "STEPS": 5, "TEMPERATURE": 0.07}},
         "OUTPUT_DIR": "",
     })

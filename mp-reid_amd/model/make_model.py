@@ -46,6 +46,8 @@ class build_transformer(nn.Module):
         self.h_resolution = int((cfg.INPUT.SIZE_TRAIN[0] - 16) // cfg.MODEL.STRIDE_SIZE[0] + 1)
         self.w_resolution = int((cfg.INPUT.SIZE_TRAIN[1] - 16) // cfg.MODEL.STRIDE_SIZE[1] + 1)
         self.img_hw = (int(cfg.INPUT.SIZE_TEST[0]), int(cfg.INPUT.SIZE_TEST[1]))
+        self.pixel_mean = tuple(float(v) for v in cfg.INPUT.PIXEL_MEAN)
+        self.pixel_std = tuple(float(v) for v in cfg.INPUT.PIXEL_STD)
         self.vit_cfg = dict(h_res=self.h_resolution, w_res=self.w_resolution, patch=16, stride=stride, width=768,
                             layers=12, heads=12, out_dim=512)
         seed = int(getattr(cfg.MODEL, "INIT_SEED", 7))
@@ -89,6 +91,9 @@ class build_transformer(nn.Module):
     def forward(self, x, label=None, cam_label=None, view_label=None):
         if self.training:
             raise NotImplementedError("training-mode forward is out of scope; call .eval()")
+        return self._encode(x, self._sie(cam_label, view_label), 0)
+
+    def _sie(self, cam_label, view_label):
         cv_embed = None
         if cam_label is not None or view_label is not None:
             # SIE: index = cam * view_num + view | cam | view (reference model/make_model.py:89-96); the table may
@@ -98,7 +103,18 @@ class build_transformer(nn.Module):
             else:
                 idx = cam_label if cam_label is not None else view_label
             cv_embed = self.sie_coe * self.cv_embed[idx.to(self.cv_embed.device)]
-        return self._get_encoder()(x, cv_embed)
+        return cv_embed
+
+    def _encode(self, x, cv_embed, view):
+        """x: fp32 [B,3,H,W] (val_transforms already applied), uint8 [B,H,W,3] (after Resize) or a RawImageBatch /
+        list of decoded uint8 [h,w,3] images (Resize, ToTensor and Normalize run on the GPU with INPUT.PIXEL_MEAN /
+        PIXEL_STD).  view: a test-time-augmentation view id (mpreid.ops.VIEW_*)."""
+        enc = self._get_encoder()
+        if isinstance(x, (list, tuple)):
+            x = _ops.resize_bilinear_u8(x, self.img_hw)
+        if view == 0 and x.dtype != torch.uint8:
+            return enc(x, cv_embed)
+        return enc.forward_view(x, view, cv_embed, self.pixel_mean, self.pixel_std)
 
     def load_param(self, trained_path):
         param_dict = torch.load(trained_path, map_location="cpu")

@@ -156,6 +156,30 @@ def tta_mean(feats: torch.Tensor, normalize: bool = True) -> torch.Tensor:
     return out
 
 
+class _HostStager:
+    """Two pinned host buffers used alternately for H2D uploads: packing batch i+1 on the host overlaps the copy of
+    batch i, and a buffer is reused only after the copy that read it has finished (event)."""
+
+    def __init__(self, n: int = 2):
+        self.bufs, self.events, self.i = [None] * n, [None] * n, 0
+
+    def stage(self, nbytes: int):
+        self.i = (self.i + 1) % len(self.bufs)
+        i = self.i
+        if self.events[i] is not None:
+            self.events[i].synchronize()
+        if self.bufs[i] is None or self.bufs[i].numel() < nbytes:
+            self.bufs[i] = torch.empty(max(int(nbytes * 1.5), 1 << 20), dtype=torch.uint8).pin_memory()
+        return self.bufs[i][:nbytes], i
+
+    def copied(self, i: int):
+        self.events[i] = torch.cuda.Event()
+        self.events[i].record(torch.cuda.current_stream())
+
+
+_stager = _HostStager()
+
+
 def resize_bilinear_u8(images, out_hw) -> torch.Tensor:
     """T.Resize(cfg.INPUT.SIZE_TEST) of val_transforms (datasets/make_dataloader.py:57-58) on the GPU, bit-exact with
     PIL.Image.resize(BILINEAR): images = sequence of uint8 [h, w, 3] arrays / tensors of any sizes (decoded RGB);
@@ -170,11 +194,12 @@ def resize_bilinear_u8(images, out_hw) -> torch.Tensor:
     sizes = hw[:, 0].astype(np.int64) * hw[:, 1] * 3
     offsets = np.zeros(B, np.int64)
     offsets[1:] = np.cumsum(sizes)[:-1]
-    packed = torch.empty(int(sizes.sum()), dtype=torch.uint8).pin_memory()
+    packed, slot = _stager.stage(int(sizes.sum()))
     pk = packed.numpy()
     for a, o, n in zip(arrs, offsets, sizes):
         pk[o:o + n] = a.reshape(-1)
     src = packed.to(dev, non_blocking=True)
+    _stager.copied(slot)
     offs_d = torch.from_numpy(offsets).to(dev)
     hw_d = torch.from_numpy(hw).to(dev)
     oh, ow = int(out_hw[0]), int(out_hw[1])

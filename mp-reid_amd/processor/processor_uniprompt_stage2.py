@@ -1,0 +1,118 @@
+"""Drop-in for the evaluation entry points of the reference's ``processor/processor_uniprompt_stage2.py``:
+
+  do_inference(cfg, model, val_loader, num_query)                 reference :225-266
+  do_inference_ttpt_option_a(cfg, model, val_loader, num_query)   reference :530-693  (TTA "option A")
+
+Same loops, log lines and return values.  In option A every QUERY batch is encoded four times (original, W-flip,
+pseudo-IR = channel mean, pseudo-RGB = channel 0 replicated), the four features are averaged and L2-normalised
+(:598-640); gallery batches are encoded once and normalised (:649-654).  Here the views are produced inside the
+patch-gather kernel (no transformed image tensors) and the average + normalise is one kernel
+(mpreid_tta_mean_f32).  Quirks kept: whether a batch is "query" is decided by the number of samples processed
+BEFORE it (:594), so a batch straddling num_query is augmented as a whole; TEST.FEAT_NORM is a truthy string.
+
+``do_inference_ttpt_clipstyle`` (option B) matches images against text features of the prompt learner and
+optimises prompts at test time: text tower, out of scope -> NotImplementedError.
+"""
+import logging
+import time
+
+import torch
+
+from mpreid import ops as _ops
+from utils.metrics import R1_mAP_eval
+
+
+def do_inference(cfg, model, val_loader, num_query):
+    device = "cuda"
+    logger = logging.getLogger("transreid.test")
+    logger.info("Enter inferencing")
+
+    evaluator = R1_mAP_eval(num_query, max_rank=50, feat_norm=cfg.TEST.FEAT_NORM)
+    evaluator.reset()
+
+    model.to(device)
+    model.eval()
+    img_path_list = []
+    for n_iter, (img, pid, camid, camids, target_view, imgpath) in enumerate(val_loader):
+        with torch.no_grad():
+            img = img.to(device)
+            camids = camids.to(device) if cfg.MODEL.SIE_CAMERA else None
+            target_view = target_view.to(device) if cfg.MODEL.SIE_VIEW else None
+            feat = model(x=img, cam_label=camids, view_label=target_view)
+            evaluator.update((feat, pid, camid))
+            img_path_list.extend(imgpath)
+
+    cmc, mAP, distmat, pids, camids, qf, gf = evaluator.compute()
+    logger.info("Validation Results ")
+    logger.info("mAP: {:.1%}".format(mAP))
+    for r in [1, 5, 10]:
+        logger.info("CMC curve, Rank-{:<3}:{:.1%}".format(r, cmc[r - 1]))
+    return cmc[0], cmc[4]
+
+
+def do_inference_ttpt_clipstyle(cfg, model, val_loader, num_query):
+    raise NotImplementedError("TTA + TTPT with CLIP-style image-text matching (option B) needs the text tower; "
+                              "only option A (image features) is on the accelerated path")
+
+
+def do_inference_ttpt_option_a(cfg, model, val_loader, num_query):
+    device = "cuda"
+    logger = logging.getLogger("transreid.test_ttpt_option_a")
+    logger.info("Enter inferencing with TTA only (Option A - Image Feature Evaluation)")
+
+    tta_enabled = cfg.TEST.get('TTA_ENABLED', True)
+    feat_norm = cfg.TEST.FEAT_NORM
+    if tta_enabled:
+        logger.info("Test Time Augmentation (TTA) enabled.")
+    logger.info("TTPT optimization part is disabled for this run.")
+
+    model.to(device)
+    evaluator = R1_mAP_eval(num_query, max_rank=50, feat_norm=cfg.TEST.FEAT_NORM)
+    evaluator.reset()
+    model.eval()
+
+    logger.info("Starting feature extraction...")
+    start_time = time.time()
+    processed_samples = 0
+    views = (_ops.VIEW_ORIGINAL, _ops.VIEW_FLIP, _ops.VIEW_PSEUDO_IR, _ops.VIEW_PSEUDO_RGB) if tta_enabled else \
+        (_ops.VIEW_ORIGINAL,)
+
+    for n_iter, (img, pid, camid, camids, target_view, _) in enumerate(val_loader):
+        img = img.to(device)
+        n_img = len(img) if isinstance(img, (list, tuple)) else img.shape[0]
+        is_query = (processed_samples < num_query)
+        cam = camids.to(device) if cfg.MODEL.SIE_CAMERA else None
+        vw = target_view.to(device) if cfg.MODEL.SIE_VIEW else None
+        with torch.no_grad():
+            if is_query:
+                if isinstance(img, (list, tuple)):      # decoded images: resize once, then the views
+                    img = _ops.resize_bilinear_u8(img, model.img_hw)
+                feats = torch.stack([model(x=img, cam_label=cam, view_label=vw, tta_view=v) for v in views], dim=0)
+                img_feat_agg = _ops.tta_mean(feats, normalize=bool(feat_norm))
+                evaluator.update((img_feat_agg, pid, camid))
+            else:
+                gallery_feat = model(x=img, cam_label=cam, view_label=vw)
+                if feat_norm:
+                    gallery_feat = _ops.l2_normalize(gallery_feat)
+                evaluator.update((gallery_feat, pid, camid))
+        processed_samples += n_img
+        if processed_samples % 1000 == 0:
+            logger.info(f"Processed {processed_samples}/{getattr(val_loader, 'n', '?')} samples...")
+
+    end_time = time.time()
+    logger.info(f"Feature extraction finished in {end_time - start_time:.2f} seconds.")
+
+    cmc, mAP, _, _, _, _, _ = evaluator.compute()
+    logger.info("Validation Results (TTPT Option A - Image Features)")
+    logger.info("mAP: {:.1%}".format(mAP))
+    for r in [1, 5, 10]:
+        eval_max_rank = getattr(evaluator, 'max_rank', 50)
+        if r <= eval_max_rank and r <= len(cmc):
+            logger.info("CMC curve, Rank-{:<3}:{:.1%}".format(r, cmc[r - 1]))
+        else:
+            logger.info(f"Rank-{r} exceeds max_rank ({eval_max_rank}) or CMC length ({len(cmc)}) ")
+
+    rank1 = cmc[0] if len(cmc) > 0 else 0.0
+    rank5 = cmc[4] if len(cmc) > 4 else 0.0
+    logger.info(f"Returning Rank-1: {rank1:.1%}, Rank-5: {rank5:.1%}")
+    return rank1, rank5

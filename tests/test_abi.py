@@ -64,3 +64,35 @@ def test_product_does_not_import_oracle():
                         "oracle/mpreid_oracle.c", ""):
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_dropin_modules_import_and_dataloader_contract_without_gpu():
+    """host logic of the drop-in modules (reference test.py:2-7, test_uniprompt.py:2-7): imports, config keys, the
+    val tuple, query-then-gallery order, decoded-image batches"""
+    import numpy as np
+    from config import cfg, cfg_base
+    from datasets.make_dataloader import make_dataloader, RawImageBatch, raw_val_collate_fn
+    from datasets import make_dataloader_uniprompt
+    import processor.processor as p1
+    import processor.processor_uniprompt_stage2 as p2
+    import model.make_model_uniprompt as mu
+    assert callable(p1.do_inference) and callable(p2.do_inference) and callable(p2.do_inference_ttpt_option_a)
+    assert callable(mu.make_model) and callable(make_dataloader_uniprompt.make_dataloader)
+    assert cfg.TEST.get('TTA_ENABLED', True) is False and cfg.TEST.TTPT.STEPS == 5 and cfg_base.TEST.FEAT_NORM == "yes"
+    c = cfg.clone()
+    c.defrost()
+    c.merge_from_list(["DATASETS.SYNTH_QUERY", 5, "DATASETS.SYNTH_GALLERY", 9, "TEST.IMS_PER_BATCH", 4,
+                       "DATASETS.SYNTH_RAW", True])
+    tl, tn, val_loader, num_query, num_classes, cam_num, view_num = make_dataloader(c)
+    assert tl is None and tn is None and num_query == 5 and len(val_loader) == 4
+    n = 0
+    for img, pids, camids, camids_t, views_t, paths in val_loader:
+        assert isinstance(img, RawImageBatch) and img.to("cuda") is img
+        assert all(a.dtype == np.uint8 and a.ndim == 3 and a.shape[2] == 3 for a in img)
+        assert len(pids) == len(img) == camids_t.shape[0] == views_t.shape[0] == len(paths)
+        n += len(img)
+    assert n == 14
+    b = raw_val_collate_fn([(np.zeros((3, 2, 3), np.uint8), 1, 2, 0, "a.jpg"), (np.zeros((5, 4, 3), np.uint8), 3, 4, 0, "b.jpg")])
+    assert isinstance(b[0], RawImageBatch) and b[1] == (1, 3) and b[3].tolist() == [2, 4] and b[5] == ("a.jpg", "b.jpg")
+    with pytest.raises(NotImplementedError):
+        p2.do_inference_ttpt_clipstyle(c, None, None, 0)

@@ -133,3 +133,119 @@ def test_sie_camera_embedding():
     rel = np.linalg.norm(got - want) / np.linalg.norm(want)
     assert rel < 4e-3, rel
     assert np.abs(got[1] - got[3]).max() > 0  # same camera, different images
+
+
+def _raw_cfg(nq, ng, batch, **extra):
+    from config import cfg
+    c = cfg.clone()
+    c.defrost()
+    opts = ["DATASETS.SYNTH_QUERY", nq, "DATASETS.SYNTH_GALLERY", ng, "DATASETS.SYNTH_IDS", 9, "DATASETS.SYNTH_RAW", True,
+            "TEST.IMS_PER_BATCH", batch, "INPUT.PIXEL_MEAN", [0.5, 0.45, 0.4], "INPUT.PIXEL_STD", [0.5, 0.3, 0.25]]
+    for k, v in extra.items():
+        opts += [k, v]
+    c.merge_from_list(opts)
+    c.freeze()
+    return c
+
+
+def _host_val_transforms(raw_batch, cfg):
+    """val_transforms on the host: Pillow-exact Resize (oracle, pinned to PIL goldens), ToTensor, Normalize"""
+    oh, ow = cfg.INPUT.SIZE_TEST
+    t = torch.from_numpy(np.stack([orc.resize_bilinear_u8(np.asarray(im), oh, ow) for im in raw_batch]))
+    t = t.permute(0, 3, 1, 2).to(torch.float32).div(255)
+    mean = torch.tensor(cfg.INPUT.PIXEL_MEAN, dtype=torch.float32)[None, :, None, None]
+    std = torch.tensor(cfg.INPUT.PIXEL_STD, dtype=torch.float32)[None, :, None, None]
+    return ((t - mean) / std).contiguous()
+
+
+def test_do_inference_on_decoded_images_equals_host_val_transforms():
+    """DATASETS.SYNTH_RAW: the loader yields decoded uint8 images of ragged sizes; Resize + ToTensor + Normalize on
+    the GPU must give the features the reference pipeline (transforms on the host, fp32 NCHW into the model) gives:
+    bit-identical (integer resize; the same fp32 normalisation arithmetic; same encoder)."""
+    from datasets.make_dataloader import make_dataloader, RawImageBatch
+    from model.make_model import make_model
+    from processor.processor import do_inference
+    from utils.metrics import R1_mAP_eval
+    cfg = _raw_cfg(10, 26, 12)
+    _, _, val_loader, num_query, num_classes, cam_num, view_num = make_dataloader(cfg)
+    model = make_model(cfg, num_class=num_classes, camera_num=cam_num, view_num=view_num)
+    r1, r5 = do_inference(cfg, model, val_loader, num_query)
+    ev = R1_mAP_eval(num_query, feat_norm=cfg.TEST.FEAT_NORM)
+    ev.reset()
+    for img, pid, camid, camids, views, paths in val_loader:
+        assert isinstance(img, RawImageBatch) and img[0].dtype == np.uint8 and img[0].shape != img[1].shape
+        f_host = model(_host_val_transforms(img, cfg).cuda())
+        f_dev = model(img)
+        assert torch.equal(f_host, f_dev)
+        ev.update((f_host, pid, camid))
+    cmc, mAP, *_ = ev.compute()
+    assert float(cmc[0]) == float(r1) and float(cmc[4]) == float(r5)
+
+
+@pytest.mark.parametrize("tta", [True, False])
+def test_uniprompt_tta_option_a_matches_reference_loop(tta, caplog):
+    """processor_uniprompt_stage2.do_inference_ttpt_option_a against the reference's own loop written with
+    materialised view tensors, torch.stack(...).mean(0) and F.normalize (:598-654), both on the HIP encoder: the
+    query features agree to fp32 rounding of the normalisation and the metrics are equal.  num_query is not a
+    multiple of the batch size, so one batch straddles the query/gallery boundary (augmented as a whole, :594)."""
+    import torch.nn.functional as F
+    from datasets.make_dataloader_uniprompt import make_dataloader
+    from model.make_model_uniprompt import make_model
+    from processor.processor_uniprompt_stage2 import do_inference, do_inference_ttpt_option_a
+    from utils.metrics import R1_mAP_eval
+    cfg = _raw_cfg(10, 26, 8, **{"TEST.TTA_ENABLED": tta, "MODEL.SIE_CAMERA": True})
+    _, _, val_loader, num_query, num_classes, cam_num, view_num = make_dataloader(cfg)
+    model = make_model(cfg, num_class=num_classes, camera_num=cam_num, view_num=view_num)
+    with caplog.at_level(logging.INFO, logger="transreid.test_ttpt_option_a"):
+        r1, r5 = do_inference_ttpt_option_a(cfg, model, val_loader, num_query)
+    assert "Validation Results (TTPT Option A - Image Features)" in caplog.text
+    ev = R1_mAP_eval(num_query, max_rank=50, feat_norm=cfg.TEST.FEAT_NORM)
+    ev.reset()
+    seen = 0
+    for img, pid, camid, camids, views, paths in val_loader:
+        x = _host_val_transforms(img, cfg).cuda()
+        cam = camids.cuda()
+        if seen < num_query:
+            fl = [model(x=x, cam_label=cam)]
+            if tta:
+                fl.append(model(x=torch.flip(x, [3]).contiguous(), cam_label=cam))
+                fl.append(model(x=x.mean(dim=1, keepdim=True).repeat(1, 3, 1, 1), cam_label=cam))
+                fl.append(model(x=x[:, 0:1].repeat(1, 3, 1, 1), cam_label=cam))
+            agg = F.normalize(torch.stack(fl, dim=0).mean(dim=0), p=2, dim=1)
+            ev.update((agg, pid, camid))
+        else:
+            ev.update((F.normalize(model(x=x, cam_label=cam), p=2, dim=1), pid, camid))
+        seen += x.shape[0]
+    cmc, mAP, *_ = ev.compute()
+    assert float(cmc[0]) == float(r1) and float(cmc[4]) == float(r5)
+    assert "mAP: {:.1%}".format(mAP) in caplog.text
+    # plain Uni-Prompt do_inference = base do_inference on the same model
+    r1b, r5b = do_inference(cfg, model, val_loader, num_query)
+    assert 0.0 <= float(r1b) <= float(r5b) <= 1.0
+
+
+def test_uniprompt_model_branches(tmp_path):
+    from mpreid import synth
+    from model.make_model_uniprompt import make_model
+    cfg = _raw_cfg(4, 4, 4, **{"TEST.NECK_FEAT": "after"})
+    m = make_model(cfg, num_class=7, camera_num=6, view_num=1)
+    imgs = torch.from_numpy(synth.synthetic_images(3, 256, 128, seed=4)).cuda()
+    full = m(x=imgs)                                   # after-BN features (identity statistics at init)
+    proj = m(x=imgs, get_image=True)                   # raw projected CLS
+    assert proj.shape == (3, 512)
+    vp = m(x=imgs, get_image_vp=True)
+    assert torch.allclose(vp - proj, m.visual_prompt[0].to(vp.device).expand_as(proj), atol=1e-6)
+    # BN with running_mean 0 / var 1 / weight 1 / bias 0: y = x / sqrt(1 + 1e-5)
+    assert torch.allclose(full[:, 768:] * float(np.sqrt(1 + 1e-5)), proj, rtol=1e-5, atol=1e-6)
+    for kw in ("get_text", "get_raw_text", "get_image_update", "get_more_image"):
+        with pytest.raises(NotImplementedError):
+            m(x=imgs, **{kw: True})
+    # a Uni-Prompt checkpoint carries text-tower tensors the evaluation path does not have: skipped, not fatal
+    ckpt = {"module." + k: v.clone() for k, v in m.state_dict().items()}
+    ckpt["module.prompt_learner.cls_ctx"] = torch.zeros(7, 4, 512)
+    ckpt["module.text_encoder.ln_final.weight"] = torch.ones(512)
+    ckpt["module.image_fusion_net.fc1.weight"] = torch.zeros(256, 1024)
+    path = tmp_path / "uniprompt.pth"
+    torch.save(ckpt, path)
+    m.load_param(str(path))
+    assert torch.equal(m(x=imgs), full)
