@@ -214,6 +214,16 @@ int mpreid_resize_bilinear_u8(const uint8_t *src_dev, const int64_t *offsets_dev
                               int max_in_h, int out_h, int out_w, uint8_t *dst_dev, void *ws_dev, size_t ws_bytes,
                               mpreid_stream_t stream);
 
+/* One convolution layer of the RN50 tower as the encoder runs it (unit tests, micro-benchmarks):
+ * NHWC fp16 in [batch][h][w][cin] (cin % 64 == 0), stride 1, taps = 1 (1x1) or 9 (3x3, pad 1); weights fp16
+ * [cout_pad][taps*cin] (k order: tap = kh*3+kw, then channel; cout_pad % 128 == 0, rows >= cout zero) with the
+ * BatchNorm of model/clip/model.py:17-24 folded in, bias fp32 [cout_pad]; optional fp16 identity [M][cout] added
+ * before the ReLU (Bottleneck.forward, model/clip/model.py:39-53); out fp16 [batch*h*w][cout]; zero_page_dev =
+ * 128 bytes of zeros. */
+int mpreid_conv_f16_nhwc(const void *act_dev, int batch, int h, int w, int cin, const void *wgt_dev, const float *bias_dev,
+                         int cout, int cout_pad, int taps, const void *identity_dev, int relu, void *out_dev,
+                         const void *zero_page_dev, mpreid_stream_t stream);
+
 /* fp16 GEMM used by the encoder, exposed for the roofline bench and unit tests:
  * C[M][N] (fp32) = A[M][K] (fp16) x B[N][K]^T (fp16).  M, N multiples of 128... see DESIGN.md. */
 int mpreid_gemm_f16_nt(const void *a_dev, const void *b_dev, float *c_dev, int64_t m, int64_t n, int64_t k,

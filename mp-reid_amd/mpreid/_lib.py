@@ -24,7 +24,7 @@ SYMBOLS = [
     "mpreid_eval_rank_positions", "mpreid_rr_dist_rows", "mpreid_rr_vcap", "mpreid_rr_krecip", "mpreid_rr_pack_rows", "mpreid_rr_qe_count",
     "mpreid_rr_qe_fill", "mpreid_rr_jaccard",
     "mpreid_vit_workspace_bytes", "mpreid_vit_forward", "mpreid_vit_forward_u8", "mpreid_vit_forward_view",
-    "mpreid_tta_mean_f32", "mpreid_resize_workspace_bytes", "mpreid_resize_bilinear_u8",
+    "mpreid_tta_mean_f32", "mpreid_resize_workspace_bytes", "mpreid_resize_bilinear_u8", "mpreid_conv_f16_nhwc",
     "mpreid_gemm_f16_nt", "mpreid_gemm_f16_nt_ex",
     "mpreid_cast_f32_to_f16", "mpreid_profile_enable", "mpreid_profile_reset", "mpreid_profile_query",
 ]
@@ -136,6 +136,8 @@ def load():
     L.mpreid_resize_workspace_bytes.argtypes = [i32, i32, i32]
     L.mpreid_resize_bilinear_u8.restype = i32
     L.mpreid_resize_bilinear_u8.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]
+    L.mpreid_conv_f16_nhwc.restype = i32
+    L.mpreid_conv_f16_nhwc.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, vp, i32, vp, vp, vp]
     L.mpreid_gemm_f16_nt.restype = i32
     L.mpreid_gemm_f16_nt.argtypes = [vp, vp, vp, i64, i64, i64, vp]
     L.mpreid_gemm_f16_nt_ex.restype = i32

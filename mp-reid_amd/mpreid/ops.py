@@ -373,3 +373,57 @@ class VitEncoder:
         other = copy.copy(self)
         other.ws_tag = ws_tag
         return other
+
+
+# ----------------------------------------------------------------------------------------------
+# RN50 image encoder (CLIP ModifiedResNet, model/clip/model.py:10-148)
+# ----------------------------------------------------------------------------------------------
+def _pad_to(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+def fold_conv_bn(weight, bn=None, cin_pad: Optional[int] = None, eps: float = 1e-5):
+    """Conv2d weight [cout, cin, k, k] (+ eval-mode BatchNorm2d (gamma, beta, running_mean, running_var)) ->
+    (fp16 [cout_pad128, k*k*cin_pad] with k order (kh, kw, c), fp32 bias [cout_pad128]); model/clip/model.py:17-24:
+    y = gamma * (conv(x) - mean) / sqrt(var + eps) + beta = conv'(x) + b'.  Folded in fp64, rounded once."""
+    w = np.asarray(weight, dtype=np.float64)
+    cout, cin, kh, kw = w.shape
+    if bn is not None:
+        gamma, beta, mean, var = (np.asarray(a, dtype=np.float64) for a in bn)
+        scale = gamma / np.sqrt(var + eps)
+        w = w * scale[:, None, None, None]
+        b = beta - mean * scale
+    else:
+        b = np.zeros(cout)
+    cpad = cin if cin_pad is None else cin_pad
+    npad = _pad_to(cout, 128)
+    wk = np.zeros((npad, kh, kw, cpad), dtype=np.float32)
+    wk[:cout, :, :, :cin] = w.transpose(0, 2, 3, 1)
+    bk = np.zeros(npad, dtype=np.float32)
+    bk[:cout] = b
+    return (torch.from_numpy(wk.reshape(npad, kh * kw * cpad)).to(torch.float16), torch.from_numpy(bk))
+
+
+_zero_pages = {}
+
+
+def _zero_page(dev):
+    if dev not in _zero_pages:
+        _zero_pages[dev] = torch.zeros(256, dtype=torch.uint8, device=dev)
+    return _zero_pages[dev]
+
+
+def conv_f16_nhwc(act: torch.Tensor, wgt: torch.Tensor, bias: torch.Tensor, cout: int, taps: int,
+                  identity: Optional[torch.Tensor] = None, relu: bool = True) -> torch.Tensor:
+    """one folded conv layer on NHWC fp16 [B,H,W,Cin] -> [B,H,W,cout] (stride 1; taps 1 or 9 with pad 1)"""
+    dev = _lib.require_gpu()
+    assert act.dtype == torch.float16 and act.is_contiguous() and act.is_cuda and wgt.dtype == torch.float16
+    B, H, W, C = act.shape
+    assert wgt.shape[1] == taps * C and wgt.shape[0] % 128 == 0 and bias.numel() == wgt.shape[0]
+    out = torch.empty((B, H, W, cout), dtype=torch.float16, device=dev)
+    if identity is not None:
+        assert identity.dtype == torch.float16 and identity.is_contiguous() and tuple(identity.shape) == tuple(out.shape)
+    _lib.check(_lib.load().mpreid_conv_f16_nhwc(_ptr(act), B, H, W, C, _ptr(wgt), _ptr(bias), cout, wgt.shape[0], taps,
+                                                _ptr(identity), int(relu), _ptr(out), _ptr(_zero_page(dev)),
+                                                _lib.stream_ptr()), "mpreid_conv_f16_nhwc")
+    return out

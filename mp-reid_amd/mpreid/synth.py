@@ -8,7 +8,8 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = ["clustered_features", "labels_for", "vit_state_dict", "synthetic_images", "VIT_B16"]
+__all__ = ["clustered_features", "labels_for", "vit_state_dict", "synthetic_images", "VIT_B16", "rn50_state_dict",
+           "RN50"]
 
 
 def clustered_features(n: int, dim: int, sigma: float, seed: int = 1234, per_id: int = 20,
@@ -73,6 +74,51 @@ def vit_state_dict(cfg: dict, seed: int = 7, std: float = 0.02, ln_jitter: float
         ln(b + ".ln_2", sd)
     ln("ln_post", sd)
     sd["proj"] = nrm(w, od, s=scale)
+    return sd
+
+
+# CLIP "RN50" visual tower as the reference builds it for a 256x128 input (model/clip/model.py:509-516:
+# heads = width * 32 // 64, spacial_dim = h_resolution * w_resolution = 16 * 8)
+RN50 = dict(layers=(3, 4, 6, 3), width=64, heads=32, out_dim=1024, h_res=16, w_res=8)
+
+
+def rn50_state_dict(cfg: dict, seed: int = 11):
+    """Deterministic random weights in the ``ModifiedResNet`` state-dict layout (model/clip/model.py:92-148):
+    He-scaled conv weights, BatchNorm with non-trivial gamma / beta / running statistics (so that folding them is
+    exercised), attention-pool projections.  float32 numpy arrays (+ int64 num_batches_tracked)."""
+    rng = np.random.default_rng(seed)
+    width, layers = cfg["width"], cfg["layers"]
+    sd = {}
+
+    def conv(name, cout, cin, k):
+        sd[name + ".weight"] = (rng.standard_normal((cout, cin, k, k)) * np.sqrt(2.0 / (cin * k * k))).astype(np.float32)
+
+    def bn(name, c, gamma=1.0):
+        sd[name + ".weight"] = (gamma * (1.0 + 0.1 * rng.standard_normal(c))).astype(np.float32)
+        sd[name + ".bias"] = (0.1 * rng.standard_normal(c)).astype(np.float32)
+        sd[name + ".running_mean"] = (0.1 * rng.standard_normal(c)).astype(np.float32)
+        sd[name + ".running_var"] = (0.5 + rng.random(c)).astype(np.float32)
+        sd[name + ".num_batches_tracked"] = np.array(0, dtype=np.int64)
+
+    conv("conv1", width // 2, 3, 3), bn("bn1", width // 2)
+    conv("conv2", width // 2, width // 2, 3), bn("bn2", width // 2)
+    conv("conv3", width, width // 2, 3), bn("bn3", width)
+    inplanes = width
+    for li, (planes, blocks, stride) in enumerate(zip((width, width * 2, width * 4, width * 8), layers, (1, 2, 2, 1)), 1):
+        for b in range(blocks):
+            pre = f"layer{li}.{b}"
+            st = stride if b == 0 else 1
+            conv(pre + ".conv1", planes, inplanes, 1), bn(pre + ".bn1", planes)
+            conv(pre + ".conv2", planes, planes, 3), bn(pre + ".bn2", planes)
+            conv(pre + ".conv3", planes * 4, planes, 1), bn(pre + ".bn3", planes * 4, gamma=0.5)
+            if st > 1 or inplanes != planes * 4:
+                conv(pre + ".downsample.0", planes * 4, inplanes, 1), bn(pre + ".downsample.1", planes * 4)
+            inplanes = planes * 4
+    e, s_dim = width * 32, cfg["h_res"] * cfg["w_res"]
+    sd["attnpool.positional_embedding"] = (rng.standard_normal((s_dim + 1, e)) / e ** 0.5).astype(np.float32)
+    for nm, od in (("k_proj", e), ("q_proj", e), ("v_proj", e), ("c_proj", cfg["out_dim"])):
+        sd[f"attnpool.{nm}.weight"] = (rng.standard_normal((od, e)) * e ** -0.5).astype(np.float32)
+        sd[f"attnpool.{nm}.bias"] = (0.01 * rng.standard_normal(od)).astype(np.float32)
     return sd
 
 

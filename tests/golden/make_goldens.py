@@ -270,6 +270,36 @@ def gen_tta():
     save("tta.npz", **out)
 
 
+def run_rn50(cfg, sd_np, imgs):
+    """reference ModifiedResNet (model/clip/model.py:92-148) + the RN50 eval branch of build_transformer.forward
+    (model/make_model.py:82-86, 113-115, NECK_FEAT 'before'): cat(avg_pool(x4), attnpool(x4)[0])"""
+    import torch.nn.functional as F
+    m = ref_clip.ModifiedResNet(layers=cfg["layers"], output_dim=cfg["out_dim"], heads=cfg["heads"],
+                                input_resolution=cfg["h_res"] * cfg["w_res"], width=cfg["width"])
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()})
+    m.eval()
+    with torch.no_grad():
+        x = torch.from_numpy(imgs)
+        x3, x4, xproj = m(x)
+        feat = F.avg_pool2d(x4, x4.shape[2:4]).view(x.shape[0], -1)
+    return torch.cat([feat, xproj[0]], dim=1).numpy(), x3.numpy(), x4.numpy()
+
+
+def gen_rn50():
+    out = {}
+    # (i) reduced: width 16, layers (1,2,1,1), 64x32 input -> 4x2 final grid, embed 512, 8 heads
+    small = dict(layers=(1, 2, 1, 1), width=16, heads=8, out_dim=64, h_res=4, w_res=2)
+    imgs = synth.synthetic_images(3, 64, 32, seed=31)
+    f, x3, x4 = run_rn50(small, synth.rn50_state_dict(small, seed=11), imgs)
+    out["small_feat"], out["small_x4"] = f, x4
+    # (ii) full RN50, 256x128 input, 3 images
+    imgs = synth.synthetic_images(3, 256, 128, seed=32)
+    f, x3, x4 = run_rn50(synth.RN50, synth.rn50_state_dict(synth.RN50, seed=11), imgs)
+    out["rn50_feat"] = f
+    out["rn50_x4_mean"] = x4.mean(axis=(2, 3))
+    save("rn50.npz", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["distance", "rerank", "vit"]
     if "distance" in which:
@@ -284,3 +314,5 @@ if __name__ == "__main__":
         gen_resize()
     if "tta" in which:
         gen_tta()
+    if "rn50" in which:
+        gen_rn50()

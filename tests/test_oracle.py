@@ -179,3 +179,18 @@ def test_resize_oracle_matches_pillow_goldens(golden):
         want = g[f"out{i}"]
         got = orc.resize_bilinear_u8(g[f"in{i}"], want.shape[0], want.shape[1])
         assert np.array_equal(got, want), i
+
+
+def test_rn50_oracle_matches_reference_goldens(golden):
+    """torch-fp32 restatement of ModifiedResNet + the RN50 eval branch against the reference classes' outputs"""
+    from mpreid import synth
+    g = golden("rn50.npz")
+    small = dict(layers=(1, 2, 1, 1), width=16, heads=8, out_dim=64, h_res=4, w_res=2)
+    f = orc.rn50_features(synth.rn50_state_dict(small, seed=11), small, synth.synthetic_images(3, 64, 32, seed=31))
+    assert f.shape == (3, 576)
+    assert np.abs(f - g["small_feat"]).max() <= 2e-5 * max(1.0, np.abs(g["small_feat"]).max())
+    f = orc.rn50_features(synth.rn50_state_dict(synth.RN50, seed=11), synth.RN50,
+                          synth.synthetic_images(3, 256, 128, seed=32))
+    assert f.shape == (3, 3072)
+    assert np.abs(f - g["rn50_feat"]).max() <= 2e-5 * np.abs(g["rn50_feat"]).max()
+    assert np.abs(f[:, :2048] - g["rn50_x4_mean"]).max() <= 2e-5 * np.abs(g["rn50_x4_mean"]).max()
