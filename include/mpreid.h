@@ -214,6 +214,49 @@ int mpreid_resize_bilinear_u8(const uint8_t *src_dev, const int64_t *offsets_dev
                               int max_in_h, int out_h, int out_w, uint8_t *dst_dev, void *ws_dev, size_t ws_bytes,
                               mpreid_stream_t stream);
 
+/* ---- CLIP "RN50" image encoder (MODEL.NAME == 'RN50': model/clip/model.py:10-148 ModifiedResNet, Bottleneck,
+ * AttentionPool2d) + the RN50 eval branch of build_transformer.forward (model/make_model.py:82-86, 102-115):
+ * out = cat(avg_pool2d(x4), attnpool(x4)[0]) (after the eval BatchNorm necks for NECK_FEAT == 'after').
+ * NHWC fp16 activations, every conv an implicit MFMA GEMM with its BatchNorm folded in (see
+ * mpreid_conv_f16_nhwc), residual add + ReLU in the GEMM epilogue. ---- */
+typedef struct { /* one folded convolution; device pointers */
+    const void *w;        /* fp16 [cout_pad][taps*cin], k order (kh, kw, c) */
+    const float *bias;    /* fp32 [cout_pad] */
+    int32_t cin, cout, cout_pad, taps;  /* cin % 64 == 0, cout % 8 == 0, cout_pad % 128 == 0, taps 1 or 9 */
+} mpreid_rn50_conv;
+
+typedef struct { /* Bottleneck (model/clip/model.py:10-53) */
+    mpreid_rn50_conv conv1, conv2, conv3, down;  /* down.w == NULL when the block has no downsample branch */
+    int32_t stride;                              /* AvgPool2d(stride) after conv2 and in front of down: 1 or 2 */
+} mpreid_rn50_block;
+
+typedef struct {
+    int32_t img_h, img_w;   /* multiples of 32 */
+    int32_t width;          /* 64: stem 32/32/64 channels, layers 64/128/256/512 planes */
+    int32_t n_blocks;       /* sum of the layers tuple (3+4+6+3 = 16) */
+    int32_t heads, out_dim; /* attention pool: embed dim = 32*width, heads, output_dim (1024) */
+} mpreid_rn50_cfg;
+
+typedef struct { /* device pointers unless noted */
+    const float *stem1_w;   /* conv1+bn1 folded, fp32 [width/2][3][3][3] = [cout][c][kh][kw] */
+    const float *stem1_b;   /* fp32 [width/2] */
+    mpreid_rn50_conv stem2, stem3;          /* cin = cout = 64 storage channels (32 real ones in stem2) */
+    const mpreid_rn50_block *blocks;        /* HOST array of n_blocks entries */
+    const float *pos_emb;                   /* attnpool.positional_embedding fp32 [S+1][E] */
+    const void *kv_w; const float *kv_b;    /* fp16 [2E][E] = [k_proj; v_proj], fp32 [2E] */
+    const void *q_w; const float *q_b;      /* fp16 [E][E], fp32 [E] */
+    const void *c_w; const float *c_b;      /* fp16 [out_pad128][E], fp32 [out_pad128] */
+    const float *bn_scale, *bn_shift;       /* eval BN necks folded, fp32 [E + out_dim], or NULL */
+} mpreid_rn50_weights;
+
+size_t mpreid_rn50_workspace_bytes(const mpreid_rn50_cfg *cfg, int batch);
+/* exactly one of img_f32_dev ([B][3][H][W] fp32, val_transforms applied) and img_hwc_u8_dev ([B][H][W][3] uint8 +
+ * pixel_mean3 / pixel_std3 host arrays: ToTensor + Normalize fused into the first convolution) is non-NULL;
+ * out_dev [B][32*width + out_dim] fp32. */
+int mpreid_rn50_forward(const mpreid_rn50_cfg *cfg, const mpreid_rn50_weights *w, const float *img_f32_dev,
+                        const uint8_t *img_hwc_u8_dev, const float *pixel_mean3, const float *pixel_std3, int batch,
+                        float *out_dev, void *ws_dev, size_t ws_bytes, mpreid_stream_t stream);
+
 /* One convolution layer of the RN50 tower as the encoder runs it (unit tests, micro-benchmarks):
  * NHWC fp16 in [batch][h][w][cin] (cin % 64 == 0), stride 1, taps = 1 (1x1) or 9 (3x3, pad 1); weights fp16
  * [cout_pad][taps*cin] (k order: tap = kh*3+kw, then channel; cout_pad % 128 == 0, rows >= cout zero) with the

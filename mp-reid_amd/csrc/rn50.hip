@@ -1,0 +1,391 @@
+// rn50.hip — CLIP "RN50" image encoder (MODEL.NAME == 'RN50'), evaluation forward, gfx950.
+//
+// Reference: model/clip/model.py:92-148 (ModifiedResNet), :10-53 (Bottleneck), :56-90 (AttentionPool2d) and the
+// RN50 branch of build_transformer.forward (model/make_model.py:82-86, 102-115).
+//
+// Data layout: activations NHWC fp16 (channels innermost) so that every convolution is an implicit GEMM whose
+// A-operand rows are contiguous 128-byte pieces (conv_f16.hip); BatchNorm folded into weights / bias on the host;
+// residual add + ReLU in the conv epilogue; AvgPool2d as its own HBM-bound pass.  The 3 -> 32 channel first
+// convolution (stride 2, K = 27: no MFMA shape) is a direct fp32 kernel that also does the NCHW fp32 (or uint8 HWC +
+// ToTensor + Normalize) -> NHWC fp16 conversion; 32-channel tensors are stored with 64 channels (upper half zero).
+//
+// Attention pool: only the output at the mean token (index 0) is used by the reference
+// (model/make_model.py:86 `image_features_proj[0]`), so: K/V projections for all S+1 tokens as ONE fp16 GEMM
+// ([k_proj; v_proj] stacked), the query projection for token 0 only, a one-query attention per (image, head), and
+// c_proj on one row per image.  avg_pool2d(x4) is the same mean the pool prepends, computed once in fp32.
+#include "common.h"
+#include "conv_f16.h"
+#include "gemm_f16.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+// ---- stem conv1 + bn1 + relu: [B][3][H][W] fp32 (or [B][H][W][3] uint8) -> [B][H/2][W/2][64] fp16 -------------
+// one thread per (output pixel, 8-channel chunk of the 64 storage channels); chunks >= cout/8 write zeros
+template <bool U8>
+__global__ __launch_bounds__(256) void rn50_stem1_kernel(const float *__restrict__ img, const unsigned char *__restrict__ img8,
+                                                         float m0, float m1, float m2, float s0, float s1, float s2,
+                                                         const float *__restrict__ w, const float *__restrict__ bias,
+                                                         int cout, int B, int H, int W, _Float16 *__restrict__ out) {
+    __shared__ float sw[32 * 27 + 32];
+    for (int i = threadIdx.x; i < cout * 27; i += 256) sw[i] = w[i];
+    for (int i = threadIdx.x; i < cout; i += 256) sw[32 * 27 + i] = bias[i];
+    __syncthreads();
+    const int OH = H / 2, OW = W / 2;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (int64_t)B * OH * OW * 8) return;
+    const int chunk = (int)(gid & 7);
+    const int64_t pix = gid >> 3;
+    const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), b = (int)(pix / ((int64_t)OW * OH));
+    h8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (chunk * 8 < cout) {
+        float x[27]; // [c][kh][kw], zero outside the image (padding = 1)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int iy = oy * 2 + kh - 1, ix = ox * 2 + kw - 1;
+                    float v = 0.f;
+                    if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                        if (U8) {
+                            const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+                            v = __fdiv_rn(__fdiv_rn((float)img8[(((int64_t)b * H + iy) * W + ix) * 3 + c], 255.0f) - mean, sd);
+                        } else {
+                            v = img[(((int64_t)b * 3 + c) * H + iy) * W + ix];
+                        }
+                    }
+                    x[c * 9 + kh * 3 + kw] = v;
+                }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int n = chunk * 8 + e;
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 27; ++k) acc = fmaf(x[k], sw[n * 27 + k], acc);
+            acc = acc + sw[32 * 27 + n];
+            o[e] = (_Float16)(acc < 0.f ? 0.f : acc);
+        }
+    }
+    *reinterpret_cast<h8 *>(out + pix * 64 + chunk * 8) = o;
+}
+
+// ---- AvgPool2d(2) on NHWC fp16: ((x00 + x01) + x10 + x11) / 4 in fp32 -----------------------------------------
+__global__ __launch_bounds__(256) void avgpool2_kernel(const _Float16 *__restrict__ in, int B, int H, int W, int C,
+                                                       _Float16 *__restrict__ out) {
+    const int OH = H / 2, OW = W / 2, cc = C / 8;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (int64_t)B * OH * OW * cc) return;
+    const int c8 = (int)(gid % cc);
+    const int64_t pix = gid / cc;
+    const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), b = (int)(pix / ((int64_t)OW * OH));
+    const _Float16 *p = in + (((int64_t)b * H + oy * 2) * W + ox * 2) * C + c8 * 8;
+    const h8 a = *reinterpret_cast<const h8 *>(p), bq = *reinterpret_cast<const h8 *>(p + C);
+    const h8 c = *reinterpret_cast<const h8 *>(p + (int64_t)W * C), d = *reinterpret_cast<const h8 *>(p + (int64_t)W * C + C);
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (_Float16)((((float)a[e] + (float)bq[e]) + (float)c[e] + (float)d[e]) * 0.25f);
+    *reinterpret_cast<h8 *>(out + pix * C + c8 * 8) = o;
+}
+
+// ---- attention-pool tokens (model/clip/model.py:66-69): x4 [B][S][E] fp16 ->
+//   mean[b][:] fp32 (= avg_pool2d(x4) = the prepended token), tok[b*(S+1) + 0] = mean + pos[0],
+//   tok[b*(S+1) + 1 + t] = x4[b][t] + pos[1 + t], tok0[b] = tok[b*(S+1)]  (fp16 GEMM operands)
+__global__ __launch_bounds__(256) void rn50_tokens_kernel(const _Float16 *__restrict__ x4, const float *__restrict__ pos, int S,
+                                                          int E, float *__restrict__ mean, _Float16 *__restrict__ tok,
+                                                          _Float16 *__restrict__ tok0) {
+    const int b = blockIdx.x;
+    for (int c8 = threadIdx.x; c8 < E / 8; c8 += 256) {
+        float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < S; ++t) {
+            const h8 v = *reinterpret_cast<const h8 *>(x4 + ((int64_t)b * S + t) * E + c8 * 8);
+            const float *pp = pos + (int64_t)(1 + t) * E + c8 * 8;
+            h8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sum[e] = sum[e] + (float)v[e];
+                o[e] = (_Float16)((float)v[e] + pp[e]);
+            }
+            *reinterpret_cast<h8 *>(tok + ((int64_t)b * (S + 1) + 1 + t) * E + c8 * 8) = o;
+        }
+        h8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float m = __fdiv_rn(sum[e], (float)S);
+            mean[(int64_t)b * E + c8 * 8 + e] = m;
+            o[e] = (_Float16)(m + pos[c8 * 8 + e]);
+        }
+        *reinterpret_cast<h8 *>(tok + (int64_t)b * (S + 1) * E + c8 * 8) = o;
+        *reinterpret_cast<h8 *>(tok0 + (int64_t)b * E + c8 * 8) = o;
+    }
+}
+
+// ---- one-query attention: per (image, head) one wave.  q [B][E], kv [B*(S+1)][2E] (k | v), head dim 64.
+//   scores over the keys on the lanes, softmax in fp32, then the lanes become the 64 output dims.
+__global__ __launch_bounds__(64) void rn50_attend_kernel(const _Float16 *__restrict__ q, const _Float16 *__restrict__ kv, int T,
+                                                         int E, _Float16 *__restrict__ o) {
+    __shared__ float sp[256];
+    const int b = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+    const _Float16 *qh = q + (int64_t)b * E + h * 64;
+    float qv[64];
+#pragma unroll
+    for (int d8 = 0; d8 < 8; ++d8) {
+        const h8 v = *reinterpret_cast<const h8 *>(qh + d8 * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[d8 * 8 + e] = (float)v[e];
+    }
+    float mx = -3.0e38f;
+    for (int t = lane; t < T; t += 64) {
+        const _Float16 *kr = kv + ((int64_t)b * T + t) * (2 * E) + h * 64;
+        float s = 0.f;
+#pragma unroll
+        for (int d8 = 0; d8 < 8; ++d8) {
+            const h8 v = *reinterpret_cast<const h8 *>(kr + d8 * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s = fmaf(qv[d8 * 8 + e], (float)v[e], s);
+        }
+        s *= 0.125f; // head_dim ** -0.5
+        sp[t] = s;
+        mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    float sum = 0.f;
+    for (int t = lane; t < T; t += 64) {
+        const float p = __expf(sp[t] - mx);
+        sp[t] = p;
+        sum += p;
+    }
+    sum = wave_bfly_add(sum);
+    __syncthreads();
+    const float inv = __fdiv_rn(1.0f, sum);
+    float acc = 0.f;
+    const _Float16 *vr = kv + (int64_t)b * T * (2 * E) + E + h * 64 + lane;
+    for (int t = 0; t < T; ++t) acc = fmaf(sp[t], (float)vr[(int64_t)t * (2 * E)], acc);
+    o[(int64_t)b * E + h * 64 + lane] = (_Float16)(acc * inv);
+}
+
+// ---- head: out[b] = cat(mean[b] (E), proj[b][:out_dim]) (* scale + shift for NECK_FEAT == 'after') ----------
+__global__ __launch_bounds__(256) void rn50_head_kernel(const float *__restrict__ mean, const float *__restrict__ proj, int E,
+                                                        int out_dim, int ldp, const float *__restrict__ scale,
+                                                        const float *__restrict__ shift, float *__restrict__ out) {
+    const int b = blockIdx.x, D = E + out_dim;
+    for (int c = threadIdx.x; c < D; c += 256) {
+        float v = c < E ? mean[(int64_t)b * E + c] : proj[(int64_t)b * ldp + (c - E)];
+        if (scale) v = fmaf(v, scale[c], shift[c]);
+        out[(int64_t)b * D + c] = v;
+    }
+}
+
+struct Rn50Layout {
+    int S, T, E, out_pad;
+    int64_t tok_rows, b_pad;
+    size_t act_elems;   // elements of one activation buffer
+    size_t zero, act[5], mean, tok, tok0, kv, q, att, proj, total;
+};
+
+Rn50Layout rn50_layout(const mpreid_rn50_cfg *cfg, int B) {
+    Rn50Layout v{};
+    const int fh = cfg->img_h / 16, fw = cfg->img_w / 16;
+    v.S = fh * fw;
+    v.T = v.S + 1;
+    v.E = cfg->width * 32;
+    v.out_pad = (int)align_up((size_t)cfg->out_dim, 128);
+    v.tok_rows = (int64_t)align_up((size_t)B * v.T, 256);
+    v.b_pad = (int64_t)align_up((size_t)B, 256);
+    // the largest tensors: stem outputs [H/2][W/2][64] and layer1 outputs [H/4][W/4][4*width]
+    const size_t stem = (size_t)(cfg->img_h / 2) * (cfg->img_w / 2) * 64;
+    const size_t l1 = (size_t)(cfg->img_h / 4) * (cfg->img_w / 4) * (size_t)(cfg->width * 4);
+    v.act_elems = (size_t)B * (stem > l1 ? stem : l1) + 128 * 64;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off += align_up(bytes, 256);
+        return o;
+    };
+    v.zero = take(256);
+    for (int i = 0; i < 5; ++i) v.act[i] = take(v.act_elems * 2);
+    v.mean = take((size_t)B * v.E * 4);
+    v.tok = take((size_t)v.tok_rows * v.E * 2);
+    v.tok0 = take((size_t)v.b_pad * v.E * 2);
+    v.kv = take((size_t)v.tok_rows * 2 * v.E * 2);
+    v.q = take((size_t)v.b_pad * v.E * 2);
+    v.att = take((size_t)v.b_pad * v.E * 2);
+    v.proj = take((size_t)v.b_pad * v.out_pad * 4);
+    v.total = off;
+    return v;
+}
+
+int rn50_check_cfg(const mpreid_rn50_cfg *c) {
+    ARG_CHECK(c != nullptr);
+    ARG_CHECK(c->img_h > 0 && c->img_w > 0 && c->img_h % 32 == 0 && c->img_w % 32 == 0);
+    ARG_CHECK(c->width >= 16 && c->width % 16 == 0 && c->width <= 64 && c->n_blocks >= 4);
+    ARG_CHECK(c->heads > 0 && (c->width * 32) % c->heads == 0 && (c->width * 32) / c->heads == 64);
+    ARG_CHECK(c->out_dim > 0 && c->out_dim % 8 == 0 && (c->img_h / 16) * (c->img_w / 16) + 1 <= 256);
+    return 0;
+}
+
+int run_conv(const mpreid_rn50_conv &c, const _Float16 *in, int B, int H, int W, const _Float16 *identity, int relu,
+             _Float16 *out, const _Float16 *zero, hipStream_t stream) {
+    ConvArgs a{};
+    a.act = in;
+    a.wgt = (const _Float16 *)c.w;
+    a.bias = c.bias;
+    a.identity = identity;
+    a.out = out;
+    a.zero_page = zero;
+    a.H = H;
+    a.W = W;
+    a.C = c.cin;
+    a.M = B * H * W;
+    a.N = c.cout;
+    a.Npad = c.cout_pad;
+    a.ldo = c.cout;
+    a.taps = c.taps;
+    a.relu = relu;
+    return launch_conv_f16(a, stream);
+}
+
+int run_pool(const _Float16 *in, int B, int H, int W, int C, _Float16 *out, hipStream_t stream) {
+    const int64_t threads = (int64_t)B * (H / 2) * (W / 2) * (C / 8);
+    hipLaunchKernelGGL(avgpool2_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, in, B, H, W, C, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+} // namespace
+
+extern "C" size_t mpreid_rn50_workspace_bytes(const mpreid_rn50_cfg *cfg, int batch) {
+    if (rn50_check_cfg(cfg) || batch <= 0) return 0;
+    return rn50_layout(cfg, batch).total;
+}
+
+extern "C" int mpreid_rn50_forward(const mpreid_rn50_cfg *cfg, const mpreid_rn50_weights *w, const float *img,
+                                   const uint8_t *img8, const float *mean3, const float *std3, int B, float *out,
+                                   void *ws, size_t ws_bytes, mpreid_stream_t stream_) {
+    int rc = rn50_check_cfg(cfg);
+    if (rc) return rc;
+    ARG_CHECK(w && out && B > 0 && w->blocks && w->stem1_w && w->stem1_b);
+    ARG_CHECK((img != nullptr) != (img8 != nullptr));
+    ARG_CHECK(!img8 || (mean3 && std3));
+    const Rn50Layout v = rn50_layout(cfg, B);
+    if (!ws || ws_bytes < v.total) {
+        mpreid_set_error("rn50 workspace too small: %zu < %zu", ws_bytes, v.total);
+        return MPREID_ERR_WORKSPACE;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    char *base = (char *)ws;
+    const _Float16 *zero = (const _Float16 *)(base + v.zero);
+    _Float16 *buf[5];
+    for (int i = 0; i < 5; ++i) buf[i] = (_Float16 *)(base + v.act[i]);
+    HIP_TRY(hipMemsetAsync(base + v.zero, 0, 256, stream));
+
+    // ---- stem (model/clip/model.py:128-134): conv1/2/3 + bn + relu, AvgPool2d(2) ----
+    int H = cfg->img_h / 2, W = cfg->img_w / 2;
+    {
+        const int64_t threads = (int64_t)B * H * W * 8;
+        const dim3 grid((unsigned)((threads + 255) / 256));
+        if (img8)
+            hipLaunchKernelGGL(rn50_stem1_kernel<true>, grid, dim3(256), 0, stream, nullptr, img8, mean3[0], mean3[1],
+                               mean3[2], std3[0], std3[1], std3[2], w->stem1_w, w->stem1_b, cfg->width / 2, B, cfg->img_h,
+                               cfg->img_w, buf[0]);
+        else
+            hipLaunchKernelGGL(rn50_stem1_kernel<false>, grid, dim3(256), 0, stream, img, nullptr, 0.f, 0.f, 0.f, 1.f, 1.f,
+                               1.f, w->stem1_w, w->stem1_b, cfg->width / 2, B, cfg->img_h, cfg->img_w, buf[0]);
+        LAUNCH_CHECK();
+    }
+    if ((rc = run_conv(w->stem2, buf[0], B, H, W, nullptr, 1, buf[1], zero, stream))) return rc;
+    if ((rc = run_conv(w->stem3, buf[1], B, H, W, nullptr, 1, buf[0], zero, stream))) return rc;
+    if ((rc = run_pool(buf[0], B, H, W, w->stem3.cout, buf[1], stream))) return rc;
+    H /= 2;
+    W /= 2;
+    int xi = 1; // index of the buffer that holds the block input x
+
+    // ---- residual layers (model/clip/model.py:39-53) ----
+    for (int bi = 0; bi < cfg->n_blocks; ++bi) {
+        const mpreid_rn50_block &blk = w->blocks[bi];
+        ARG_CHECK(blk.stride == 1 || blk.stride == 2);
+        int free_i[4], nf = 0;
+        for (int i = 0; i < 5; ++i)
+            if (i != xi) free_i[nf++] = i;
+        _Float16 *x = buf[xi], *t1 = buf[free_i[0]], *t2 = buf[free_i[1]], *t3 = buf[free_i[2]], *t4 = buf[free_i[3]];
+        if ((rc = run_conv(blk.conv1, x, B, H, W, nullptr, 1, t1, zero, stream))) return rc;
+        if ((rc = run_conv(blk.conv2, t1, B, H, W, nullptr, 1, t2, zero, stream))) return rc;
+        int OH = H, OW = W;
+        const _Float16 *o2 = t2;
+        if (blk.stride == 2) {
+            if ((rc = run_pool(t2, B, H, W, blk.conv2.cout, t1, stream))) return rc;
+            o2 = t1;
+            OH = H / 2;
+            OW = W / 2;
+        }
+        const _Float16 *idt = x;
+        if (blk.down.w) {
+            const _Float16 *xin = x;
+            if (blk.stride == 2) {
+                if ((rc = run_pool(x, B, H, W, blk.down.cin, t3, stream))) return rc;
+                xin = t3;
+            }
+            if ((rc = run_conv(blk.down, xin, B, OH, OW, nullptr, 0, t4, zero, stream))) return rc;
+            idt = t4;
+        } else {
+            ARG_CHECK(blk.stride == 1 && blk.conv3.cout == blk.conv1.cin);
+        }
+        // out = relu(bn3(conv3(o2)) + identity); written to a buffer that is neither o2 nor the identity
+        _Float16 *dst = (o2 == t1) ? t2 : t1;
+        if ((rc = run_conv(blk.conv3, o2, B, OH, OW, idt, 1, dst, zero, stream))) return rc;
+        xi = (dst == t1) ? free_i[0] : free_i[1];
+        H = OH;
+        W = OW;
+    }
+    ARG_CHECK(H * W == v.S && w->blocks[cfg->n_blocks - 1].conv3.cout == v.E);
+
+    // ---- attention pool + head ----
+    float *mean = (float *)(base + v.mean);
+    _Float16 *tok = (_Float16 *)(base + v.tok), *tok0 = (_Float16 *)(base + v.tok0);
+    _Float16 *kv = (_Float16 *)(base + v.kv), *q = (_Float16 *)(base + v.q), *att = (_Float16 *)(base + v.att);
+    float *proj = (float *)(base + v.proj);
+    hipLaunchKernelGGL(rn50_tokens_kernel, dim3(B), dim3(256), 0, stream, buf[xi], w->pos_emb, v.S, v.E, mean, tok, tok0);
+    LAUNCH_CHECK();
+    {
+        GemmArgs g{};
+        g.A = tok;
+        g.W = (const _Float16 *)w->kv_w;
+        g.M = (int)v.tok_rows;
+        g.N = 2 * v.E;
+        g.K = v.E;
+        g.out = kv;
+        g.ldo = 2 * v.E;
+        g.bias = w->kv_b;
+        if ((rc = launch_gemm_f16(g, GE_BIAS_F16, stream))) return rc;
+        g.A = tok0;
+        g.W = (const _Float16 *)w->q_w;
+        g.M = (int)v.b_pad;
+        g.N = v.E;
+        g.out = q;
+        g.ldo = v.E;
+        g.bias = w->q_b;
+        if ((rc = launch_gemm_f16(g, GE_BIAS_F16, stream))) return rc;
+    }
+    hipLaunchKernelGGL(rn50_attend_kernel, dim3(B, cfg->heads), dim3(64), 0, stream, q, kv, v.T, v.E, att);
+    LAUNCH_CHECK();
+    {
+        HIP_TRY(hipMemsetAsync(proj, 0, (size_t)v.b_pad * v.out_pad * 4, stream));
+        GemmArgs g{};
+        g.A = att;
+        g.W = (const _Float16 *)w->c_w;
+        g.M = (int)v.b_pad;
+        g.N = v.out_pad;
+        g.K = v.E;
+        g.out = proj;
+        g.ldo = v.out_pad;
+        g.bias = w->c_b;
+        if ((rc = launch_gemm_f16(g, GE_BIAS_RES, stream))) return rc;
+    }
+    hipLaunchKernelGGL(rn50_head_kernel, dim3(B), dim3(256), 0, stream, mean, proj, v.E, cfg->out_dim, v.out_pad,
+                       w->bn_scale, w->bn_shift, out);
+    LAUNCH_CHECK();
+    return 0;
+}

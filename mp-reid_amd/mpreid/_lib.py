@@ -25,6 +25,7 @@ SYMBOLS = [
     "mpreid_rr_qe_fill", "mpreid_rr_jaccard",
     "mpreid_vit_workspace_bytes", "mpreid_vit_forward", "mpreid_vit_forward_u8", "mpreid_vit_forward_view",
     "mpreid_tta_mean_f32", "mpreid_resize_workspace_bytes", "mpreid_resize_bilinear_u8", "mpreid_conv_f16_nhwc",
+    "mpreid_rn50_workspace_bytes", "mpreid_rn50_forward",
     "mpreid_gemm_f16_nt", "mpreid_gemm_f16_nt_ex",
     "mpreid_cast_f32_to_f16", "mpreid_profile_enable", "mpreid_profile_reset", "mpreid_profile_query",
 ]
@@ -55,6 +56,26 @@ class VitWeights(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("conv_w", "class_emb", "pos_emb", "ln_pre_g", "ln_pre_b", "ln_post_g",
                                           "ln_post_b", "proj", "bn_scale", "bn_shift", "bn_proj_scale",
                                           "bn_proj_shift")] + [("layers", C.POINTER(VitLayer))]
+
+
+class Rn50Conv(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("bias", C.c_void_p), ("cin", C.c_int32), ("cout", C.c_int32),
+                ("cout_pad", C.c_int32), ("taps", C.c_int32)]
+
+
+class Rn50Block(C.Structure):
+    _fields_ = [("conv1", Rn50Conv), ("conv2", Rn50Conv), ("conv3", Rn50Conv), ("down", Rn50Conv), ("stride", C.c_int32)]
+
+
+class Rn50Cfg(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("img_h", "img_w", "width", "n_blocks", "heads", "out_dim")]
+
+
+class Rn50Weights(C.Structure):
+    _fields_ = [("stem1_w", C.c_void_p), ("stem1_b", C.c_void_p), ("stem2", Rn50Conv), ("stem3", Rn50Conv),
+                ("blocks", C.POINTER(Rn50Block)), ("pos_emb", C.c_void_p), ("kv_w", C.c_void_p), ("kv_b", C.c_void_p),
+                ("q_w", C.c_void_p), ("q_b", C.c_void_p), ("c_w", C.c_void_p), ("c_b", C.c_void_p),
+                ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p)]
 
 
 class ProfileEntry(C.Structure):
@@ -136,6 +157,11 @@ def load():
     L.mpreid_resize_workspace_bytes.argtypes = [i32, i32, i32]
     L.mpreid_resize_bilinear_u8.restype = i32
     L.mpreid_resize_bilinear_u8.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, sz, vp]
+    L.mpreid_rn50_workspace_bytes.restype = sz
+    L.mpreid_rn50_workspace_bytes.argtypes = [C.POINTER(Rn50Cfg), i32]
+    L.mpreid_rn50_forward.restype = i32
+    L.mpreid_rn50_forward.argtypes = [C.POINTER(Rn50Cfg), C.POINTER(Rn50Weights), vp, vp, C.POINTER(C.c_float),
+                                      C.POINTER(C.c_float), i32, vp, vp, sz, vp]
     L.mpreid_conv_f16_nhwc.restype = i32
     L.mpreid_conv_f16_nhwc.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, vp, i32, vp, vp, vp]
     L.mpreid_gemm_f16_nt.restype = i32

@@ -382,6 +382,10 @@ def _pad_to(n: int, m: int) -> int:
     return (n + m - 1) // m * m
 
 
+def _np64(a):
+    return (a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)).astype(np.float64)
+
+
 def fold_conv_bn(weight, bn=None, cin_pad: Optional[int] = None, eps: float = 1e-5):
     """Conv2d weight [cout, cin, k, k] (+ eval-mode BatchNorm2d (gamma, beta, running_mean, running_var)) ->
     (fp16 [cout_pad128, k*k*cin_pad] with k order (kh, kw, c), fp32 bias [cout_pad128]); model/clip/model.py:17-24:
@@ -427,3 +431,132 @@ def conv_f16_nhwc(act: torch.Tensor, wgt: torch.Tensor, bias: torch.Tensor, cout
                                                 _ptr(identity), int(relu), _ptr(out), _ptr(_zero_page(dev)),
                                                 _lib.stream_ptr()), "mpreid_conv_f16_nhwc")
     return out
+
+
+class Rn50Encoder:
+    """Device-resident CLIP RN50 image encoder + the RN50 eval head of build_transformer.
+
+    cfg keys: layers (4-tuple), width, heads, out_dim, h_res, w_res (mpreid.synth.RN50 layout);
+    state_dict: ModifiedResNet key names (optionally prefixed 'image_encoder.'), numpy or torch;
+    bn: optional dict(bottleneck=(w, b, mean, var), bottleneck_proj=(...)) applied when neck_after.
+    Every BatchNorm2d is folded into its convolution here, once (fold_conv_bn); channel counts that are not
+    multiples of 64 are stored zero-padded to 64 (the 32-channel stem; reduced test configurations)."""
+
+    def __init__(self, cfg: dict, state_dict: dict, img_hw, neck_after: bool = False, bn: Optional[dict] = None,
+                 device=None, ws_tag: str = "rn50"):
+        self.device = dev = device or _lib.require_gpu()
+        self.ws_tag, self.cfg, self.img_hw = ws_tag, dict(cfg), tuple(img_hw)
+        width, layers = cfg["width"], tuple(cfg["layers"])
+        assert self.img_hw[0] // 16 == cfg["h_res"] and self.img_hw[1] // 16 == cfg["w_res"], (img_hw, cfg)
+
+        def get(name):
+            for k in (name, "image_encoder." + name):
+                if k in state_dict:
+                    v = state_dict[k]
+                    return v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            raise KeyError(name)
+
+        def bn_of(prefix):
+            return tuple(get(f"{prefix}.{a}") for a in ("weight", "bias", "running_mean", "running_var"))
+
+        self._keep = []
+
+        def conv(cname, bname, taps):
+            w = get(cname + ".weight")
+            cout, cin = w.shape[0], w.shape[1]
+            cs_in, cs_out = _pad_to(cin, 64), _pad_to(cout, 64)
+            wk, bk = fold_conv_bn(w, bn_of(bname), cin_pad=cs_in)
+            if wk.shape[0] < _pad_to(cs_out, 128):  # never: fold pads cout to 128 already
+                raise AssertionError
+            wk, bk = wk.to(dev).contiguous(), bk.to(dev).contiguous()
+            self._keep += [wk, bk]
+            return _lib.Rn50Conv(_ptr(wk), _ptr(bk), cs_in, cs_out, wk.shape[0], taps)
+
+        # stem conv1 + bn1 folded, fp32, original [cout][c][kh][kw] order
+        g1, b1, m1, v1 = (a.astype(np.float64) for a in bn_of("bn1"))
+        sc = g1 / np.sqrt(v1 + 1e-5)
+        s1w = torch.from_numpy((get("conv1.weight").astype(np.float64) * sc[:, None, None, None]).astype(np.float32)).to(dev)
+        s1b = torch.from_numpy((b1 - m1 * sc).astype(np.float32)).to(dev)
+        self._keep += [s1w, s1b]
+        blocks = []
+        inplanes = width
+        for li, (planes, nb, stride) in enumerate(zip((width, width * 2, width * 4, width * 8), layers, (1, 2, 2, 1)), 1):
+            for b in range(nb):
+                pre = f"layer{li}.{b}"
+                blk = _lib.Rn50Block()
+                blk.conv1 = conv(pre + ".conv1", pre + ".bn1", 1)
+                blk.conv2 = conv(pre + ".conv2", pre + ".bn2", 9)
+                blk.conv3 = conv(pre + ".conv3", pre + ".bn3", 1)
+                blk.stride = stride if b == 0 else 1
+                if blk.stride > 1 or inplanes != planes * 4:
+                    blk.down = conv(pre + ".downsample.0", pre + ".downsample.1", 1)
+                blocks.append(blk)
+                inplanes = planes * 4
+        self.c_blocks = (_lib.Rn50Block * len(blocks))(*blocks)
+        E, od = width * 32, cfg["out_dim"]
+        self.feat_dim = E + od
+
+        def lin(names, pad_rows=None):
+            w = np.concatenate([get(f"attnpool.{n}.weight") for n in names]).astype(np.float32)
+            b = np.concatenate([get(f"attnpool.{n}.bias") for n in names]).astype(np.float32)
+            if pad_rows and w.shape[0] < pad_rows:
+                w = np.concatenate([w, np.zeros((pad_rows - w.shape[0], w.shape[1]), np.float32)])
+                b = np.concatenate([b, np.zeros(pad_rows - b.shape[0], np.float32)])
+            wt, bt = torch.from_numpy(w).to(torch.float16).to(dev), torch.from_numpy(b).to(dev)
+            self._keep += [wt, bt]
+            return wt, bt
+
+        kvw, kvb = lin(("k_proj", "v_proj"))
+        qw, qb = lin(("q_proj",))
+        cw, cb = lin(("c_proj",), pad_rows=_pad_to(od, 128))
+        pos = torch.from_numpy(get("attnpool.positional_embedding").astype(np.float32)).to(dev)
+        self._keep.append(pos)
+        scale = shift = None
+        if neck_after:
+            assert bn is not None
+            parts = []
+            for name in ("bottleneck", "bottleneck_proj"):
+                w_, b_, m_, v_ = (_np64(a) for a in bn[name])
+                s_ = w_ / np.sqrt(v_ + 1e-5)
+                parts.append((s_, b_ - m_ * s_))
+            scale = torch.from_numpy(np.concatenate([p[0] for p in parts]).astype(np.float32)).to(dev)
+            shift = torch.from_numpy(np.concatenate([p[1] for p in parts]).astype(np.float32)).to(dev)
+            self._keep += [scale, shift]
+        self.c_cfg = _lib.Rn50Cfg(self.img_hw[0], self.img_hw[1], width, len(blocks), cfg["heads"], od)
+        self.c_w = _lib.Rn50Weights()
+        self.c_w.stem1_w, self.c_w.stem1_b = _ptr(s1w), _ptr(s1b)
+        self.c_w.stem2, self.c_w.stem3 = conv("conv2", "bn2", 9), conv("conv3", "bn3", 9)
+        self.c_w.blocks = C.cast(self.c_blocks, C.POINTER(_lib.Rn50Block))
+        self.c_w.pos_emb = _ptr(pos)
+        self.c_w.kv_w, self.c_w.kv_b, self.c_w.q_w, self.c_w.q_b = _ptr(kvw), _ptr(kvb), _ptr(qw), _ptr(qb)
+        self.c_w.c_w, self.c_w.c_b = _ptr(cw), _ptr(cb)
+        self.c_w.bn_scale, self.c_w.bn_shift = _ptr(scale), _ptr(shift)
+
+    @torch.no_grad()
+    def forward(self, img: torch.Tensor, cv_emb=None, pixel_mean=(0.5, 0.5, 0.5), pixel_std=(0.5, 0.5, 0.5),
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """img: fp32 [B,3,H,W] (val_transforms applied) or uint8 [B,H,W,3] (after Resize).  cv_emb is ignored: the
+        reference's RN50 branch has no SIE embedding (model/make_model.py:82-86)."""
+        L = _lib.load()
+        u8 = img.dtype == torch.uint8
+        if u8:
+            img = img.detach().to(device=self.device).contiguous()
+            assert tuple(img.shape[1:]) == self.img_hw + (3,), img.shape
+        else:
+            img = _dev_f32(img, self.device)
+            assert tuple(img.shape[1:]) == (3,) + self.img_hw, img.shape
+        B = img.shape[0]
+        if out is None:
+            out = torch.empty((B, self.feat_dim), dtype=torch.float32, device=self.device)
+        mean = (C.c_float * 3)(*[float(x) for x in pixel_mean])
+        std = (C.c_float * 3)(*[float(x) for x in pixel_std])
+        ws = _workspace(self.ws_tag, L.mpreid_rn50_workspace_bytes(C.byref(self.c_cfg), B), self.device)
+        _lib.check(L.mpreid_rn50_forward(C.byref(self.c_cfg), C.byref(self.c_w), None if u8 else _ptr(img),
+                                         _ptr(img) if u8 else None, mean, std, B, _ptr(out), _ptr(ws), ws.numel(),
+                                         _lib.stream_ptr()), "mpreid_rn50_forward")
+        return out
+
+    __call__ = forward
+
+    def forward_u8(self, img_hwc, pixel_mean=(0.5, 0.5, 0.5), pixel_std=(0.5, 0.5, 0.5), cv_emb=None, out=None):
+        return self.forward(img_hwc, None, pixel_mean, pixel_std, out)

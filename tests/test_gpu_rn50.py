@@ -47,3 +47,59 @@ def test_conv_layer_vs_torch_fp32(B, H, W, cin, cout, k, with_id, relu):
     got = out.float().cpu().permute(0, 3, 1, 2).numpy()
     assert _rel(got, ref.numpy()) <= 1e-3, _rel(got, ref.numpy())
     assert np.abs(got - ref.numpy()).max() <= 2e-3 * float(ref.abs().max()) + 2e-3
+
+
+SMALL = dict(layers=(1, 2, 1, 1), width=16, heads=8, out_dim=64, h_res=4, w_res=2)
+
+
+def _check(got, want, rel):
+    r = _rel(got, want)
+    cos = (got * want).sum(1) / (np.linalg.norm(got, axis=1) * np.linalg.norm(want, axis=1))
+    assert r <= rel and cos.min() >= 0.9999, (r, cos.min())
+    return r
+
+
+def test_rn50_small_vs_reference(golden):
+    """reduced ModifiedResNet (every channel count padded to 64 in storage) against the reference class's output:
+    fp16 activations + fp16 MFMA operands through ~20 layers: relative L2 <= 5e-3"""
+    from mpreid import ops, synth
+    g = golden("rn50.npz")
+    enc = ops.Rn50Encoder(SMALL, synth.rn50_state_dict(SMALL, seed=11), (64, 32))
+    f = enc(torch.from_numpy(synth.synthetic_images(3, 64, 32, seed=31))).cpu().numpy()
+    assert f.shape == (3, 576)
+    print("rn50 small rel-L2:", _check(f, g["small_feat"], 5e-3))
+
+
+def test_rn50_full_vs_reference(golden):
+    from mpreid import ops, synth
+    g = golden("rn50.npz")
+    sd = synth.rn50_state_dict(synth.RN50, seed=11)
+    enc = ops.Rn50Encoder(synth.RN50, sd, (256, 128))
+    imgs = synth.synthetic_images(3, 256, 128, seed=32)
+    f = enc(torch.from_numpy(imgs)).cpu().numpy()
+    assert f.shape == (3, 3072)
+    print("rn50 rel-L2 vs reference:", _check(f, g["rn50_feat"], 5e-3))
+    # batch independence: the same images inside a larger batch give the same rows bit for bit
+    more = synth.synthetic_images(9, 256, 128, seed=99)
+    more[4:7] = imgs
+    f2 = enc(torch.from_numpy(more)).cpu().numpy()
+    assert np.array_equal(f2[4:7], f)
+
+
+def test_rn50_u8_and_bn_neck_vs_oracle():
+    from mpreid import ops, synth
+    sd = synth.rn50_state_dict(SMALL, seed=12)
+    rng = np.random.default_rng(4)
+    bn = {n: (1 + 0.1 * rng.standard_normal(d).astype(np.float32), 0.1 * rng.standard_normal(d).astype(np.float32),
+              0.1 * rng.standard_normal(d).astype(np.float32), (0.5 + rng.random(d)).astype(np.float32))
+          for n, d in (("bottleneck", 512), ("bottleneck_proj", 64))}
+    enc = ops.Rn50Encoder(SMALL, sd, (64, 32), neck_after=True, bn=bn)
+    u8 = rng.integers(0, 256, (5, 64, 32, 3), dtype=np.uint8)
+    mean, std = (0.5, 0.4, 0.45), (0.5, 0.25, 0.3)
+    t = torch.from_numpy(u8).permute(0, 3, 1, 2).float().div(255)
+    t = (t - torch.tensor(mean)[None, :, None, None]) / torch.tensor(std)[None, :, None, None]
+    want = orc.rn50_features(sd, SMALL, t.numpy(), bn=bn, neck_feat="after")
+    got_u8 = enc.forward_u8(torch.from_numpy(u8), mean, std).cpu().numpy()
+    got_f32 = enc(t.contiguous()).cpu().numpy()
+    assert np.array_equal(got_u8, got_f32)       # ToTensor + Normalize fused into the first conv: same bits
+    _check(got_u8, want, 5e-3)
