@@ -4,12 +4,12 @@ encoder + feature head of ``build_transformer``, executed by the HIP kernels of 
 Kept from the reference (model/make_model.py:81-133): ``make_model(cfg, num_class, camera_num, view_num)``
 returns an object with ``.load_param(path)``, ``.eval()``, ``.to(device)``, ``.state_dict()`` (same key
 layout as the reference's checkpoints: ``image_encoder.*``, ``bottleneck*``, ``classifier*``, ``cv_embed``)
-and ``__call__(x, label=None, cam_label=None, view_label=None) -> Tensor[B, 1280]``.
+and ``__call__(x, label=None, cam_label=None, view_label=None) -> Tensor[B, 1280]`` (3072 for RN50).
 
 Not kept on purpose: the constructor does not download the pretrained CLIP archive (the reference
 does, even at test time, model/make_model.py:137-139); weights are seeded random until
-``load_param`` is called.  Training-mode forward, the RN50 backbone and the text tower are out of
-scope.
+``load_param`` is called.  MODEL.NAME 'RN50' selects the CLIP ModifiedResNet tower (2048 + 1024 = 3072-d feature,
+model/make_model.py:40-42, 82-86).  Training-mode forward and the text tower are out of scope.
 """
 import numpy as np
 import torch
@@ -34,11 +34,10 @@ class build_transformer(nn.Module):
     def __init__(self, num_classes, camera_num, view_num, cfg):
         super().__init__()
         self.model_name = cfg.MODEL.NAME
-        if self.model_name != 'ViT-B-16':
-            raise NotImplementedError("only MODEL.NAME == 'ViT-B-16' is on the accelerated path "
-                                      f"(got {self.model_name!r}; RN50 is listed as 'next' in SURVEY.md §8f)")
+        if self.model_name not in ('ViT-B-16', 'RN50'):
+            raise NotImplementedError(f"MODEL.NAME {self.model_name!r}: the reference knows 'ViT-B-16' and 'RN50'")
         self.neck_feat = cfg.TEST.NECK_FEAT
-        self.in_planes, self.in_planes_proj = 768, 512
+        self.in_planes, self.in_planes_proj = (768, 512) if self.model_name == 'ViT-B-16' else (2048, 1024)
         self.num_classes, self.camera_num, self.view_num = num_classes, camera_num, view_num
         self.sie_coe = cfg.MODEL.SIE_COE
         stride = cfg.MODEL.STRIDE_SIZE[0]
@@ -51,8 +50,24 @@ class build_transformer(nn.Module):
         self.vit_cfg = dict(h_res=self.h_resolution, w_res=self.w_resolution, patch=16, stride=stride, width=768,
                             layers=12, heads=12, out_dim=512)
         seed = int(getattr(cfg.MODEL, "INIT_SEED", 7))
-        for k, v in _synth.vit_state_dict(self.vit_cfg, seed=seed).items():
-            _put(self, "image_encoder." + k, torch.from_numpy(v))
+        if self.model_name == 'RN50':
+            # model/clip/model.py:509-516: heads = width * 32 // 64, attention-pool grid = h_resolution x w_resolution
+            self.rn_cfg = dict(_synth.RN50, h_res=self.h_resolution, w_res=self.w_resolution)
+            for k, v in _synth.rn50_state_dict(self.rn_cfg, seed=seed).items():
+                path = "image_encoder." + k
+                if k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+                    parts = path.split(".")
+                    mod = self
+                    for p_ in parts[:-1]:
+                        if p_ not in mod._modules:
+                            mod.add_module(p_, nn.Module())
+                        mod = mod._modules[p_]
+                    mod.register_buffer(parts[-1], torch.from_numpy(np.asarray(v)))
+                else:
+                    _put(self, path, torch.from_numpy(v))
+        else:
+            for k, v in _synth.vit_state_dict(self.vit_cfg, seed=seed).items():
+                _put(self, "image_encoder." + k, torch.from_numpy(v))
         g = torch.Generator().manual_seed(seed)
         _put(self, "classifier.weight", torch.randn(num_classes, self.in_planes, generator=g) * 0.001)
         _put(self, "classifier_proj.weight", torch.randn(num_classes, self.in_planes_proj, generator=g) * 0.001)
@@ -84,8 +99,12 @@ class build_transformer(nn.Module):
             if self.neck_feat == 'after':
                 bn = {n: (self._modules[n].weight, self._modules[n].bias, self._modules[n].running_mean,
                           self._modules[n].running_var) for n in ("bottleneck", "bottleneck_proj")}
-            self._encoder = _ops.VitEncoder(self.vit_cfg, sd, self.img_hw, neck_after=(self.neck_feat == 'after'),
-                                            bn=bn)
+            if self.model_name == 'RN50':
+                self._encoder = _ops.Rn50Encoder(self.rn_cfg, sd, self.img_hw, neck_after=(self.neck_feat == 'after'),
+                                                 bn=bn)
+            else:
+                self._encoder = _ops.VitEncoder(self.vit_cfg, sd, self.img_hw, neck_after=(self.neck_feat == 'after'),
+                                                bn=bn)
         return self._encoder
 
     def forward(self, x, label=None, cam_label=None, view_label=None):
@@ -112,6 +131,11 @@ class build_transformer(nn.Module):
         enc = self._get_encoder()
         if isinstance(x, (list, tuple)):
             x = _ops.resize_bilinear_u8(x, self.img_hw)
+        if self.model_name == 'RN50':
+            if view != 0:
+                raise NotImplementedError("test-time-augmentation views are fused into the ViT patch gather only; "
+                                          "pass a materialised view tensor to the RN50 model")
+            return enc(x, None, self.pixel_mean, self.pixel_std)   # no SIE embedding in the reference's RN50 branch
         if view == 0 and x.dtype != torch.uint8:
             return enc(x, cv_embed)
         return enc.forward_view(x, view, cv_embed, self.pixel_mean, self.pixel_std)

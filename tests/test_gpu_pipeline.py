@@ -249,3 +249,44 @@ def test_uniprompt_model_branches(tmp_path):
     torch.save(ckpt, path)
     m.load_param(str(path))
     assert torch.equal(m(x=imgs), full)
+
+
+def test_do_inference_rn50_matches_oracle_pipeline(tmp_path):
+    """MODEL.NAME 'RN50' (configs/person/cnn_base.yml): 3072-d features, same evaluator; checkpoint key layout of
+    the reference's ModifiedResNet (BatchNorm buffers included) round-trips through load_param"""
+    from config import cfg_base
+    from datasets.make_dataloader import make_dataloader
+    from model.make_model import make_model
+    from processor.processor import do_inference
+    from utils.metrics import R1_mAP_eval
+    from mpreid import synth
+    cfg = cfg_base.clone()
+    cfg.defrost()
+    cfg.merge_from_list(["MODEL.NAME", "RN50", "DATASETS.SYNTH_QUERY", 6, "DATASETS.SYNTH_GALLERY", 14,
+                         "DATASETS.SYNTH_IDS", 5, "TEST.IMS_PER_BATCH", 8])
+    cfg.freeze()
+    _, _, val_loader, num_query, num_classes, cam_num, view_num = make_dataloader(cfg)
+    model = make_model(cfg, num_class=num_classes, camera_num=cam_num, view_num=view_num)
+    keys = set(model.state_dict().keys())
+    for k in ("image_encoder.conv1.weight", "image_encoder.bn1.running_var", "image_encoder.bn1.num_batches_tracked",
+              "image_encoder.layer4.2.conv3.weight", "image_encoder.layer2.0.downsample.1.running_mean",
+              "image_encoder.attnpool.positional_embedding", "image_encoder.attnpool.c_proj.bias", "bottleneck.weight"):
+        assert k in keys, k
+    assert model.state_dict()["bottleneck.weight"].shape == (2048,)
+    # different weights through a checkpoint
+    sd = synth.rn50_state_dict(model.rn_cfg, seed=77)
+    path = tmp_path / "RN50_120.pth"
+    torch.save({"module.image_encoder." + k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, path)
+    model.load_param(str(path))
+    r1, r5 = do_inference(cfg, model, val_loader, num_query)
+    ev = R1_mAP_eval(num_query, feat_norm=cfg.TEST.FEAT_NORM)
+    ev.reset()
+    for img, pid, camid, camids, views, paths in val_loader:
+        f = model(img.cuda())
+        assert f.shape == (img.shape[0], 3072)
+        want = orc.rn50_features(sd, model.rn_cfg, img.numpy())
+        rel = np.linalg.norm(f.cpu().numpy() - want) / np.linalg.norm(want)
+        assert rel < 5e-3, rel
+        ev.update((f, pid, camid))
+    cmc, mAP, *_ = ev.compute()
+    assert float(cmc[0]) == float(r1) and float(cmc[4]) == float(r5)
