@@ -119,6 +119,24 @@ def extras(ops, dev):
     out["rerank_N20000_nq4000_d768_k50_15_ms"] = round(st["ms_total"], 3)
     out["rerank_stages_ms"] = {k[3:]: round(v, 3) for k, v in st.items() if k.startswith("ms_") and k != "ms_total"}
     out["rerank_nnz"] = {"v": st["v_nnz"], "vqe": st["vqe_nnz"], "jaccard_pairs": st["jaccard_pairs"]}
+    del ft
+    # widened rows: the RN50 tower, the Pillow-exact Resize, the TTA query encoder
+    enc = ops.Rn50Encoder(synth.RN50, synth.rn50_state_dict(synth.RN50, seed=11), (256, 128))
+    img = torch.from_numpy(synth.synthetic_images(64, 256, 128, seed=1)).to(dev).repeat(4, 1, 1, 1).contiguous()
+    fo = torch.empty((256, enc.feat_dim), device=dev)
+    ms = timed(lambda: enc(img, out=fo), 3)
+    out["rn50_images_per_s_batch256"] = round(256 / ms * 1e3, 1)
+    out["rn50_tflops_11.5gflop_per_img"] = round(256 * 11.51 / ms, 1)
+    del enc, img, fo
+    rng = np.random.default_rng(5)
+    raws = [rng.integers(0, 256, (128, 64, 3), dtype=np.uint8) for _ in range(512)]   # Market-1501 native size
+    ops.resize_bilinear_u8(raws, (256, 128))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        ops.resize_bilinear_u8(raws, (256, 128))
+    torch.cuda.synchronize()
+    out["resize_128x64_to_256x128_images_per_s_incl_pack_and_h2d"] = round(3 * 512 / (time.perf_counter() - t0), 1)
     return out
 
 
