@@ -545,169 +545,6 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
 }
 
 // ---------------------------------------------------------------------------------------------
-// "p2" kernel: PERSISTENT, two independent 4-wave workgroups per CU.
-//   tile 256 (M) x 128 (N), waves 2 x 2 (128 x 64 per wave, same fragment code as the big kernel),
-//   K in 32-wide stages, 3-slot LDS ring per workgroup (3 x 24 KB = 72 KB -> two workgroups per CU),
-//   LDS-DMA two stages ahead, counted vmcnt + raw s_barrier, one barrier per 32 MFMAs.
-// Why: the ablation of the one-workgroup-per-CU kernel (tools/gemm_bench.py, MPREID_GEMM_DBG) showed
-// its MFMA loop near the clock-limited ceiling while ~45 % of the time went to phases in which the
-// matrix pipe idles: workgroup dispatch + cold prologue (52 us of 260 on the QKV shape) and the
-// epilogue, which is simply the HBM time of the output (50-63 us).  Two workgroups per CU that walk
-// tiles out of phase (odd workgroups start half a tile late) put one's epilogue/prologue beside the
-// other's MFMA loop.
-// ---------------------------------------------------------------------------------------------
-constexpr int PBM = 256, PBN = 128, PBK = 32, P_NSTAGE = 3;
-constexpr int P_A_BYTES = PBM * PBK * 2;                 // 16 KB
-constexpr int P_B_BYTES = PBN * PBK * 2;                 // 8 KB
-constexpr int P_STAGE_BYTES = P_A_BYTES + P_B_BYTES;     // 24 KB
-constexpr int P_LDS_BYTES = P_NSTAGE * P_STAGE_BYTES;    // 72 KB
-#ifndef P2_NAPS_PER_STAGE
-#define P2_NAPS_PER_STAGE 2 // ~1000 cycles per stage = about half of a stage pair's time
-#endif
-
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_f16_p2_kernel(GemmArgs g, int tiles_m, int tiles_n) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-    const int K = g.K;
-    const int nst = K / PBK;
-    const int ntiles = tiles_m * tiles_n;
-    const int nb = (int)gridDim.x;
-    // logical tile order: the workgroups of one XCD (blockIdx % 8) take neighbouring tiles of every sweep
-    const int per_xcd = nb >> 3;
-    const int slot = (nb % 8 == 0) ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-
-    // odd workgroups start half a main loop late (once), so that the two workgroups of a CU alternate
-    // between the MFMA loop and the memory-bound epilogue / prologue
-    // (the second workgroup of a CU is, in practice, the one dispatched in the second half of the grid)
-    if ((int)blockIdx.x >= (nb >> 1)) {
-        const int naps = nst * P2_NAPS_PER_STAGE; // units of s_sleep 8 (~512 cycles)
-        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(8);
-    }
-
-    // DMA geometry: one piece = 16 rows x 64 B.  A part: 16 pieces, wave w takes 4w..4w+3; B part: 8 pieces,
-    // wave w takes 2w, 2w+1.
-    const int drow = lane >> 2;
-    const int dchunk = (lane & 3) ^ (((drow >> 3) & 1) * 3);
-    const int frow = lane & 15, fq = lane >> 4;
-    const int fsw = (fq ^ (((lane >> 3) & 1) * 3)) << 4;
-    const int a_off = (wr * 128 + frow) * 64 + fsw;                // + i * 1024
-    const int b_off = P_A_BYTES + (wc * 64 + frow) * 64 + fsw;     // + j * 1024
-
-    for (int tile = slot; tile < ntiles; tile += nb) {
-        int tm, tn;
-        tile_coords((unsigned)tile, tiles_m, tiles_n, 8, tm, tn);
-        const int m0 = tm * PBM, n0 = tn * PBN;
-        const _Float16 *a_src = g.A + (int64_t)(m0 + wave * 64 + drow) * K + dchunk * 8;
-        const _Float16 *b_src = g.W + (int64_t)(n0 + wave * 32 + drow) * K + dchunk * 8;
-        auto dma_stage = [&](int st) {
-            unsigned char *sb = smem + (st % P_NSTAGE) * P_STAGE_BYTES;
-            const int koff = st * PBK;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) dma16(a_src + (int64_t)t * 16 * K + koff, sb + wave * 4096 + t * 1024);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-                dma16(b_src + (int64_t)t * 16 * K + koff, sb + P_A_BYTES + wave * 2048 + t * 1024);
-        };
-
-        f32x4 acc[8][4];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-        __syncthreads(); // previous tile's epilogue is done with the LDS (also drains its stores)
-        dma_stage(0);
-        if (nst > 1) dma_stage(1);
-        for (int t = 0; t < nst; ++t) {
-            // stage t landed everywhere (stage t+1 may stay in flight); slot (t+2)%3 = slot of stage t-1 is free
-            if (t + 1 < nst) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            if (t + 2 < nst) dma_stage(t + 2);
-            const unsigned char *sb = smem + (t % P_NSTAGE) * P_STAGE_BYTES;
-            f16x8 fa[8], fb[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const f16x8 *>(sb + b_off + j * 1024);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const f16x8 *>(sb + a_off + i * 1024);
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
-
-        // ---- epilogue (through LDS patches private to each wave) ----
-        __syncthreads();
-        if constexpr (EPI == GE_BIAS_F16 || EPI == GE_BIAS_GELU) {
-            _Float16 *wreg = reinterpret_cast<_Float16 *>(smem) + wave * (64 * 72);
-            _Float16 *out = reinterpret_cast<_Float16 *>(g.out);
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float bias = g.bias[n0 + wc * 64 + j * 16 + frow];
-#pragma unroll
-                    for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float v = acc[half * 4 + ii][j][r] + bias;
-                            if (EPI == GE_BIAS_GELU) v = quick_gelu(v);
-                            wreg[(ii * 16 + fq * 4 + r) * 72 + j * 16 + frow] = (_Float16)v;
-                        }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int lr = it * 8 + (lane >> 3), ch = lane & 7;
-                    const uint4 v = *reinterpret_cast<const uint4 *>(wreg + lr * 72 + ch * 8);
-                    *reinterpret_cast<uint4 *>(out + (int64_t)(m0 + wr * 128 + half * 64 + lr) * g.ldo + n0 + wc * 64 +
-                                               ch * 8) = v;
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        } else { // GE_BIAS_RES (fp32 read-modify-write, ldo % 4 == 0 checked by the launcher)
-            float *wreg = reinterpret_cast<float *>(smem) + wave * (32 * 68);
-            float *outp = reinterpret_cast<float *>(g.out);
-            const int nbase = n0 + wc * 64;
-            const int c4 = (lane & 15) * 4;
-            const float4 bias4 = *reinterpret_cast<const float4 *>(g.bias + nbase + c4);
-#pragma unroll
-            for (int part = 0; part < 4; ++part) {
-#pragma unroll
-                for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            wreg[(ii * 16 + fq * 4 + r) * 68 + j * 16 + frow] = acc[part * 2 + ii][j][r];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int mbase = m0 + wr * 128 + part * 32;
-#pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int lr = it * 4 + (lane >> 4);
-                    const float4 a = *reinterpret_cast<const float4 *>(wreg + lr * 68 + c4);
-                    float *dst = outp + (int64_t)(mbase + lr) * g.ldo + nbase + c4;
-                    float4 x = *reinterpret_cast<const float4 *>(dst);
-                    x.x = x.x + (a.x + bias4.x);
-                    x.y = x.y + (a.y + bias4.y);
-                    x.z = x.z + (a.z + bias4.z);
-                    x.w = x.w + (a.w + bias4.w);
-                    *reinterpret_cast<float4 *>(dst) = x;
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // optional per-launch event timing (bench.py's roofline leg): hipEvents recorded on the launch
 // stream around every GEMM launch while enabled, aggregated per (epilogue, N, K) class.
 // ---------------------------------------------------------------------------------------------
@@ -800,44 +637,6 @@ static int launch_one(const GemmArgs &a, hipStream_t stream) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_big_kernel<EPI>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_TOTAL));
         big_attr_set = true;
-    }
-    // MPREID_GEMM_BIG=3: persistent two-workgroups-per-CU kernel (bias->f16, GELU, residual epilogues)
-    constexpr bool HAS_P2 = (EPI == GE_BIAS_F16 || EPI == GE_BIAS_RES || EPI == GE_BIAS_GELU);
-    const bool use_p2 = HAS_P2 && bm == 3 && (a.M % PBM == 0) && (a.N % PBN == 0) && (a.ldo % 4 == 0) &&
-                        ((int64_t)(a.M / PBM) * (a.N / PBN) >= 512);
-    if (use_p2) {
-        if constexpr (HAS_P2) {
-            static bool p2_attr = false;
-            static int p2_grid = 512;
-            if (!p2_attr) {
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_p2_kernel<EPI>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES));
-                int dev = 0, cus = 256;
-                HIP_TRY(hipGetDevice(&dev));
-                HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-                p2_grid = 2 * cus;
-                p2_attr = true;
-            }
-            const int ptm = a.M / PBM, ptn = a.N / PBN;
-            hipEvent_t pe0 = nullptr, pe1 = nullptr;
-            if (g_prof_on) {
-                HIP_TRY(hipEventCreate(&pe0));
-                HIP_TRY(hipEventCreate(&pe1));
-                HIP_TRY(hipEventRecord(pe0, stream));
-            }
-            hipLaunchKernelGGL(gemm_f16_p2_kernel<EPI>, dim3((unsigned)p2_grid), dim3(256), P_LDS_BYTES, stream, a, ptm,
-                               ptn);
-            LAUNCH_CHECK();
-            if (pe0) {
-                HIP_TRY(hipEventRecord(pe1, stream));
-                std::lock_guard<std::mutex> lk(g_prof_mu);
-                ProfClass &pc = g_prof[std::make_tuple(EPI, a.N, a.K)];
-                pc.ev.emplace_back(pe0, pe1);
-                pc.m = std::max<int64_t>(pc.m, a.M);
-                pc.flops_total += 2.0 * (double)a.M * (double)a.N * (double)a.K;
-            }
-            return MPREID_OK;
-        }
     }
     const int tiles_m = use_big ? a.M / BBM : a.M / GBM, tiles_n = use_big ? a.N / BBN : a.N / GBN;
     hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -92,19 +92,20 @@ class build_transformer(nn.Module):
     def _invalidate(self):
         self._encoder = None
 
+    def _build_encoder(self, neck_after, ws_tag=None):
+        sd = {k: v for k, v in self.state_dict().items() if k.startswith("image_encoder.")}
+        bn = None
+        if neck_after:
+            bn = {n: (self._modules[n].weight, self._modules[n].bias, self._modules[n].running_mean,
+                      self._modules[n].running_var) for n in ("bottleneck", "bottleneck_proj")}
+        kw = {} if ws_tag is None else {"ws_tag": ws_tag}
+        if self.model_name == 'RN50':
+            return _ops.Rn50Encoder(self.rn_cfg, sd, self.img_hw, neck_after=neck_after, bn=bn, **kw)
+        return _ops.VitEncoder(self.vit_cfg, sd, self.img_hw, neck_after=neck_after, bn=bn, **kw)
+
     def _get_encoder(self):
         if self._encoder is None:
-            sd = {k: v for k, v in self.state_dict().items() if k.startswith("image_encoder.")}
-            bn = None
-            if self.neck_feat == 'after':
-                bn = {n: (self._modules[n].weight, self._modules[n].bias, self._modules[n].running_mean,
-                          self._modules[n].running_var) for n in ("bottleneck", "bottleneck_proj")}
-            if self.model_name == 'RN50':
-                self._encoder = _ops.Rn50Encoder(self.rn_cfg, sd, self.img_hw, neck_after=(self.neck_feat == 'after'),
-                                                 bn=bn)
-            else:
-                self._encoder = _ops.VitEncoder(self.vit_cfg, sd, self.img_hw, neck_after=(self.neck_feat == 'after'),
-                                                bn=bn)
+            self._encoder = self._build_encoder(self.neck_feat == 'after')
         return self._encoder
 
     def forward(self, x, label=None, cam_label=None, view_label=None):
@@ -133,8 +134,16 @@ class build_transformer(nn.Module):
             x = _ops.resize_bilinear_u8(x, self.img_hw)
         if self.model_name == 'RN50':
             if view != 0:
-                raise NotImplementedError("test-time-augmentation views are fused into the ViT patch gather only; "
-                                          "pass a materialised view tensor to the RN50 model")
+                # the view gather is fused into the ViT patch kernel only; for RN50 the view tensor is materialised
+                # on the device the way the reference does it (processor/processor_uniprompt_stage2.py:605-633)
+                if x.dtype == torch.uint8:
+                    mean = torch.tensor(self.pixel_mean, device=x.device)[None, :, None, None]
+                    std = torch.tensor(self.pixel_std, device=x.device)[None, :, None, None]
+                    x = (x.permute(0, 3, 1, 2).to(torch.float32).div(255) - mean) / std
+                x = x.to(enc.device)
+                x = (torch.flip(x, [3]) if view == 1 else
+                     x.mean(dim=1, keepdim=True).repeat(1, 3, 1, 1) if view == 2 else x[:, 0:1].repeat(1, 3, 1, 1))
+                x = x.contiguous()
             return enc(x, None, self.pixel_mean, self.pixel_std)   # no SIE embedding in the reference's RN50 branch
         if view == 0 and x.dtype != torch.uint8:
             return enc(x, cv_embed)

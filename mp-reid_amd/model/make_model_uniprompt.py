@@ -30,7 +30,7 @@ _SKIPPED_PREFIXES = ("prompt_learner.", "text_encoder.", "image_fusion_net.")
 class build_transformer(_base.build_transformer):
     def __init__(self, num_classes, camera_num, view_num, cfg):
         super().__init__(num_classes, camera_num, view_num, cfg)
-        self.prompt_dim = 512
+        self.prompt_dim = 512   # hard-coded in the reference (:89), whatever the backbone
         g = torch.Generator().manual_seed(int(getattr(cfg.MODEL, "INIT_SEED", 7)) + 1)
         self.visual_prompt = nn.Parameter(torch.randn(1, 1, self.prompt_dim, generator=g) * 0.02, requires_grad=False)
         self._proj_encoder = None
@@ -44,8 +44,7 @@ class build_transformer(_base.build_transformer):
         if self.neck_feat != 'after':
             return self._encode(x, None, view)
         if self._proj_encoder is None:
-            sd = {k: v for k, v in self.state_dict().items() if k.startswith("image_encoder.")}
-            self._proj_encoder = _base._ops.VitEncoder(self.vit_cfg, sd, self.img_hw, ws_tag="vit_proj")
+            self._proj_encoder = self._build_encoder(False, ws_tag="enc_proj")
         keep, self._encoder = self._encoder, self._proj_encoder
         try:
             return self._encode(x, None, view)

@@ -290,3 +290,21 @@ def test_do_inference_rn50_matches_oracle_pipeline(tmp_path):
         ev.update((f, pid, camid))
     cmc, mAP, *_ = ev.compute()
     assert float(cmc[0]) == float(r1) and float(cmc[4]) == float(r5)
+
+
+def test_rn50_tta_views_and_uniprompt_branches():
+    """RN50 under the Uni-Prompt evaluation: the TTA views are materialised tensors (as in the reference) and
+    get_image returns the attention-pool output"""
+    from mpreid import synth
+    from model.make_model_uniprompt import make_model
+    cfg = _raw_cfg(4, 4, 4, **{"MODEL.NAME": "RN50", "TEST.NECK_FEAT": "after"})
+    m = make_model(cfg, num_class=7, camera_num=6, view_num=1)
+    x = torch.from_numpy(synth.synthetic_images(3, 256, 128, seed=6)).cuda()
+    assert torch.equal(m(x=x, tta_view=1), m(x=torch.flip(x, [3]).contiguous()))
+    assert torch.equal(m(x=x, tta_view=2), m(x=x.mean(dim=1, keepdim=True).repeat(1, 3, 1, 1)))
+    assert torch.equal(m(x=x, tta_view=3), m(x=x[:, 0:1].repeat(1, 3, 1, 1)))
+    proj = m(x=x, get_image=True)
+    assert proj.shape == (3, 1024)
+    full = m(x=x)
+    assert full.shape == (3, 3072)
+    assert torch.allclose(full[:, 2048:] * float(np.sqrt(1 + 1e-5)), proj, rtol=1e-5, atol=1e-5)
