@@ -18,6 +18,20 @@ __device__ __forceinline__ float quick_gelu(float h) {
     return h * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.702f * 1.44269504088896340736f * h));
 }
 
+// streaming (non-temporal) 16-byte store: the big outputs (hundreds of MB per launch) are read again only by a
+// later kernel, long after they have left the 4 MB L2 -- written with the default policy they evict the A / W
+// panels the MFMA loop is re-reading and back-pressure the store path at the end of every tile
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_nt(void *p, const uint4 &v) {
+    const u32x4_t nv = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(nv, reinterpret_cast<u32x4_t *>(p));
+}
+__device__ __forceinline__ void store_nt(float *p, const float4 &v) {
+    const f32x4_t nv = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(nv, reinterpret_cast<f32x4_t *>(p));
+}
+
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -448,8 +462,7 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
             for (int it = 0; it < 2; ++it) {
                 const int lr = it * 8 + (lane >> 3), ch = lane & 7;
                 const uint4 v = *reinterpret_cast<const uint4 *>(wreg + lr * 72 + ch * 8);
-                *reinterpret_cast<uint4 *>(out + (int64_t)(cur_m0 + wr * 128 + i * 16 + lr) * g.ldo + cur_n0 + wc * 64 +
-                                           ch * 8) = v;
+                store_nt(out + (int64_t)(cur_m0 + wr * 128 + i * 16 + lr) * g.ldo + cur_n0 + wc * 64 + ch * 8, v);
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -499,7 +512,7 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
                         x.y = x.y + (a.y + bias4.y);
                         x.z = x.z + (a.z + bias4.z);
                         x.w = x.w + (a.w + bias4.w);
-                        *reinterpret_cast<float4 *>(dst) = x;
+                        *reinterpret_cast<float4 *>(dst) = x;   // (streaming stores measured neutral here)
                     } else if (m < g.m_valid) { // GE_EUCLID
                         const float am = g.aux[m];
                         float4 o;
