@@ -507,7 +507,8 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
                     if (EPI == GE_F32) {
                         *reinterpret_cast<float4 *>(dst) = a;
                     } else if (EPI == GE_BIAS_RES) {
-                        float4 x = *reinterpret_cast<const float4 *>(dst);
+                        const f32x4_t xv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(dst));
+                        float4 x = make_float4(xv[0], xv[1], xv[2], xv[3]);
                         x.x = x.x + (a.x + bias4.x);
                         x.y = x.y + (a.y + bias4.y);
                         x.z = x.z + (a.z + bias4.z);

@@ -133,7 +133,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
     for (int i = 0; i < 4; ++i) {
         act[i] = (i * 256 + lane * 4) < W;
         v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (act[i]) v[i] = *reinterpret_cast<const float4 *>(xr + i * 256 + lane * 4);
+        if (act[i]) {
+            typedef float ln_f4 __attribute__((ext_vector_type(4)));
+            const ln_f4 t = __builtin_nontemporal_load(reinterpret_cast<const ln_f4 *>(xr + i * 256 + lane * 4));
+            v[i] = make_float4(t[0], t[1], t[2], t[3]);
+        }
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     }
 #pragma unroll
@@ -188,14 +192,25 @@ typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
 // lines.  Rows past L are clamped (always a valid address): a guarded load would put every load in its own
 // branch with a vmcnt(0) behind it; clamped copies are harmless because keys >= L are masked before softmax.
 #define ATT_FOR_EACH_ITER(X) X(0) X(1) X(2) X(3) X(4)
+// K / V are read exactly once and O is read only by a later kernel: streaming loads / stores keep them from evicting
+// the operand panels of the GEMMs that run beside this kernel on other streams
+typedef unsigned att_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 load_nt16(const _Float16 *p) {
+    const att_u4 v = __builtin_nontemporal_load(reinterpret_cast<const att_u4 *>(p));
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void store_nt16(_Float16 *p, const uint4 &v) {
+    const att_u4 nv = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(nv, reinterpret_cast<att_u4 *>(p));
+}
 #define ATT_DECL(i) uint4 k##i = make_uint4(0, 0, 0, 0), v##i = k##i;
 #define ATT_LOAD(i)                                                                                  \
     if constexpr (K_ITERS > i) {                                                                     \
         const int idx_ = tid + i * NT;                                                               \
         const int row_ = idx_ >> 3, c_ = idx_ & 7;                                                   \
         const int rc_ = row_ < L ? row_ : L - 1;                                                     \
-        k##i = *reinterpret_cast<const uint4 *>(pbase_ + (int64_t)rc_ * ld + W + c_ * 8);           \
-        v##i = *reinterpret_cast<const uint4 *>(pbase_ + (int64_t)rc_ * ld + 2 * W + c_ * 8);       \
+        k##i = load_nt16(pbase_ + (int64_t)rc_ * ld + W + c_ * 8);                                   \
+        v##i = load_nt16(pbase_ + (int64_t)rc_ * ld + 2 * W + c_ * 8);                               \
     }
 #define ATT_STORE(i)                                                                                 \
     if constexpr (K_ITERS > i) {                                                                     \
@@ -371,7 +386,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && KTP <= 10) ? 4 : 2) void atten
                 const uint4 v = *reinterpret_cast<const uint4 *>(ot + row * OS + ch * 8);
                 const int qrow = qt * 16 + row;
                 if (qrow < L && !(dbg & 4))
-                    *reinterpret_cast<uint4 *>(out + ((int64_t)b * L + qrow) * W + h * 64 + ch * 8) = v;
+                    store_nt16(out + ((int64_t)b * L + qrow) * W + h * 64 + ch * 8, v);
             }
             __builtin_amdgcn_wave_barrier();
         }
