@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--rerank", action="store_true",
                     help="also run k-reciprocal re-ranking (k1=50, k2=15, lambda=0.3) in every step "
                          "(BASELINE configs[2] stand-in; rows sharded over the ranks when N > 1)")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the encoder batches alternate on (HBM-bound phases of one batch overlap "
                          "MFMA phases of the other)")
     return ap.parse_args()
