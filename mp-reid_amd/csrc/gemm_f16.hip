@@ -12,6 +12,39 @@ __device__ __forceinline__ void dma16(const void *gsrc, unsigned char *lds_dst_w
     __builtin_amdgcn_global_load_lds((glb_ptr_t *)gsrc, (lds_ptr_t *)lds_dst_wave_base, 16, 0, 0);
 }
 
+__device__ __forceinline__ unsigned lds_addr(const void *p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+// 16-byte LDS-DMA / store with the address split as wave-uniform 64-bit base (SGPR pair) + 32-bit per-lane offset.
+// hipcc materialises one 64-bit VGPR pointer per access instead (32 of them in the residual epilogue: spills);
+// written out, the base is scalar arithmetic and the lane offset one register.  M0 (LDS destination of the DMA)
+// is saved and restored: the compiler tracks its own M0 values across the asm.
+__device__ __forceinline__ void dma16_sv(uint64_t sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %3\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %2, %1\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(sbase), "v"(voff), "s"(lds_dst)
+                 : "memory");
+}
+__device__ __forceinline__ void store16_sv(uint64_t sbase, unsigned voff, const f32x4 &v) {
+    asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+
+// s_waitcnt takes an immediate: callers pass a value that is a constant after unrolling, the switch folds away
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    switch (n) {
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
 __device__ __forceinline__ float quick_gelu(float h) {
     // model/clip/model.py:159-161  x * sigmoid(1.702 x)
     // v_exp + v_rcp (1 ulp) instead of the ~15-instruction IEEE divide: the result is rounded to fp16
@@ -466,6 +499,79 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
             }
             __builtin_amdgcn_wave_barrier();
         }
+    } else if (EPI == GE_BIAS_RES && (g.ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.out) & 15) == 0)) {
+        // x[m][n] += acc + bias, x fp32 (residual stream).  The x values are the expensive part: fetched pass by pass
+        // into VGPRs every pass pays a full HBM round trip (8 per tile, matrix pipe idle), and there are no registers
+        // to fetch them ahead.  So they are fetched ahead into LDS instead: the k-loop's ring is idle during the
+        // epilogue, each wave owns 16 KB of it as a 4-slot queue of x blocks ([16 rows][64 floats] = one pass),
+        // filled by LDS-DMA (no VGPRs) four passes ahead and read back lane-linearly.  vmcnt retires in order, so
+        // the wait for pass i's block counts the younger DMAs and stores (constants below).  The patch and queue
+        // reads are inline asm: hipcc guards LDS loads it knows about with vmcnt(0) while an LDS-DMA is in flight.
+        // (per-lane constants are derived from an opaque copy of the lane id HERE: hoisted to kernel start they
+        // would be spilled across the k-loop and reloaded -- scratch loads count on vmcnt -- in every pass)
+        int el = lane;
+        asm volatile("" : "+v"(el));
+        const int efrow = el & 15, efq = el >> 4;
+        float *outp = reinterpret_cast<float *>(g.out);
+        const int nbase = cur_n0 + wc * 64;
+        const int c4 = efrow * 4;
+        float4 bias4 = *reinterpret_cast<const float4 *>(g.bias + nbase + c4);
+        // "use" the bias now: hipcc then waits for it HERE, before any DMA goes out, not with a vmcnt(0) in pass 0
+        asm volatile("" : "+v"(bias4.x), "+v"(bias4.y), "+v"(bias4.z), "+v"(bias4.w)::"memory");
+        float *wreg = reinterpret_cast<float *>(patch + wave * 4096);
+        const unsigned x_loff = ((unsigned)efq * (unsigned)g.ldo + (unsigned)c4) * 4u;
+        auto x_base = [&](int row16) -> uint64_t {   // row16: first row of a 4-row piece inside the wave's 128 rows
+            return reinterpret_cast<uint64_t>(outp) + (uint64_t)(((int64_t)(cur_m0 + wr * 128 + row16) * g.ldo + nbase) * 4);
+        };
+        unsigned char *xq = smem + wave * 16384;
+        const unsigned xq_lds = __builtin_amdgcn_readfirstlane(lds_addr(xq));
+        const unsigned p_addr = lds_addr(wreg) + el * 16, q_addr = lds_addr(xq) + el * 16;
+        auto x_dma = [&](int pass) {   // 16 rows x 256 B: four 1 KB pieces, lane l -> row l >> 4, 16 B at column c4
+            const int slot = pass & 3;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dma16_sv(x_base(pass * 16 + q * 4), x_loff, xq_lds + slot * 4096 + q * 1024);
+        };
+#pragma unroll
+        for (int pq = 0; pq < 4; ++pq) x_dma(pq);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) wreg[(efq * 4 + r) * 64 + j * 16 + efrow] = acc[i][j][r];
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            // younger than pass i's block: 4 DMAs per queued pass behind it + 4 stores per finished pass since
+            wait_vmcnt(i < 4 ? 12 + 4 * i : 24 - 4 * (i - 4));   // 12 16 20 24 | 24 20 16 12
+            f32x4_t a[4], x[4];
+            asm volatile("ds_read_b128 %0, %8\n\t"
+                         "ds_read_b128 %1, %8 offset:1024\n\t"
+                         "ds_read_b128 %2, %8 offset:2048\n\t"
+                         "ds_read_b128 %3, %8 offset:3072\n\t"
+                         "ds_read_b128 %4, %9\n\t"
+                         "ds_read_b128 %5, %9 offset:1024\n\t"
+                         "ds_read_b128 %6, %9 offset:2048\n\t"
+                         "ds_read_b128 %7, %9 offset:3072\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(x[0]), "=&v"(x[1]), "=&v"(x[2]),
+                           "=&v"(x[3])
+                         : "v"(p_addr), "v"(q_addr + (i & 3) * 4096)
+                         : "memory");
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                f32x4_t o;
+                o[0] = x[it][0] + (a[it][0] + bias4.x);
+                o[1] = x[it][1] + (a[it][1] + bias4.y);
+                o[2] = x[it][2] + (a[it][2] + bias4.z);
+                o[3] = x[it][3] + (a[it][3] + bias4.w);
+                store16_sv(x_base(i * 16 + it * 4), x_loff, o);
+            }
+            if (i + 4 < 8) x_dma(i + 4);
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+        }
+        // the queues alias the stages the next tile's prologue is about to fill: every wave must be done reading
+        asm volatile("s_barrier" ::: "memory");
     } else {
         // fp32 outputs: patch [16][64] floats (4 KB) per pass
         float *wreg = reinterpret_cast<float *>(patch + wave * 4096);
