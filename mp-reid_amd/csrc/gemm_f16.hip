@@ -24,7 +24,7 @@ __device__ __forceinline__ void dma16_sv(uint64_t sbase, unsigned voff, unsigned
     asm volatile("s_mov_b32 %0, m0\n\t"
                  "s_mov_b32 m0, %3\n\t"
                  "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %2, %1\n\t"
+                 "global_load_lds_dwordx4 %2, %1 nt\n\t"
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "s"(sbase), "v"(voff), "s"(lds_dst)
