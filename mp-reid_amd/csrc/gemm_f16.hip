@@ -612,6 +612,14 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
                     float *dst = outp + (int64_t)m * g.ldo + nbase + c4;
                     if (EPI == GE_F32) {
                         *reinterpret_cast<float4 *>(dst) = a;
+                    } else if (EPI == GE_PATCH) {
+                        // patch embedding: row m = b*P + p goes to token 1 + p of image b, + positional embedding
+                        if (m < g.m_valid) {
+                            const int b = m / g.P, pp = m - b * g.P;
+                            const float4 pe = *reinterpret_cast<const float4 *>(g.aux + (int64_t)(1 + pp) * g.N + nbase + c4);
+                            *reinterpret_cast<float4 *>(outp + ((int64_t)b * g.L + 1 + pp) * g.ldo + nbase + c4) =
+                                make_float4(a.x + pe.x, a.y + pe.y, a.z + pe.z, a.w + pe.w);
+                        }
                     } else if (EPI == GE_BIAS_RES) {
                         const f32x4_t xv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(dst));
                         float4 x = make_float4(xv[0], xv[1], xv[2], xv[3]);
@@ -645,6 +653,11 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
                     float *dst = outp + (int64_t)m * g.ldo + n;
                     if (EPI == GE_F32) {
                         *dst = a;
+                    } else if (EPI == GE_PATCH) {
+                        if (m < g.m_valid) {
+                            const int b = m / g.P, pp = m - b * g.P;
+                            outp[((int64_t)b * g.L + 1 + pp) * g.ldo + n] = a + g.aux[(int64_t)(1 + pp) * g.N + n];
+                        }
                     } else if (EPI == GE_BIAS_RES) {
                         *dst = *dst + (a + bias1);
                     } else if (m < g.m_valid && n < g.n_valid) {
@@ -747,7 +760,7 @@ static int launch_one(const GemmArgs &a, hipStream_t stream) {
         attr_set = true;
     }
     constexpr bool HAS_BIG = (EPI == GE_F32 || EPI == GE_BIAS_F16 || EPI == GE_BIAS_RES || EPI == GE_BIAS_GELU ||
-                              EPI == GE_EUCLID);
+                              EPI == GE_EUCLID || EPI == GE_PATCH);
     const int bm = big_mode();
     const bool use_big = HAS_BIG && bm > 0 && (a.M % BBM == 0) && (a.N % BBN == 0) &&
                          (bm >= 2 || (int64_t)(a.M / BBM) * (a.N / BBN) >= 128);
