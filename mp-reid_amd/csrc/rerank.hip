@@ -25,6 +25,27 @@ int mpreid_distance_launch(const float *q, const float *g, int64_t nq, int64_t n
                            const float *gn, float *out, int64_t ldo, int epi, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
+// Native binary16 on the device.  include/mpreid_numerics.h spells numpy's float16 arithmetic out in integer code
+// (fp32 operation, then a branchy RNE conversion: ~50 instructions), which is what the oracle compiles.  On gfx950
+// v_cvt_f16_f32 / v_cvt_f32_f16 / v_add_f16 are IEEE round-to-nearest-even with subnormals (the f16 denormal
+// mode is always on), and "add in fp32, round to fp16" equals one correctly rounded fp16 add (double rounding is
+// innocuous when the wide format has >= 2p+2 = 24 significand bits).  Same bits, one instruction: the Jaccard
+// accumulation was ALU-bound on the integer form.  tests/test_gpu_rerank.py compares every output bit with the
+// oracle, so a device on which this did not hold would fail there.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint16_t h_from_f32(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+__device__ __forceinline__ float h_to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+// numpy's float16 sub / mul / div, literally: the operation in fp32, one RNE conversion to fp16
+__device__ __forceinline__ uint16_t h_sub_native(uint16_t a, uint16_t b) { return h_from_f32(h_to_f32(a) - h_to_f32(b)); }
+__device__ __forceinline__ uint16_t h_mul_native(uint16_t a, uint16_t b) { return h_from_f32(h_to_f32(a) * h_to_f32(b)); }
+__device__ __forceinline__ uint16_t h_div_native(uint16_t a, uint16_t b) {
+    return h_from_f32(__fdiv_rn(h_to_f32(a), h_to_f32(b)));
+}
+__device__ __forceinline__ uint16_t h_add_native(uint16_t a, uint16_t b) {
+    return __builtin_bit_cast(uint16_t, (_Float16)(__builtin_bit_cast(_Float16, a) + __builtin_bit_cast(_Float16, b)));
+}
+
+// ---------------------------------------------------------------------------------------------
 // workspace layout
 // ---------------------------------------------------------------------------------------------
 struct RerankLayout {
@@ -608,7 +629,7 @@ __global__ __launch_bounds__(64) void krecip_kernel(const float *__restrict__ MT
     for (int t0 = 0; t0 < nE; t0 += 64) {
         const int t = t0 + lane;
         uint16_t hv = 0;
-        if (t < nE) hv = mpreid_f32_to_f16(__fdiv_rn(wbuf[t], s));
+        if (t < nE) hv = h_from_f32(__fdiv_rn(wbuf[t], s));
         const bool nz = (hv & 0x7fffu) != 0;
         const unsigned long long m = __ballot(nz);
         if (nz) {
@@ -701,7 +722,7 @@ __global__ __launch_bounds__(64) void qe_fill_kernel(int64_t N, const int *__res
         for (int a = lane; a < cnt; a += 64) {
             const int c = ix[a];
             const int slot = wpre[c >> 5] + __popc(mask[c >> 5] & ((1u << (c & 31)) - 1u));
-            acc[slot] = acc[slot] + mpreid_f16_to_f32(vv[a]);
+            acc[slot] = acc[slot] + h_to_f32(vv[a]);
         }
         __syncthreads();
     }
@@ -712,7 +733,7 @@ __global__ __launch_bounds__(64) void qe_fill_kernel(int64_t N, const int *__res
     for (int t0 = 0; t0 < nU; t0 += 64) {
         const int t = t0 + lane;
         uint16_t hv = 0;
-        if (t < nU) hv = mpreid_f32_to_f16(__fdiv_rn(acc[t], k2f));
+        if (t < nU) hv = h_from_f32(__fdiv_rn(acc[t], k2f));
         const bool nz = (hv & 0x7fffu) != 0;
         const unsigned long long mm = __ballot(nz);
         if (nz) {
@@ -836,63 +857,73 @@ __global__ __launch_bounds__(JT) void jaccard_kernel(int64_t N, int64_t nq, cons
         // pairs of column a+1 are requested into registers before column a is applied, so the L2/HBM
         // latency of the gathers is paid once per pipeline fill instead of once per column.
         constexpr int NPF = 2; // entries per thread held in registers (columns up to 1024 entries)
-        int pr[NPF];
-        uint16_t pv[NPF];
-        auto fetch = [&](int a) {
+        constexpr int PD = 4;  // columns of gathers in flight: the (row, value) pairs of columns a+1 .. a+PD are
+                               // requested before column a is applied (one column ahead left ~1.6 us per column
+                               // exposed: a barrier plus most of an L2 / HBM round trip)
+        int pr[PD][NPF];
+        uint16_t pv[PD][NPF];
+        auto fetch = [&](int a, int (&er)[NPF], uint16_t (&ev)[NPF]) {
             const long long p0 = cp0[a];
             const int len = clen[a];
 #pragma unroll
-            for (int i = 0; i < NPF; ++i) {
-                const int e = tid + i * JT;
-                pr[i] = -1;
-                pv[i] = 0;
+            for (int k = 0; k < NPF; ++k) {
+                const int e = tid + k * JT;
+                er[k] = -1;
+                ev[k] = 0;
                 if (e < len) {
-                    pr[i] = crow[p0 + e];
-                    pv[i] = cval[p0 + e];
+                    er[k] = crow[p0 + e];
+                    ev[k] = cval[p0 + e];
                 }
             }
         };
-        if (cnt > 0) fetch(0);
-        for (int a = 0; a < cnt; ++a) {
-            int cr[NPF];
-            uint16_t cv[NPF];
 #pragma unroll
-            for (int i = 0; i < NPF; ++i) {
-                cr[i] = pr[i];
-                cv[i] = pv[i];
-            }
-            if (a + 1 < cnt) fetch(a + 1);
-            const uint16_t vic = vi[a];
+        for (int d = 0; d < PD; ++d)
+            if (d < cnt) fetch(d, pr[d], pv[d]);
+        for (int a0 = 0; a0 < cnt; a0 += PD) {
 #pragma unroll
-            for (int i = 0; i < NPF; ++i) {
-                const int r = cr[i];
-                if (r >= r0 && r < r1) { // r == -1 (no entry) fails r >= r0
-                    const uint16_t m = mpreid_h_min_nonneg(vic, cv[i]);
-                    t[r - r0] = mpreid_h_add(t[r - r0], m);
+            for (int d = 0; d < PD; ++d) {
+                const int a = a0 + d;
+                if (a >= cnt) break;
+                int cr[NPF];
+                uint16_t cv[NPF];
+#pragma unroll
+                for (int k = 0; k < NPF; ++k) {
+                    cr[k] = pr[d][k];
+                    cv[k] = pv[d][k];
                 }
-            }
-            const int len = clen[a];
-            if (len > NPF * JT) { // rare long column: the tail is gathered directly
-                const long long p0 = cp0[a];
-                for (int e = tid + NPF * JT; e < len; e += JT) {
-                    const int r = crow[p0 + e];
-                    if (r >= r0 && r < r1) {
-                        const uint16_t m = mpreid_h_min_nonneg(vic, cval[p0 + e]);
-                        t[r - r0] = mpreid_h_add(t[r - r0], m);
+                if (a + PD < cnt) fetch(a + PD, pr[d], pv[d]);
+                const uint16_t vic = vi[a];
+#pragma unroll
+                for (int k = 0; k < NPF; ++k) {
+                    const int r = cr[k];
+                    if (r >= r0 && r < r1) { // r == -1 (no entry) fails r >= r0
+                        const uint16_t m = mpreid_h_min_nonneg(vic, cv[k]);
+                        t[r - r0] = h_add_native(t[r - r0], m);
                     }
                 }
+                const int len = clen[a];
+                if (len > NPF * JT) { // rare long column: the tail is gathered directly
+                    const long long p0 = cp0[a];
+                    for (int e = tid + NPF * JT; e < len; e += JT) {
+                        const int r = crow[p0 + e];
+                        if (r >= r0 && r < r1) {
+                            const uint16_t m = mpreid_h_min_nonneg(vic, cval[p0 + e]);
+                            t[r - r0] = h_add_native(t[r - r0], m);
+                        }
+                    }
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
         const int64_t jlo = (r0 > nq) ? r0 : nq;
         for (int64_t j = jlo + tid; j < r1; j += JT) {
             const uint16_t tv = t[j - r0];
-            const uint16_t den = mpreid_h_sub(H2, tv);
-            const uint16_t qt = mpreid_h_div(tv, den);
-            const uint16_t jac = mpreid_h_sub(H1, qt);
-            const uint16_t jl = mpreid_h_mul(jac, one_minus_lam_h);
+            const uint16_t den = h_sub_native(H2, tv);
+            const uint16_t qt = h_div_native(tv, den);
+            const uint16_t jac = h_sub_native(H1, qt);
+            const uint16_t jl = h_mul_native(jac, one_minus_lam_h);
             const float o = __fdiv_rn(row[j], mx);
-            out[i * ldo + (j - nq)] = mpreid_f16_to_f32(jl) + o * lam32;
+            out[i * ldo + (j - nq)] = h_to_f32(jl) + o * lam32;
         }
         __syncthreads();
     }
