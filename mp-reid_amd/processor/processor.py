@@ -12,6 +12,39 @@ import torch
 from utils.metrics import R1_mAP_eval
 
 
+#: images encoded per model call.  The reference encodes one loader batch (TEST.IMS_PER_BATCH = 64 in every shipped
+#: YAML) at a time; the persistent GEMMs want ~65 000 token rows to fill 256 CUs without a ragged last round
+#: (22 k images/s at 64 per call, 36 k at 512), and a feature row does not depend on which images share its batch
+#: (tests/test_gpu_vit.py: bit for bit), so consecutive loader batches are encoded together and handed to the
+#: evaluator one loader batch at a time, exactly as before.
+ENCODE_GROUP = 512
+
+
+def grouped_batches(val_loader, target):
+    """consecutive loader batches whose image count reaches `target` (the last group may be smaller)"""
+    group, n = [], 0
+    for batch in val_loader:
+        group.append(batch)
+        n += len(batch[1])
+        if n >= target:
+            yield group
+            group, n = [], 0
+    if group:
+        yield group
+
+
+def merge_batches(group, device):
+    """(images, camids tensor, viewids tensor) of a group of loader batches, on `device`"""
+    imgs = [b[0] for b in group]
+    if isinstance(imgs[0], (list, tuple)):           # decoded uint8 images: stay a flat list (RawImageBatch)
+        img = type(imgs[0])(x for b in imgs for x in b)
+    else:
+        img = (imgs[0] if len(imgs) == 1 else torch.cat(imgs, dim=0)).to(device)
+    camids = torch.cat([b[3] for b in group]).to(device)
+    views = torch.cat([b[4] for b in group]).to(device)
+    return img, camids, views
+
+
 def do_inference(cfg, model, val_loader, num_query):
     device = "cuda"
     logger = logging.getLogger("transreid.test")
@@ -24,14 +57,17 @@ def do_inference(cfg, model, val_loader, num_query):
     model.to(device)
     model.eval()
     img_path_list = []
-    for n_iter, (img, pid, camid, camids, target_view, imgpath) in enumerate(val_loader):
+    for group in grouped_batches(val_loader, ENCODE_GROUP):
         with torch.no_grad():
-            img = img.to(device)
-            camids = camids.to(device) if cfg.MODEL.SIE_CAMERA else None
-            target_view = target_view.to(device) if cfg.MODEL.SIE_VIEW else None
+            img, camids, target_view = merge_batches(group, device)
+            camids = camids if cfg.MODEL.SIE_CAMERA else None
+            target_view = target_view if cfg.MODEL.SIE_VIEW else None
             feat = model(img, cam_label=camids, view_label=target_view)
-            evaluator.update((feat, pid, camid))
-            img_path_list.extend(imgpath)
+            lo = 0
+            for (_, pid, camid, _, _, imgpath) in group:      # the evaluator sees the loader's own batches
+                evaluator.update((feat[lo:lo + len(pid)], pid, camid))
+                img_path_list.extend(imgpath)
+                lo += len(pid)
 
     cmc, mAP, _, _, _, _, _ = evaluator.compute()
     logger.info("Validation Results ")

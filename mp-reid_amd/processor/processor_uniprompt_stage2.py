@@ -19,6 +19,7 @@ import time
 import torch
 
 from mpreid import ops as _ops
+from processor.processor import ENCODE_GROUP, grouped_batches, merge_batches
 from utils.metrics import R1_mAP_eval
 
 
@@ -33,14 +34,17 @@ def do_inference(cfg, model, val_loader, num_query):
     model.to(device)
     model.eval()
     img_path_list = []
-    for n_iter, (img, pid, camid, camids, target_view, imgpath) in enumerate(val_loader):
+    for group in grouped_batches(val_loader, ENCODE_GROUP):   # see processor/processor.py: same features, fuller GPU
         with torch.no_grad():
-            img = img.to(device)
-            camids = camids.to(device) if cfg.MODEL.SIE_CAMERA else None
-            target_view = target_view.to(device) if cfg.MODEL.SIE_VIEW else None
+            img, camids, target_view = merge_batches(group, device)
+            camids = camids if cfg.MODEL.SIE_CAMERA else None
+            target_view = target_view if cfg.MODEL.SIE_VIEW else None
             feat = model(x=img, cam_label=camids, view_label=target_view)
-            evaluator.update((feat, pid, camid))
-            img_path_list.extend(imgpath)
+            lo = 0
+            for (_, pid, camid, _, _, imgpath) in group:
+                evaluator.update((feat[lo:lo + len(pid)], pid, camid))
+                img_path_list.extend(imgpath)
+                lo += len(pid)
 
     cmc, mAP, distmat, pids, camids, qf, gf = evaluator.compute()
     logger.info("Validation Results ")
@@ -77,27 +81,43 @@ def do_inference_ttpt_option_a(cfg, model, val_loader, num_query):
     views = (_ops.VIEW_ORIGINAL, _ops.VIEW_FLIP, _ops.VIEW_PSEUDO_IR, _ops.VIEW_PSEUDO_RGB) if tta_enabled else \
         (_ops.VIEW_ORIGINAL,)
 
-    for n_iter, (img, pid, camid, camids, target_view, _) in enumerate(val_loader):
-        img = img.to(device)
-        n_img = len(img) if isinstance(img, (list, tuple)) else img.shape[0]
-        is_query = (processed_samples < num_query)
-        cam = camids.to(device) if cfg.MODEL.SIE_CAMERA else None
-        vw = target_view.to(device) if cfg.MODEL.SIE_VIEW else None
+    def tagged():
+        """loader batches tagged query / gallery by the reference's rule (:594: decided by the number of samples
+        processed BEFORE the batch), consecutive batches of one kind grouped up to ENCODE_GROUP images"""
+        seen, kind, group, n = 0, None, [], 0
+        for batch in val_loader:
+            k = seen < num_query
+            if group and (k != kind or n >= ENCODE_GROUP):
+                yield kind, group
+                group, n = [], 0
+            kind = k
+            group.append(batch)
+            n += len(batch[1])
+            seen += len(batch[1])
+        if group:
+            yield kind, group
+
+    for is_query, group in tagged():
+        img, cam, vw = merge_batches(group, device)
+        cam = cam if cfg.MODEL.SIE_CAMERA else None
+        vw = vw if cfg.MODEL.SIE_VIEW else None
         with torch.no_grad():
             if is_query:
                 if isinstance(img, (list, tuple)):      # decoded images: resize once, then the views
                     img = _ops.resize_bilinear_u8(img, model.img_hw)
                 feats = torch.stack([model(x=img, cam_label=cam, view_label=vw, tta_view=v) for v in views], dim=0)
-                img_feat_agg = _ops.tta_mean(feats, normalize=bool(feat_norm))
-                evaluator.update((img_feat_agg, pid, camid))
+                feat = _ops.tta_mean(feats, normalize=bool(feat_norm))
             else:
-                gallery_feat = model(x=img, cam_label=cam, view_label=vw)
+                feat = model(x=img, cam_label=cam, view_label=vw)
                 if feat_norm:
-                    gallery_feat = _ops.l2_normalize(gallery_feat)
-                evaluator.update((gallery_feat, pid, camid))
-        processed_samples += n_img
-        if processed_samples % 1000 == 0:
-            logger.info(f"Processed {processed_samples}/{getattr(val_loader, 'n', '?')} samples...")
+                    feat = _ops.l2_normalize(feat)
+            lo = 0
+            for (_, pid, camid, _, _, _) in group:
+                evaluator.update((feat[lo:lo + len(pid)], pid, camid))
+                lo += len(pid)
+                processed_samples += len(pid)
+                if processed_samples % 1000 == 0:
+                    logger.info(f"Processed {processed_samples}/{getattr(val_loader, 'n', '?')} samples...")
 
     end_time = time.time()
     logger.info(f"Feature extraction finished in {end_time - start_time:.2f} seconds.")
