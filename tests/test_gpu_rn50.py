@@ -103,3 +103,16 @@ def test_rn50_u8_and_bn_neck_vs_oracle():
     got_f32 = enc(t.contiguous()).cpu().numpy()
     assert np.array_equal(got_u8, got_f32)       # ToTensor + Normalize fused into the first conv: same bits
     _check(got_u8, want, 5e-3)
+
+
+def test_rn50_other_resolution_vs_oracle():
+    """a non-square grid that is not a power of two (96x64 input -> 6x4 = 24 attention-pool tokens, M not a
+    multiple of the 128-row GEMM tile in the deeper layers), ragged batch of 5"""
+    from mpreid import ops, synth
+    cfg = dict(layers=(1, 1, 2, 1), width=16, heads=8, out_dim=64, h_res=6, w_res=4)
+    sd = synth.rn50_state_dict(cfg, seed=21)
+    enc = ops.Rn50Encoder(cfg, sd, (96, 64))
+    imgs = synth.synthetic_images(5, 96, 64, seed=41)
+    got = enc(torch.from_numpy(imgs)).cpu().numpy()
+    want = orc.rn50_features(sd, cfg, imgs)
+    _check(got, want, 5e-3)
