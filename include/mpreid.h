@@ -272,7 +272,8 @@ int mpreid_conv_f16_nhwc(const void *act_dev, int batch, int h, int w, int cin, 
 int mpreid_gemm_f16_nt(const void *a_dev, const void *b_dev, float *c_dev, int64_t m, int64_t n, int64_t k,
                        mpreid_stream_t stream);
 /* same GEMM with a fused epilogue: 0 = fp32 out, 1 = +bias -> fp16, 2 = out(fp32) += acc + bias,
- * 3 = QuickGELU(acc + bias) -> fp16.  Used by the unit tests and tools/gemm_bench.py. */
+ * 3 = QuickGELU(acc + bias) -> fp16, 7 = relu(acc + bias) -> fp16, 8 = out(fp16) = relu(acc + bias + out), one
+ * rounding (the RN50 1x1 convolutions).  Used by the unit tests and tools/gemm_bench.py. */
 int mpreid_gemm_f16_nt_ex(const void *a_dev, const void *b_dev, void *out_dev, const float *bias_dev, int64_t m,
                           int64_t n, int64_t k, int epilogue, mpreid_stream_t stream);
 /* fp32 -> fp16 (RNE) conversion of a flat array */

@@ -33,7 +33,9 @@ enum GemmEpi {
     GE_BIAS_GELU = 3,  // out fp16 = quickgelu(acc + bias[n])           (MLP c_fc)
     GE_PATCH = 4,      // x fp32[b*L + 1 + p][n] = acc + pos[1 + p][n]  (patch embed; m = b*P + p)
     GE_EUCLID = 5,     // out fp32 = fmaf(-2, acc, an[m] + bn[n])       (bounds checked)
-    GE_COSINE = 6      // out fp32 = acos(clip(acc / (an[m]*bn[n])))    (bounds checked)
+    GE_COSINE = 6,     // out fp32 = acos(clip(acc / (an[m]*bn[n])))    (bounds checked)
+    GE_BIAS_RELU = 7,  // out fp16 = relu(acc + bias[n])                (RN50 1x1 conv + folded BN + ReLU)
+    GE_BIAS_ADD_RELU = 8 // out fp16 = relu(acc + bias[n] + identity[m][n]), one rounding (Bottleneck conv3)
 };
 
 struct GemmArgs {
@@ -47,6 +49,7 @@ struct GemmArgs {
     const float *aux2;   // bn [N] (distance)
     int m_valid, n_valid; // logical bounds for the bounds-checked epilogues
     int P, L;            // GE_PATCH: patches per image, tokens per image
+    const _Float16 *identity; // GE_BIAS_ADD_RELU: fp16 [M][ldo] residual
 };
 
 int launch_gemm_f16(const GemmArgs &a, int epi, hipStream_t stream);

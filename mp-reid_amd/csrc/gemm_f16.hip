@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
     compute(cur);
 
     // ---- epilogue.  C/D map of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg ----
-    if constexpr (EPI == GE_BIAS_F16 || EPI == GE_BIAS_GELU) {
+    if constexpr (EPI == GE_BIAS_F16 || EPI == GE_BIAS_GELU || EPI == GE_BIAS_RELU) {
         __syncthreads(); // every wave is done reading the staging buffers
         _Float16 *wreg = reinterpret_cast<_Float16 *>(smem) + wave * (64 * 72);
 #pragma unroll
@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
                 for (int r = 0; r < 4; ++r) {
                     float v = acc[i][j][r] + bias;
                     if (EPI == GE_BIAS_GELU) v = quick_gelu(v);
+                    if (EPI == GE_BIAS_RELU) v = v < 0.f ? 0.f : v;   // relu commutes with the rounding below
                     wreg[(i * 16 + fq * 4 + r) * 72 + j * 16 + frow] = (_Float16)v;
                 }
         }
@@ -160,6 +161,42 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
             const int lr = it * 8 + (lane >> 3), ch = lane & 7;
             const uint4 v = *reinterpret_cast<const uint4 *>(wreg + lr * 72 + ch * 8);
             *reinterpret_cast<uint4 *>(out + (int64_t)(m0 + wm * 64 + lr) * g.ldo + n0 + wn * 64 + ch * 8) = v;
+        }
+    } else if constexpr (EPI == GE_BIAS_ADD_RELU) {
+        // out fp16 = relu(acc + bias + identity): the sum stays fp32 through the patch and is rounded ONCE (the
+        // arithmetic of conv_f16.hip's epilogue, so either kernel may serve a layer); 8-byte pieces per lane
+        __syncthreads();
+        typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+        float *wreg = reinterpret_cast<float *>(smem) + wave * (32 * 68);
+        _Float16 *outh = reinterpret_cast<_Float16 *>(g.out);
+        const int nbase = n0 + wn * 64, c4 = (lane & 15) * 4;
+        const float4 bias4 = *reinterpret_cast<const float4 *>(g.bias + nbase + c4);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        wreg[(ii * 16 + fq * 4 + r) * 68 + j * 16 + frow] = acc[half * 2 + ii][j][r];
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int lr = it * 4 + (lane >> 4);
+                const int64_t off = (int64_t)(m0 + wm * 64 + half * 32 + lr) * g.ldo + nbase + c4;
+                const float4 a = *reinterpret_cast<const float4 *>(wreg + lr * 68 + c4);
+                const h4v idv = *reinterpret_cast<const h4v *>(g.identity + off);
+                float v[4] = {a.x + bias4.x, a.y + bias4.y, a.z + bias4.z, a.w + bias4.w};
+                h4v o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = v[e] + (float)idv[e];
+                    o[e] = (_Float16)(v[e] < 0.f ? 0.f : v[e]);
+                }
+                *reinterpret_cast<h4v *>(outh + off) = o;
+            }
+            __syncthreads();
         }
     } else if constexpr (EPI == GE_BIAS_RES || EPI == GE_EUCLID || EPI == GE_F32) {
         // fp32 outputs: transpose each wave's 64x64 accumulator block through LDS in two 32-row
@@ -471,7 +508,7 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
-    } else if constexpr (EPI == GE_BIAS_F16 || EPI == GE_BIAS_GELU) {
+    } else if constexpr (EPI == GE_BIAS_F16 || EPI == GE_BIAS_GELU || EPI == GE_BIAS_RELU) {
         // one 16-row MFMA tile row per pass: patch [16][72] halfs (2304 B) -> two 16-byte row pieces per lane
         _Float16 *wreg = reinterpret_cast<_Float16 *>(patch + wave * 4096);
         _Float16 *out = reinterpret_cast<_Float16 *>(g.out);
@@ -486,6 +523,7 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
                 for (int r = 0; r < 4; ++r) {
                     float v = acc[i][j][r] + bias[j];
                     if (EPI == GE_BIAS_GELU) v = quick_gelu(v);
+                    if (EPI == GE_BIAS_RELU) v = v < 0.f ? 0.f : v;
                     wreg[(fq * 4 + r) * 72 + j * 16 + frow] = (_Float16)v;
                 }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -495,10 +533,64 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
             for (int it = 0; it < 2; ++it) {
                 const int lr = it * 8 + (lane >> 3), ch = lane & 7;
                 const uint4 v = *reinterpret_cast<const uint4 *>(wreg + lr * 72 + ch * 8);
-                store_nt(out + (int64_t)(cur_m0 + wr * 128 + i * 16 + lr) * g.ldo + cur_n0 + wc * 64 + ch * 8, v);
+                _Float16 *dsth = out + (int64_t)(cur_m0 + wr * 128 + i * 16 + lr) * g.ldo + cur_n0 + wc * 64 + ch * 8;
+                if (EPI == GE_BIAS_RELU) *reinterpret_cast<uint4 *>(dsth) = v;   // conv activations: read again at once
+                else store_nt(dsth, v);
             }
             __builtin_amdgcn_wave_barrier();
         }
+    } else if constexpr (EPI == GE_BIAS_ADD_RELU) {
+        // out fp16 = relu(acc + bias + identity) with ONE rounding: the identity must meet the fp32 accumulators in
+        // THEIR layout (one column, four rows per lane), but it should be read from memory as whole rows.  So each
+        // pass's 16 x 64 identity block is loaded coalesced (16 B per lane, one pass ahead), laid into a second
+        // wave-private LDS patch (in the idle k-loop ring) and picked up per element from there; the result leaves
+        // through the usual fp16 patch as whole 128-byte rows.
+        _Float16 *wreg = reinterpret_cast<_Float16 *>(patch + wave * 4096);          // result patch [16][72]
+        _Float16 *pid = reinterpret_cast<_Float16 *>(smem + wave * 4096);            // identity patch [16][72]
+        _Float16 *outh = reinterpret_cast<_Float16 *>(g.out);
+        const int nb0 = cur_n0 + wc * 64;
+        float bias[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bias[j] = g.bias[nb0 + j * 16 + frow];
+        const int lr0 = lane >> 3, ch = lane & 7;
+        auto id_load = [&](int i, int it) -> uint4 {
+            return *reinterpret_cast<const uint4 *>(g.identity + (int64_t)(cur_m0 + wr * 128 + i * 16 + it * 8 + lr0) * g.ldo +
+                                                    nb0 + ch * 8);
+        };
+        uint4 idn0 = id_load(0, 0), idn1 = id_load(0, 1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            *reinterpret_cast<uint4 *>(pid + lr0 * 72 + ch * 8) = idn0;
+            *reinterpret_cast<uint4 *>(pid + (8 + lr0) * 72 + ch * 8) = idn1;
+            if (i + 1 < 8) {
+                idn0 = id_load(i + 1, 0);
+                idn1 = id_load(i + 1, 1);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int e = (fq * 4 + r) * 72 + j * 16 + frow;
+                    float v = acc[i][j][r] + bias[j];
+                    v = v + (float)pid[e];
+                    wreg[e] = (_Float16)(v < 0.f ? 0.f : v);
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int lr = it * 8 + lr0;
+                const uint4 v = *reinterpret_cast<const uint4 *>(wreg + lr * 72 + ch * 8);
+                *reinterpret_cast<uint4 *>(outh + (int64_t)(cur_m0 + wr * 128 + i * 16 + lr) * g.ldo + nb0 + ch * 8) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // the identity patches alias stage 0 of the ring, which the next tile's prologue fills: all waves done first
+        asm volatile("s_barrier" ::: "memory");
     } else if (EPI == GE_BIAS_RES && (g.ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.out) & 15) == 0)) {
         // x[m][n] += acc + bias, x fp32 (residual stream).  The x values are the expensive part: fetched pass by pass
         // into VGPRs every pass pays a full HBM round trip (8 per tile, matrix pipe idle), and there are no registers
@@ -760,7 +852,7 @@ static int launch_one(const GemmArgs &a, hipStream_t stream) {
         attr_set = true;
     }
     constexpr bool HAS_BIG = (EPI == GE_F32 || EPI == GE_BIAS_F16 || EPI == GE_BIAS_RES || EPI == GE_BIAS_GELU ||
-                              EPI == GE_EUCLID || EPI == GE_PATCH);
+                              EPI == GE_EUCLID || EPI == GE_PATCH || EPI == GE_BIAS_RELU || EPI == GE_BIAS_ADD_RELU);
     const int bm = big_mode();
     const bool use_big = HAS_BIG && bm > 0 && (a.M % BBM == 0) && (a.N % BBN == 0) &&
                          (bm >= 2 || (int64_t)(a.M / BBM) * (a.N / BBN) >= 128);
@@ -843,6 +935,8 @@ int launch_gemm_f16(const GemmArgs &a, int epi, hipStream_t stream) {
     case GE_PATCH: return launch_one<GE_PATCH>(a, stream);
     case GE_EUCLID: return launch_one<GE_EUCLID>(a, stream);
     case GE_COSINE: return launch_one<GE_COSINE>(a, stream);
+    case GE_BIAS_RELU: return launch_one<GE_BIAS_RELU>(a, stream);
+    case GE_BIAS_ADD_RELU: return launch_one<GE_BIAS_ADD_RELU>(a, stream);
     }
     mpreid_set_error("gemm_f16: unknown epilogue %d", epi);
     return MPREID_ERR_ARG;
@@ -903,8 +997,10 @@ extern "C" int mpreid_gemm_f16_nt(const void *a, const void *b, float *c, int64_
 // 3 +bias,QuickGELU->f16): unit tests and the GEMM micro-benchmark (tools/gemm_bench.py).
 extern "C" int mpreid_gemm_f16_nt_ex(const void *a, const void *b, void *out, const float *bias, int64_t m, int64_t n,
                                      int64_t k, int epilogue, mpreid_stream_t stream) {
-    ARG_CHECK(a && b && out && epilogue >= 0 && epilogue <= 3 && (epilogue == 0 || bias));
+    ARG_CHECK(a && b && out && ((epilogue >= 0 && epilogue <= 3) || epilogue == GE_BIAS_RELU || epilogue == GE_BIAS_ADD_RELU) &&
+              (epilogue == 0 || bias));
     GemmArgs g{};
+    g.identity = (const _Float16 *)out;   // epilogue 8: the residual is what out holds on entry (updated in place)
     g.A = (const _Float16 *)a;
     g.W = (const _Float16 *)b;
     g.M = (int)m;

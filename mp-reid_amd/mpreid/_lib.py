@@ -84,7 +84,7 @@ class ProfileEntry(C.Structure):
 
 
 GEMM_EPILOGUE_NAMES = {0: "f32", 1: "qkv_bias_f16", 2: "bias_residual", 3: "fc_bias_quickgelu", 4: "patch_embed",
-                       5: "euclid", 6: "cosine"}
+                       5: "euclid", 6: "cosine", 7: "conv1x1_bias_relu", 8: "conv1x1_bias_residual_relu"}
 
 _lib = None
 

@@ -110,7 +110,8 @@ def test_vit_uint8_input_matches_float_path():
 
 
 @pytest.mark.parametrize("name,n,k,epi", [("qkv", 2304, 768, 1), ("out", 768, 768, 2), ("fc1", 3072, 768, 3),
-                                            ("fc2", 768, 3072, 2), ("f32", 768, 768, 0)])
+                                            ("fc2", 768, 3072, 2), ("f32", 768, 768, 0),
+                                            ("conv1x1_relu", 512, 2048, 7), ("conv1x1_add_relu", 2048, 512, 8)])
 def test_gemm_kernels_agree_bitwise(name, n, k, epi):
     """The dispatcher picks the 128x128 or the persistent 256x256 kernel by tile count, so the same image goes
     through either depending on the batch it arrives in: both must give the same bits for every epilogue."""
@@ -123,7 +124,7 @@ def test_gemm_kernels_agree_bitwise(name, n, k, epi):
     a = (torch.rand((mb, k), generator=gen) * 2 - 1).half().to(dev)
     w = ((torch.rand((n, k), generator=gen) * 2 - 1) * 0.05).half().to(dev)
     bias = torch.randn(n, generator=gen).to(dev)
-    dt = torch.float16 if epi in (1, 3) else torch.float32
+    dt = torch.float16 if epi in (1, 3, 7, 8) else torch.float32
     init = torch.randn((mb, n), generator=gen).to(dt).to(dev)
     ob, osm = init.clone(), init[:ms].clone()
     for x, o in ((a, ob), (a[:ms].contiguous(), osm)):
@@ -137,4 +138,8 @@ def test_gemm_kernels_agree_bitwise(name, n, k, epi):
         ref = ref * torch.sigmoid(1.702 * ref) if epi == 3 else ref
     elif epi == 2:
         ref = init[:ms].float() + (ref + bias)
+    elif epi == 7:
+        ref = torch.relu(ref + bias)
+    elif epi == 8:
+        ref = torch.relu(init[:ms].float() + (ref + bias))
     assert torch.allclose(osm.float(), ref, rtol=2e-3, atol=2e-3)
