@@ -11,7 +11,8 @@
 // BatchNorm is folded into w and bias on the host once (mpreid/ops.py); padding pixels read a 128-byte page of
 // zeros; rows past M and channels past N are masked in the epilogue.
 //
-//   tile      128 (pixels) x 128 (channels) per 256-thread workgroup, 2x2 waves, 4x4 MFMA 16x16x32 f16 per wave
+//   tile      128 (pixels) x 128 (channels) per 256-thread workgroup, 2x2 waves, 4x4 MFMA 16x16x32 f16 per wave;
+//             128 x 64 (4x1 waves) for layers with <= 64 output channels
 //   K step    64 halfs = one tap x 64 channels; A and W tiles double-buffered in LDS (64 KB -> 2 workgroups / CU)
 //   staging   global_load_lds_dwordx4, 8 rows x 128 B per wave instruction; bank swizzle (chunk ^= row & 7) on the
 //             SOURCE address and on the ds_read_b128 address (cdna_hip_programming.md §5.4 rule 21)
@@ -34,20 +35,26 @@ __device__ __forceinline__ void dma16(const _Float16 *gsrc, unsigned char *lds_d
     __builtin_amdgcn_global_load_lds((glb_ptr_t *)gsrc, (lds_ptr_t *)lds_dst_wave_base, 16, 0, 0);
 }
 
-constexpr int CBM = 128, CBN = 128, CBK = 64;
-constexpr int C_TILE_BYTES = CBM * CBK * 2;      // 16 KB
-constexpr int C_STAGE_BYTES = 2 * C_TILE_BYTES;  // A + W
-constexpr int C_LDS_BYTES = 2 * C_STAGE_BYTES;   // 64 KB
+constexpr int CBM = 128, CBK = 64;
+constexpr int C_TILE_BYTES = CBM * CBK * 2;      // 16 KB: the A (pixel) tile of a stage
+constexpr int conv_stage_bytes(int BN) { return C_TILE_BYTES + BN * CBK * 2; }   // A + W
+constexpr int conv_lds_bytes(int BN) { return 2 * conv_stage_bytes(BN); }        // 64 KB (BN 128) / 48 KB (BN 64)
 
-template <int TAPS, bool RELU>
+// BN = output channels per tile: 128 (2 x 2 waves of 64 x 64) or 64 (4 x 1 waves of 32 x 64) for the layers with
+// <= 64 output channels (stem, layer1): a 128-wide tile would spend half of its MFMAs on zero weight rows
+template <int TAPS, bool RELU, int BN>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs g, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int C_STAGE_BYTES = conv_stage_bytes(BN);
+    constexpr int WM = (BN == 128) ? 64 : 32;   // pixel rows per wave
+    constexpr int MI = WM / 16;                 // 16-row MFMA tiles per wave
+    constexpr int BROWS = BN / 4;               // weight rows staged per wave
     int tm, tn;
     tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, 8, tm, tn);
-    const int m0 = tm * CBM, n0 = tn * CBN;
+    const int m0 = tm * CBM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = (BN == 128) ? (wave >> 1) : wave, wn = (BN == 128) ? (wave & 1) : 0;
     const int C = g.C, K = TAPS * C;
     const int cpt = C / CBK; // K-steps per tap
 
@@ -76,10 +83,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs g, int tiles
         tapmask[t] = mask;
     }
     const _Float16 *zero = g.zero_page + gchunk * 8;
-    const _Float16 *b_src = g.wgt + (int64_t)(n0 + wave * 32 + srow) * K + gchunk * 8;
+    const _Float16 *b_src = g.wgt + (int64_t)(n0 + wave * BROWS + srow) * K + gchunk * 8;
     auto stage = [&](int s, int kt) {
         unsigned char *abase = smem + s * C_STAGE_BYTES + wave * 4096;
-        unsigned char *bbase = abase + C_TILE_BYTES;
+        unsigned char *bbase = smem + s * C_STAGE_BYTES + C_TILE_BYTES + wave * (BROWS * 128);
         const int tap = (TAPS == 1) ? 0 : kt / cpt;
         const int c0 = (kt - tap * cpt) * CBK;
         const int64_t shift = (TAPS == 1) ? (int64_t)c0 : (int64_t)((tap / 3 - 1) * g.W + (tap % 3 - 1)) * C + c0;
@@ -87,21 +94,21 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs g, int tiles
         for (int t = 0; t < 4; ++t) {
             const _Float16 *src = ((tapmask[t] >> tap) & 1u) ? a_row[t] + shift : zero;
             dma16(src, abase + t * 1024);
-            dma16(b_src + (int64_t)t * 8 * K + kt * CBK, bbase + t * 1024);
+            if (t < BROWS / 8) dma16(b_src + (int64_t)t * 8 * K + kt * CBK, bbase + t * 1024);
         }
     };
 
     // ---- fragment addresses ----
     const int frow = lane & 15, fq = lane >> 4;
-    const int a_row_off = (wm * 64 + frow) * 128;
+    const int a_row_off = (wm * WM + frow) * 128;
     const int b_row_off = (wn * 64 + frow) * 128;
     int ksw[2];
     ksw[0] = ((0 + fq) ^ (lane & 7)) << 4;
     ksw[1] = ((4 + fq) ^ (lane & 7)) << 4;
 
-    f32x4 acc[4][4];
+    f32x4 acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -110,13 +117,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs g, int tiles
         const unsigned char *bt = at + C_TILE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            f16x8 af[4], bf[4];
+            f16x8 af[MI], bf[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const f16x8 *>(at + a_row_off + i * 2048 + ksw[ks]);
+            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const f16x8 *>(at + a_row_off + i * 2048 + ksw[ks]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const f16x8 *>(bt + b_row_off + j * 2048 + ksw[ks]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs g, int tiles
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias[e] = g.bias[n + e]; // bias is padded to Npad
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < WM / 32; ++half) {
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs g, int tiles
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int lr = it * 8 + (lane >> 3);
-            const int m = m0 + wm * 64 + half * 32 + lr;
+            const int m = m0 + wm * WM + half * 32 + lr;
             const float4 v0 = *reinterpret_cast<const float4 *>(wreg + lr * 68 + ch * 8);
             const float4 v1 = *reinterpret_cast<const float4 *>(wreg + lr * 68 + ch * 8 + 4);
             float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
@@ -182,34 +189,33 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs g, int tiles
 
 } // namespace
 
+template <int TAPS, bool RELU, int BN>
+static int launch_conv_variant(const ConvArgs &a, hipStream_t stream) {
+    const int tiles_m = (a.M + CBM - 1) / CBM, tiles_n = (a.N + BN - 1) / BN;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm_kernel<TAPS, RELU, BN>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_bytes(BN)));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_gemm_kernel<TAPS, RELU, BN>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), conv_lds_bytes(BN),
+                       stream, a, tiles_m, tiles_n);
+    LAUNCH_CHECK();
+    return 0;
+}
+
 int launch_conv_f16(const ConvArgs &a, hipStream_t stream) {
     ARG_CHECK(a.act && a.wgt && a.bias && a.out && a.zero_page);
     ARG_CHECK((a.taps == 1 || a.taps == 9) && a.C > 0 && a.C % CBK == 0 && a.M > 0 && a.N > 0);
-    ARG_CHECK(a.Npad % CBN == 0 && a.Npad >= a.N && a.N % 8 == 0 && a.ldo % 8 == 0 && a.ldo >= a.N);
+    ARG_CHECK(a.Npad % 128 == 0 && a.Npad >= a.N && a.N % 8 == 0 && a.ldo % 8 == 0 && a.ldo >= a.N);
     ARG_CHECK(a.taps == 1 || (a.H > 0 && a.W > 0 && a.M % (a.H * a.W) == 0));
-    const int tiles_m = (a.M + CBM - 1) / CBM, tiles_n = a.Npad / CBN;
-    const dim3 grid((unsigned)(tiles_m * tiles_n)), block(256);
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm_kernel<1, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, C_LDS_BYTES));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm_kernel<1, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, C_LDS_BYTES));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm_kernel<9, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, C_LDS_BYTES));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm_kernel<9, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, C_LDS_BYTES));
-        attr_set = true;
-    }
+    const bool narrow = a.N <= 64;   // 64-channel tiles: no MFMAs on the zero rows that pad the weights to 128
     if (a.taps == 1) {
-        if (a.relu) hipLaunchKernelGGL((conv_gemm_kernel<1, true>), grid, block, C_LDS_BYTES, stream, a, tiles_m, tiles_n);
-        else hipLaunchKernelGGL((conv_gemm_kernel<1, false>), grid, block, C_LDS_BYTES, stream, a, tiles_m, tiles_n);
-    } else {
-        if (a.relu) hipLaunchKernelGGL((conv_gemm_kernel<9, true>), grid, block, C_LDS_BYTES, stream, a, tiles_m, tiles_n);
-        else hipLaunchKernelGGL((conv_gemm_kernel<9, false>), grid, block, C_LDS_BYTES, stream, a, tiles_m, tiles_n);
+        if (a.relu) return narrow ? launch_conv_variant<1, true, 64>(a, stream) : launch_conv_variant<1, true, 128>(a, stream);
+        return narrow ? launch_conv_variant<1, false, 64>(a, stream) : launch_conv_variant<1, false, 128>(a, stream);
     }
-    LAUNCH_CHECK();
-    return 0;
+    if (a.relu) return narrow ? launch_conv_variant<9, true, 64>(a, stream) : launch_conv_variant<9, true, 128>(a, stream);
+    return narrow ? launch_conv_variant<9, false, 64>(a, stream) : launch_conv_variant<9, false, 128>(a, stream);
 }
 
 // unit-test / micro-benchmark entry: one convolution layer on NHWC fp16 (include/mpreid.h)
