@@ -22,54 +22,71 @@ namespace {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 // ---- stem conv1 + bn1 + relu: [B][3][H][W] fp32 (or [B][H][W][3] uint8) -> [B][H/2][W/2][64] fp16 -------------
-// one thread per (output pixel, 8-channel chunk of the 64 storage channels); chunks >= cout/8 write zeros
+// one thread per output pixel: 27 inputs (coalesced along the image row), all cout <= 32 channels from weights in
+// LDS (broadcast float4 reads), 128 contiguous bytes out (channels cout..63 are the zero padding of the storage)
 template <bool U8>
 __global__ __launch_bounds__(256) void rn50_stem1_kernel(const float *__restrict__ img, const unsigned char *__restrict__ img8,
                                                          float m0, float m1, float m2, float s0, float s1, float s2,
                                                          const float *__restrict__ w, const float *__restrict__ bias,
                                                          int cout, int B, int H, int W, _Float16 *__restrict__ out) {
-    __shared__ float sw[32 * 27 + 32];
-    for (int i = threadIdx.x; i < cout * 27; i += 256) sw[i] = w[i];
-    for (int i = threadIdx.x; i < cout; i += 256) sw[32 * 27 + i] = bias[i];
+    __shared__ __attribute__((aligned(16))) float sw[27 * 32 + 32]; // [k = c*9 + kh*3 + kw][n], then bias[n]
+    for (int i = threadIdx.x; i < 27 * 32; i += 256) {
+        const int k = i >> 5, n = i & 31;
+        sw[i] = n < cout ? w[n * 27 + k] : 0.f;
+    }
+    for (int i = threadIdx.x; i < 32; i += 256) sw[27 * 32 + i] = i < cout ? bias[i] : 0.f;
     __syncthreads();
     const int OH = H / 2, OW = W / 2;
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= (int64_t)B * OH * OW * 8) return;
-    const int chunk = (int)(gid & 7);
-    const int64_t pix = gid >> 3;
+    const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= (int64_t)B * OH * OW) return;
     const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), b = (int)(pix / ((int64_t)OW * OH));
-    h8 o = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (chunk * 8 < cout) {
-        float x[27]; // [c][kh][kw], zero outside the image (padding = 1)
+    float x[27]; // [c][kh][kw], zero outside the image (padding = 1)
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
+    for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
+        for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int iy = oy * 2 + kh - 1, ix = ox * 2 + kw - 1;
-                    float v = 0.f;
-                    if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-                        if (U8) {
-                            const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
-                            v = __fdiv_rn(__fdiv_rn((float)img8[(((int64_t)b * H + iy) * W + ix) * 3 + c], 255.0f) - mean, sd);
-                        } else {
-                            v = img[(((int64_t)b * 3 + c) * H + iy) * W + ix];
-                        }
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iy = oy * 2 + kh - 1, ix = ox * 2 + kw - 1;
+                float v = 0.f;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                    if (U8) {
+                        const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2), sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+                        v = __fdiv_rn(__fdiv_rn((float)img8[(((int64_t)b * H + iy) * W + ix) * 3 + c], 255.0f) - mean, sd);
+                    } else {
+                        v = img[(((int64_t)b * 3 + c) * H + iy) * W + ix];
                     }
-                    x[c * 9 + kh * 3 + kw] = v;
                 }
+                x[c * 9 + kh * 3 + kw] = v;
+            }
+    _Float16 *o = out + pix * 64;
+#pragma unroll
+    for (int n8 = 0; n8 < 4; ++n8) {       // 8 output channels at a time: k-ascending fmaf chains from 0, + bias
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 27; ++k) {
+            const float4 w0 = *reinterpret_cast<const float4 *>(sw + k * 32 + n8 * 8);
+            const float4 w1 = *reinterpret_cast<const float4 *>(sw + k * 32 + n8 * 8 + 4);
+            acc[0] = fmaf(x[k], w0.x, acc[0]);
+            acc[1] = fmaf(x[k], w0.y, acc[1]);
+            acc[2] = fmaf(x[k], w0.z, acc[2]);
+            acc[3] = fmaf(x[k], w0.w, acc[3]);
+            acc[4] = fmaf(x[k], w1.x, acc[4]);
+            acc[5] = fmaf(x[k], w1.y, acc[5]);
+            acc[6] = fmaf(x[k], w1.z, acc[6]);
+            acc[7] = fmaf(x[k], w1.w, acc[7]);
+        }
+        h8 hv;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const int n = chunk * 8 + e;
-            float acc = 0.f;
-#pragma unroll
-            for (int k = 0; k < 27; ++k) acc = fmaf(x[k], sw[n * 27 + k], acc);
-            acc = acc + sw[32 * 27 + n];
-            o[e] = (_Float16)(acc < 0.f ? 0.f : acc);
+            const float v = acc[e] + sw[27 * 32 + n8 * 8 + e];
+            hv[e] = (_Float16)(v < 0.f ? 0.f : v);
         }
+        *reinterpret_cast<h8 *>(o + n8 * 8) = hv;
     }
-    *reinterpret_cast<h8 *>(out + pix * 64 + chunk * 8) = o;
+    const h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int n8 = 4; n8 < 8; ++n8) *reinterpret_cast<h8 *>(o + n8 * 8) = z;
 }
 
 // ---- AvgPool2d(2) on NHWC fp16: ((x00 + x01) + x10 + x11) / 4 in fp32 -----------------------------------------
@@ -302,7 +319,7 @@ extern "C" int mpreid_rn50_forward(const mpreid_rn50_cfg *cfg, const mpreid_rn50
     // ---- stem (model/clip/model.py:128-134): conv1/2/3 + bn + relu, AvgPool2d(2) ----
     int H = cfg->img_h / 2, W = cfg->img_w / 2;
     {
-        const int64_t threads = (int64_t)B * H * W * 8;
+        const int64_t threads = (int64_t)B * H * W;   // one per output pixel
         const dim3 grid((unsigned)((threads + 255) / 256));
         if (img8)
             hipLaunchKernelGGL(rn50_stem1_kernel<true>, grid, dim3(256), 0, stream, nullptr, img8, mean3[0], mean3[1],
