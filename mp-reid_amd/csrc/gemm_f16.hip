@@ -728,7 +728,7 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
                         o.z = fmaf(-2.0f, a.z, am + bn4.z);
                         o.w = fmaf(-2.0f, a.w, am + bn4.w);
                         if (nbase + c4 + 3 < g.n_valid) {
-                            *reinterpret_cast<float4 *>(dst) = o;
+                            store_nt(dst, o);   // N x N distances: written once, far larger than any cache
                         } else {
                             if (nbase + c4 + 0 < g.n_valid) dst[0] = o.x;
                             if (nbase + c4 + 1 < g.n_valid) dst[1] = o.y;
