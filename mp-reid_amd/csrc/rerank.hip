@@ -224,10 +224,13 @@ __device__ __forceinline__ int block_excl_scan_256(int v, int tid, int *s_wave, 
     return base + ex;
 }
 
+constexpr int TOPK_CAND = 1024;
 __global__ __launch_bounds__(256) void rowmax_topk_kernel(const float *__restrict__ MT, int64_t ld, int64_t N, int KR,
                                                           float *__restrict__ rowmax, int *__restrict__ rank) {
     __shared__ unsigned hist[2048];
     __shared__ unsigned long long sel[256];
+    __shared__ unsigned long long cand[TOPK_CAND];   // (key, index) of the entries that share the first 22 key bits with
+    __shared__ unsigned s_ncand, s_nsel;             // the KR-th smallest, gathered during the last radix pass
     __shared__ float s_red[4];
     __shared__ int s_wave[4];
     __shared__ unsigned s_bin, s_below, s_cnt;
@@ -246,7 +249,14 @@ __global__ __launch_bounds__(256) void rowmax_topk_kernel(const float *__restric
     mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
     if (tid == 0) rowmax[i] = mx;
 
-    // radix select of the KR-th smallest key, 11 + 11 + 10 bits
+    if (tid == 0) {
+        s_ncand = 0;
+        s_nsel = 0;
+    }
+    for (int b = tid; b < 256; b += 256) sel[b] = ~0ull;
+    // radix select of the KR-th smallest key, 11 + 11 + 10 bits.  The last pass also gathers what the collection
+    // needs -- entries below the 22-bit prefix class go straight to the selection, the class itself (normally a few
+    // dozen entries) into cand[] -- so that the row is read four times instead of five
     unsigned prefix = 0;
     int kk = KR; // 1-based rank still to find inside the current prefix class
     int bits_done = 0;
@@ -261,6 +271,16 @@ __global__ __launch_bounds__(256) void rowmax_topk_kernel(const float *__restric
         for (int j = tid; j < n; j += 256) {
             const unsigned key = fkey(__fdiv_rn(row[j], mx));
             if (bits_done == 0 || (key >> (32 - bits_done)) == prefix) atomicAdd(&hist[(key >> shift) & mask], 1u);
+            if (pass == 2) {
+                const unsigned top = key >> 10;
+                if (top < prefix) {
+                    const unsigned p = atomicAdd(&s_nsel, 1u);
+                    if (p < 256u) sel[p] = ((unsigned long long)key << 32) | (unsigned)j;
+                } else if (top == prefix) {
+                    const unsigned p = atomicAdd(&s_ncand, 1u);
+                    if (p < (unsigned)TOPK_CAND) cand[p] = ((unsigned long long)key << 32) | (unsigned)j;
+                }
+            }
         }
         __syncthreads();
         // each thread owns 8 consecutive bins
@@ -295,6 +315,20 @@ __global__ __launch_bounds__(256) void rowmax_topk_kernel(const float *__restric
     const unsigned T = prefix; // exact key of the KR-th smallest; kk of the cnt_eq equal keys are needed
 
     // collect (key, index) of the KR selected entries
+    const bool from_lds = ((int)cnt_eq == kk) && s_ncand <= (unsigned)TOPK_CAND;
+    __syncthreads();
+    if (from_lds) {
+        // no tie straddles the cut and the prefix class fitted cand[]: everything below the class is in sel[]
+        // already, the class contributes its keys <= T; order fixed later by the sort
+        const unsigned nc = s_ncand;
+        for (unsigned c = tid; c < nc; c += 256) {
+            const unsigned long long e = cand[c];
+            if ((unsigned)(e >> 32) <= T) {
+                const unsigned p = atomicAdd(&s_nsel, 1u);
+                if (p < 256u) sel[p] = e;
+            }
+        }
+    } else {
     if (tid == 0) s_cnt = 0;
     for (int b = tid; b < 256; b += 256) sel[b] = ~0ull;
     __syncthreads();
@@ -327,6 +361,7 @@ __global__ __launch_bounds__(256) void rowmax_topk_kernel(const float *__restric
             run_acc += acc_tot;
             run_eq += eq_tot;
         }
+    }
     }
     __syncthreads();
     // bitonic sort of 256 64-bit keys (padding = ~0) ascending => (value, index) order
