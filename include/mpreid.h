@@ -243,7 +243,8 @@ typedef struct { /* device pointers unless noted */
     mpreid_rn50_conv stem2, stem3;          /* cin = cout = 64 storage channels (32 real ones in stem2) */
     const mpreid_rn50_block *blocks;        /* HOST array of n_blocks entries */
     const float *pos_emb;                   /* attnpool.positional_embedding fp32 [S+1][E] */
-    const void *kv_w; const float *kv_b;    /* fp16 [2E][E] = [k_proj; v_proj], fp32 [2E] */
+    const void *kt_w;                       /* fp16 [E][E] = k_proj.weight TRANSPOSED (k_proj.bias cancels in the softmax) */
+    const void *v_w; const float *v_b;      /* fp16 [E][E] = v_proj.weight, fp32 [E] */
     const void *q_w; const float *q_b;      /* fp16 [E][E], fp32 [E] */
     const void *c_w; const float *c_b;      /* fp16 [out_pad128][E], fp32 [out_pad128] */
     const float *bn_scale, *bn_shift;       /* eval BN necks folded, fp32 [E + out_dim], or NULL */

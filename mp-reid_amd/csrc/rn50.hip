@@ -139,49 +139,109 @@ __global__ __launch_bounds__(256) void rn50_tokens_kernel(const _Float16 *__rest
     }
 }
 
-// ---- one-query attention: per (image, head) one wave.  q [B][E], kv [B*(S+1)][2E] (k | v), head dim 64.
-//   scores over the keys on the lanes, softmax in fp32, then the lanes become the 64 output dims.
-__global__ __launch_bounds__(64) void rn50_attend_kernel(const _Float16 *__restrict__ q, const _Float16 *__restrict__ kv, int T,
-                                                         int E, _Float16 *__restrict__ o) {
-    __shared__ float sp[256];
-    const int b = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
-    const _Float16 *qh = q + (int64_t)b * E + h * 64;
-    float qv[64];
-#pragma unroll
-    for (int d8 = 0; d8 < 8; ++d8) {
-        const h8 v = *reinterpret_cast<const h8 *>(qh + d8 * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) qv[d8 * 8 + e] = (float)v[e];
+// ---- attention pool, one query (model/clip/model.py:56-90; only the output at the mean token is used) ----------
+// The reference projects K and V for all T = S + 1 tokens (2 x T x E x E MACs per image: 2.16 GFLOP at E = 2048, a
+// fifth of the tower) to use them against ONE query.  With q = Wq tok_0 + bq per head h (64 dims):
+//     score_t = q_h . (Wk_h tok_t + bk_h) / 8 = (Wk_h^T q_h) . tok_t / 8 + const      (the constant cancels in softmax)
+//     out_h   = sum_t p_t (Wv_h tok_t + bv_h) = Wv_h (sum_t p_t tok_t) + bv_h
+// so K and V are never formed: u_h = Wk_h^T q_h and z_h = sum_t p_t tok_t are E-vectors per (image, head).
+//   rn50_pool_expand_kernel : A[b*H + h][:] = q[b] restricted to head h's 64 dims (zeros elsewhere), so that ONE plain
+//                             GEMM against Wk^T yields all u_h (32x redundant MACs, still 70 us instead of 540)
+//   rn50_pool_core_kernel   : per image: scores of the T tokens against the H vectors u_h (in LDS), softmax, z_h
+//   second GEMM             : z_h against Wv (+ bv); rn50_pool_gather_kernel keeps head h's own 64 outputs
+__global__ __launch_bounds__(256) void rn50_pool_expand_kernel(const _Float16 *__restrict__ q, int H, int E,
+                                                               _Float16 *__restrict__ a_exp) {
+    const int64_t row = blockIdx.x;   // b * H + h
+    const int b = (int)(row / H), h = (int)(row % H);
+    const int hd = E / H;
+    for (int c8 = threadIdx.x; c8 < E / 8; c8 += 256) {
+        h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if ((c8 * 8) / hd == h) v = *reinterpret_cast<const h8 *>(q + (int64_t)b * E + c8 * 8);
+        *reinterpret_cast<h8 *>(a_exp + row * E + c8 * 8) = v;
     }
-    float mx = -3.0e38f;
-    for (int t = lane; t < T; t += 64) {
-        const _Float16 *kr = kv + ((int64_t)b * T + t) * (2 * E) + h * 64;
-        float s = 0.f;
-#pragma unroll
-        for (int d8 = 0; d8 < 8; ++d8) {
-            const h8 v = *reinterpret_cast<const h8 *>(kr + d8 * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s = fmaf(qv[d8 * 8 + e], (float)v[e], s);
-        }
-        s *= 0.125f; // head_dim ** -0.5
-        sp[t] = s;
-        mx = fmaxf(mx, s);
+}
+
+__global__ __launch_bounds__(256) void rn50_pool_core_kernel(const _Float16 *__restrict__ U, const _Float16 *__restrict__ tok,
+                                                             int T, int E, int H, _Float16 *__restrict__ Z) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int ES = E + 8;                                          // padded row: 16-byte reads of H rows spread over the banks
+    _Float16 *Us = reinterpret_cast<_Float16 *>(lds);              // [H][ES]
+    float *sc = reinterpret_cast<float *>(lds + (size_t)H * ES * 2); // [H][T]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const _Float16 *Ub = U + (int64_t)b * H * E;
+    const _Float16 *tb = tok + (int64_t)b * T * E;
+    for (int i = tid; i < H * (E / 8); i += 256) {
+        const int h = i / (E / 8), c8 = i % (E / 8);
+        *reinterpret_cast<h8 *>(Us + h * ES + c8 * 8) = *reinterpret_cast<const h8 *>(Ub + (int64_t)h * E + c8 * 8);
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-    float sum = 0.f;
-    for (int t = lane; t < T; t += 64) {
-        const float p = __expf(sp[t] - mx);
-        sp[t] = p;
-        sum += p;
-    }
-    sum = wave_bfly_add(sum);
     __syncthreads();
-    const float inv = __fdiv_rn(1.0f, sum);
-    float acc = 0.f;
-    const _Float16 *vr = kv + (int64_t)b * T * (2 * E) + E + h * 64 + lane;
-    for (int t = 0; t < T; ++t) acc = fmaf(sp[t], (float)vr[(int64_t)t * (2 * E)], acc);
-    o[(int64_t)b * E + h * 64 + lane] = (_Float16)(acc * inv);
+    // scores: item (t, h); neighbouring threads share the token row (broadcast loads) and read different u rows
+    const float scale = 1.0f / __fsqrt_rn((float)(E / H));
+    for (int i = tid; i < T * H; i += 256) {
+        const int t = i / H, h = i % H;
+        const _Float16 *tr = tb + (int64_t)t * E;
+        const _Float16 *ur = Us + h * ES;
+        float acc = 0.f;
+        for (int c8 = 0; c8 < E / 8; ++c8) {
+            const h8 tv = *reinterpret_cast<const h8 *>(tr + c8 * 8);
+            const h8 uv = *reinterpret_cast<const h8 *>(ur + c8 * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = fmaf((float)tv[e], (float)uv[e], acc);
+        }
+        sc[h * T + t] = acc * scale;
+    }
+    __syncthreads();
+    if (tid < H) { // softmax over the T tokens of one head
+        float *r = sc + tid * T;
+        float mx = -3.0e38f;
+        for (int t = 0; t < T; ++t) mx = fmaxf(mx, r[t]);
+        float sum = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const float p = __expf(r[t] - mx);
+            r[t] = p;
+            sum += p;
+        }
+        const float inv = __fdiv_rn(1.0f, sum);
+        for (int t = 0; t < T; ++t) r[t] *= inv;
+    }
+    __syncthreads();
+    // z_h = sum_t p[h][t] tok_t: a thread owns 8 columns, four heads at a time
+    for (int c8 = tid; c8 < E / 8; c8 += 256) {
+        for (int h0 = 0; h0 < H; h0 += 4) {
+            float acc[4][8];
+#pragma unroll
+            for (int hh = 0; hh < 4; ++hh)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[hh][e] = 0.f;
+            for (int t = 0; t < T; ++t) {
+                const h8 tv = *reinterpret_cast<const h8 *>(tb + (int64_t)t * E + c8 * 8);
+#pragma unroll
+                for (int hh = 0; hh < 4; ++hh) {
+                    const float p = sc[(h0 + hh) * T + t];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[hh][e] = fmaf(p, (float)tv[e], acc[hh][e]);
+                }
+            }
+#pragma unroll
+            for (int hh = 0; hh < 4; ++hh) {
+                h8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (_Float16)acc[hh][e];
+                *reinterpret_cast<h8 *>(Z + ((int64_t)b * H + h0 + hh) * E + c8 * 8) = o;
+            }
+        }
+    }
+}
+
+// att[b][h*hd + d] = O[(b*H + h)][h*hd + d]: head h keeps its own output dims of the redundant product
+__global__ __launch_bounds__(256) void rn50_pool_gather_kernel(const _Float16 *__restrict__ O, int H, int E,
+                                                               _Float16 *__restrict__ att) {
+    const int b = blockIdx.x, hd = E / H;
+    for (int c8 = threadIdx.x; c8 < E / 8; c8 += 256) {
+        const int h = (c8 * 8) / hd;
+        *reinterpret_cast<h8 *>(att + (int64_t)b * E + c8 * 8) =
+            *reinterpret_cast<const h8 *>(O + ((int64_t)b * H + h) * E + c8 * 8);
+    }
 }
 
 // ---- head: out[b] = cat(mean[b] (E), proj[b][:out_dim]) (* scale + shift for NECK_FEAT == 'after') ----------
@@ -198,9 +258,9 @@ __global__ __launch_bounds__(256) void rn50_head_kernel(const float *__restrict_
 
 struct Rn50Layout {
     int S, T, E, out_pad;
-    int64_t tok_rows, b_pad;
+    int64_t tok_rows, b_pad, q_rows;
     size_t act_elems;   // elements of one activation buffer
-    size_t zero, act[5], mean, tok, tok0, kv, q, att, proj, total;
+    size_t zero, act[5], mean, tok, tok0, aexp, uvec, zvec, ofull, zbias, q, att, proj, total;
 };
 
 Rn50Layout rn50_layout(const mpreid_rn50_cfg *cfg, int B) {
@@ -212,6 +272,7 @@ Rn50Layout rn50_layout(const mpreid_rn50_cfg *cfg, int B) {
     v.out_pad = (int)align_up((size_t)cfg->out_dim, 128);
     v.tok_rows = (int64_t)align_up((size_t)B * v.T, 256);
     v.b_pad = (int64_t)align_up((size_t)B, 256);
+    v.q_rows = (int64_t)align_up((size_t)B * cfg->heads, 256);
     // the largest tensors: stem outputs [H/2][W/2][64] and layer1 outputs [H/4][W/4][4*width]
     const size_t stem = (size_t)(cfg->img_h / 2) * (cfg->img_w / 2) * 64;
     const size_t l1 = (size_t)(cfg->img_h / 4) * (cfg->img_w / 4) * (size_t)(cfg->width * 4);
@@ -227,7 +288,11 @@ Rn50Layout rn50_layout(const mpreid_rn50_cfg *cfg, int B) {
     v.mean = take((size_t)B * v.E * 4);
     v.tok = take((size_t)v.tok_rows * v.E * 2);
     v.tok0 = take((size_t)v.b_pad * v.E * 2);
-    v.kv = take((size_t)v.tok_rows * 2 * v.E * 2);
+    v.aexp = take((size_t)v.q_rows * v.E * 2);
+    v.uvec = take((size_t)v.q_rows * v.E * 2);
+    v.zvec = take((size_t)v.q_rows * v.E * 2);
+    v.ofull = take((size_t)v.q_rows * v.E * 2);
+    v.zbias = take((size_t)v.E * 4);
     v.q = take((size_t)v.b_pad * v.E * 2);
     v.att = take((size_t)v.b_pad * v.E * 2);
     v.proj = take((size_t)v.b_pad * v.out_pad * 4);
@@ -301,7 +366,7 @@ extern "C" int mpreid_rn50_forward(const mpreid_rn50_cfg *cfg, const mpreid_rn50
                                    void *ws, size_t ws_bytes, mpreid_stream_t stream_) {
     int rc = rn50_check_cfg(cfg);
     if (rc) return rc;
-    ARG_CHECK(w && out && B > 0 && w->blocks && w->stem1_w && w->stem1_b);
+    ARG_CHECK(w && out && B > 0 && w->blocks && w->stem1_w && w->stem1_b && w->kt_w && w->v_w && w->v_b && w->q_w);
     ARG_CHECK((img != nullptr) != (img8 != nullptr));
     ARG_CHECK(!img8 || (mean3 && std3));
     const Rn50Layout v = rn50_layout(cfg, B);
@@ -379,32 +444,59 @@ extern "C" int mpreid_rn50_forward(const mpreid_rn50_cfg *cfg, const mpreid_rn50
     // ---- attention pool + head ----
     float *mean = (float *)(base + v.mean);
     _Float16 *tok = (_Float16 *)(base + v.tok), *tok0 = (_Float16 *)(base + v.tok0);
-    _Float16 *kv = (_Float16 *)(base + v.kv), *q = (_Float16 *)(base + v.q), *att = (_Float16 *)(base + v.att);
+    _Float16 *q = (_Float16 *)(base + v.q), *att = (_Float16 *)(base + v.att);
+    _Float16 *aexp = (_Float16 *)(base + v.aexp), *uvec = (_Float16 *)(base + v.uvec), *zvec = (_Float16 *)(base + v.zvec);
+    _Float16 *ofull = (_Float16 *)(base + v.ofull);
+    float *zbias = (float *)(base + v.zbias);
     float *proj = (float *)(base + v.proj);
+    const int Hh = cfg->heads;
     hipLaunchKernelGGL(rn50_tokens_kernel, dim3(B), dim3(256), 0, stream, buf[xi], w->pos_emb, v.S, v.E, mean, tok, tok0);
     LAUNCH_CHECK();
+    HIP_TRY(hipMemsetAsync(zbias, 0, (size_t)v.E * 4, stream));
     {
-        GemmArgs g{};
-        g.A = tok;
-        g.W = (const _Float16 *)w->kv_w;
-        g.M = (int)v.tok_rows;
-        g.N = 2 * v.E;
-        g.K = v.E;
-        g.out = kv;
-        g.ldo = 2 * v.E;
-        g.bias = w->kv_b;
-        if ((rc = launch_gemm_f16(g, GE_BIAS_F16, stream))) return rc;
+        GemmArgs g{};   // q = Wq tok_0 + bq
         g.A = tok0;
         g.W = (const _Float16 *)w->q_w;
         g.M = (int)v.b_pad;
         g.N = v.E;
+        g.K = v.E;
         g.out = q;
         g.ldo = v.E;
         g.bias = w->q_b;
         if ((rc = launch_gemm_f16(g, GE_BIAS_F16, stream))) return rc;
+        hipLaunchKernelGGL(rn50_pool_expand_kernel, dim3((unsigned)(B * Hh)), dim3(256), 0, stream, q, Hh, v.E, aexp);
+        LAUNCH_CHECK();
+        g.A = aexp;     // u_h = Wk_h^T q_h for every (image, head)
+        g.W = (const _Float16 *)w->kt_w;
+        g.M = (int)v.q_rows;
+        g.out = uvec;
+        g.bias = zbias;
+        if ((rc = launch_gemm_f16(g, GE_BIAS_F16, stream))) return rc;
     }
-    hipLaunchKernelGGL(rn50_attend_kernel, dim3(B, cfg->heads), dim3(64), 0, stream, q, kv, v.T, v.E, att);
-    LAUNCH_CHECK();
+    {
+        const size_t lds = (size_t)Hh * (v.E + 8) * 2 + (size_t)Hh * v.T * 4;
+        ARG_CHECK(lds <= 160 * 1024 && Hh % 4 == 0);
+        static size_t lds_set = 0;
+        if (lds > 48 * 1024 && lds > lds_set) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(rn50_pool_core_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            lds_set = lds;
+        }
+        hipLaunchKernelGGL(rn50_pool_core_kernel, dim3(B), dim3(256), lds, stream, uvec, tok, v.T, v.E, Hh, zvec);
+        LAUNCH_CHECK();
+        GemmArgs g{};   // out_h = Wv_h z_h + bv_h (all heads' rows against all of Wv; the gather keeps the diagonal blocks)
+        g.A = zvec;
+        g.W = (const _Float16 *)w->v_w;
+        g.M = (int)v.q_rows;
+        g.N = v.E;
+        g.K = v.E;
+        g.out = ofull;
+        g.ldo = v.E;
+        g.bias = w->v_b;
+        if ((rc = launch_gemm_f16(g, GE_BIAS_F16, stream))) return rc;
+        hipLaunchKernelGGL(rn50_pool_gather_kernel, dim3(B), dim3(256), 0, stream, ofull, Hh, v.E, att);
+        LAUNCH_CHECK();
+    }
     {
         HIP_TRY(hipMemsetAsync(proj, 0, (size_t)v.b_pad * v.out_pad * 4, stream));
         GemmArgs g{};

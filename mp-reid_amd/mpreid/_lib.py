@@ -73,7 +73,7 @@ class Rn50Cfg(C.Structure):
 
 class Rn50Weights(C.Structure):
     _fields_ = [("stem1_w", C.c_void_p), ("stem1_b", C.c_void_p), ("stem2", Rn50Conv), ("stem3", Rn50Conv),
-                ("blocks", C.POINTER(Rn50Block)), ("pos_emb", C.c_void_p), ("kv_w", C.c_void_p), ("kv_b", C.c_void_p),
+                ("blocks", C.POINTER(Rn50Block)), ("pos_emb", C.c_void_p), ("kt_w", C.c_void_p), ("v_w", C.c_void_p), ("v_b", C.c_void_p),
                 ("q_w", C.c_void_p), ("q_b", C.c_void_p), ("c_w", C.c_void_p), ("c_b", C.c_void_p),
                 ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p)]
 

@@ -506,7 +506,12 @@ class Rn50Encoder:
             self._keep += [wt, bt]
             return wt, bt
 
-        kvw, kvb = lin(("k_proj", "v_proj"))
+        vw, vb = lin(("v_proj",))
+        # k_proj is used transposed (u_h = Wk_h^T q_h, see csrc/rn50.hip); its bias shifts every score of a head by the
+        # same amount and cancels in the softmax
+        ktw = torch.from_numpy(np.ascontiguousarray(get("attnpool.k_proj.weight").astype(np.float32).T)).to(
+            torch.float16).to(dev)
+        self._keep.append(ktw)
         qw, qb = lin(("q_proj",))
         cw, cb = lin(("c_proj",), pad_rows=_pad_to(od, 128))
         pos = torch.from_numpy(get("attnpool.positional_embedding").astype(np.float32)).to(dev)
@@ -528,7 +533,8 @@ class Rn50Encoder:
         self.c_w.stem2, self.c_w.stem3 = conv("conv2", "bn2", 9), conv("conv3", "bn3", 9)
         self.c_w.blocks = C.cast(self.c_blocks, C.POINTER(_lib.Rn50Block))
         self.c_w.pos_emb = _ptr(pos)
-        self.c_w.kv_w, self.c_w.kv_b, self.c_w.q_w, self.c_w.q_b = _ptr(kvw), _ptr(kvb), _ptr(qw), _ptr(qb)
+        self.c_w.kt_w, self.c_w.v_w, self.c_w.v_b = _ptr(ktw), _ptr(vw), _ptr(vb)
+        self.c_w.q_w, self.c_w.q_b = _ptr(qw), _ptr(qb)
         self.c_w.c_w, self.c_w.c_b = _ptr(cw), _ptr(cb)
         self.c_w.bn_scale, self.c_w.bn_shift = _ptr(scale), _ptr(shift)
 
