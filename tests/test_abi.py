@@ -96,3 +96,46 @@ def test_dropin_modules_import_and_dataloader_contract_without_gpu():
     assert isinstance(b[0], RawImageBatch) and b[1] == (1, 3) and b[3].tolist() == [2, 4] and b[5] == ("a.jpg", "b.jpg")
     with pytest.raises(NotImplementedError):
         p2.do_inference_ttpt_clipstyle(c, None, None, 0)
+
+
+def test_fold_conv_bn_matches_conv_plus_batchnorm_on_cpu():
+    """host-side BatchNorm folding of the RN50 path (mpreid.ops.fold_conv_bn): conv'(x) + b' == BN(conv(x)) in fp32,
+    k order (kh, kw, c), output rows padded to 128, input channels padded on request"""
+    import torch.nn.functional as F
+    from mpreid import ops
+    g = torch.Generator().manual_seed(5)
+    for cout, cin, k, cpad in ((24, 16, 3, 64), (64, 32, 1, None), (130, 8, 3, 8)):
+        w = torch.randn((cout, cin, k, k), generator=g) * 0.1
+        bn = (1 + 0.1 * torch.randn(cout, generator=g), 0.1 * torch.randn(cout, generator=g),
+              0.1 * torch.randn(cout, generator=g), 0.5 + torch.rand(cout, generator=g))
+        x = torch.randn((2, cin, 6, 5), generator=g)
+        ref = F.batch_norm(F.conv2d(x, w, None, padding=k // 2), bn[2], bn[3], bn[0], bn[1], training=False, eps=1e-5)
+        wk, bk = ops.fold_conv_bn(w.numpy(), tuple(t.numpy() for t in bn), cin_pad=cpad)
+        cp = cpad or cin
+        assert wk.dtype == torch.float16 and wk.shape == ((cout + 127) // 128 * 128, k * k * cp) and bk.shape[0] == wk.shape[0]
+        assert float(wk[cout:].abs().max()) == 0.0 if wk.shape[0] > cout else True
+        w4 = wk[:cout].float().reshape(cout, k, k, cp)[..., :cin].permute(0, 3, 1, 2).contiguous()
+        got = F.conv2d(x, w4, bk[:cout], padding=k // 2)
+        assert torch.allclose(got, ref, rtol=2e-3, atol=2e-3)          # fp16 rounding of the folded weights only
+        if cp > cin:
+            assert float(wk[:cout].float().reshape(cout, k, k, cp)[..., cin:].abs().max()) == 0.0
+
+
+def test_do_inference_batch_grouping_helpers():
+    """processor.grouped_batches / merge_batches: consecutive loader batches up to the target, order kept, the
+    evaluator still gets the loader's own batches (reference processor/processor.py:187-198 semantics)"""
+    from processor.processor import grouped_batches, merge_batches
+    from datasets.make_dataloader import RawImageBatch
+    batches = []
+    for i, n in enumerate((3, 4, 2, 5, 1)):
+        batches.append((torch.full((n, 3, 2, 2), float(i)), tuple(range(n)), tuple([i] * n),
+                        torch.full((n,), i, dtype=torch.int64), torch.zeros(n, dtype=torch.int64), tuple(f"{i}_{j}" for j in range(n))))
+    groups = list(grouped_batches(batches, 6))
+    assert [[len(b[1]) for b in g] for g in groups] == [[3, 4], [2, 5], [1]]
+    img, cam, view = merge_batches(groups[0], "cpu")
+    assert img.shape == (7, 3, 2, 2) and cam.tolist() == [0, 0, 0, 1, 1, 1, 1] and view.shape == (7,)
+    assert float(img[2, 0, 0, 0]) == 0.0 and float(img[3, 0, 0, 0]) == 1.0
+    raw = [(RawImageBatch([np.zeros((2, 2, 3), np.uint8)] * n), tuple(range(n)), tuple([0] * n),
+            torch.zeros(n, dtype=torch.int64), torch.zeros(n, dtype=torch.int64), ("p",) * n) for n in (2, 3)]
+    img, cam, view = merge_batches(raw, "cpu")
+    assert isinstance(img, RawImageBatch) and len(img) == 5
