@@ -10,9 +10,9 @@
 // ToTensor + Normalize) -> NHWC fp16 conversion; 32-channel tensors are stored with 64 channels (upper half zero).
 //
 // Attention pool: only the output at the mean token (index 0) is used by the reference
-// (model/make_model.py:86 `image_features_proj[0]`), so: K/V projections for all S+1 tokens as ONE fp16 GEMM
-// ([k_proj; v_proj] stacked), the query projection for token 0 only, a one-query attention per (image, head), and
-// c_proj on one row per image.  avg_pool2d(x4) is the same mean the pool prepends, computed once in fp32.
+// (model/make_model.py:86 `image_features_proj[0]`), so: the query projection for token 0 only, the one-query
+// attention WITHOUT forming K or V (see "attention pool, one query" below), and c_proj on one row per image.
+// avg_pool2d(x4) is the same mean the pool prepends, computed once in fp32.
 #include "common.h"
 #include "conv_f16.h"
 #include "gemm_f16.h"
@@ -161,73 +161,156 @@ __global__ __launch_bounds__(256) void rn50_pool_expand_kernel(const _Float16 *_
     }
 }
 
-__global__ __launch_bounds__(256) void rn50_pool_core_kernel(const _Float16 *__restrict__ U, const _Float16 *__restrict__ tok,
+typedef _Float16 pf16x8 __attribute__((ext_vector_type(8)));
+typedef float pf32x4 __attribute__((ext_vector_type(4)));
+typedef float pf32x2 __attribute__((ext_vector_type(2)));
+
+// One workgroup (4 waves) per image.
+//   scores  S^T[t][h] = tok_t . u_h on the matrix cores: the token rows are the MFMA A operand exactly as they lie in
+//           memory (16 B per lane straight from global, eight k-steps requested ahead), the u rows the B operand from
+//           LDS (row pitch E + 8 halfs: the 16 rows of a fragment fall on distinct banks); wave w takes token tiles
+//           w, w + 4, ...
+//   softmax one thread per head over its T scores
+//   z       z_h = sum_t p[h][t] tok_t: the contraction runs over the SLOW index of tok, which the MFMA operand
+//           layout cannot read without a transpose, so this part is packed fp32 FMAs: a thread owns 8 columns and 8
+//           heads at a time, token rows prefetched four ahead
+__global__ __launch_bounds__(512) void rn50_pool_core_kernel(const _Float16 *__restrict__ U, const _Float16 *__restrict__ tok,
                                                              int T, int E, int H, _Float16 *__restrict__ Z) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const int ES = E + 8;                                          // padded row: 16-byte reads of H rows spread over the banks
-    _Float16 *Us = reinterpret_cast<_Float16 *>(lds);              // [H][ES]
-    float *sc = reinterpret_cast<float *>(lds + (size_t)H * ES * 2); // [H][T]
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int ES = E + 8;
+    const int H16 = (H + 15) & ~15;
+    _Float16 *Us = reinterpret_cast<_Float16 *>(lds);                  // [H16][ES], rows >= H zero
+    float *sc = reinterpret_cast<float *>(lds + (size_t)H16 * ES * 2);  // [T][H16] (token-major: a token's H weights are one vector)
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const _Float16 *Ub = U + (int64_t)b * H * E;
     const _Float16 *tb = tok + (int64_t)b * T * E;
-    for (int i = tid; i < H * (E / 8); i += 256) {
+    for (int i = tid; i < H16 * (E / 8); i += 512) {
         const int h = i / (E / 8), c8 = i % (E / 8);
-        *reinterpret_cast<h8 *>(Us + h * ES + c8 * 8) = *reinterpret_cast<const h8 *>(Ub + (int64_t)h * E + c8 * 8);
+        pf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (h < H) v = *reinterpret_cast<const pf16x8 *>(Ub + (int64_t)h * E + c8 * 8);
+        *reinterpret_cast<pf16x8 *>(Us + h * ES + c8 * 8) = v;
     }
     __syncthreads();
-    // scores: item (t, h); neighbouring threads share the token row (broadcast loads) and read different u rows
-    const float scale = 1.0f / __fsqrt_rn((float)(E / H));
-    for (int i = tid; i < T * H; i += 256) {
-        const int t = i / H, h = i % H;
-        const _Float16 *tr = tb + (int64_t)t * E;
-        const _Float16 *ur = Us + h * ES;
-        float acc = 0.f;
-        for (int c8 = 0; c8 < E / 8; ++c8) {
-            const h8 tv = *reinterpret_cast<const h8 *>(tr + c8 * 8);
-            const h8 uv = *reinterpret_cast<const h8 *>(ur + c8 * 8);
+    {
+        const float scale = 1.0f / __fsqrt_rn((float)(E / H));
+        const int frow = lane & 15, fq = lane >> 4;
+        const int nsteps = E / 32, ntt = (T + 15) / 16, nht = H16 / 16;
+        for (int tt = wave; tt < ntt; tt += 8) {
+            const int t = tt * 16 + frow;
+            const _Float16 *ar = tb + (int64_t)(t < T ? t : T - 1) * E + fq * 8;
+            const _Float16 *br = Us + frow * ES + fq * 8;
+            pf32x4 acc[2] = {pf32x4{0.f, 0.f, 0.f, 0.f}, pf32x4{0.f, 0.f, 0.f, 0.f}};
+            constexpr int PD = 8;   // k-steps of A fragments in flight
+            pf16x8 an[PD];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc = fmaf((float)tv[e], (float)uv[e], acc);
+            for (int u = 0; u < PD; ++u) an[u] = *reinterpret_cast<const pf16x8 *>(ar + (u < nsteps ? u : 0) * 32);
+            for (int k0 = 0; k0 < nsteps; k0 += PD) {
+                pf16x8 ac[PD];
+#pragma unroll
+                for (int u = 0; u < PD; ++u) ac[u] = an[u];
+#pragma unroll
+                for (int u = 0; u < PD; ++u) {
+                    const int kn = k0 + PD + u;
+                    an[u] = *reinterpret_cast<const pf16x8 *>(ar + (kn < nsteps ? kn : 0) * 32);
+                }
+#pragma unroll
+                for (int u = 0; u < PD; ++u) {
+                    if (k0 + u < nsteps) {
+                        const pf16x8 b0 = *reinterpret_cast<const pf16x8 *>(br + (k0 + u) * 32);
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ac[u], b0, acc[0], 0, 0, 0);
+                        if (nht > 1) {
+                            const pf16x8 b1 = *reinterpret_cast<const pf16x8 *>(br + 16 * ES + (k0 + u) * 32);
+                            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ac[u], b1, acc[1], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            // C layout: col = lane & 15 (head), row = (lane >> 4) * 4 + r (token)
+#pragma unroll
+            for (int ht = 0; ht < 2; ++ht) {
+                if (ht >= nht) break;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int tr = tt * 16 + fq * 4 + r;
+                    if (tr < T) sc[tr * H16 + ht * 16 + frow] = acc[ht][r] * scale;
+                }
+            }
         }
-        sc[h * T + t] = acc * scale;
     }
     __syncthreads();
-    if (tid < H) { // softmax over the T tokens of one head
-        float *r = sc + tid * T;
+    // softmax over the T tokens of each head: a wave per head (lanes over the tokens); padding heads get zero weights
+    for (int h = wave; h < H16; h += 8) {
+        float *r = sc + h;
+        if (h >= H) {
+            for (int t = lane; t < T; t += 64) r[t * H16] = 0.f;
+            continue;
+        }
         float mx = -3.0e38f;
-        for (int t = 0; t < T; ++t) mx = fmaxf(mx, r[t]);
+        for (int t = lane; t < T; t += 64) mx = fmaxf(mx, r[t * H16]);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
         float sum = 0.f;
-        for (int t = 0; t < T; ++t) {
-            const float p = __expf(r[t] - mx);
-            r[t] = p;
+        for (int t = lane; t < T; t += 64) {
+            const float p = __expf(r[t * H16] - mx);
+            r[t * H16] = p;
             sum += p;
         }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
         const float inv = __fdiv_rn(1.0f, sum);
-        for (int t = 0; t < T; ++t) r[t] *= inv;
+        for (int t = lane; t < T; t += 64) r[t * H16] *= inv;
     }
     __syncthreads();
-    // z_h = sum_t p[h][t] tok_t: a thread owns 8 columns, four heads at a time
-    for (int c8 = tid; c8 < E / 8; c8 += 256) {
-        for (int h0 = 0; h0 < H; h0 += 4) {
-            float acc[4][8];
+    // z: a thread owns 4 columns and up to 32 heads (one pass over the token rows: they are the HBM traffic here)
+    typedef _Float16 pf16x4 __attribute__((ext_vector_type(4)));
+    for (int c4 = tid; c4 < E / 4; c4 += 512) {
+        const _Float16 *tc = tb + c4 * 4;
+        for (int h0 = 0; h0 < H16; h0 += 32) {
+            const int nh = (H16 - h0 < 32) ? H16 - h0 : 32;   // 16 or 32
+            pf32x2 acc[32][2];
 #pragma unroll
-            for (int hh = 0; hh < 4; ++hh)
+            for (int hh = 0; hh < 32; ++hh) acc[hh][0] = acc[hh][1] = pf32x2{0.f, 0.f};
+            constexpr int PD = 8;
+            pf16x4 tn[PD];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[hh][e] = 0.f;
-            for (int t = 0; t < T; ++t) {
-                const h8 tv = *reinterpret_cast<const h8 *>(tb + (int64_t)t * E + c8 * 8);
+            for (int u = 0; u < PD; ++u) tn[u] = *reinterpret_cast<const pf16x4 *>(tc + (int64_t)(u < T ? u : 0) * E);
+            for (int t0 = 0; t0 < T; t0 += PD) {
+                pf16x4 tcur[PD];
 #pragma unroll
-                for (int hh = 0; hh < 4; ++hh) {
-                    const float p = sc[(h0 + hh) * T + t];
+                for (int u = 0; u < PD; ++u) tcur[u] = tn[u];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[hh][e] = fmaf(p, (float)tv[e], acc[hh][e]);
+                for (int u = 0; u < PD; ++u) {
+                    const int tnx = t0 + PD + u;
+                    tn[u] = *reinterpret_cast<const pf16x4 *>(tc + (int64_t)(tnx < T ? tnx : 0) * E);
+                }
+#pragma unroll
+                for (int u = 0; u < PD; ++u) {
+                    const int t = t0 + u;
+                    if (t < T) {
+                        const pf32x2 tv0 = {(float)tcur[u][0], (float)tcur[u][1]}, tv1 = {(float)tcur[u][2], (float)tcur[u][3]};
+                        const float *pr = sc + t * H16 + h0;
+#pragma unroll
+                        for (int h4 = 0; h4 < 8; ++h4) {
+                            if (h4 * 4 < nh) {
+                                const pf32x4 p4 = *reinterpret_cast<const pf32x4 *>(pr + h4 * 4);
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const pf32x2 p2 = {p4[q], p4[q]};
+                                    acc[h4 * 4 + q][0] = __builtin_elementwise_fma(p2, tv0, acc[h4 * 4 + q][0]);
+                                    acc[h4 * 4 + q][1] = __builtin_elementwise_fma(p2, tv1, acc[h4 * 4 + q][1]);
+                                }
+                            }
+                        }
+                    }
                 }
             }
 #pragma unroll
-            for (int hh = 0; hh < 4; ++hh) {
-                h8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (_Float16)acc[hh][e];
-                *reinterpret_cast<h8 *>(Z + ((int64_t)b * H + h0 + hh) * E + c8 * 8) = o;
+            for (int hh = 0; hh < 32; ++hh) {
+                if (h0 + hh < H) {
+                    const pf16x4 o = {(_Float16)acc[hh][0][0], (_Float16)acc[hh][0][1], (_Float16)acc[hh][1][0],
+                                      (_Float16)acc[hh][1][1]};
+                    *reinterpret_cast<pf16x4 *>(Z + ((int64_t)b * H + h0 + hh) * E + c4 * 4) = o;
+                }
             }
         }
     }
@@ -474,15 +557,16 @@ extern "C" int mpreid_rn50_forward(const mpreid_rn50_cfg *cfg, const mpreid_rn50
         if ((rc = launch_gemm_f16(g, GE_BIAS_F16, stream))) return rc;
     }
     {
-        const size_t lds = (size_t)Hh * (v.E + 8) * 2 + (size_t)Hh * v.T * 4;
-        ARG_CHECK(lds <= 160 * 1024 && Hh % 4 == 0);
+        const int H16 = (Hh + 15) & ~15;
+        const size_t lds = (size_t)H16 * (v.E + 8) * 2 + (size_t)H16 * v.T * 4;
+        ARG_CHECK(lds <= 160 * 1024 && v.E % 32 == 0 && H16 % 4 == 0);
         static size_t lds_set = 0;
         if (lds > 48 * 1024 && lds > lds_set) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(rn50_pool_core_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             lds_set = lds;
         }
-        hipLaunchKernelGGL(rn50_pool_core_kernel, dim3(B), dim3(256), lds, stream, uvec, tok, v.T, v.E, Hh, zvec);
+        hipLaunchKernelGGL(rn50_pool_core_kernel, dim3(B), dim3(512), lds, stream, uvec, tok, v.T, v.E, Hh, zvec);
         LAUNCH_CHECK();
         GemmArgs g{};   // out_h = Wv_h z_h + bv_h (all heads' rows against all of Wv; the gather keeps the diagonal blocks)
         g.A = zvec;
