@@ -223,6 +223,11 @@ def re_ranking_sharded(qf_all, gf_all, k1, k2, lambda_value):
     final_dist[q_lo:q_hi, nq:] block on the GPU; use gather_row_blocks_to_host() for the full matrix."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
+    if world == 1:
+        # one GPU: the single call (symmetric distance GEMM: half the tiles) gives the same bits as the phases below
+        # (tests/test_gpu_rerank.py::test_sharded_rerank_is_rank_count_independent)
+        from . import ops
+        return ops.re_ranking(qf_all, gf_all, k1, k2, lambda_value)[0]
     feat, norms = _rr_prepare(qf_all, gf_all)
     N, nq = feat.shape[0], qf_all.shape[0]
     sh = _RerankShard(feat, norms, nq, int(k1), int(k2), float(lambda_value), rank, world)
