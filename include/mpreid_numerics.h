@@ -11,7 +11,7 @@
  *                                           subnormals kept (numpy's float16 cast semantics)
  *   mpreid_h_add/sub/mul/div                numpy float16 arithmetic: operate in fp32, round the
  *                                           fp32 result to fp16 (double rounding included, as numpy)
- *   mpreid_expf                             exp() in fp32, < 1 ulp, branch-free core
+ *   mpreid_np_expf                          numpy's float32 exp (SIMD rational kernel), same bits
  *
  * Plain C99; also valid HIP device code (MPREID_HD expands to __host__ __device__ under hipcc).
  */
@@ -110,31 +110,47 @@ MPREID_HD uint16_t mpreid_h_div(uint16_t a, uint16_t b) {
 /* np.minimum on two finite non-negative halves == min of the bit patterns */
 MPREID_HD uint16_t mpreid_h_min_nonneg(uint16_t a, uint16_t b) { return a < b ? a : b; }
 
-/* exp(x) in fp32.  n = rint(x*log2(e)); r = x - n*ln2 (Cody-Waite, two fmaf); degree-7 Horner
- * polynomial for e^r on |r| <= ln2/2 (truncation error 5e-9 relative); scale by 2^n through the
- * exponent field (two-step so that results in the subnormal range are still produced by one
- * correctly rounded multiply).  Max error measured against double exp(): see tests/test_oracle.py. */
-MPREID_HD float mpreid_expf(float x) {
+/* np.exp on float32 arrays, restated (utils/reranking.py:70 `np.exp(-original_dist[i, idx])`).
+ *
+ * Third-party arithmetic: numpy is a pinned dependency of the reference (requirements.txt:98, numpy 1.24.4;
+ * 2.2.6 in this image) and is NOT under /root/reference.  Its float32 exp is the SIMD kernel of
+ * numpy/_core/src/umath/loops_exponent_log.dispatch.c.src (simd_exp_FLOAT, AVX512F / AVX2+FMA3 dispatch; unchanged
+ * between 1.20 and 2.2), a published algorithm restated here operation for operation:
+ *   q = rint(x * log2(e))            by adding and subtracting 1.5 * 2^23 (round-to-nearest-even)
+ *   r = fma(q, -ln2_hi, x); r = fma(q, -ln2_lo, r)                     (Cody-Waite, constants of npy_math)
+ *   exp(r) ~ P(r) / Q(r)             degree-5 / degree-2 rational minimax, both by Horner with fma
+ *   result = (P / Q) * 2^q           (vscalefps: one rounding, also when the result is subnormal)
+ * It is not correctly rounded (about 40 % of arguments are off by 1 ulp from the rounded exact value), which is why
+ * a generic < 1 ulp expf cannot give the reference's bits.  Pinned: tests/golden/np_exp.npz holds np.exp outputs
+ * of this image's numpy; beyond the fixture, every float32 in [-2, -0] (the only range the re-ranking feeds:
+ * x = -O with O in [0, 1]) was compared once, exhaustively, in the build container (2^30 + 1 arguments, 0 differ;
+ * tools/check_np_exp.py).  hipcc and gcc both evaluate fmaf, *, +, - and / as single IEEE operations under
+ * -ffp-contract=off, so the device result has the same bits. */
+MPREID_HD float mpreid_np_expf(float x) {
     if (x != x) return x;
-    if (x > 88.72283935546875f) return mpreid_bits_f32(0x7f800000u);
-    if (x < -103.97208404541015625f) return 0.0f;
+    if (x >= 88.72283935546875f) return mpreid_bits_f32(0x7f800000u);
+    if (x <= -103.97208404541015625f) return 0.0f;
     {
-        float n = rintf(x * 1.44269502162933349609375f);
-        float r = fmaf(n, -0.693145751953125f, x);            /* ln2 high part: 12 significant bits */
-        r = fmaf(n, -1.42860676533018704e-06f, r);            /* ln2 low part */
-        float p = 1.98412701138295233249664306640625e-4f;     /* 1/5040 */
-        p = fmaf(p, r, 1.388888922519981861114501953125e-3f); /* 1/720 */
-        p = fmaf(p, r, 8.3333337679505348205566406250e-3f);   /* 1/120 */
-        p = fmaf(p, r, 4.16666679084300994873046875e-2f);     /* 1/24 */
-        p = fmaf(p, r, 0.16666667163372039794921875f);        /* 1/6 */
-        p = fmaf(p, r, 0.5f);
-        p = fmaf(p, r, 1.0f);
-        p = fmaf(p, r, 1.0f);
+        const float magic = 12582912.0f;                       /* NPY_RINT_CVT_MAGICf = 0x1.8p23 */
+        float q = x * 1.442695040888963407359924681001892137f; /* NPY_LOG2Ef */
+        q = q + magic;
+        q = q - magic;
+        float r = fmaf(q, -6.93145752e-1f, x);                 /* NPY_CODY_WAITE_LOGE_2_HIGHf */
+        r = fmaf(q, -1.42860677e-6f, r);                       /* NPY_CODY_WAITE_LOGE_2_LOWf */
+        float num = fmaf(5.082762527590693718096e-04f, r, 6.757896990527504603057e-03f); /* P5, P4 */
+        num = fmaf(num, r, 5.114512081637298353406e-02f);      /* P3 */
+        num = fmaf(num, r, 2.473615434895520810817e-01f);      /* P2 */
+        num = fmaf(num, r, 7.257664613233124478488e-01f);      /* P1 */
+        num = fmaf(num, r, 9.999999999980870924916e-01f);      /* P0 */
+        float den = fmaf(2.159509375685829852307e-02f, r, -2.742335390411667452936e-01f); /* Q2, Q1 */
+        den = fmaf(den, r, 1.0f);                              /* Q0 */
+        const float p = num / den;
         {
-            int ni = (int)n; /* in [-150, 128] */
-            int n1 = ni / 2, n2 = ni - n1;
-            float s1 = mpreid_bits_f32((uint32_t)(n1 + 127) << 23);
-            float s2 = mpreid_bits_f32((uint32_t)(n2 + 127) << 23);
+            /* p * 2^q in two exact-then-rounded steps (p in [0.5, 2], so p * 2^n1 is exact) */
+            const int ni = (int)q; /* in [-150, 128] */
+            const int n1 = ni / 2, n2 = ni - n1;
+            const float s1 = mpreid_bits_f32((uint32_t)(n1 + 127) << 23);
+            const float s2 = mpreid_bits_f32((uint32_t)(n2 + 127) << 23);
             return (p * s1) * s2;
         }
     }

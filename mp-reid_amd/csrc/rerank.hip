@@ -656,7 +656,7 @@ __global__ __launch_bounds__(64) void krecip_kernel(const float *__restrict__ MT
     __syncthreads();
     const float mx = rowmax[li];
     const float *row = MT + (int64_t)li * ld;
-    for (int t = lane; t < nE; t += 64) wbuf[t] = mpreid_expf(-__fdiv_rn(row[Elist[t]], mx));
+    for (int t = lane; t < nE; t += 64) wbuf[t] = mpreid_np_expf(-__fdiv_rn(row[Elist[t]], mx));
     __syncthreads();
     const float s = wave_pairwise_sum(wbuf, nE, lane);
     // V[i, E] = fp16(weight / sum); only non-zero halves are kept (V != 0 tests later)

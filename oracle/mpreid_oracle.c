@@ -85,7 +85,7 @@ ORC_API double orc_pairwise_sum_f64(const double *a, long n) {
 }
 
 /* exposed so that the tests can pin the shared scalar numerics against numpy */
-ORC_API float orc_expf(float x) { return mpreid_expf(x); }
+ORC_API float orc_expf(float x) { return mpreid_np_expf(x); }
 ORC_API uint16_t orc_f32_to_f16(float x) { return mpreid_f32_to_f16(x); }
 ORC_API float orc_f16_to_f32(uint16_t h) { return mpreid_f16_to_f32(h); }
 ORC_API int orc_half_k1(int k1) { return mpreid_half_k1(k1); }
@@ -339,7 +339,7 @@ ORC_API int orc_rerank(const float *q, const float *g, long nq, long ng, int d, 
         int u = 0;
         for (int a = 0; a < nE; a++) if (a == 0 || E[a] != E[a - 1]) E[u++] = E[a];
         nE = u;
-        for (int a = 0; a < nE; a++) w[a] = mpreid_expf(-O[i * N + E[a]]);
+        for (int a = 0; a < nE; a++) w[a] = mpreid_np_expf(-O[i * N + E[a]]);
         const float s = orc_pairwise_sum_f32(w, nE);
         V[i].idx = (int *)malloc(sizeof(int) * (nE ? nE : 1));
         V[i].val = (uint16_t *)malloc(sizeof(uint16_t) * (nE ? nE : 1));

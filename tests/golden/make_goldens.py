@@ -172,6 +172,87 @@ def gen_rerank_small():
 
 
 # --------------------------------------------------------------------------------------------
+# (3b) re_ranking on UNSELECTED seeds at larger N (round-2: the seed of gen_rerank() is chosen for well separated
+# neighbour lists; these are not), and np.exp itself
+# --------------------------------------------------------------------------------------------
+SEED_CASES = [  # (seed, N, D, sigma, per_id, k1, k2, lambda) -- seeds are consecutive integers, nothing is scanned
+    (101, 1500, 512, 2.6, 10, 50, 15, 0.3),
+    (102, 1000, 256, 2.2, 8, 20, 6, 0.3),
+    (103, 2000, 768, 3.0, 20, 50, 15, 0.3),
+    (104, 1000, 1280, 3.5, 20, 50, 15, 0.3),
+    (105, 3000, 1280, 3.5, 20, 50, 15, 0.3),
+    (106, 4000, 768, 3.0, 20, 20, 6, 0.3),
+    (107, 2500, 512, 2.6, 10, 50, 15, 0.5),
+    (108, 1800, 768, 3.0, 12, 30, 10, 0.3),
+    (109, 2000, 1280, 5.5, 20, 50, 15, 0.3),   # noisier: mAP well below 1 so that rank errors would show
+    (110, 1500, 768, 4.5, 20, 20, 6, 0.3),
+]
+N_SAMPLES = 16384
+
+
+def seed_case_inputs(seed, N, D, sigma, per_id):
+    """features of a seed case: raw clustered features (element-wise fp32 arithmetic only, so the same bytes on any
+    host) normalised by the ORACLE's l2_normalize (fixed summation order) -- the tests regenerate exactly this."""
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as orc
+    raw, pid = synth.clustered_features(N, D, sigma, seed=seed, per_id=per_id, normalize=False)
+    return orc.l2_normalize(raw), pid
+
+
+def gen_rerank_seeds():
+    import hashlib
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as orc
+    out = {"cases": np.array(SEED_CASES, dtype=np.float64), "n_samples": np.int64(N_SAMPLES)}
+    for (seed, N, D, sigma, per_id, k1, k2, lam) in SEED_CASES:
+        nq = N // 5
+        feat, pid = seed_case_inputs(seed, N, D, sigma, per_id)
+        q, g = torch.from_numpy(feat[:nq]), torch.from_numpy(feat[nq:])
+        cam = synth.labels_for(N)
+        tag = f"s{seed}"
+        out[f"{tag}_feat_sha"] = np.array(hashlib.sha256(feat.tobytes()).hexdigest())
+        # (i) the reference as it is called (its own MKL distance GEMM)
+        r = ref_reranking.re_ranking(q, g, k1, k2, lam)
+        cmc, mAP = quiet(ref_metrics.eval_func, r, pid[:nq], pid[nq:], cam[:nq], cam[nq:])
+        rng = np.random.default_rng(seed)
+        flat = rng.choice(r.size, size=N_SAMPLES, replace=False).astype(np.int64)
+        out[f"{tag}_idx"] = flat.astype(np.int32)
+        out[f"{tag}_val"] = r.reshape(-1)[flat]
+        out[f"{tag}_mAP"] = np.float64(mAP)
+        out[f"{tag}_cmc"] = cmc
+        # (ii) both sides fed the SAME distance matrix (the oracle's k-ascending fmaf-chain GEMM) through
+        # local_distmat / only_local=True: everything after the GEMM is then comparable bit for bit
+        d_or = orc.euclidean_distance(feat, feat)
+        r2 = ref_reranking.re_ranking(q, g, k1, k2, lam, local_distmat=d_or.copy(), only_local=True)
+        out[f"{tag}_sameD_sha"] = np.array(hashlib.sha256(np.ascontiguousarray(r2).tobytes()).hexdigest())
+        out[f"{tag}_sameD_val"] = r2.reshape(-1)[flat]
+        cmc2, mAP2 = quiet(ref_metrics.eval_func, r2, pid[:nq], pid[nq:], cam[:nq], cam[nq:])
+        out[f"{tag}_sameD_mAP"] = np.float64(mAP2)
+        # measured oracle-vs-reference deviation over the FULL matrices (reported in DESIGN.md section 2)
+        o1 = orc.re_ranking(feat[:nq], feat[nq:], k1, k2, lam)
+        o2 = orc.re_ranking(feat[:nq], feat[nq:], k1, k2, lam, local_distmat=d_or, only_local=True)
+        d1, d2 = np.abs(o1 - r), np.abs(o2 - r2)
+        cmc_o, mAP_o = orc.eval_func(o1, pid[:nq], pid[nq:])
+        out[f"{tag}_measured"] = np.array([(d1 > 1e-5).mean(), d1.max(), (d2 != 0).mean(), d2.max(),
+                                           abs(mAP_o - mAP), np.abs(cmc_o - cmc).max()], dtype=np.float64)
+        print(f"{tag}: N={N} D={D} k=({k1},{k2}) lam={lam} mAP_ref={mAP:.4f}  as-called: frac>1e-5 {(d1 > 1e-5).mean():.2e} "
+              f"max {d1.max():.2e} dmAP {abs(mAP_o - mAP):.1e} | same-D: differing entries {(d2 != 0).mean():.2e} "
+              f"max {d2.max():.2e} bit-equal {np.array_equal(o2, r2)}")
+    save("rerank_seeds.npz", **out)
+
+
+def gen_np_exp():
+    """np.exp(float32) of this image's numpy (the reference calls it at utils/reranking.py:70)"""
+    rng = np.random.default_rng(3)
+    x = np.concatenate([-rng.random(30000), rng.uniform(-104.5, 89.0, 6000), rng.standard_normal(4000) * 1e-3,
+                        np.array([0.0, -0.0, -1.0, 1.0, -87.5, -103.9, -103.98, 88.72, 88.73, -1e-8])]).astype(np.float32)
+    with np.errstate(over="ignore"):
+        y = np.exp(x)
+    assert y.dtype == np.float32
+    save("np_exp.npz", x=x, y=y, numpy_version=np.array(np.__version__))
+
+
+# --------------------------------------------------------------------------------------------
 # (4) VisionTransformer
 # --------------------------------------------------------------------------------------------
 def run_vit(cfg, sd_np, imgs, cv=None):
@@ -308,6 +389,10 @@ if __name__ == "__main__":
         gen_rerank()
     if "rerank_small" in which:
         gen_rerank_small()
+    if "rerank_seeds" in which:
+        gen_rerank_seeds()
+    if "np_exp" in which:
+        gen_np_exp()
     if "vit" in which:
         gen_vit()
     if "resize" in which:

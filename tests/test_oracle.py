@@ -1,10 +1,13 @@
 """CPU oracle vs the golden vectors captured from the reference (tests/golden/make_goldens.py).
 
-Tolerances (SURVEY.md §7 "Hard parts" 1):
+Tolerances (DESIGN.md section 2 holds the measured distribution they are set from):
   * euclid / cosine entries: 1e-5 (fp32 GEMM order differs from MKL's)
-  * re-ranked entries: frac(|d| > 1e-5) <= 1e-4 on these small fixtures and max |d| <= one fp16
-    quantum of J*(1-lambda) (4.9e-4 * ... ) — isolated single-quantum flips come from np.exp not
-    being correctly rounded and from 1-ulp differences in the fp32 GEMM.
+  * re-ranking fed the SAME distance matrix as the reference (local_distmat / only_local): bit-exact on every seed
+    (np.exp, np.sum, the float16 steps and the 2/3 test are restated operation for operation).
+  * re-ranking as called (the reference's distance GEMM is MKL's, ours is the k-ascending fmaf chain): a 1-ulp
+    difference in D can move a V entry by one fp16 quantum; measured over 10 unselected seeds (N 1000-4000,
+    D 256-1280): frac(|d| > 1e-5) <= 4.7e-5, max |d| = 4.88e-4 (one quantum), |dmAP| <= 7e-7.  Bounds asserted:
+    frac <= 3e-4 on the 16384 sampled entries (<= 4 entries), max <= 1e-3 (two quanta), |dmAP| <= 1e-5.
   * mAP / CMC: 1e-4
 """
 import numpy as np
@@ -39,14 +42,21 @@ def test_f16_conversion_matches_numpy():
         assert orc.f64_to_f16_bits(d) == int(np.float16(d).view(np.uint16)), d
 
 
-def test_expf_accuracy():
+def test_np_exp_restatement_matches_numpy_bits(golden):
+    """mpreid_np_expf (include/mpreid_numerics.h) == np.exp(float32) of the build container's numpy, bit for bit:
+    the committed fixture, and the numpy that is installed wherever this test runs."""
+    g = golden("np_exp.npz")
+    L = orc.lib()
+    got = np.array([L.orc_expf(float(v)) for v in g["x"]], np.float32)
+    assert np.array_equal(got.view(np.uint32), g["y"].view(np.uint32))
     rng = np.random.default_rng(2)
-    x = np.concatenate([-rng.random(200000), rng.standard_normal(20000) * 20]).astype(np.float32)
-    got = np.array([orc.expf(v) for v in x[:40000]], np.float32)
-    ref = np.exp(x[:40000].astype(np.float64))
-    ulp = np.spacing(ref.astype(np.float32)).astype(np.float64)
-    err = np.abs(got.astype(np.float64) - ref) / ulp
-    assert err.max() < 1.0, err.max()
+    x = (-rng.random(20000)).astype(np.float32)   # the range the re-ranking feeds: -O, O in [0, 1]
+    live = np.exp(x)
+    got = np.array([L.orc_expf(float(v)) for v in x], np.float32)
+    assert np.array_equal(got.view(np.uint32), live.view(np.uint32))
+    # and it is NOT the correctly rounded exp (which is why a generic expf cannot stand in for it)
+    exact = np.exp(x.astype(np.float64)).astype(np.float32)
+    assert 0.2 < float((got != exact).mean()) < 0.6
 
 
 def test_half_k1_rounding():
@@ -83,6 +93,10 @@ def test_eval_func_vs_reference(golden):
     assert mAP == float(g["mAP_small"])
 
 
+# as-called re-rank deviation from the reference (MKL GEMM order only, see the module docstring)
+RR_FRAC, RR_MAX = 3e-4, 1e-3
+
+
 def _rr_check(got, want, lam):
     d = np.abs(got - want)
     frac = float((d > 1e-5).mean())
@@ -98,7 +112,7 @@ def test_rerank_vs_reference(golden, case):
     feat = g["feat"]
     got = orc.re_ranking(feat[:nq], feat[nq:], k1, k2, lam)
     frac, mx = _rr_check(got, g[f"rr_{case}"], lam)
-    assert frac <= 1e-4 and mx <= 5e-4, (frac, mx)
+    assert frac <= RR_FRAC and mx <= RR_MAX, (frac, mx)
 
 
 def test_rerank_local_vs_reference(golden):
@@ -108,10 +122,10 @@ def test_rerank_local_vs_reference(golden):
     local = g["local"].astype(np.float32)
     got = orc.re_ranking(feat[:nq], feat[nq:], 20, 6, 0.3, local_distmat=local)
     frac, mx = _rr_check(got, g["rr_local_20_6_0.3"], 0.3)
-    assert frac <= 1e-4 and mx <= 5e-4, (frac, mx)
+    assert frac <= RR_FRAC and mx <= RR_MAX, (frac, mx)
     got = orc.re_ranking(feat[:nq], feat[nq:], 20, 6, 0.3, local_distmat=local, only_local=True)
     frac, mx = _rr_check(got, g["rr_onlylocal_20_6_0.3"], 0.3)
-    assert frac <= 1e-4 and mx <= 5e-4, (frac, mx)
+    assert frac <= RR_FRAC and mx <= RR_MAX, (frac, mx)
 
 
 def test_r1_map_eval_pipeline_vs_reference(golden):
@@ -133,7 +147,7 @@ def test_r1_map_eval_pipeline_vs_reference(golden):
             scale = max(1.0, float(np.abs(want).max()))
             dd = np.abs(d - want) / scale
             if rr:
-                assert (dd > 1e-5).mean() <= 1e-4 and dd.max() <= 5e-4, (tag, (dd > 1e-5).mean(), dd.max())
+                assert (dd > 1e-5).mean() <= RR_FRAC and dd.max() <= RR_MAX, (tag, (dd > 1e-5).mean(), dd.max())
             else:
                 assert dd.max() < 1e-5, (tag, dd.max())
 
@@ -194,3 +208,37 @@ def test_rn50_oracle_matches_reference_goldens(golden):
     assert f.shape == (3, 3072)
     assert np.abs(f - g["rn50_feat"]).max() <= 2e-5 * np.abs(g["rn50_feat"]).max()
     assert np.abs(f[:, :2048] - g["rn50_x4_mean"]).max() <= 2e-5 * np.abs(g["rn50_x4_mean"]).max()
+
+
+def _seed_case(g, row):
+    from mpreid import synth
+    import hashlib
+    seed, N, D, sigma, per_id, k1, k2, lam = row
+    seed, N, D, per_id, k1, k2 = int(seed), int(N), int(D), int(per_id), int(k1), int(k2)
+    raw, pid = synth.clustered_features(N, D, float(sigma), seed=seed, per_id=per_id, normalize=False)
+    feat = orc.l2_normalize(raw)
+    assert hashlib.sha256(feat.tobytes()).hexdigest() == str(g[f"s{seed}_feat_sha"]), "input drift: seeded features differ"
+    return f"s{seed}", feat, pid, N // 5, k1, k2, float(lam)
+
+
+SEED_ROWS = list(range(10))
+
+
+@pytest.mark.parametrize("row", SEED_ROWS)
+def test_rerank_unselected_seeds_vs_reference(golden, row):
+    """10 seeds that were NOT chosen for separation (tests/golden/make_goldens.py:SEED_CASES), N up to 4000."""
+    import hashlib
+    g = golden("rerank_seeds.npz")
+    tag, feat, pid, nq, k1, k2, lam = _seed_case(g, g["cases"][row])
+    idx = g[f"{tag}_idx"].astype(np.int64)
+    # as called: the only un-restatable step is the order of MKL's fp32 GEMM
+    got = orc.re_ranking(feat[:nq], feat[nq:], k1, k2, lam)
+    d = np.abs(got.reshape(-1)[idx] - g[f"{tag}_val"])
+    assert (d > 1e-5).mean() <= RR_FRAC and d.max() <= RR_MAX, (tag, (d > 1e-5).mean(), d.max())
+    cmc, mAP = orc.eval_func(got, pid[:nq], pid[nq:])
+    assert abs(mAP - float(g[f"{tag}_mAP"])) <= 1e-5 and np.abs(cmc - g[f"{tag}_cmc"]).max() <= 1e-4, tag
+    # same distance matrix on both sides: every bit of the output
+    d_or = orc.euclidean_distance(feat, feat)
+    got2 = orc.re_ranking(feat[:nq], feat[nq:], k1, k2, lam, local_distmat=d_or, only_local=True)
+    assert np.array_equal(got2.reshape(-1)[idx], g[f"{tag}_sameD_val"]), tag
+    assert hashlib.sha256(np.ascontiguousarray(got2).tobytes()).hexdigest() == str(g[f"{tag}_sameD_sha"]), tag
