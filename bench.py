@@ -1,18 +1,32 @@
 #!/usr/bin/env python3
-"""bench.py — MP-ReID evaluation hot path on MI355X: ViT-B/16 encode of query+gallery -> L2-normalise
--> euclidean distance matrix (BASELINE.json configs[1], Market-1501 shape, no re-rank).
+"""bench.py — MP-ReID evaluation hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload market|synth|msmt17] [--rerank]
 
-One "step" = one full pass: encode every resident synthetic image (3368 queries + 15913 gallery per
-GPU shard) in batches, normalise, all-gather the query features (N > 1), compute this rank's
-[3368, 15913] distance block.  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE
-JSON line (contract in the task statement) with `roofline` (dominant kernel, hipEvents on the launch
-stream inside the timed region) and `cpu_baseline` (the CPU oracle on a bounded sample, N = 1 only).
+Launch: with --gpus N > 1 and no WORLD_SIZE in the environment this process stays GPU-free, starts N fresh child
+processes (one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set) and relays
+rank 0's JSON line; under `python -m torch.distributed.run` the ranks are the launcher's.  It never re-execs.
+
+Workloads (BASELINE.json configs):
+  market  (default; configs[1], with --rerank the configs[2] stand-in)  ViT-B/16 encode of 3368 query + 15913 gallery
+          images PER GPU SHARD -> L2-normalise -> all-gather of the query features -> [3368, 15913] exact distance
+          block per GPU.  Weak scaling (per-GPU gallery fixed).
+  synth   (configs[3])  ONE 20 000-query x 80 000-gallery x 768 problem, gallery rows sharded over the N GPUs,
+          all-gather of the query features, per-shard [20000, 80000/N] distance blocks; --rerank adds the row-sharded
+          k-reciprocal re-ranking of the N = 100 000 problem.  Strong scaling (total work fixed).
+  msmt17  (configs[4])  MSMT17 shape: encode 11 659 + 82 161 images sharded over the GPUs, distance blocks at
+          D = 1280, row-sharded re-ranking, fp16-MFMA distance mode checked against the exact fp32 mode.  Strong.
+
+One "step" = one full pass over the workload; inputs are resident in HBM before the timed region.  Rank 0 prints ONE
+JSON line with `roofline` (dominant kernel of the step, hipEvents on the launch stream), `roofline_all` (every stage
+of the metric incl. the 20k x 20k feat-GEMM and the re-rank stages, N = 1 only) and `cpu_baseline` (the CPU oracle
+on a bounded sample, N = 1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,13 +35,14 @@ for p in (ROOT, os.path.join(ROOT, "mp-reid_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 NQ, NG, H, W = 3368, 15913, 256, 128          # Market-1501 test split (datasets/market1501.py:24), vit_base.yml
+MSMT_NQ, MSMT_NG = 11659, 82161                 # datasets/msmt17.py:21 (SURVEY.md §8d shape D)
+SYN_NQ, SYN_NG, SYN_D = 20000, 80000, 768       # BASELINE configs[3] (SURVEY.md §8d shape C)
 GFLOP_PER_IMG = 21.12                           # last block CLS-only (22.68 if computed for all tokens)
 PEAK_F16_TFLOPS = 2500.0                        # MI355X_MICROARCH.md: dense fp16/bf16 MFMA
-PEAK_F32_TFLOPS = 157.3
+PEAK_F32_TFLOPS = 157.3                         # fp32 MFMA
+PEAK_HBM_GBS = 8000.0                           # HBM3E
+METRIC = "gallery images/s encode + distmat+rerank ms, 20k×20k; mAP/Rank-1 parity"
 
 
 def parse():
@@ -35,6 +50,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=("market", "synth", "msmt17"), default="market")
     ap.add_argument("--batch", type=int, default=508,
                     help="images per encoder call; 508*129 tokens = 256 row tiles of 256 rows = whole waves of "
                          "tiles on 256 CUs (reference yml: 64)")
@@ -44,14 +60,56 @@ def parse():
     ap.add_argument("--small", action="store_true", help="debug: 1/16 of the workload")
     ap.add_argument("--rerank", action="store_true",
                     help="also run k-reciprocal re-ranking (k1=50, k2=15, lambda=0.3) in every step "
-                         "(BASELINE configs[2] stand-in; rows sharded over the ranks when N > 1)")
+                         "(rows sharded over the ranks when N > 1)")
+    ap.add_argument("--dist-mode", choices=("exact", "f16", "split3"), default="exact",
+                    help="arithmetic of the distance GEMM blocks: exact fp32 MFMA (parity mode), one-pass fp16 "
+                         "(speed mode, |err| ~1e-4), 3-term fp16 split (|err| <= 1e-6)")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the encoder batches alternate on (HBM-bound phases of one batch overlap "
                          "MFMA phases of the other)")
     return ap.parse_args()
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# self-launch (parent process: no torch.cuda call, no HIP library loaded)
+# ----------------------------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_children(n):
+    """Start n ranks of this script as fresh processes and relay rank 0's JSON line.  The parent never touches the
+    GPU, so nothing that has initialised HIP is ever exec-ed or forked."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    line = None
+    for ln in (out0 or "").splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if any(codes) or line is None:
+        print(f"bench.py: child ranks exited with {codes}", file=sys.stderr)
+        sys.exit(1)
+    print(line, flush=True)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# helpers (rank processes)
+# ----------------------------------------------------------------------------------------------------------------
 def make_images(n, seed, device, chunk=1024):
+    import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     out = torch.empty((n, 3, H, W), dtype=torch.float32, device=device)
@@ -61,72 +119,178 @@ def make_images(n, seed, device, chunk=1024):
     return out
 
 
+def make_features(n, d, sigma, seed, device, per_id=20):
+    """clustered unit-norm features (SURVEY.md §8d recipe) generated on the device: identical on every rank"""
+    import torch
+    from mpreid import ops
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    n_ids = max(1, n // per_id)
+    cent = torch.randn((n_ids, d), generator=g, device=device)
+    pid = torch.randint(0, n_ids, (n,), generator=g, device=device)
+    x = cent[pid] + sigma * torch.randn((n, d), generator=g, device=device)
+    return ops.l2_normalize(x), pid
+
+
+def timed_ms(fn, reps, warm=1):
+    import torch
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
 def cpu_baseline(n_img):
-    """CPU oracle (kind 'port') on a bounded sample of the same workload, all host cores."""
+    """CPU oracle (kind 'port') on a bounded sample of the same workload: all host cores, and one thread."""
+    import numpy as np
+    import torch
     from mpreid import synth
     from oracle import oracle as orc
     cores = min(os.cpu_count() or 1, 32)   # more threads than this only add contention for these sizes
     torch.set_num_threads(cores)
-    os.environ["OMP_NUM_THREADS"] = str(cores)
     sd = synth.vit_state_dict(synth.VIT_B16, seed=7)
     imgs = synth.synthetic_images(n_img, H, W, seed=1)
     orc.vit_features(sd, synth.VIT_B16, imgs[:2])  # warm
     t0 = time.perf_counter()
     orc.vit_features(sd, synth.VIT_B16, imgs)
     t_enc = time.perf_counter() - t0
+    torch.set_num_threads(1)
+    t0 = time.perf_counter()
+    orc.vit_features(sd, synth.VIT_B16, imgs[:3])
+    t_enc1 = (time.perf_counter() - t0) / 3
+    torch.set_num_threads(cores)
     f, _ = synth.clustered_features(NQ + 1024, 1280, 3.5, seed=2)
     orc.euclidean_distance(f[:64], f[NQ:])
     t0 = time.perf_counter()
     orc.euclidean_distance(f[:NQ], f[NQ:])
     t_dist = time.perf_counter() - t0
     total = (NQ + NG) / n_img * t_enc + NG / 1024.0 * t_dist
+    # re-rank leg: the oracle at the bench's own N = 20 000 (nq 4000, D 768, k1 50, k2 15) on all cores; one thread
+    # on an N = 6000 sample (the dense N x N passes make it ~quadratic in N)
+    f, _ = synth.clustered_features(20000, 768, 3.0, seed=1234)
+    t0 = time.perf_counter()
+    orc.re_ranking(f[:4000], f[4000:], 50, 15, 0.3)
+    t_rr = time.perf_counter() - t0
+    code = ("import sys,time;sys.path[:0]=[%r,%r];from mpreid import synth;from oracle import oracle as orc;"
+            "f,_=synth.clustered_features(6000,768,3.0,seed=1234);t=time.perf_counter();"
+            "orc.re_ranking(f[:1200],f[1200:],50,15,0.3);print(time.perf_counter()-t)" %
+            (ROOT, os.path.join(ROOT, "mp-reid_amd")))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True,
+                       text=True)
+    t_rr1 = float(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else None
     return {"value": round((NQ + NG) / total, 3), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"oracle ViT-B/16 fp32 (torch CPU) on {n_img} images: {t_enc:.2f} s; oracle euclid "
-                      f"{NQ}x1024x1280: {t_dist:.2f} s; extrapolated linearly to {NQ}+{NG} images",
-            "encode_images_per_s": round(n_img / t_enc, 3)}
+                      f"{NQ}x1024x1280: {t_dist:.2f} s; extrapolated linearly to {NQ}+{NG} images; oracle re-rank "
+                      f"N=20000 (nq 4000, D 768, k1 50, k2 15) on {cores} threads: {t_rr:.2f} s; on 1 thread at "
+                      f"N=6000: {t_rr1 if t_rr1 is None else round(t_rr1, 2)} s",
+            "encode_images_per_s": round(n_img / t_enc, 3), "encode_images_per_s_1thread": round(1.0 / t_enc1, 3),
+            "rerank_s": round(t_rr, 3), "rerank_n": 20000, "rerank_s_1thread_n6000": t_rr1}
 
 
-def extras(ops, dev):
-    """secondary figures named by BASELINE.json's metric: 20k x 20k feat-GEMM and re-rank (one run each)"""
+def rerank_roofline(st):
+    """per-stage roofline entries of one re-rank call from its logged nnz (SURVEY.md §8d byte formulas)"""
+    N, k1, k2, h = st["n"], st["k1"], st["k2"], st["half_k1"]
+    nq = st.get("nq", 0)
+    ng = N - nq
+    rbar = st.get("krecip_r_sum", 0) / max(N, 1)
+    kr = max(k1 + 1, k2)
+    rows = []
+
+    def add(stage, kernel, ms, bound, work, note=None):
+        if not ms or ms <= 0:
+            return
+        if bound == "hbm":
+            ach, peak, unit = work / ms / 1e6, PEAK_HBM_GBS, "GB/s"
+        else:
+            ach, peak, unit = work / ms / 1e9, (PEAK_F32_TFLOPS if bound == "mfma_f32" else PEAK_F16_TFLOPS), "TFLOP/s"
+        e = {"stage": stage, "kernel": kernel, "bound": "mfma" if bound.startswith("mfma") else "hbm",
+             "achieved": round(ach, 1), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
+             "algorithmic_" + ("bytes" if bound == "hbm" else "flop"): int(work), "avg_launch_ms": round(ms, 4),
+             "traffic": None}
+        if note:
+            e["note"] = note
+        rows.append(e)
+
+    d = st.get("d", 0)
+    gemm_kind = st.get("gemm_kind", "exact")
+    if gemm_kind == "exact":
+        add("rerank.distance", "gemm_f32_exact_kernel<SYM>", st["ms_gemm"], "mfma_f32", 1.0 * N * N * d,
+            "executed FLOPs: the symmetric kernel computes the upper-triangular tiles only (2*N*N*D/2)")
+    else:
+        add("rerank.distance", "gemm_f16_big_kernel<split3>", st["ms_gemm"], "mfma_f16", 6.0 * N * N * d,
+            "3-term fp16 split: 3 x 2*N*N*D executed")
+    add("rerank.topk", "rowmax_topk_kernel", st["ms_topk"], "hbm", 4.0 * N * N + 4.0 * N * kr)
+    add("rerank.krecip", "krecip_kernel", st["ms_krecip"], "hbm", 4.0 * N * ((k1 + 1) ** 2 + rbar * (h + h * h)),
+        f"mean |R| = {rbar:.1f}")
+    add("rerank.qe", "qe_count/fill_kernel", st["ms_qe"], "hbm", 6.0 * st["v_nnz"] * (1 + k2))
+    add("rerank.csc", "csc_*", st["ms_csc"], "hbm", 12.0 * st["vqe_nnz"])
+    add("rerank.jaccard", "jaccard_kernel", st["ms_jaccard"], "hbm", 6.0 * st["jaccard_pairs"] + 8.0 * nq * ng)
+    return rows
+
+
+def extras(ops, dev, with_widened=True):
+    """secondary figures named by BASELINE.json's metric: 20k x 20k feat-GEMM and re-rank; returns (extras dict,
+    roofline entries)"""
+    import numpy as np
+    import torch
     from mpreid import synth
-    out = {}
+    out, roofs = {}, []
     f, _ = synth.clustered_features(20000, 768, 3.0, seed=1234)
     ft = torch.from_numpy(f).to(dev)
-
-    def timed(fn, reps):
-        fn()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps
-
     buf = torch.empty((20000, 20000), dtype=torch.float32, device=dev)
     flop = 2.0 * 20000 * 20000 * 768
-    ms = timed(lambda: ops.euclidean_distance(ft, ft, mode=ops.GEMM_F16_FAST, out=buf), 5)
+    byts = 2.0 * 2 * 20000 * 768 + 4.0 * 20000 * 20000
+    ms = timed_ms(lambda: ops.euclidean_distance(ft, ft, mode=ops.GEMM_F16_FAST, out=buf), 5)
     out["feat_gemm_20kx20k_d768_fp16_ms"] = round(ms, 4)
     out["feat_gemm_20kx20k_d768_fp16_tflops"] = round(flop / ms / 1e9, 1)
     out["feat_gemm_20kx20k_d768_fp16_frac_of_peak"] = round(flop / ms / 1e9 / PEAK_F16_TFLOPS, 4)
-    ms = timed(lambda: ops.euclidean_distance(ft, ft, mode=ops.GEMM_F32_EXACT, out=buf), 3)
+    roofs.append({"stage": "feat_gemm_20kx20k_d768 (fp16 one pass, fp32 N x N stored)", "kernel": "gemm_f16_big_kernel<euclid>",
+                  "bound": "mfma", "achieved": round(flop / ms / 1e9, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                  "frac": round(flop / ms / 1e9 / PEAK_F16_TFLOPS, 4), "algorithmic_flop": int(flop),
+                  "avg_launch_ms": round(ms, 4), "traffic": None,
+                  "hbm": {"achieved": round(byts / ms / 1e6, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                          "frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 4), "algorithmic_bytes": int(byts)}})
+    if hasattr(ops, "GEMM_F16_SPLIT3"):
+        ms = timed_ms(lambda: ops.euclidean_distance(ft, ft, mode=ops.GEMM_F16_SPLIT3, out=buf), 5)
+        out["feat_gemm_20kx20k_d768_split3_ms"] = round(ms, 4)
+        out["feat_gemm_20kx20k_d768_split3_executed_tflops"] = round(3 * flop / ms / 1e9, 1)
+        roofs.append({"stage": "feat_gemm_20kx20k_d768 (3-term fp16 split, |err| <= 1e-6)", "kernel": "gemm_f16_big_kernel<euclid_split3>",
+                      "bound": "mfma", "achieved": round(3 * flop / ms / 1e9, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                      "frac": round(3 * flop / ms / 1e9 / PEAK_F16_TFLOPS, 4), "algorithmic_flop": int(3 * flop),
+                      "avg_launch_ms": round(ms, 4), "traffic": None})
+    ms = timed_ms(lambda: ops.euclidean_distance(ft, ft, mode=ops.GEMM_F32_EXACT, out=buf), 3)
     out["feat_gemm_20kx20k_d768_fp32exact_ms"] = round(ms, 4)
     out["feat_gemm_20kx20k_d768_fp32exact_tflops"] = round(flop / ms / 1e9, 1)
+    roofs.append({"stage": "feat_gemm_20kx20k_d768 (exact fp32 MFMA, bit-parity mode)", "kernel": "gemm_f32_exact_kernel",
+                  "bound": "mfma", "achieved": round(flop / ms / 1e9, 1), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                  "frac": round(flop / ms / 1e9 / PEAK_F32_TFLOPS, 4), "algorithmic_flop": int(flop),
+                  "avg_launch_ms": round(ms, 4), "traffic": None})
     del buf
     ops.re_ranking(ft[:4000], ft[4000:], 50, 15, 0.3)
     _, st = ops.re_ranking(ft[:4000], ft[4000:], 50, 15, 0.3, timing=True)
+    st.update(nq=4000, d=768)
     out["rerank_N20000_nq4000_d768_k50_15_ms"] = round(st["ms_total"], 3)
     out["rerank_stages_ms"] = {k[3:]: round(v, 3) for k, v in st.items() if k.startswith("ms_") and k != "ms_total"}
     out["rerank_nnz"] = {"v": st["v_nnz"], "vqe": st["vqe_nnz"], "jaccard_pairs": st["jaccard_pairs"]}
+    roofs += rerank_roofline(st)
+    ms = timed_ms(lambda: ops.re_ranking(ft[:4000], ft[4000:], 50, 15, 0.3), 3)
+    out["rerank_N20000_untimed_stages_ms"] = round(ms, 3)
+    out["distmat_plus_rerank_20kx20k_ms"] = round(ms, 3)   # the re-rank computes its own all-pairs distance matrix
     del ft
-    # widened rows (SURVEY.md §8f): the RN50 tower, the Pillow-exact Resize, the TTA query encoder
+    if not with_widened:
+        return out, roofs
+    # widened rows (SURVEY.md §8f): the RN50 tower, the Pillow-exact Resize, the PCIe-inclusive encoder
     enc = ops.Rn50Encoder(synth.RN50, synth.rn50_state_dict(synth.RN50, seed=11), (256, 128))
     img = torch.from_numpy(synth.synthetic_images(64, 256, 128, seed=1)).to(dev).repeat(4, 1, 1, 1).contiguous()
     fo = torch.empty((256, enc.feat_dim), device=dev)
-    ms = timed(lambda: enc(img, out=fo), 3)
+    ms = timed_ms(lambda: enc(img, out=fo), 3)
     out["rn50_images_per_s_batch256"] = round(256 / ms * 1e3, 1)
-    out["rn50_tflops_11.5gflop_per_img"] = round(256 * 11.51 / ms, 1)
     del enc, img, fo
     rng = np.random.default_rng(5)
     raws = [rng.integers(0, 256, (128, 64, 3), dtype=np.uint8) for _ in range(512)]   # Market-1501 native size
@@ -171,38 +335,55 @@ def extras(ops, dev):
     dt = time.perf_counter() - t0
     out["encode_from_pinned_host_uint8_images_per_s"] = round(nb * B / dt, 1)
     out["encode_from_pinned_host_uint8_h2d_gb_per_s"] = round(nb * B * 256 * 128 * 3 / dt / 1e9, 2)
-    return out
+    return out, roofs
 
 
-def main():
-    a = parse()
-    from mpreid import _lib, distributed as D, ops, synth
+# ----------------------------------------------------------------------------------------------------------------
+# one rank
+# ----------------------------------------------------------------------------------------------------------------
+def run_rank(a):
+    import numpy as np  # noqa: F401
+    import torch
     import torch.distributed as dist
+    from mpreid import _lib, distributed as D, ops, synth
 
     rank, world, local = D.init_from_env()
-    assert world == a.gpus or world == 1 and a.gpus == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     local = local % max(torch.cuda.device_count(), 1)   # (debug) more ranks than GPUs share devices
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     L = _lib.load()
+    mode = {"exact": ops.GEMM_F32_EXACT, "f16": ops.GEMM_F16_FAST, "split3": getattr(ops, "GEMM_F16_SPLIT3", None)}[a.dist_mode]
+    assert mode is not None, "--dist-mode split3 needs the 3-term split GEMM"
+    comm = {"bytes": 0, "ms": 0.0, "calls": 0}
 
-    nq, ng = (NQ // 16, NG // 16) if a.small else (NQ, NG)
-    q_lo, q_hi = D.shard_range(nq, rank, world)
-    nq_local = q_hi - q_lo
-    n_local = nq_local + ng
-    enc = ops.VitEncoder(synth.VIT_B16, synth.vit_state_dict(synth.VIT_B16, seed=7), (H, W))
-    imgs = make_images(n_local, 1234 + rank, dev)
-    feats = torch.empty((n_local, enc.feat_dim), dtype=torch.float32, device=dev)
-    block = torch.empty((nq, ng), dtype=torch.float32, device=dev)
+    def gather_rows(x, n_total):
+        """all_gather_rows with its bytes and (event-timed) duration recorded"""
+        if world == 1:
+            return x
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        y = D.all_gather_rows(x, n_total)
+        e1.record()
+        comm["ev"] = comm.get("ev", []) + [(e0, e1)]
+        comm["bytes"] += y.numel() * y.element_size()
+        comm["calls"] += 1
+        return y
 
     nstreams = max(1, a.streams)
-    side = [torch.cuda.Stream(device=dev) for _ in range(nstreams - 1)]
-    encs = [enc] + [enc.clone_for_stream(f"vit{i + 1}") for i in range(nstreams - 1)]
+    div = 16 if a.small else 1
+    wl = a.workload
+    enc = None
+    if wl in ("market", "msmt17"):
+        enc = ops.VitEncoder(synth.VIT_B16, synth.vit_state_dict(synth.VIT_B16, seed=7), (H, W))
+        side = [torch.cuda.Stream(device=dev) for _ in range(nstreams - 1)]
+        encs = [enc] + [enc.clone_for_stream(f"vit{i + 1}") for i in range(nstreams - 1)]
 
-    def step():
+    def encode_all(imgs, feats):
         main = torch.cuda.current_stream()
         for st in side:
             st.wait_stream(main)
+        n_local = imgs.shape[0]
         for bi, s in enumerate(range(0, n_local, a.batch)):
             e = min(n_local, s + a.batch)
             k = bi % len(encs)
@@ -213,13 +394,57 @@ def main():
                     encs[k](imgs[s:e], out=feats[s:e])
         for st in side:
             main.wait_stream(st)
-        fn = ops.l2_normalize(feats)
-        qf = D.all_gather_rows(fn[:nq_local], nq)   # RCCL all-gather of the query features (N > 1)
-        ops.euclidean_distance(qf, fn[nq_local:], out=block)
+
+    if wl == "market":
+        # weak scaling: every rank owns a whole Market-1501-sized gallery shard + 1/world of the queries
+        nq, ng = NQ // div, NG // div
+        q_lo, q_hi = D.shard_range(nq, rank, world)
+        nq_local, ng_local = q_hi - q_lo, ng
+        ng_total = world * ng
+        scaling = "weak"
+        imgs = make_images(nq_local + ng_local, 1234 + rank, dev)
+        feat_dim = enc.feat_dim
+        images_per_step = nq + ng_total
+    elif wl == "msmt17":
+        nq, ng_total = MSMT_NQ // div, MSMT_NG // div
+        q_lo, q_hi = D.shard_range(nq, rank, world)
+        g_lo, g_hi = D.shard_range(ng_total, rank, world)
+        nq_local, ng_local = q_hi - q_lo, g_hi - g_lo
+        scaling = "strong"
+        imgs = make_images(nq_local + ng_local, 1234 + rank, dev)
+        feat_dim = enc.feat_dim
+        images_per_step = nq + ng_total
+    else:  # synth: features are the input (BASELINE configs[3] "768-d feats")
+        nq, ng_total = SYN_NQ // div, SYN_NG // div
+        q_lo, q_hi = D.shard_range(nq, rank, world)
+        g_lo, g_hi = D.shard_range(ng_total, rank, world)
+        nq_local, ng_local = q_hi - q_lo, g_hi - g_lo
+        scaling = "strong"
+        allf, _ = make_features(nq + ng_total, SYN_D, 3.0, 1234, dev)
+        fq_local = allf[q_lo:q_hi].clone()
+        fg_local = allf[nq + g_lo: nq + g_hi].clone()
+        del allf
+        feat_dim = SYN_D
+        images_per_step = nq + ng_total
+    if wl != "synth":
+        feats = torch.empty((nq_local + ng_local, feat_dim), dtype=torch.float32, device=dev)
+    block = torch.empty((nq, ng_local), dtype=torch.float32, device=dev)
+    rr_holder = {}
+
+    def step():
+        if wl == "synth":
+            fq, fg = fq_local, fg_local
+        else:
+            encode_all(imgs, feats)
+            fn = ops.l2_normalize(feats)
+            fq, fg = fn[:nq_local], fn[nq_local:]
+        qf = gather_rows(fq, nq)                       # RCCL all-gather of the query features (N > 1)
+        ops.euclidean_distance(qf, fg, mode=mode, out=block)
         if a.rerank:
-            gf_all = D.all_gather_rows(fn[nq_local:], world * ng) if world > 1 else fn[nq_local:]
+            gf_all = gather_rows(fg, ng_total)          # every rank needs all features for its rows of the N x N problem
             rr = D.re_ranking_sharded(qf, gf_all, 50, 15, 0.3)   # this rank's final_dist[q_lo:q_hi, nq:]
-            assert rr.shape[1] == world * ng
+            assert rr.shape[1] == ng_total
+            rr_holder["rr"] = rr
 
     def fence():
         torch.cuda.synchronize()
@@ -230,7 +455,8 @@ def main():
     for _ in range(a.warmup):
         step()
     fence()
-    instrument_live = nstreams == 1   # event pairs on one stream also span other streams' kernels
+    comm.update(bytes=0, calls=0, ev=[])
+    instrument_live = nstreams == 1 or enc is None   # event pairs on one stream also span other streams' kernels
     L.mpreid_profile_reset()
     if instrument_live:
         L.mpreid_profile_enable(1)
@@ -240,15 +466,17 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     L.mpreid_profile_enable(0)
+    comm_ms = sum(e0.elapsed_time(e1) for e0, e1 in comm.get("ev", []))
+    comm_bytes, comm_calls = comm["bytes"], comm["calls"]
     if not instrument_live:
         # roofline leg: one more pass of the same work on ONE stream with per-launch hipEvents
-        saved = (nstreams, list(side), list(encs))
-        nstreams, side[:], encs[:] = 1, [], [enc]
+        saved = (list(side), list(encs))
+        side[:], encs[:] = [], [enc]
         L.mpreid_profile_enable(1)
         step()
         fence()
         L.mpreid_profile_enable(0)
-        nstreams, side[:], encs[:] = saved[0], saved[1], saved[2]
+        side[:], encs[:] = saved
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -256,14 +484,15 @@ def main():
     assert torch.isfinite(block).all()
 
     if rank == 0:
-        total_images = (nq + world * ng) * a.steps
         ents = (_lib.ProfileEntry * 16)()
         n_ent = L.mpreid_profile_query(ents, 16)
         classes = []
         for i in range(min(n_ent, 16)):
             e = ents[i]
             avg_ms = e.total_ms / max(e.launches, 1)
-            classes.append({"kernel": f"gemm_f16_big_kernel<{_lib.GEMM_EPILOGUE_NAMES.get(e.epilogue, e.epilogue)}>" if e.m % 256 == 0 and e.m * e.n >= 128 * 65536 else f"gemm_f16_kernel<{_lib.GEMM_EPILOGUE_NAMES.get(e.epilogue, e.epilogue)}>",
+            big = e.m % 256 == 0 and e.m * e.n >= 128 * 65536
+            classes.append({"kernel": ("gemm_f16_big_kernel<%s>" if big else "gemm_f16_kernel<%s>") %
+                                      _lib.GEMM_EPILOGUE_NAMES.get(e.epilogue, e.epilogue),
                             "M": e.m, "N": e.n, "K": e.k, "launches": e.launches, "avg_ms": round(avg_ms, 4),
                             "total_ms": round(e.total_ms, 2), "gflop_per_launch": round(e.flops_total / max(e.launches, 1) / 1e9, 2),
                             "tflops": round(e.flops_total / e.total_ms / 1e9, 1) if e.total_ms > 0 else None})
@@ -278,6 +507,7 @@ def main():
         except Exception:
             traffic = None
         if top:
+            step_ms = dt / a.steps * 1e3
             roof = {"bound": "mfma", "kernel": top["kernel"], "shape": [top["M"], top["N"], top["K"]],
                     "achieved": top["tflops"], "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                     "algorithmic_gflop_per_launch": top["gflop_per_launch"],
@@ -292,33 +522,79 @@ def main():
                     "all_gemm_tflops": round(sum(c["tflops"] * c["total_ms"] for c in classes) /
                                              max(sum(c["total_ms"] for c in classes), 1e-9), 1),
                     "gemm_share_of_step": round(sum(c["total_ms"] for c in classes) /
-                                                (dt * 1e3 if instrument_live else dt / a.steps * 1e3), 3)}
+                                                (dt * 1e3 if instrument_live else step_ms), 3)}
+        desc = {
+            "market": "Market-1501 shape on MI355X (BASELINE configs[1]): ViT-B/16 encode of "
+                      f"{nq} query + {NG // div} gallery 3x256x128 images per GPU shard (seeded random init), "
+                      "L2-normalise, all-gather query features, euclidean distmat "
+                      f"[{nq} x {NG // div}] per GPU ({a.dist_mode})",
+            "msmt17": f"MSMT17 shape (BASELINE configs[4]): ViT-B/16 encode of {nq} query + {ng_total} gallery "
+                      f"images sharded over {world} GPU(s), L2-normalise, all-gather query features, euclidean "
+                      f"distmat [{nq} x {ng_total}/{world}] at D=1280 ({a.dist_mode})",
+            "synth": f"synthetic {nq}-query x {ng_total}-gallery x {SYN_D} features (BASELINE configs[3]), gallery rows "
+                     f"sharded over {world} GPU(s), all-gather query features, euclidean distmat "
+                     f"[{nq} x {ng_total}/{world}] per GPU ({a.dist_mode})",
+        }[wl] + (", plus k-reciprocal re-ranking (k1=50, k2=15, lambda=0.3) of all queries against the whole gallery, "
+                 "rows sharded over the GPUs" if a.rerank else ", no re-rank")
         res = {
-            "metric": "gallery images/s encode + distmat+rerank ms, 20k×20k; mAP/Rank-1 parity",
-            "value": round(total_images / dt, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps,
+            "metric": METRIC,
+            "value": round(images_per_step * a.steps / dt, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f16 MFMA operands, f32 accumulate/residual; distmat f32",
+            "scaling": scaling, "vs_baseline": None,
+            "dtype": ("f16 MFMA operands, f32 accumulate/residual; " if enc is not None else "") +
+                     {"exact": "distmat f32 (exact fp32 MFMA)", "f16": "distmat f16 operands one pass, f32 accumulate",
+                      "split3": "distmat 3-term f16 split, f32 accumulate"}[a.dist_mode],
             "data": "synthetic",
-            "config": {"workload": "Market-1501 shape on MI355X (BASELINE configs[1]): ViT-B/16 encode of "
-                                   f"{nq} query + {ng} gallery 3x256x128 images per GPU shard (seeded random init), "
-                                   "L2-normalise, all-gather query features, euclidean distmat "
-                                   f"[{nq} x {ng}] per GPU (exact fp32 MFMA), " +
-                                   ("plus k-reciprocal re-ranking (k1=50, k2=15, lambda=0.3) of all queries against the "
-                                    "whole gallery, rows sharded over the GPUs" if a.rerank else "no re-rank"),
-                       "images_per_step": nq + world * ng, "encoder_batch": a.batch, "encoder_streams": nstreams,
-                       "sharding": f"gallery rows over {world} GPU(s), queries 1/{world} each + all-gather"},
-            "encode_tflops_algorithmic": round(total_images * GFLOP_PER_IMG / dt / 1e3, 1),
+            "config": {"workload": desc, "images_per_step": images_per_step, "encoder_batch": a.batch if enc else None,
+                       "encoder_streams": nstreams if enc else None,
+                       "sharding": (f"gallery rows over {world} GPU(s), queries 1/{world} each + all-gather")},
             "roofline": roof, "gemm_classes": classes,
         }
+        if enc is not None:
+            res["encode_tflops_algorithmic"] = round(images_per_step * a.steps * GFLOP_PER_IMG / dt / 1e3, 1)
+        else:
+            res["distmat_tflops_algorithmic"] = round(2.0 * nq * ng_total * SYN_D * a.steps / dt / 1e12, 1)
+            res["unit_note"] = "images/s = (query + gallery feature rows) per second through distmat (+ re-rank)"
+        if world > 1:
+            res["all_gather"] = {"calls_per_step": comm_calls / max(a.steps, 1),
+                                 "bytes_per_step": int(comm_bytes / max(a.steps, 1)),
+                                 "ms_per_step": round(comm_ms / max(a.steps, 1), 3),
+                                 "gb_per_s": round(comm_bytes / max(comm_ms, 1e-9) / 1e6, 2),
+                                 "note": "bytes = gathered output per rank (RCCL all_gather_into_tensor over xGMI); "
+                                         "hipEvents on the launch stream of rank 0"}
+        if wl == "msmt17" or (wl == "synth" and a.dist_mode == "exact"):
+            # fp16-MFMA distance mode against the exact fp32 mode on this rank's first 2048 x 8192 block
+            qf_s = (ops.l2_normalize(feats)[:min(nq_local, 2048)] if wl != "synth" else fq_local[:2048])
+            gf_s = (ops.l2_normalize(feats)[nq_local:nq_local + 8192] if wl != "synth" else fg_local[:8192])
+            ex = ops.euclidean_distance(qf_s, gf_s)
+            f16 = ops.euclidean_distance(qf_s, gf_s, mode=ops.GEMM_F16_FAST)
+            chk = {"fp16_one_pass_max_abs_err": float((ex - f16).abs().max())}
+            if hasattr(ops, "GEMM_F16_SPLIT3"):
+                s3 = ops.euclidean_distance(qf_s, gf_s, mode=ops.GEMM_F16_SPLIT3)
+                chk["fp16_split3_max_abs_err"] = float((ex - s3).abs().max())
+            res["tolerance_check_vs_exact_fp32"] = chk
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.cpu_images)
         if world == 1 and not a.no_extras and not a.small:
+            del block
+            if wl != "synth":
+                del imgs, feats
+            ops.release_workspaces()
             torch.cuda.empty_cache()
-            res["extras"] = extras(ops, dev)
+            res["extras"], roofs = extras(ops, dev, with_widened=(wl == "market"))
+            res["roofline_all"] = ([dict(roof, stage="encoder dominant GEMM class")] if roof else []) + roofs
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    a = parse()
+    if a.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        launch_children(a.gpus)
+        return
+    run_rank(a)
 
 
 if __name__ == "__main__":

@@ -67,6 +67,7 @@ typedef struct {
     int64_t v_nnz;        /* nnz(V) before query expansion */
     int64_t vqe_nnz;      /* nnz(V) after query expansion (== v_nnz when k2 == 1) */
     int64_t jaccard_pairs;/* sum over queries i, columns c in nz(V[i]) of nnz(V[:,c]) */
+    int64_t krecip_r_sum; /* sum over rows of |R(i, k1)| (k-reciprocal set sizes before expansion) */
     float ms_gemm, ms_topk, ms_krecip, ms_qe, ms_csc, ms_jaccard, ms_total; /* filled when timing != 0 */
 } mpreid_rerank_stats;
 

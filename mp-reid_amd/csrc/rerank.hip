@@ -578,7 +578,8 @@ __device__ __forceinline__ int extract_bits_sorted(const unsigned *mask, int nw,
 __global__ __launch_bounds__(64) void krecip_kernel(const float *__restrict__ MT, int64_t ld, int64_t N,
                                                     const float *__restrict__ rowmax, const int *__restrict__ rank,
                                                     int K, int KR, int h, int vcap, int *__restrict__ vcnt,
-                                                    int *__restrict__ vidx, uint16_t *__restrict__ vval, int row0) {
+                                                    int *__restrict__ vidx, uint16_t *__restrict__ vval, int row0,
+                                                    unsigned long long *__restrict__ r_counter) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nw = (int)((N + 31) >> 5);
     unsigned *Rmask = (unsigned *)smem;
@@ -618,6 +619,7 @@ __global__ __launch_bounds__(64) void krecip_kernel(const float *__restrict__ MT
         }
         nR += __popcll(m);
     }
+    if (r_counter && lane == 0) atomicAdd(r_counter, (unsigned long long)nR);
     __syncthreads();
 
     // expansion: candidates in R order; their own k/2-reciprocal sets, accepted on > 2/3 overlap with R
@@ -1056,6 +1058,7 @@ extern "C" int mpreid_rerank_f32(const float *q, const float *g, int64_t nq, int
     const int nw = (int)((N + 31) >> 5);
 
     StageTimer tm(timing != 0, stream);
+    HIP_TRY(hipMemsetAsync(counters, 0, 64, stream));
     tm.mark(); // 0
     // (1) original_dist
     if (!only_local) {
@@ -1085,7 +1088,7 @@ extern "C" int mpreid_rerank_f32(const float *q, const float *g, int64_t nq, int
         int rc = set_dyn_lds(krecip_kernel, lds);
         if (rc) return rc;
         hipLaunchKernelGGL(krecip_kernel, dim3((unsigned)N), dim3(64), lds, stream, MT, L.ld, N, rowmax, rank, L.K,
-                           L.KR, L.h, L.vcap, vcnt, vidx, vval, 0);
+                           L.KR, L.h, L.vcap, vcnt, vidx, vval, 0, counters + 1);
         LAUNCH_CHECK();
     }
     tm.mark(); // 3
@@ -1129,7 +1132,6 @@ extern "C" int mpreid_rerank_f32(const float *q, const float *g, int64_t nq, int
     tm.mark(); // 4
     // inverted index
     HIP_TRY(hipMemsetAsync(ccnt, 0, (size_t)(N + 1) * 4, stream));
-    HIP_TRY(hipMemsetAsync(counters, 0, 64, stream));
     hipLaunchKernelGGL(csc_count_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, N, fcnt, fidx, qcap,
                        ccnt);
     hipLaunchKernelGGL(csc_scan_kernel, dim3(1), dim3(1024), 0, stream, N, ccnt, cptr);
@@ -1151,9 +1153,10 @@ extern "C" int mpreid_rerank_f32(const float *q, const float *g, int64_t nq, int
         LAUNCH_CHECK();
     }
     tm.mark(); // 6
-    unsigned long long pairs = 0;
+    unsigned long long pairs = 0, r_sum = 0;
     long long nnz_total = 0;
     HIP_TRY(hipMemcpyAsync(&pairs, counters, 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(&r_sum, counters + 1, 8, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(&nnz_total, cptr + N, 8, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     q_nnz = nnz_total;
@@ -1167,6 +1170,7 @@ extern "C" int mpreid_rerank_f32(const float *q, const float *g, int64_t nq, int
         stats->v_nnz = v_nnz;
         stats->vqe_nnz = q_nnz;
         stats->jaccard_pairs = (int64_t)pairs;
+        stats->krecip_r_sum = (int64_t)r_sum;
         stats->ms_gemm = tm.ms(0, 1);
         stats->ms_topk = tm.ms(1, 2);
         stats->ms_krecip = tm.ms(2, 3);
@@ -1274,7 +1278,8 @@ extern "C" int mpreid_rr_krecip(const float *d_local, int64_t ld, int64_t n, con
     int rc = set_dyn_lds(krecip_kernel, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(krecip_kernel, dim3((unsigned)rows), dim3(64), lds, (hipStream_t)stream_, d_local, ld, n,
-                       rowmax_local, rank_all, K, kr, h, vcap, vcnt, vidx, vval, (int)r_lo);
+                       rowmax_local, rank_all, K, kr, h, vcap, vcnt, vidx, vval, (int)r_lo,
+                       (unsigned long long *)nullptr);
     LAUNCH_CHECK();
     return MPREID_OK;
 }

@@ -34,7 +34,7 @@ SYMBOLS = [
 class RerankStats(C.Structure):
     _fields_ = [("n", C.c_int64), ("k1", C.c_int32), ("k2", C.c_int32), ("half_k1", C.c_int32),
                 ("v_cap", C.c_int32), ("vqe_cap", C.c_int32), ("v_nnz", C.c_int64), ("vqe_nnz", C.c_int64),
-                ("jaccard_pairs", C.c_int64), ("ms_gemm", C.c_float), ("ms_topk", C.c_float),
+                ("jaccard_pairs", C.c_int64), ("krecip_r_sum", C.c_int64), ("ms_gemm", C.c_float), ("ms_topk", C.c_float),
                 ("ms_krecip", C.c_float), ("ms_qe", C.c_float), ("ms_csc", C.c_float),
                 ("ms_jaccard", C.c_float), ("ms_total", C.c_float)]
 

@@ -56,3 +56,21 @@ def test_two_rank_sharded_distmat_matches_single_rank(tmp_path):
     want = orc.euclidean_distance(orc.l2_normalize(f[:nq] * 3.0), orc.l2_normalize(f[nq:] * 3.0))
     got = np.load(out)
     assert got.shape == (nq, ng) and np.array_equal(got, want)
+
+
+def test_bench_parent_launches_ranks_without_touching_the_gpu():
+    """`python bench.py --gpus 2` with no launcher: the parent spawns 2 fresh rank processes itself (it must not
+    assert on WORLD_SIZE, import the HIP library or re-exec).  Without a GPU the ranks fail loudly and the parent
+    reports that with exit code 1 instead of hanging or printing a bogus line."""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("CPU-only check of the launcher's failure path (the success path is tests/test_gpu_distributed.py)")
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--small", "--steps", "1",
+                        "--warmup", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 1
+    assert "child ranks exited with" in r.stderr and "AssertionError: --gpus" not in r.stderr
+    assert r.stdout.strip() == ""
