@@ -81,7 +81,10 @@ size_t mpreid_rerank_workspace_bytes(int64_t nq, int64_t ng, int d, int k1, int 
  * lambda is a double because the reference rounds (1 - lambda) from a Python float straight to
  * float16 and lambda to float32.  The call synchronises `stream` internally (sizes of the sparse
  * structures are read back) and returns after the result is complete.
- * stats may be NULL; with timing != 0 per-stage times are measured with hipEvents on `stream`. */
+ * stats may be NULL; with timing != 0 per-stage times are measured with hipEvents on `stream`.
+ * Limits: max(k1 + 1, k2) <= 256 (the neighbour selection sorts its winners in one 256-entry LDS network; the
+ * reference is called with k1 = 50, k2 = 15, utils/metrics.py:127) -> MPREID_ERR_UNSUPPORTED above that;
+ * N = nq + ng < 2^31 - 64. */
 int mpreid_rerank_f32(const float *q_dev, const float *g_dev, int64_t nq, int64_t ng, int d, int k1, int k2,
                       double lambda_value, const float *local_dev, int only_local, float *out_dev,
                       int64_t ldo, void *ws_dev, size_t ws_bytes, mpreid_stream_t stream,
@@ -98,7 +101,9 @@ int mpreid_rerank_debug_copy(const void *ws_dev, int64_t nq, int64_t ng, int d, 
  * For every query: the 0-based positions, in the ascending (distance, gallery index) order of its row, of the
  * gallery items whose pid equals the query's pid (what the reference reads off np.argsort + matches).
  * pos_out [nq][rcap] int32 ascending, padded with -1; cnt_out [nq] = number of relevant items, or -1 when a
- * query has more than min(rcap, 2048) of them (the caller ranks that row on the host).  CMC / AP are finished
+ * query has more than min(rcap, 2048) of them (LIMIT: the sorted relevant keys of a query live in LDS, 2048 entries;
+ * the caller ranks such a row on the host -- utils/metrics.py:eval_func_device does -- Market-1501 / MSMT17 queries
+ * have at most a few hundred relevant gallery images).  CMC / AP are finished
  * on the host from the positions (float64, numpy's summation order): mp-reid_amd/utils/metrics.py. */
 int mpreid_eval_rank_positions(const float *dist_dev, int64_t ld, int nq, int ng, const int64_t *q_pids_dev,
                                const int64_t *g_pids_dev, int rcap, int32_t *pos_out_dev, int32_t *cnt_out_dev,

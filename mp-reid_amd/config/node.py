@@ -39,6 +39,8 @@ class CfgNode(dict):
 
     def _merge(self, other):
         for k, v in other.items():
+            if v is None:      # a section whose keys are all commented out (reference YAMLs have these)
+                continue
             if isinstance(v, dict):
                 if k not in self or not isinstance(self[k], CfgNode):
                     self[k] = CfgNode()

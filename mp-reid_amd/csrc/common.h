@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 
 #include "../../include/mpreid.h"
 #include "../../include/mpreid_numerics.h"
@@ -56,3 +57,21 @@ __device__ __forceinline__ float wave_bfly_add(float s) {
     for (int off = 32; off >= 1; off >>= 1) s = s + __shfl_xor(s, off, 64);
     return s;
 }
+
+
+// Run `f` (returns an mpreid/hip status) once per HIP device for the call site that owns this object: function
+// attributes (dynamic LDS size) and occupancy queries are per device, and one process may drive several GPUs.
+struct PerDeviceOnce {
+    std::mutex mu;
+    bool done[64] = {};
+    template <typename F>
+    int run(F f) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev >= 0 && dev < 64 && done[dev]) return MPREID_OK;
+        const int rc = f();
+        if (rc == MPREID_OK && dev >= 0 && dev < 64) done[dev] = true;
+        return rc;
+    }
+};

@@ -192,11 +192,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs g, int tiles
 template <int TAPS, bool RELU, int BN>
 static int launch_conv_variant(const ConvArgs &a, hipStream_t stream) {
     const int tiles_m = (a.M + CBM - 1) / CBM, tiles_n = (a.N + BN - 1) / BN;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm_kernel<TAPS, RELU, BN>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_bytes(BN)));
-        attr_set = true;
+    static PerDeviceOnce attr_once;
+    {
+        const int rc = attr_once.run([]() -> int {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm_kernel<TAPS, RELU, BN>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_bytes(BN)));
+            return MPREID_OK;
+        });
+        if (rc) return rc;
     }
     hipLaunchKernelGGL((conv_gemm_kernel<TAPS, RELU, BN>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), conv_lds_bytes(BN),
                        stream, a, tiles_m, tiles_n);

@@ -845,23 +845,28 @@ extern "C" int mpreid_profile_query(mpreid_profile_entry *out, int cap) {
 
 template <int EPI>
 static int launch_one(const GemmArgs &a, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_kernel<EPI>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES));
-        attr_set = true;
+    static PerDeviceOnce attr_once;
+    {
+        const int rc = attr_once.run([]() -> int {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_kernel<EPI>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES));
+            return MPREID_OK;
+        });
+        if (rc) return rc;
     }
     constexpr bool HAS_BIG = (EPI == GE_F32 || EPI == GE_BIAS_F16 || EPI == GE_BIAS_RES || EPI == GE_BIAS_GELU ||
                               EPI == GE_EUCLID || EPI == GE_PATCH || EPI == GE_BIAS_RELU || EPI == GE_BIAS_ADD_RELU);
     const int bm = big_mode();
     const bool use_big = HAS_BIG && bm > 0 && (a.M % BBM == 0) && (a.N % BBN == 0) &&
                          (bm >= 2 || (int64_t)(a.M / BBM) * (a.N / BBN) >= 128);
-    static bool big_attr_set = false;
-    if (HAS_BIG && !big_attr_set) {
-        if constexpr (HAS_BIG)
+    if constexpr (HAS_BIG) {
+        static PerDeviceOnce big_attr_once;
+        const int rc = big_attr_once.run([]() -> int {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_big_kernel<EPI>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_TOTAL));
-        big_attr_set = true;
+            return MPREID_OK;
+        });
+        if (rc) return rc;
     }
     const int tiles_m = use_big ? a.M / BBM : a.M / GBM, tiles_n = use_big ? a.N / BBN : a.N / GBN;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -874,23 +879,23 @@ static int launch_one(const GemmArgs &a, hipStream_t stream) {
         if constexpr (HAS_BIG) {
             static const int dbg = getenv("MPREID_GEMM_DBG") ? atoi(getenv("MPREID_GEMM_DBG")) : 0;
             // persistent: one workgroup per CU (the kernel owns the CU's whole LDS), each walking tiles
-            static int big_cus = 0;
-            if (big_cus == 0) {
+            int big_cus = 0;
+            {
                 int dev = 0;
                 HIP_TRY(hipGetDevice(&dev));
-                HIP_TRY(hipDeviceGetAttribute(&big_cus, hipDeviceAttributeMultiprocessorCount, dev));
+                static int cus_of[64] = {0};   // benign race: every writer stores the same value
+                const int slot = (dev >= 0 && dev < 64) ? dev : 0;
+                if (cus_of[slot] == 0 || slot != dev)
+                    HIP_TRY(hipDeviceGetAttribute(&cus_of[slot], hipDeviceAttributeMultiprocessorCount, dev));
+                big_cus = cus_of[slot];
             }
             const unsigned total_tiles = (unsigned)tiles_m * (unsigned)tiles_n;
             const dim3 grid(total_tiles < (unsigned)big_cus ? total_tiles : (unsigned)big_cus);
             if constexpr (EPI == GE_BIAS_F16) {
 #define MPREID_DBG_CASE(D)                                                                                  \
     case D: {                                                                                               \
-        static bool once = false;                                                                           \
-        if (!once) {                                                                                        \
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_big_kernel<EPI, D>),        \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_TOTAL));          \
-            once = true;                                                                                    \
-        }                                                                                                   \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_big_kernel<EPI, D>),            \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_TOTAL));              \
         hipLaunchKernelGGL((gemm_f16_big_kernel<EPI, D>), grid, dim3(512), B_LDS_TOTAL, stream, a, tiles_m, tiles_n); \
         break;                                                                                              \
     }

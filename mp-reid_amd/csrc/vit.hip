@@ -16,6 +16,7 @@
 // Kernels: im2col (HBM), GEMM+epilogues (MFMA, gemm_f16.hip), LayerNorm (HBM), attention (MFMA +
 // LDS; L = 129 keys fit one workgroup), head (L2).
 #include <cstdlib>
+#include <mutex>
 
 #include "gemm_f16.h"
 
@@ -541,26 +542,34 @@ static int launch_attention(const _Float16 *qkv, int B, int L, int W, int heads,
                             hipStream_t stream) {
     constexpr int KEYS = KTP * 16;
     const size_t lds = (size_t)2 * KEYS * 128 + (size_t)NW * 16 * 72 * 2;
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_kernel<KTP, NW, EXACT>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
-    // persistent grid: as many workgroups as fit the chip at once (LDS and the 4-waves/SIMD register
-    // bound), each walking pairs with stride gridDim
-    static int blocks_per_cu = 0;
-    if (blocks_per_cu == 0) {
-        int occ = 0;
-        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void *>(attention_kernel<KTP, NW, EXACT>),
-                                                            64 * NW, lds));
-        blocks_per_cu = occ > 0 ? occ : 1;
-        if (getenv("MPREID_DEBUG"))
-            fprintf(stderr, "[mpreid] attention<%d,%d>: %d workgroups/CU by the occupancy API (lds %zu B, %d threads)\n", KTP,
-                    NW, occ, lds, 64 * NW);
-    }
+    // per-device state (a process may drive several GPUs: the reference's do_inference is multi-device in one
+    // process, processor/processor.py:178-182): the dynamic-LDS attribute and the occupancy are set / queried once
+    // per HIP device, under a mutex
+    constexpr int MAX_DEV = 64;
+    static std::mutex mu;
+    static int blocks_per_cu_dev[MAX_DEV] = {0};
     int dev = 0, cus = 256;
     HIP_TRY(hipGetDevice(&dev));
+    int blocks_per_cu;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        const int slot = dev < MAX_DEV ? dev : MAX_DEV - 1;
+        if (blocks_per_cu_dev[slot] == 0 || dev >= MAX_DEV) {
+            if (lds > 48 * 1024)
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_kernel<KTP, NW, EXACT>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            // persistent grid: as many workgroups as fit the chip at once (LDS and the 4-waves/SIMD register
+            // bound), each walking pairs with stride gridDim
+            int occ = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+                &occ, reinterpret_cast<const void *>(attention_kernel<KTP, NW, EXACT>), 64 * NW, lds));
+            blocks_per_cu_dev[slot] = occ > 0 ? occ : 1;
+            if (getenv("MPREID_DEBUG"))
+                fprintf(stderr, "[mpreid] attention<%d,%d> on device %d: %d workgroups/CU by the occupancy API (lds %zu B, %d threads)\n",
+                        KTP, NW, dev, occ, lds, 64 * NW);
+        }
+        blocks_per_cu = blocks_per_cu_dev[slot];
+    }
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const int total = B * heads;
     int grid = cus * blocks_per_cu;

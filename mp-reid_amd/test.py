@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Evaluation entry point of the HIP build -- the counterpart of the reference's ``test.py`` (test.py:10-65):
+
+    python test.py --config_file configs/person/vit_base.yml [KEY VALUE ...]
+
+config (YAML + command-line overrides, frozen) -> logger ("transreid", <OUTPUT_DIR>/test_log.txt) -> val loader ->
+model -> ``load_param(TEST.WEIGHT)`` -> ``do_inference`` (ViT-B/16 on the GPU, R1_mAP_eval with the HIP distance /
+re-ranking kernels).  Differences from the reference, on purpose: TEST.WEIGHT may be empty (seeded random weights, for
+smoke runs); MODEL.DEVICE_ID selects the HIP device through HIP_VISIBLE_DEVICES *before* anything touches the GPU;
+the VehicleID 10-trial loop is not reproduced (VehicleID's parser is out of scope); ``main`` returns
+(rank1, rank5) so that tests can call it in-process.
+"""
+import argparse
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="MP-ReID evaluation on MI355X (HIP build)")
+    p.add_argument("--config_file", default=os.path.join("configs", "person", "vit_base.yml"), type=str,
+                   help="path to config file ('' = built-in defaults only)")
+    p.add_argument("opts", default=None, nargs=argparse.REMAINDER,
+                   help="KEY VALUE pairs overriding config options, e.g. TEST.RE_RANKING True")
+    return p
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    from config import cfg_base
+    cfg = cfg_base.clone()
+    cfg.defrost()
+    if args.config_file:
+        cfg.merge_from_file(args.config_file)
+    cfg.merge_from_list(args.opts)
+    cfg.freeze()
+
+    if cfg.OUTPUT_DIR:
+        os.makedirs(cfg.OUTPUT_DIR, exist_ok=True)
+    # device selection has to happen before the HIP runtime initialises (the reference sets CUDA_VISIBLE_DEVICES here)
+    os.environ.setdefault("HIP_VISIBLE_DEVICES", str(cfg.MODEL.DEVICE_ID))
+
+    from utils.logger import setup_logger
+    logger = setup_logger("transreid", cfg.OUTPUT_DIR, if_train=False)
+    logger.info(args)
+    if args.config_file:
+        logger.info("Loaded configuration file {}".format(args.config_file))
+        with open(args.config_file) as fh:
+            logger.info("\n" + fh.read())
+    logger.info("Running with config:\n{}".format(cfg))
+
+    from datasets.make_dataloader import make_dataloader
+    from model.make_model import make_model
+    from processor.processor import do_inference
+
+    _, _, val_loader, num_query, num_classes, camera_num, view_num = make_dataloader(cfg)
+    model = make_model(cfg, num_class=num_classes, camera_num=camera_num, view_num=view_num)
+    if cfg.TEST.WEIGHT:
+        model.load_param(cfg.TEST.WEIGHT)
+    else:
+        logger.info("TEST.WEIGHT is empty: evaluating the seeded random initialisation (MODEL.INIT_SEED)")
+    return do_inference(cfg, model, val_loader, num_query)
+
+
+if __name__ == "__main__":
+    main()

@@ -85,6 +85,11 @@ def test_do_inference_matches_oracle_pipeline(neck, rerank, caplog):
     if not rerank:
         # distances between fp16-encoder features vs fp32-oracle features: feature error 4e-3 relative
         assert np.abs(distmat - d_or).max() < 2e-2 * max(1.0, np.abs(d_or).max())
+    # Rank-1 / mAP of the HIP pipeline against the ORACLE pipeline's (24 queries of random-init features: one
+    # swapped pair moves mAP by ~1e-2; the tight image -> mAP bound is tests/test_gpu_map_parity.py)
+    cmc_or, map_or = orc.eval_func(d_or, pids[:num_query], pids[num_query:])
+    assert abs(mAP - map_or) <= 3e-2 and np.abs(cmc[:len(cmc_or)] - cmc_or).max() <= 1.0 / num_query + 1e-6, \
+        (mAP, map_or, np.abs(cmc[:len(cmc_or)] - cmc_or).max())
 
 
 def test_load_param_roundtrip(tmp_path):
@@ -308,3 +313,76 @@ def test_rn50_tta_views_and_uniprompt_branches():
     full = m(x=x)
     assert full.shape == (3, 3072)
     assert torch.allclose(full[:, 2048:] * float(np.sqrt(1 + 1e-5)), proj, rtol=1e-5, atol=1e-5)
+
+
+def test_cli_harness_end_to_end(tmp_path, capsys):
+    """the build's own test.py: argparse -> cfg.merge_from_file(yaml) + overrides -> setup_logger -> make_dataloader
+    -> make_model -> load_param(TEST.WEIGHT) -> do_inference, with a YAML shaped like the reference's
+    configs/person/vit_base.yml (training sections included, a section with every key commented out) and
+    TEST.RE_RANKING True.  The numbers it logs must be those of the same model driven directly."""
+    import importlib.util
+    import os
+    import re
+    from mpreid import synth
+    from datasets.make_dataloader import make_dataloader
+    from model.make_model import make_model
+    from processor.processor import do_inference
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mp-reid_amd")
+    yml = tmp_path / "vit_base.yml"
+    yml.write_text("""
+MODEL:
+  PRETRAIN_CHOICE: 'imagenet'
+  METRIC_LOSS_TYPE: 'triplet'
+  NAME: 'ViT-B-16'
+  STRIDE_SIZE: [16, 16]
+INPUT:
+  SIZE_TRAIN: [256, 128]
+  SIZE_TEST: [256, 128]
+  PROB: 0.5
+  PIXEL_MEAN: [0.5, 0.5, 0.5]
+  PIXEL_STD: [0.5, 0.5, 0.5]
+DATALOADER:
+  SAMPLER: 'softmax_triplet'
+  NUM_WORKERS: 8
+SOLVER:
+  IMS_PER_BATCH: 64
+  BASE_LR: 0.000005
+  STEPS: [30, 50]
+TEST:
+  EVAL: True
+  IMS_PER_BATCH: 64
+  RE_RANKING: False
+  WEIGHT: ''
+  NECK_FEAT: 'before'
+  FEAT_NORM: 'yes'
+DATASETS:
+#   NAMES: ('market1501')
+#   ROOT_DIR: ('')
+""")
+    # a checkpoint whose weights differ from the constructor's seeded initialisation
+    sd = synth.vit_state_dict(synth.VIT_B16, seed=41, std=0.02, ln_jitter=0.05)
+    ckpt = tmp_path / "ViT-B-16_60.pth"
+    torch.save({"image_encoder." + k: torch.from_numpy(v) for k, v in sd.items()}, ckpt)
+    out_dir = tmp_path / "logs"
+    overrides = ["TEST.WEIGHT", str(ckpt), "TEST.RE_RANKING", "True", "OUTPUT_DIR", str(out_dir),
+                 "DATASETS.SYNTH_QUERY", "40", "DATASETS.SYNTH_GALLERY", "120", "DATASETS.SYNTH_IDS", "16",
+                 "TEST.IMS_PER_BATCH", "48"]
+    spec = importlib.util.spec_from_file_location("mpreid_test_cli", os.path.join(pkg, "test.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    r1, r5 = cli.main(["--config_file", str(yml)] + overrides)
+    log = (out_dir / "test_log.txt").read_text()
+    assert "Loaded configuration file" in log and "Running with config:" in log and "Enter inferencing" in log
+    assert "=> Enter reranking" in capsys.readouterr().out          # utils/metrics.py:126 prints it
+    m = re.search(r"mAP: ([0-9.]+)%", log)
+    assert m and "CMC curve, Rank-1  :" in log and "CMC curve, Rank-10 :" in log
+    # the same evaluation driven directly
+    cfg = _cfg(nq=40, ng=120, batch=48, rerank=True)
+    cfg.defrost()
+    cfg.merge_from_list(["DATASETS.SYNTH_IDS", 16])
+    cfg.freeze()
+    _, _, loader, nq, ncls, ncam, nview = make_dataloader(cfg)
+    model = make_model(cfg, num_class=ncls, camera_num=ncam, view_num=nview)
+    model.load_param(str(ckpt))
+    r1d, r5d = do_inference(cfg, model, loader, nq)
+    assert float(r1) == float(r1d) and float(r5) == float(r5d)

@@ -78,10 +78,12 @@ def test_rerank_full_size_properties(ops, name, nq, ng, d, sigma):
     r1, _ = ops.re_ranking(q, g, 50, 15, 1.0)
     colmax = torch.empty(nq, device="cuda")
     for s in range(0, nq, 4096):                                 # max over column i of D == max over row i (symmetric)
-        colmax[s:s + 4096] = ops.euclidean_distance(f[s:s + 4096], f).max(dim=1).values
+        e = min(nq, s + 4096)
+        colmax[s:e] = ops.euclidean_distance(f[s:e], f).max(dim=1).values
     for s in range(0, nq, 4096):
-        want = ops.euclidean_distance(f[s:s + 4096], g) / colmax[s:s + 4096, None] * np.float32(1.0)
-        assert torch.equal(r1[s:s + 4096], want), s
+        e = min(nq, s + 4096)
+        want = ops.euclidean_distance(f[s:e], g) / colmax[s:e, None] * np.float32(1.0)
+        assert torch.equal(r1[s:e], want), s
     del r1, want
     ra, st = ops.re_ranking(q, g, 50, 15, 0.3, timing=True)
     rb, _ = ops.re_ranking(q, g, 50, 15, 0.3)
