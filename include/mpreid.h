@@ -38,6 +38,9 @@ int mpreid_device_info(char *name, int name_len, int *cu_count, size_t *hbm_byte
 /* Arithmetic modes of the feat x feat^T GEMM */
 #define MPREID_GEMM_F32_EXACT 0 /* v_mfma_f32_32x32x2_f32: k-ascending fmaf chain, bit-reproducible  */
 #define MPREID_GEMM_F16_FAST 1  /* fp16 inputs, fp32 accumulate, one pass (|err| ~1e-4 on unit rows)  */
+#define MPREID_GEMM_F16_SPLIT3 2 /* x = hi + lo (fp16 pair): hi.hi' + lo.hi' + hi.lo' on the fp16 matrix cores,
+                                    fp32 accumulate; |err| <= 1e-6 on unit rows (the exact chain's own rounding
+                                    level) -- meets the 1e-5 entry bound, not bit-reproducible against the oracle */
 
 /* squared L2 norm of each row, out[n].  Order of summation is fixed (see oracle/mpreid_oracle.c). */
 int mpreid_sqnorm_f32(const float *x_dev, int64_t n, int d, float *out_dev, mpreid_stream_t stream);

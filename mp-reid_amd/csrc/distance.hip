@@ -248,10 +248,16 @@ int mpreid_distance_f16_fast(const float *q, const float *g, int64_t nq, int64_t
                              const float *gn, float *out, int64_t ldo, int epi, void *ws, size_t ws_bytes,
                              hipStream_t stream);
 size_t mpreid_distance_f16_ws_bytes(int64_t nq, int64_t ng, int d);
+// 3-term fp16 split (mode MPREID_GEMM_F16_SPLIT3)
+int mpreid_distance_f16_split3(const float *q, const float *g, int64_t nq, int64_t ng, int d, const float *qn,
+                               const float *gn, float *out, int64_t ldo, int epi, void *ws, size_t ws_bytes,
+                               hipStream_t stream);
+size_t mpreid_distance_split3_ws_bytes(int64_t nq, int64_t ng, int d);
 
 extern "C" size_t mpreid_distance_workspace_bytes(int64_t nq, int64_t ng, int d, int mode) {
     size_t b = align_up((size_t)(nq + ng) * sizeof(float), 256);
     if (mode == MPREID_GEMM_F16_FAST) b += mpreid_distance_f16_ws_bytes(nq, ng, d);
+    if (mode == MPREID_GEMM_F16_SPLIT3) b += mpreid_distance_split3_ws_bytes(nq, ng, d);
     return b;
 }
 
@@ -278,7 +284,7 @@ int mpreid_distance_launch(const float *q, const float *g, int64_t nq, int64_t n
 static int distance_common(const float *q, const float *g, int64_t nq, int64_t ng, int d, float *out, int64_t ldo,
                            int mode, void *ws, size_t ws_bytes, mpreid_stream_t stream_, int epi) {
     ARG_CHECK(q && g && out && nq >= 0 && ng >= 0 && d > 0 && ldo >= ng);
-    ARG_CHECK(mode == MPREID_GEMM_F32_EXACT || mode == MPREID_GEMM_F16_FAST);
+    ARG_CHECK(mode == MPREID_GEMM_F32_EXACT || mode == MPREID_GEMM_F16_FAST || mode == MPREID_GEMM_F16_SPLIT3);
     if (nq == 0 || ng == 0) return MPREID_OK;
     if (ws == nullptr || ws_bytes < mpreid_distance_workspace_bytes(nq, ng, d, mode)) {
         mpreid_set_error("distance workspace too small: %zu < %zu", ws_bytes,
@@ -295,6 +301,11 @@ static int distance_common(const float *q, const float *g, int64_t nq, int64_t n
         char *rest = (char *)ws + align_up((size_t)(nq + ng) * sizeof(float), 256);
         return mpreid_distance_f16_fast(q, g, nq, ng, d, qn, gn, out, ldo, epi, rest,
                                         ws_bytes - (size_t)(rest - (char *)ws), stream);
+    }
+    if (mode == MPREID_GEMM_F16_SPLIT3) {
+        char *rest = (char *)ws + align_up((size_t)(nq + ng) * sizeof(float), 256);
+        return mpreid_distance_f16_split3(q, g, nq, ng, d, qn, gn, out, ldo, epi, rest,
+                                          ws_bytes - (size_t)(rest - (char *)ws), stream);
     }
     return mpreid_distance_launch(q, g, nq, ng, d, qn, gn, out, ldo, epi, stream);
 }

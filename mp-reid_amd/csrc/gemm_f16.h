@@ -50,6 +50,8 @@ struct GemmArgs {
     int m_valid, n_valid; // logical bounds for the bounds-checked epilogues
     int P, L;            // GE_PATCH: patches per image, tokens per image
     const _Float16 *identity; // GE_BIAS_ADD_RELU: fp16 [M][ldo] residual
+    const float *rscale;  // distance epilogues, optional: acc is multiplied by rscale[m] * cscale[n] (exact powers of
+    const float *cscale;  // two undoing the per-row operand scaling of the 3-term split mode) before the epilogue
 };
 
 int launch_gemm_f16(const GemmArgs &a, int epi, hipStream_t stream);

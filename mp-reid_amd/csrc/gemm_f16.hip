@@ -244,11 +244,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
                     } else { // GE_EUCLID
                         if (m < g.m_valid) {
                             const float am = g.aux[m];
-                            float4 o;
-                            o.x = fmaf(-2.0f, a.x, am + bn4.x);
-                            o.y = fmaf(-2.0f, a.y, am + bn4.y);
-                            o.z = fmaf(-2.0f, a.z, am + bn4.z);
-                            o.w = fmaf(-2.0f, a.w, am + bn4.w);
+                            float4 o, s4 = make_float4(1.f, 1.f, 1.f, 1.f);
+                            if (g.rscale) {
+                                const float rs = g.rscale[m];
+                                s4 = make_float4(rs * g.cscale[nbase + c4 + 0], rs * g.cscale[nbase + c4 + 1],
+                                                 rs * g.cscale[nbase + c4 + 2], rs * g.cscale[nbase + c4 + 3]);
+                            }
+                            o.x = fmaf(-2.0f, a.x * s4.x, am + bn4.x);
+                            o.y = fmaf(-2.0f, a.y * s4.y, am + bn4.y);
+                            o.z = fmaf(-2.0f, a.z * s4.z, am + bn4.z);
+                            o.w = fmaf(-2.0f, a.w * s4.w, am + bn4.w);
                             if (nbase + c4 + 3 < g.n_valid) {
                                 *reinterpret_cast<float4 *>(dst) = o;
                             } else {
@@ -275,7 +280,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
                     } else if (EPI == GE_BIAS_RES) {
                         *dst = *dst + (a + bias);
                     } else if (m < g.m_valid && n < g.n_valid) {
-                        *dst = fmaf(-2.0f, a, g.aux[m] + bnv);
+                        const float sc = g.rscale ? g.rscale[m] * g.cscale[n] : 1.0f;
+                        *dst = fmaf(-2.0f, a * sc, g.aux[m] + bnv);
                     }
                 }
             }
@@ -301,7 +307,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
                         }
                     } else if (EPI == GE_COSINE) {
                         if (m < g.m_valid && n < g.n_valid) {
-                            float c = a * __fdiv_rn(1.0f, g.aux[m] * bnv);
+                            const float sc = g.rscale ? g.rscale[m] * g.cscale[n] : 1.0f;
+                            float c = (a * sc) * __fdiv_rn(1.0f, g.aux[m] * bnv);
                             const float lo = (float)(-1.0 + 0.00001), hi = (float)(1.0 - 0.00001);
                             c = c < lo ? lo : (c > hi ? hi : c);
                             reinterpret_cast<float *>(g.out)[(int64_t)m * g.ldo + n] = acosf(c);
@@ -671,8 +678,12 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
         const bool vec_ok = (g.ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(outp) & 15) == 0);
         const int nbase = cur_n0 + wc * 64;
         const int c4 = (lane & 15) * 4;
-        float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), bn4 = bias4;
-        float bias1 = 0.f, bnv1 = 0.f;
+        float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), bn4 = bias4, cs4 = make_float4(1.f, 1.f, 1.f, 1.f);
+        float bias1 = 0.f, bnv1 = 0.f, cs1 = 1.f;
+        if (EPI == GE_EUCLID && g.rscale) {   // buffers are padded to the tile size: no bounds needed
+            cs4 = *reinterpret_cast<const float4 *>(g.cscale + nbase + c4);
+            cs1 = g.cscale[nbase + lane];
+        }
         if (vec_ok) {
             if (EPI == GE_BIAS_RES) bias4 = *reinterpret_cast<const float4 *>(g.bias + nbase + c4);
             if (EPI == GE_EUCLID) {
@@ -722,11 +733,15 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
                         *reinterpret_cast<float4 *>(dst) = x;   // (streaming stores measured neutral here)
                     } else if (m < g.m_valid) { // GE_EUCLID
                         const float am = g.aux[m];
-                        float4 o;
-                        o.x = fmaf(-2.0f, a.x, am + bn4.x);
-                        o.y = fmaf(-2.0f, a.y, am + bn4.y);
-                        o.z = fmaf(-2.0f, a.z, am + bn4.z);
-                        o.w = fmaf(-2.0f, a.w, am + bn4.w);
+                        float4 o, s4 = make_float4(1.f, 1.f, 1.f, 1.f);
+                        if (g.rscale) {
+                            const float rs = g.rscale[m];
+                            s4 = make_float4(rs * cs4.x, rs * cs4.y, rs * cs4.z, rs * cs4.w);
+                        }
+                        o.x = fmaf(-2.0f, a.x * s4.x, am + bn4.x);
+                        o.y = fmaf(-2.0f, a.y * s4.y, am + bn4.y);
+                        o.z = fmaf(-2.0f, a.z * s4.z, am + bn4.z);
+                        o.w = fmaf(-2.0f, a.w * s4.w, am + bn4.w);
                         if (nbase + c4 + 3 < g.n_valid) {
                             store_nt(dst, o);   // N x N distances: written once, far larger than any cache
                         } else {
@@ -753,7 +768,8 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
                     } else if (EPI == GE_BIAS_RES) {
                         *dst = *dst + (a + bias1);
                     } else if (m < g.m_valid && n < g.n_valid) {
-                        *dst = fmaf(-2.0f, a, g.aux[m] + bnv1);
+                        const float sc = g.rscale ? g.rscale[m] * cs1 : 1.0f;
+                        *dst = fmaf(-2.0f, a * sc, g.aux[m] + bnv1);
                     }
                 }
             }
@@ -1015,6 +1031,86 @@ extern "C" int mpreid_gemm_f16_nt_ex(const void *a, const void *b, void *out, co
     g.ldo = n;
     g.bias = bias;
     return launch_gemm_f16(g, epilogue, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3-term fp16 split: x * 2^e = hi + lo (both fp16, e per row so that |x * 2^e| < 2^10),
+// q.g = 2^-(eq+eg) * (hi.hi' + lo.hi' + hi.lo') + O(2^-22) -- ONE ordinary GEMM over operands concatenated along K:
+//   A' = [hi | lo | hi]   B' = [hi' | hi' | lo']   (K' = 3 * K)
+// fp16 x fp16 products are exact in the fp32 accumulator, so the error is the dropped lo.lo' term, the rounding of lo
+// and the fp32 accumulation: max |delta| <= 1e-6 on unit-norm rows (tests/test_gpu_distance.py), the level of the
+// exact fp32 chain's own rounding error, at 3/16 of the fp32-MFMA time.  The scaling keeps lo out of the fp16
+// subnormal range; it is undone exactly (powers of two) by rscale[m] * cscale[n] in the epilogue.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void split3_pack_kernel(const float *__restrict__ x, const float *__restrict__ sqn,
+                                                          int norm_is_sqrt, int64_t n, int d, _Float16 *__restrict__ y,
+                                                          int d_pad, float *__restrict__ unscale, int is_b) {
+    const int64_t row = blockIdx.x;
+    float sc = 1.0f, un = 1.0f;
+    if (row < n) {
+        const float nrm = norm_is_sqrt ? sqn[row] : sqrtf(sqn[row]);
+        if (nrm > 0.0f && nrm < 3.0e38f) {
+            int ex;
+            (void)frexpf(nrm, &ex);          // nrm < 2^ex, so |x_k| * 2^(10-ex) < 2^10
+            sc = ldexpf(1.0f, 10 - ex);
+            un = ldexpf(1.0f, ex - 10);
+        }
+    }
+    if (threadIdx.x == 0) unscale[row] = un;
+    _Float16 *yr = y + row * (int64_t)(3 * d_pad);
+    for (int k = threadIdx.x; k < d_pad; k += 256) {
+        float v = 0.f;
+        if (row < n && k < d) v = x[row * (int64_t)d + k] * sc;
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        yr[k] = hi;
+        yr[d_pad + k] = is_b ? hi : lo;
+        yr[2 * d_pad + k] = is_b ? lo : hi;
+    }
+}
+
+size_t mpreid_distance_split3_ws_bytes(int64_t nq, int64_t ng, int d) {
+    const size_t dp = align_up((size_t)d, GBK);
+    const size_t mp = align_up((size_t)nq, 256), np = align_up((size_t)ng, 256);
+    return align_up(mp * 3 * dp * 2, 256) + align_up(np * 3 * dp * 2, 256) + align_up(mp * 4, 256) + align_up(np * 4, 256);
+}
+
+int mpreid_distance_f16_split3(const float *q, const float *g, int64_t nq, int64_t ng, int d, const float *qn,
+                               const float *gn, float *out, int64_t ldo, int epi, void *ws, size_t ws_bytes,
+                               hipStream_t stream) {
+    if (ws_bytes < mpreid_distance_split3_ws_bytes(nq, ng, d)) {
+        mpreid_set_error("split3 distance workspace too small");
+        return MPREID_ERR_WORKSPACE;
+    }
+    const int dp = (int)align_up((size_t)d, GBK);
+    const int64_t mp = (int64_t)align_up((size_t)nq, BBM), np = (int64_t)align_up((size_t)ng, BBN);
+    char *p = (char *)ws;
+    _Float16 *qh = (_Float16 *)p;
+    p += align_up((size_t)mp * 3 * dp * 2, 256);
+    _Float16 *gh = (_Float16 *)p;
+    p += align_up((size_t)np * 3 * dp * 2, 256);
+    float *qs = (float *)p;
+    p += align_up((size_t)mp * 4, 256);
+    float *gs = (float *)p;
+    // qn / gn are squared norms for the Euclidean epilogue and norms for the cosine one (distance_common)
+    hipLaunchKernelGGL(split3_pack_kernel, dim3((unsigned)mp), dim3(256), 0, stream, q, qn, epi != 0, nq, d, qh, dp, qs, 0);
+    hipLaunchKernelGGL(split3_pack_kernel, dim3((unsigned)np), dim3(256), 0, stream, g, gn, epi != 0, ng, d, gh, dp, gs, 1);
+    LAUNCH_CHECK();
+    GemmArgs a{};
+    a.A = qh;
+    a.W = gh;
+    a.M = (int)mp;
+    a.N = (int)np;
+    a.K = 3 * dp;
+    a.out = out;
+    a.ldo = ldo;
+    a.aux = qn;
+    a.aux2 = gn;
+    a.m_valid = (int)nq;
+    a.n_valid = (int)ng;
+    a.rscale = qs;
+    a.cscale = gs;
+    return launch_gemm_f16(a, epi == 0 ? GE_EUCLID : GE_COSINE, stream);
 }
 
 size_t mpreid_distance_f16_ws_bytes(int64_t nq, int64_t ng, int d) {

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("MPREID_LIB") or os.path.join(_HERE, "libmpreid_hip.so
 
 GEMM_F32_EXACT = 0
 GEMM_F16_FAST = 1
+GEMM_F16_SPLIT3 = 2
 
 #: every symbol include/mpreid.h declares (tests check the library exports all of them)
 SYMBOLS = [

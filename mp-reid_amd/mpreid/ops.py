@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import GEMM_F16_FAST, GEMM_F32_EXACT  # noqa: F401  (re-exported)
+from ._lib import GEMM_F16_FAST, GEMM_F16_SPLIT3, GEMM_F32_EXACT  # noqa: F401  (re-exported)
 
 _ws_cache: Dict[tuple, torch.Tensor] = {}
 

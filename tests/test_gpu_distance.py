@@ -192,3 +192,51 @@ def test_gemm_kernels_agree_across_variants(epi):
         ref = ref * torch.sigmoid(1.702 * ref)
     err = (torch.from_numpy(outs[0]).cuda() - ref).abs().max().item()
     assert err < (2e-3 if epi == 2 else 2e-2), err
+
+
+# ---------------------------------------------------------------------------------------------
+# 3-term fp16 split mode (MPREID_GEMM_F16_SPLIT3): parity-grade on the fp16 matrix cores
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nq,ng,d", [(300, 515, 768), (500, 1000, 1280), (129, 257, 100), (1024, 2048, 768), (64, 256, 2048)])
+def test_euclid_split3_within_1e6_of_oracle(ops, nq, ng, d):
+    f = _feat(nq + ng, d, seed=nq * 7 + ng)
+    got = ops.euclidean_distance(torch.from_numpy(f[:nq]), torch.from_numpy(f[nq:]), mode=ops.GEMM_F16_SPLIT3).cpu().numpy()
+    want = orc.euclidean_distance(f[:nq], f[nq:])
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 1e-6, np.abs(got - want).max()
+    # against an fp64 evaluation it is as accurate as the exact fp32 chain itself
+    q64, g64 = f[:nq].astype(np.float64), f[nq:].astype(np.float64)
+    ref = (q64 * q64).sum(1)[:, None] + (g64 * g64).sum(1)[None, :] - 2.0 * q64 @ g64.T
+    assert np.abs(got - ref).max() <= 1.5 * max(np.abs(want - ref).max(), 4e-7)
+
+
+def test_split3_unnormalised_and_cosine(ops, golden):
+    from mpreid import synth
+    f = _feat(400, 1280, seed=5, normalize=False) * np.float32(37.0)       # row norms ~ 4e3: per-row scaling at work
+    got = ops.euclidean_distance(torch.from_numpy(f[:100]), torch.from_numpy(f[100:]), mode=ops.GEMM_F16_SPLIT3).cpu().numpy()
+    want = orc.euclidean_distance(f[:100], f[100:])
+    assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
+    g = golden("distance.npz")
+    feat, _ = synth.clustered_features(int(g["n"]), int(g["dim"]), float(g["sigma"]), seed=int(g["seed"]),
+                                       per_id=int(g["per_id"]))
+    nq = int(g["nq"])
+    q, ga = torch.from_numpy(feat[:nq]), torch.from_numpy(feat[nq:])
+    assert np.abs(ops.euclidean_distance(q, ga, mode=ops.GEMM_F16_SPLIT3).cpu().numpy() - g["euclid"]).max() < 1e-5
+    assert np.abs(ops.cosine_similarity(q, ga, mode=ops.GEMM_F16_SPLIT3).cpu().numpy() - g["cosine"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("case", ["50_15_0.3", "20_6_0.3", "7_3_0.5"])
+def test_split3_gives_the_oracles_neighbour_tables_on_the_goldens(ops, golden, case):
+    """initial_rank[:, :k1+1] computed from split-3 distances == the oracle's (the goldens are tie-free in the
+    top-(k1+2), tests/golden/make_goldens.py)"""
+    g = golden("rerank.npz")
+    k1 = int(case.split("_")[0])
+    k2, lam = int(case.split("_")[1]), float(case.split("_")[2])
+    feat = g["feat"]
+    nq = int(g["nq"])
+    _, orank, _, _ = orc.re_ranking(feat[:nq], feat[nq:], k1, k2, lam, debug=True)
+    ft = torch.from_numpy(feat).cuda()
+    d = ops.euclidean_distance(ft, ft, mode=ops.GEMM_F16_SPLIT3)
+    o = (d / d.max(dim=0).values[None, :]).t().contiguous()            # utils/reranking.py:46
+    rank = torch.argsort(o, dim=1, stable=True)[:, :k1 + 1].cpu().numpy()
+    assert np.array_equal(rank, orank)
