@@ -24,6 +24,7 @@ extern "C" {
 #define MPREID_ERR_WORKSPACE (-2)
 #define MPREID_ERR_UNSUPPORTED (-3)
 #define MPREID_ERR_NODEVICE (-4)
+#define MPREID_ERR_RETRY_DENSE (-5) /* sparse re-ranking hit a data-dependent capacity: repeat with MPREID_RERANK_DENSE */
 
 typedef void *mpreid_stream_t; /* hipStream_t */
 
@@ -71,12 +72,30 @@ typedef struct {
     int64_t vqe_nnz;      /* nnz(V) after query expansion (== v_nnz when k2 == 1) */
     int64_t jaccard_pairs;/* sum over queries i, columns c in nz(V[i]) of nnz(V[:,c]) */
     int64_t krecip_r_sum; /* sum over rows of |R(i, k1)| (k-reciprocal set sizes before expansion) */
+    int64_t fallback_rows;/* sparse algorithm: rows whose candidate list could not be certified (done densely) */
+    int64_t cand_total;   /* sparse algorithm: neighbour candidates emitted by the fused GEMM (sum over rows) */
+    int32_t algo;         /* MPREID_RERANK_DENSE or MPREID_RERANK_SPARSE: what the call actually ran */
     float ms_gemm, ms_topk, ms_krecip, ms_qe, ms_csc, ms_jaccard, ms_total; /* filled when timing != 0 */
 } mpreid_rerank_stats;
 
-/* Bytes of device workspace re_ranking needs for this problem (dominated by the N x N fp32
- * distance matrix that stays resident in HBM: 4*N*N). */
-size_t mpreid_rerank_workspace_bytes(int64_t nq, int64_t ng, int d, int k1, int k2, int has_local);
+/* Two algorithms, the same bits out (tests/test_gpu_rerank.py):
+ *   DENSE   the N x N fp32 distance matrix is computed (exact fp32 MFMA), kept in HBM and scanned for the first
+ *           max(k1+1, k2) neighbours of every row.  Any N, local_distmat / only_local supported.
+ *   SPARSE  the N x N matrix is never materialised: a one-pass fp16 GEMM on the matrix cores emits, per row, the
+ *           ~180 entries that can still be among its neighbours or be its maximum (thresholds from a 1/16 column
+ *           sample, a proven error bound), those are re-evaluated with the exact fp32 chain, and the exact distance
+ *           rows exist only for the queries ([nq][N], what the Jaccard blend reads).  Rows that cannot be certified
+ *           fall back to the dense computation of that row.  Needs N >= 2048, max(k1+1, k2) <= 64, no local_distmat.
+ *   AUTO    SPARSE when it applies, else DENSE.  A sparse call may return MPREID_ERR_RETRY_DENSE (degenerate data:
+ *           too many fallback rows, a query-expansion row above 4096 entries, row norms >= 3e4): repeat it with
+ *           MPREID_RERANK_DENSE and a workspace sized for DENSE. */
+#define MPREID_RERANK_AUTO 0
+#define MPREID_RERANK_DENSE 1
+#define MPREID_RERANK_SPARSE 2
+/* Bytes of device workspace re_ranking needs for this problem (DENSE: dominated by the N x N fp32 distance matrix,
+ * 4*N*N; SPARSE: by the sample distances N*N/4 bytes and the query rows 4*nq*N). */
+size_t mpreid_rerank_workspace_bytes(int64_t nq, int64_t ng, int d, int k1, int k2, int has_local);      /* AUTO */
+size_t mpreid_rerank_workspace_bytes_ex(int64_t nq, int64_t ng, int d, int k1, int k2, int has_local, int algo);
 
 /* re_ranking(probFea, galFea, k1, k2, lambda_value, local_distmat=None, only_local=False)
  *   q [nq][d], g [ng][d] fp32 device; local_dev: NULL or [N][N] fp32 device (N = nq+ng);
@@ -93,12 +112,20 @@ int mpreid_rerank_f32(const float *q_dev, const float *g_dev, int64_t nq, int64_
                       int64_t ldo, void *ws_dev, size_t ws_bytes, mpreid_stream_t stream,
                       mpreid_rerank_stats *stats, int timing);
 
+int mpreid_rerank_f32_ex(const float *q_dev, const float *g_dev, int64_t nq, int64_t ng, int d, int k1, int k2,
+                         double lambda_value, const float *local_dev, int only_local, float *out_dev,
+                         int64_t ldo, void *ws_dev, size_t ws_bytes, mpreid_stream_t stream,
+                         mpreid_rerank_stats *stats, int timing, int algo);
+
 /* debug/inspection taps used by the parity tests: copies of intermediate results of the LAST
  * mpreid_rerank_f32 call that used workspace ws_dev (valid until the workspace is reused).
  *   rank_out [N][k1+1] int32 (initial_rank[:, :k1+1]); v_cnt/vqe_cnt [N] int32 nnz per row. */
 int mpreid_rerank_debug_copy(const void *ws_dev, int64_t nq, int64_t ng, int d, int k1, int k2, int has_local,
                              int32_t *rank_out_host, int32_t *v_cnt_host, int32_t *vqe_cnt_host,
-                             mpreid_stream_t stream);
+                             mpreid_stream_t stream);   /* layout of the AUTO choice */
+int mpreid_rerank_debug_copy_ex(const void *ws_dev, int64_t nq, int64_t ng, int d, int k1, int k2, int has_local,
+                                int32_t *rank_out_host, int32_t *v_cnt_host, int32_t *vqe_cnt_host,
+                                mpreid_stream_t stream, int algo);
 
 /* ---- eval_func ranking, utils/metrics.py:28-88 ---------------------------------------------------------
  * For every query: the 0-based positions, in the ascending (distance, gallery index) order of its row, of the

@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256) void gemm_f32_exact_kernel(const float *__rest
                                                              int64_t M, int64_t N, int K,
                                                              const float *__restrict__ an,
                                                              const float *__restrict__ bn, float *__restrict__ C,
-                                                             int64_t ldc, int tiles_m, int tiles_n, int vec_ok) {
+                                                             int64_t ldc, int tiles_m, int tiles_n, int vec_ok,
+                                                             const unsigned *__restrict__ m_count) {
     __shared__ float Sm[2][2][XBK][XLD]; // one object: A stages, then B stages (33,792 B, reused by the mirror)
     float (&As)[2][XBK][XLD] = Sm[0];
     float (&Bs)[2][XBK][XLD] = Sm[1];
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(256) void gemm_f32_exact_kernel(const float *__rest
         tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, 8, tm, tn);
     }
     const int64_t m0 = (int64_t)tm * XBM, n0 = (int64_t)tn * XBN;
+    if (m_count && m0 >= (int64_t)*m_count) return;   // rows past a device-side count (uniform per workgroup)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -262,7 +264,8 @@ extern "C" size_t mpreid_distance_workspace_bytes(int64_t nq, int64_t ng, int d,
 }
 
 int mpreid_distance_launch(const float *q, const float *g, int64_t nq, int64_t ng, int d, const float *qn,
-                           const float *gn, float *out, int64_t ldo, int epi, hipStream_t stream) {
+                           const float *gn, float *out, int64_t ldo, int epi, hipStream_t stream,
+                           const unsigned *m_count) {
     const int tiles_m = (int)((nq + XBM - 1) / XBM), tiles_n = (int)((ng + XBN - 1) / XBN);
     const int vec_ok = (d % 4 == 0) && (((uintptr_t)q | (uintptr_t)g) % 16 == 0);
     const dim3 grid((unsigned)tiles_m * (unsigned)tiles_n);
@@ -270,13 +273,13 @@ int mpreid_distance_launch(const float *q, const float *g, int64_t nq, int64_t n
         // all-pairs distance of one set: upper-triangular tiles + mirrored writes
         const dim3 tri((unsigned)tiles_m * (unsigned)(tiles_m + 1) / 2u);
         hipLaunchKernelGGL((gemm_f32_exact_kernel<EPI_EUCLID, true>), tri, dim3(256), 0, stream, q, g, nq, ng, d, qn, gn,
-                           out, ldo, tiles_m, tiles_n, vec_ok);
+                           out, ldo, tiles_m, tiles_n, vec_ok, m_count);
     } else if (epi == EPI_EUCLID)
         hipLaunchKernelGGL((gemm_f32_exact_kernel<EPI_EUCLID, false>), grid, dim3(256), 0, stream, q, g, nq, ng, d, qn,
-                           gn, out, ldo, tiles_m, tiles_n, vec_ok);
+                           gn, out, ldo, tiles_m, tiles_n, vec_ok, m_count);
     else
         hipLaunchKernelGGL((gemm_f32_exact_kernel<EPI_COSINE, false>), grid, dim3(256), 0, stream, q, g, nq, ng, d, qn,
-                           gn, out, ldo, tiles_m, tiles_n, vec_ok);
+                           gn, out, ldo, tiles_m, tiles_n, vec_ok, m_count);
     LAUNCH_CHECK();
     return MPREID_OK;
 }
@@ -307,7 +310,7 @@ static int distance_common(const float *q, const float *g, int64_t nq, int64_t n
         return mpreid_distance_f16_split3(q, g, nq, ng, d, qn, gn, out, ldo, epi, rest,
                                           ws_bytes - (size_t)(rest - (char *)ws), stream);
     }
-    return mpreid_distance_launch(q, g, nq, ng, d, qn, gn, out, ldo, epi, stream);
+    return mpreid_distance_launch(q, g, nq, ng, d, qn, gn, out, ldo, epi, stream, nullptr);
 }
 
 extern "C" int mpreid_euclidean_distance_f32(const float *q, const float *g, int64_t nq, int64_t ng, int d, float *out,

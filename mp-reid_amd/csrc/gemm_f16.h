@@ -35,7 +35,10 @@ enum GemmEpi {
     GE_EUCLID = 5,     // out fp32 = fmaf(-2, acc, an[m] + bn[n])       (bounds checked)
     GE_COSINE = 6,     // out fp32 = acos(clip(acc / (an[m]*bn[n])))    (bounds checked)
     GE_BIAS_RELU = 7,  // out fp16 = relu(acc + bias[n])                (RN50 1x1 conv + folded BN + ReLU)
-    GE_BIAS_ADD_RELU = 8 // out fp16 = relu(acc + bias[n] + identity[m][n]), one rounding (Bottleneck conv3)
+    GE_BIAS_ADD_RELU = 8, // out fp16 = relu(acc + bias[n] + identity[m][n]), one rounding (Bottleneck conv3)
+    GE_CAND = 9        // nothing is stored: d = fmaf(-2, acc, an[m] + bn[n]) is compared with per-row thresholds and the
+                       // few (row, col, d) that pass are appended to per-row candidate lists (re-ranking: the N x N
+                       // distance matrix is never materialised; csrc/rerank2.hip)
 };
 
 struct GemmArgs {
@@ -52,6 +55,17 @@ struct GemmArgs {
     const _Float16 *identity; // GE_BIAS_ADD_RELU: fp16 [M][ldo] residual
     const float *rscale;  // distance epilogues, optional: acc is multiplied by rscale[m] * cscale[n] (exact powers of
     const float *cscale;  // two undoing the per-row operand scaling of the 3-term split mode) before the epilogue
+    // GE_CAND: row m keeps column n when d <= tlo[m] (list_lo) or d >= thi[m] (list_hi); with sym != 0 (A == W, only
+    // tiles with tn >= tm are computed) the transposed pair is tested as well: column n keeps row m.  tlo / thi are
+    // padded to M (= N) entries with -inf / +inf.  Lists: uint2 {partner index, float bits of d}, row stride cap_*;
+    // cnt_* count every append (entries past the capacity are dropped: the consumer sees cnt > cap and falls back).
+    const float *tlo, *thi;
+    unsigned *cnt_lo, *cnt_hi;
+    uint2 *list_lo, *list_hi;
+    int cap_lo, cap_hi, sym;
+    int stagger;          // persistent kernel: workgroup b starts (b mod 256) / 256 * stagger ticks of the 100 MHz
+                          // real-time counter late, so that the CUs reach their store-heavy epilogues at different
+                          // times instead of all at once (0 = off)
 };
 
 int launch_gemm_f16(const GemmArgs &a, int epi, hipStream_t stream);

@@ -356,15 +356,49 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
     const int ntiles = tiles_m * tiles_n;
     const int nb = (int)gridDim.x;
     const bool owned = (tiles_m % 8 == 0) && (nb % 8 == 0);
+    // Any other shape on a full grid (the distance GEMMs: 79 x 79 tiles at N = 20 000): "blocked" walk.  In round r
+    // XCD x works on block r*8 + x of the tile grid cut into blocks of 8 tile rows x (CUs per XCD / 8) tile columns
+    // (8 x 4 on 256 CUs), one tile per CU: 12 operand panels feed 32 tiles.  (The plain grouped walk gave an XCD ONE
+    // tile row x 32 columns per round: 33 panels per 32 tiles, every B panel fetched by all eight L2s -- measured
+    // 2.66 GB of fabric reads against 62 MB of operands on the 20k x 20k x 768 distance GEMM.)  Edge blocks have
+    // unused slots, which are skipped.
+    const bool blocked = !owned && (nb % 64 == 0) && ntiles >= nb;
     const int xcd = (int)(blockIdx.x & 7), per_xcd = nb >> 3, per_group = 8 * tiles_n, ngroups = tiles_m >> 3;
-    int pos = owned ? (int)(blockIdx.x >> 3) : (int)blockIdx.x; // position in this XCD's (or the global) tile list
-    const int pos_step = owned ? per_xcd : nb;
-    auto tile_at = [&](int p) -> int { // -1 when the list is exhausted
-        if (!owned) return p < ntiles ? p : -1;
+    const int bc_w = per_xcd >> 3;                                   // tile columns per block (blocked mode)
+    const int nbc = blocked ? (tiles_n + bc_w - 1) / bc_w : 1, nbr = (tiles_m + 7) >> 3;
+    int pos = owned ? (int)(blockIdx.x >> 3) : (blocked ? 0 : (int)blockIdx.x); // position in this CU's tile list
+    const int pos_step = owned ? per_xcd : (blocked ? 1 : nb);
+    auto tile_at_raw = [&](int p) -> int { // -1 when the list is exhausted, -2 for an unused slot of an edge block
+        if (blocked) {
+            const int b = p * 8 + xcd, br = b / nbc, bcol = b - br * nbc;
+            if (br >= nbr) return -1;
+            const int slot = (int)(blockIdx.x >> 3);
+            const int tm = br * 8 + (slot & 7), tn = bcol * bc_w + (slot >> 3);
+            if (EPI == GE_CAND && g.sym && tn < tm) return -2;   // symmetric problem: upper-triangular tiles only
+            return (tm < tiles_m && tn < tiles_n) ? tm * tiles_n + tn : -2;
+        }
+        if (!owned) {
+            if (p >= ntiles) return -1;
+            if (EPI == GE_CAND && g.sym) {
+                int tm, tn;
+                tile_coords((unsigned)p, tiles_m, tiles_n, 8, tm, tn);
+                if (tn < tm) return -2;
+            }
+            return p;
+        }
         const int grp = xcd + 8 * (p / per_group);
         if (grp >= ngroups) return -1;
         const int within = p % per_group;
+        if (EPI == GE_CAND && g.sym && (within >> 3) < grp * 8 + (within & 7)) return -2;
         return (grp * 8 + (within & 7)) * tiles_n + (within >> 3); // row-major tile id
+    };
+    auto tile_at = [&](int &p) -> int {    // advances p past unused slots
+        int t = tile_at_raw(p);
+        while (t == -2) {
+            p += pos_step;
+            t = tile_at_raw(p);
+        }
+        return t;
     };
 
     // ---- DMA: wave w moves rows [32w, 32w+32) of the A part and of the B part of every stage ----
@@ -374,7 +408,7 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
     int m0 = 0, n0 = 0;
     auto set_tile = [&](int tile) {
         int tm, tn;
-        if (owned) {
+        if (owned || blocked) {
             tm = tile / tiles_n;
             tn = tile - tm * tiles_n;
         } else {
@@ -413,8 +447,51 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
         for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const f16x8 *>(sb + a_off + i * 1024);
     };
 
+    // GE_CAND: wave-private candidate list in the 4 KB patch above the ring (SoA: row, col, d), kept across tiles and
+    // flushed to the global per-row lists only when it fills up (and at the end): a tile's epilogue then touches
+    // no global memory at all, so the next tile's first DMA wait does not sit behind store / atomic round trips
+    constexpr int CL_CAP = 336;
+    int cl_n = 0;
+    unsigned *cl_row = reinterpret_cast<unsigned *>(smem + B_LDS_BYTES + wave * 4096);
+    unsigned *cl_col = cl_row + CL_CAP;
+    unsigned *cl_d = cl_col + CL_CAP;
+    auto cl_flush = [&]() {
+        if constexpr (EPI == GE_CAND) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int e = lane; e < cl_n; e += 64) {
+                const unsigned rw = cl_row[e], cw = cl_col[e], dv = cl_d[e];
+                const unsigned fl = rw >> 28, row = rw & 0x0fffffffu;
+                if (fl & 1u) {
+                    const unsigned p = atomicAdd(&g.cnt_lo[row], 1u);
+                    if (p < (unsigned)g.cap_lo) g.list_lo[(size_t)row * g.cap_lo + p] = make_uint2(cw, dv);
+                }
+                if (fl & 2u) {
+                    const unsigned p = atomicAdd(&g.cnt_hi[row], 1u);
+                    if (p < (unsigned)g.cap_hi) g.list_hi[(size_t)row * g.cap_hi + p] = make_uint2(cw, dv);
+                }
+                if (fl & 4u) {
+                    const unsigned p = atomicAdd(&g.cnt_lo[cw], 1u);
+                    if (p < (unsigned)g.cap_lo) g.list_lo[(size_t)cw * g.cap_lo + p] = make_uint2(row, dv);
+                }
+                if (fl & 8u) {
+                    const unsigned p = atomicAdd(&g.cnt_hi[cw], 1u);
+                    if (p < (unsigned)g.cap_hi) g.list_hi[(size_t)cw * g.cap_hi + p] = make_uint2(row, dv);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            cl_n = 0;
+        }
+    };
+
     int tile = tile_at(pos);
     if (tile < 0) return;
+    if (g.stagger > 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long wait = (unsigned long long)g.stagger * (blockIdx.x & 255u) / 256u;
+        while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
     set_tile(tile);
     dma_prologue();
     for (;;) {
@@ -515,6 +592,87 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+    } else if constexpr (EPI == GE_CAND) {
+        // Two phases per 16-row block i, both in the accumulator layout (lane: rows fq*4 + r, column frow of each
+        // 16-column block j):
+        //   A  straight-line: d for the lane's 16 elements, four comparisons each, a 16-bit hit mask per lane
+        //      (~1.6 % of the elements pass; the block's values are also laid into a [16][64] LDS patch)
+        //   B  while any lane still has a hit: every such lane takes its lowest one -- up to 64 appends per iteration
+        //      -- re-reads the value from the patch (dynamic index), recomputes d and its flags, and appends
+        //      (row, column, d, flags) to the wave's LDS candidate list.  Typically 1-2 iterations.
+        // No global traffic unless the list fills up.
+        const bool mirror = g.sym != 0 && cur_m0 != cur_n0;   // off-diagonal tile of a symmetric problem
+        float *tp = reinterpret_cast<float *>(smem + wave * 16384);   // patch in the idle k-loop ring
+        const int rb = cur_m0 + wr * 128, cb = cur_n0 + wc * 64;
+        const float NEG = -__builtin_huge_valf(), POS = __builtin_huge_valf();
+        float bnv[4], tlc[4], thc[4];
+        unsigned cvm = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = cb + j * 16 + frow;
+            const bool cv = c < g.n_valid;
+            cvm |= cv ? (0xfu << (4 * j)) : 0u;
+            bnv[j] = cv ? g.aux2[c] : 0.f;
+            tlc[j] = (mirror && cv) ? g.tlo[c] : NEG;
+            thc[j] = (mirror && cv) ? g.thi[c] : POS;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r0 = rb + i * 16 + fq * 4;
+            // arrays are padded to M entries (0 / -inf / +inf past m_valid)
+            const float4 an4 = *reinterpret_cast<const float4 *>(g.aux + r0);
+            const float4 tl4 = *reinterpret_cast<const float4 *>(g.tlo + r0);
+            const float4 th4 = *reinterpret_cast<const float4 *>(g.thi + r0);
+            const float anr[4] = {an4.x, an4.y, an4.z, an4.w}, tlr[4] = {tl4.x, tl4.y, tl4.z, tl4.w},
+                        thr[4] = {th4.x, th4.y, th4.z, th4.w};
+            unsigned rvm = 0u;   // rows inside the problem (the mirrored tests need it: a padded row has d = |g|^2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rvm |= (r0 + r < g.m_valid) ? (0x1111u << r) : 0u;
+            unsigned hit = 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float a = acc[i][j][r];
+                    tp[(fq * 4 + r) * 64 + j * 16 + frow] = a;
+                    const float d = fmaf(-2.0f, a, anr[r] + bnv[j]);
+                    const bool h = (d <= tlr[r]) | (d >= thr[r]) | (d <= tlc[j]) | (d >= thc[j]);
+                    hit |= h ? (1u << (j * 4 + r)) : 0u;
+                }
+            hit &= cvm & rvm;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            unsigned long long bal = __ballot(hit != 0u);
+            while (bal) {
+                const int add = __popcll(bal);
+                if (cl_n + add > CL_CAP) cl_flush();
+                if (hit) {
+                    const int e = __ffs((int)hit) - 1;
+                    hit &= hit - 1u;
+                    const int j = e >> 2, r = e & 3;
+                    const float a = tp[(fq * 4 + r) * 64 + j * 16 + frow];
+                    const float anx = r == 0 ? anr[0] : (r == 1 ? anr[1] : (r == 2 ? anr[2] : anr[3]));
+                    const float tlx = r == 0 ? tlr[0] : (r == 1 ? tlr[1] : (r == 2 ? tlr[2] : tlr[3]));
+                    const float thx = r == 0 ? thr[0] : (r == 1 ? thr[1] : (r == 2 ? thr[2] : thr[3]));
+                    const float bnx = j == 0 ? bnv[0] : (j == 1 ? bnv[1] : (j == 2 ? bnv[2] : bnv[3]));
+                    const float tcx = j == 0 ? tlc[0] : (j == 1 ? tlc[1] : (j == 2 ? tlc[2] : tlc[3]));
+                    const float hcx = j == 0 ? thc[0] : (j == 1 ? thc[1] : (j == 2 ? thc[2] : thc[3]));
+                    const float d = fmaf(-2.0f, a, anx + bnx);
+                    const unsigned fl = (d <= tlx ? 1u : 0u) | (d >= thx ? 2u : 0u) | (d <= tcx ? 4u : 0u) | (d >= hcx ? 8u : 0u);
+                    const int p = cl_n + __popcll(bal & ((1ull << lane) - 1ull));
+                    cl_row[p] = (unsigned)(r0 + r) | (fl << 28);
+                    cl_col[p] = (unsigned)(cb + j * 16 + frow);
+                    cl_d[p] = __float_as_uint(d);
+                }
+                cl_n += add;
+                bal = __ballot(hit != 0u);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (next_tile < 0) cl_flush();
+        // the transposition patches alias stage slots the next tile's prologue is about to fill
+        asm volatile("s_barrier" ::: "memory");
     } else if constexpr (EPI == GE_BIAS_F16 || EPI == GE_BIAS_GELU || EPI == GE_BIAS_RELU) {
         // one 16-row MFMA tile row per pass: patch [16][72] halfs (2304 B) -> two 16-byte row pieces per lane
         _Float16 *wreg = reinterpret_cast<_Float16 *>(patch + wave * 4096);
@@ -871,10 +1029,17 @@ static int launch_one(const GemmArgs &a, hipStream_t stream) {
         if (rc) return rc;
     }
     constexpr bool HAS_BIG = (EPI == GE_F32 || EPI == GE_BIAS_F16 || EPI == GE_BIAS_RES || EPI == GE_BIAS_GELU ||
-                              EPI == GE_EUCLID || EPI == GE_PATCH || EPI == GE_BIAS_RELU || EPI == GE_BIAS_ADD_RELU);
+                              EPI == GE_EUCLID || EPI == GE_PATCH || EPI == GE_BIAS_RELU || EPI == GE_BIAS_ADD_RELU ||
+                              EPI == GE_CAND);
+    if constexpr (EPI == GE_CAND) {
+        if (a.M % BBM || a.N % BBN) {
+            mpreid_set_error("gemm_f16: the candidate epilogue needs M, N multiples of %d", BBM);
+            return MPREID_ERR_ARG;
+        }
+    }
     const int bm = big_mode();
-    const bool use_big = HAS_BIG && bm > 0 && (a.M % BBM == 0) && (a.N % BBN == 0) &&
-                         (bm >= 2 || (int64_t)(a.M / BBM) * (a.N / BBN) >= 128);
+    const bool use_big = HAS_BIG && (EPI == GE_CAND || (bm > 0 && (a.M % BBM == 0) && (a.N % BBN == 0) &&
+                                                        (bm >= 2 || (int64_t)(a.M / BBM) * (a.N / BBN) >= 128)));
     if constexpr (HAS_BIG) {
         static PerDeviceOnce big_attr_once;
         const int rc = big_attr_once.run([]() -> int {
@@ -958,6 +1123,7 @@ int launch_gemm_f16(const GemmArgs &a, int epi, hipStream_t stream) {
     case GE_COSINE: return launch_one<GE_COSINE>(a, stream);
     case GE_BIAS_RELU: return launch_one<GE_BIAS_RELU>(a, stream);
     case GE_BIAS_ADD_RELU: return launch_one<GE_BIAS_ADD_RELU>(a, stream);
+    case GE_CAND: return launch_one<GE_CAND>(a, stream);
     }
     mpreid_set_error("gemm_f16: unknown epilogue %d", epi);
     return MPREID_ERR_ARG;
@@ -1069,6 +1235,14 @@ __global__ __launch_bounds__(256) void split3_pack_kernel(const float *__restric
     }
 }
 
+// start stagger of the persistent distance GEMM (see GemmArgs::stagger); MPREID_GEMM_STAGGER overrides (ticks, 0 = off)
+static int euclid_stagger_ticks(int M, int N, int K) {
+    static const char *e = getenv("MPREID_GEMM_STAGGER");
+    if (e) return atoi(e);
+    (void)M; (void)N; (void)K;
+    return 0;
+}
+
 size_t mpreid_distance_split3_ws_bytes(int64_t nq, int64_t ng, int d) {
     const size_t dp = align_up((size_t)d, GBK);
     const size_t mp = align_up((size_t)nq, 256), np = align_up((size_t)ng, 256);
@@ -1110,6 +1284,7 @@ int mpreid_distance_f16_split3(const float *q, const float *g, int64_t nq, int64
     a.n_valid = (int)ng;
     a.rscale = qs;
     a.cscale = gs;
+    a.stagger = euclid_stagger_ticks(a.M, a.N, a.K);
     return launch_gemm_f16(a, epi == 0 ? GE_EUCLID : GE_COSINE, stream);
 }
 
@@ -1144,5 +1319,6 @@ int mpreid_distance_f16_fast(const float *q, const float *g, int64_t nq, int64_t
     a.aux2 = gn;
     a.m_valid = (int)nq;
     a.n_valid = (int)ng;
+    a.stagger = euclid_stagger_ticks(a.M, a.N, a.K);
     return launch_gemm_f16(a, epi == 0 ? GE_EUCLID : GE_COSINE, stream);
 }

@@ -17,12 +17,15 @@
 // same code the CPU oracle runs, so the result is bit-identical to oracle/mpreid_oracle.c.
 // All kernels here are HBM/L2-bound integer+fp16 work (no MFMA); the GEMM is in distance.hip.
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
+#include "gemm_f16.h"
 
 int mpreid_distance_launch(const float *q, const float *g, int64_t nq, int64_t ng, int d, const float *qn,
-                           const float *gn, float *out, int64_t ldo, int epi, hipStream_t stream);
+                           const float *gn, float *out, int64_t ldo, int epi, hipStream_t stream,
+                           const unsigned *m_count = nullptr);
 
 // ---------------------------------------------------------------------------------------------
 // Native binary16 on the device.  include/mpreid_numerics.h spells numpy's float16 arithmetic out in integer code
@@ -52,7 +55,7 @@ struct RerankLayout {
     int64_t N, ld;
     int K, KR, h, vcap;
     int64_t qcap_bound;
-    size_t feat, norms, D, MT, rowmax, rank, vcnt, vidx, vval, ucnt, qcnt, qidx, qval, ccnt, cptr, crow, cval,
+    size_t feat, norms, D, MT, rowmax, rank, vcnt, vidx, vval, ucnt, qcnt, qidx, qval, ccnt, chist, cptr, crow, cval,
         counters, total;
 };
 
@@ -89,6 +92,7 @@ static RerankLayout make_layout(int64_t nq, int64_t ng, int d, int k1, int k2, i
     L.qidx = take(N * (size_t)L.qcap_bound * 4);
     L.qval = take(N * (size_t)L.qcap_bound * 2);
     L.ccnt = take((N + 1) * 4);
+    L.chist = take(N * (size_t)256 * 4);   // CSC_B block histograms
     L.cptr = take((N + 1) * 8);
     L.crow = take(N * (size_t)L.qcap_bound * 4);
     L.cval = take(N * (size_t)L.qcap_bound * 2);
@@ -97,10 +101,6 @@ static RerankLayout make_layout(int64_t nq, int64_t ng, int d, int k1, int k2, i
     return L;
 }
 
-extern "C" size_t mpreid_rerank_workspace_bytes(int64_t nq, int64_t ng, int d, int k1, int k2, int has_local) {
-    if (nq < 0 || ng < 0 || d <= 0 || k1 < 0 || k2 < 1) return 0;
-    return make_layout(nq, ng, d, k1, k2, has_local).total;
-}
 
 // ---------------------------------------------------------------------------------------------
 // small device helpers
@@ -177,6 +177,22 @@ __device__ float wave_pairwise_sum(const float *a, int n, int lane) {
     return ret;
 }
 
+// out[0] = sum of x[0..n) (one workgroup; statistics only)
+__global__ __launch_bounds__(1024) void sum_i32_kernel(const int *__restrict__ x, int64_t n, unsigned long long *__restrict__ out) {
+    __shared__ unsigned long long part[16];
+    unsigned long long s = 0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) s += (unsigned long long)(unsigned)x[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < 16; ++w) t += part[w];
+        out[0] = t;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // (D + local)^T  /  local^T  (only when local_distmat is given; utils/reranking.py:33-34,43-46)
 // ---------------------------------------------------------------------------------------------
@@ -226,7 +242,9 @@ __device__ __forceinline__ int block_excl_scan_256(int v, int tid, int *s_wave, 
 
 constexpr int TOPK_CAND = 1024;
 __global__ __launch_bounds__(256) void rowmax_topk_kernel(const float *__restrict__ MT, int64_t ld, int64_t N, int KR,
-                                                          float *__restrict__ rowmax, int *__restrict__ rank) {
+                                                          float *__restrict__ rowmax, int *__restrict__ rank,
+                                                          const unsigned *__restrict__ row_count) {
+    if (row_count && blockIdx.x >= *row_count) return;   // rows past a device-side count (fallback rows) are skipped
     __shared__ unsigned hist[2048];
     __shared__ unsigned long long sel[256];
     __shared__ unsigned long long cand[TOPK_CAND];   // (key, index) of the entries that share the first 22 key bits with
@@ -387,7 +405,9 @@ __global__ __launch_bounds__(256) void rowmax_topk_kernel(const float *__restric
 // radix-histogram passes and the collection run from registers (+ LDS atomics for the histograms).
 template <int CHUNK>
 __global__ __launch_bounds__(256) void rowmax_topk_reg_kernel(const float *__restrict__ MT, int64_t ld, int64_t N, int KR,
-                                                              float *__restrict__ rowmax, int *__restrict__ rank) {
+                                                              float *__restrict__ rowmax, int *__restrict__ rank,
+                                                              const unsigned *__restrict__ row_count) {
+    if (row_count && blockIdx.x >= *row_count) return;
     __shared__ unsigned long long sel[256];
     __shared__ float s_red[4];
     __shared__ int s_wave[4];
@@ -538,15 +558,17 @@ __global__ __launch_bounds__(256) void rowmax_topk_reg_kernel(const float *__res
 }
 
 static int launch_rowmax_topk(const float *MT, int64_t ld, int64_t N, int KR, int64_t rows, float *rowmax, int *rank,
-                              hipStream_t stream) {
+                              hipStream_t stream, const unsigned *row_count = nullptr) {
     // measured on MI355X: the register-resident kernel wins for N <= 8192 (0.25 vs 0.34 ms at N = 8000); with 80+
     // keys per thread it drops to 2 waves/SIMD and loses to the radix kernel that re-reads rows from L2
     // (3.3 vs 1.9 ms at N = 20 000)
     const int64_t per = (N + 255) / 256;
     if (per <= 32)
-        hipLaunchKernelGGL(rowmax_topk_reg_kernel<32>, dim3((unsigned)rows), dim3(256), 0, stream, MT, ld, N, KR, rowmax, rank);
+        hipLaunchKernelGGL(rowmax_topk_reg_kernel<32>, dim3((unsigned)rows), dim3(256), 0, stream, MT, ld, N, KR, rowmax, rank,
+                           row_count);
     else
-        hipLaunchKernelGGL(rowmax_topk_kernel, dim3((unsigned)rows), dim3(256), 0, stream, MT, ld, N, KR, rowmax, rank);
+        hipLaunchKernelGGL(rowmax_topk_kernel, dim3((unsigned)rows), dim3(256), 0, stream, MT, ld, N, KR, rowmax, rank,
+                           row_count);
     LAUNCH_CHECK();
     return MPREID_OK;
 }
@@ -573,13 +595,112 @@ __device__ __forceinline__ int extract_bits_sorted(const unsigned *mask, int nw,
     return base;
 }
 
+// exact squared distance of rows i and j of `feat`, the oracle's arithmetic (oracle/mpreid_oracle.c: dot_block +
+// orc_euclid): a k-ascending fmaf chain from 0, then fmaf(-2, dot, |f_i|^2 + |f_j|^2) -- the same bits as one entry
+// of the exact distance GEMM.  qrow: row i (LDS or global), grow: row j in global memory.
+__device__ __forceinline__ float exact_dist_chain(const float *qrow, const float *__restrict__ grow, int d, float ni, float nj) {
+    float acc = 0.0f;
+    int k = 0;
+    if ((reinterpret_cast<uintptr_t>(grow) & 15) == 0 && d >= 32) {
+        // one 128-byte line of row j per batch (8 x 16 B issued back to back: the lanes of a wave walk 64 different
+        // rows, so a batch touches 64 lines once), the next batch in flight while this one feeds the chain
+        float4 nx[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) nx[u] = *reinterpret_cast<const float4 *>(grow + 4 * u);
+        const int nb = d >> 5;
+        for (int b = 0; b < nb; ++b) {
+            float4 cur[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cur[u] = nx[u];
+            if (b + 1 < nb) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) nx[u] = *reinterpret_cast<const float4 *>(grow + (b + 1) * 32 + 4 * u);
+            }
+            const float *qk = qrow + b * 32;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                acc = fmaf(qk[4 * u + 0], cur[u].x, acc);
+                acc = fmaf(qk[4 * u + 1], cur[u].y, acc);
+                acc = fmaf(qk[4 * u + 2], cur[u].z, acc);
+                acc = fmaf(qk[4 * u + 3], cur[u].w, acc);
+            }
+        }
+        k = nb << 5;
+    }
+    for (; k < d; ++k) acc = fmaf(qrow[k], grow[k], acc);
+    return fmaf(-2.0f, acc, ni + nj);
+}
+
+// Wave-cooperative form of exact_dist_chain: lane l receives the exact distance of row i (qrow, in LDS) to ITS
+// candidate row jl (jl < 0: none).  The 64 candidate rows are fetched 32 floats at a time with COALESCED loads (8
+// lanes take one 128-byte line of one candidate; a per-lane walk of its own row costs 64 tag look-ups per load
+// instruction and ran the texture path at ~0.4 requests per clock), laid into a wave-private LDS tile [64][36] and
+// read back by the owning lane, whose fmaf chain therefore keeps the oracle's k-ascending order.  The loads of the next
+// 32 floats are in flight while the current ones feed the chain.  tile: 64 * 36 floats of LDS per wave.
+constexpr int WXD_STRIDE = 36;
+__device__ __forceinline__ float wave_exact_dists(const float *qrow, const float *__restrict__ feat, int d, int jl, float ni,
+                                                  const float *__restrict__ sqn, float *tile, int lane) {
+    float acc = 0.0f;
+    int k0 = 0;
+    const bool fast = (d % 4 == 0) && ((reinterpret_cast<uintptr_t>(feat) & 15) == 0) && d >= 32;
+    if (fast) {
+        const int piece = lane & 7, sub = lane >> 3;
+        const float *src[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int jc = __shfl(jl, 8 * u + sub, 64);
+            src[u] = (jc >= 0) ? feat + (int64_t)jc * d + piece * 4 : nullptr;
+        }
+        const int nb = d >> 5;
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[u] ? *reinterpret_cast<const float4 *>(src[u]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int b = 0; b < nb; ++b) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) *reinterpret_cast<float4 *>(tile + (8 * u + sub) * WXD_STRIDE + piece * 4) = v[u];
+            if (b + 1 < nb) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    v[u] = src[u] ? *reinterpret_cast<const float4 *>(src[u] + (b + 1) * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const float *qk = qrow + b * 32;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                const float4 g4 = *reinterpret_cast<const float4 *>(tile + lane * WXD_STRIDE + p * 4);
+                acc = fmaf(qk[4 * p + 0], g4.x, acc);
+                acc = fmaf(qk[4 * p + 1], g4.y, acc);
+                acc = fmaf(qk[4 * p + 2], g4.z, acc);
+                acc = fmaf(qk[4 * p + 3], g4.w, acc);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        k0 = nb << 5;
+    }
+    if (jl < 0) return 0.0f;
+    const float *grow = feat + (int64_t)jl * d;
+    for (int k = k0; k < d; ++k) acc = fmaf(qrow[k], grow[k], acc);
+    return fmaf(-2.0f, acc, ni + sqn[jl]);
+}
+
 // MT / rowmax / vcnt / vidx / vval are indexed by the LOCAL row (blockIdx.x); `rank` is the global table and
 // row0 the global index of local row 0 (0 on a single GPU; the rank's first row when rows are sharded).
-__global__ __launch_bounds__(64) void krecip_kernel(const float *__restrict__ MT, int64_t ld, int64_t N,
-                                                    const float *__restrict__ rowmax, const int *__restrict__ rank,
-                                                    int K, int KR, int h, int vcap, int *__restrict__ vcnt,
-                                                    int *__restrict__ vidx, uint16_t *__restrict__ vval, int row0,
-                                                    unsigned long long *__restrict__ r_counter) {
+// SPARSE (candidate pipeline, no N x N matrix): the distances of row i to its expansion set are evaluated on the fly
+// from the features (exact_dist_chain); MT is unused, feat [N][d] / norms [N] are the inputs.
+// One 256-thread workgroup per row.  (First version: one wave per row walking the expansion candidates one after the
+// other -- ~47 iterations of two dependent global loads with 26 active lanes, 130 us per row.  Now a half-wave per
+// candidate, eight candidates per iteration.)  Wave 0 keeps the ordered steps (rank-order compaction of R, bitmap
+// extraction, numpy-order pairwise sum, ordered write of the V row).
+template <bool SPARSE>
+__global__ __launch_bounds__(256) void krecip_kernel(const float *__restrict__ MT, int64_t ld, int64_t N,
+                                                     const float *__restrict__ rowmax, const int *__restrict__ rank,
+                                                     int K, int KR, int h, int vcap, int *__restrict__ vcnt,
+                                                     int *__restrict__ vidx, uint16_t *__restrict__ vval, int row0,
+                                                     int *__restrict__ r_count,
+                                                     const float *__restrict__ feat, const float *__restrict__ norms,
+                                                     int d, const float *__restrict__ rankd) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nw = (int)((N + 31) >> 5);
     unsigned *Rmask = (unsigned *)smem;
@@ -588,65 +709,89 @@ __global__ __launch_bounds__(64) void krecip_kernel(const float *__restrict__ MT
     int *R = fwd + K;
     int *Elist = R + K;
     float *wbuf = (float *)(Elist + vcap);
-    const int lane = threadIdx.x;
+    // SPARSE only: exact distances of the first K neighbours (from the refinement), the indices of expansion entries
+    // that are not among them, row i of feat and the wave_exact_dists tile (16-byte aligned)
+    float *fdist = wbuf + vcap;
+    int *miss = (int *)(fdist + K);
+    float *qrow = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(miss + vcap) + 15) & ~(uintptr_t)15);
+    float *xtile = qrow + ((d + 3) & ~3);
+    __shared__ int s_nR, s_nE, s_nmiss;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = blockIdx.x;      // local row
     const int i = row0 + li;        // global row
 
-    for (int w = lane; w < nw; w += 64) {
+    for (int w = tid; w < nw; w += 256) {
         Rmask[w] = 0u;
         Emask[w] = 0u;
     }
-    for (int a = lane; a < K; a += 64) fwd[a] = rank[(int64_t)i * KR + a];
-    __syncthreads();
-
-    // k_reciprocal_index: fwd[a] such that i is among the first K neighbours of fwd[a]; rank order kept
-    int nR = 0;
-    for (int a0 = 0; a0 < K; a0 += 64) {
-        const int a = a0 + lane;
-        bool f = false;
-        int c = -1;
-        if (a < K) {
-            c = fwd[a];
-            const int *br = rank + (int64_t)c * KR;
-            for (int b = 0; b < K; ++b) f |= (br[b] == i);
-        }
-        const unsigned long long m = __ballot(f);
-        if (f) {
-            const int pos = nR + __popcll(m & ((1ull << lane) - 1ull));
-            R[pos] = c;
-            atomicOr(&Rmask[c >> 5], 1u << (c & 31));
-            atomicOr(&Emask[c >> 5], 1u << (c & 31));
-        }
-        nR += __popcll(m);
+    for (int a = tid; a < K; a += 256) {
+        fwd[a] = rank[(int64_t)i * KR + a];
+        if (SPARSE) fdist[a] = rankd[(int64_t)i * KR + a];
     }
-    if (r_counter && lane == 0) atomicAdd(r_counter, (unsigned long long)nR);
+    if (tid == 0) s_nmiss = 0;
     __syncthreads();
 
-    // expansion: candidates in R order; their own k/2-reciprocal sets, accepted on > 2/3 overlap with R
-    for (int a = 0; a < nR; ++a) {
-        const int cand = R[a];
-        const int *cf = rank + (int64_t)cand * KR;
-        int nRc = 0, inter = 0;
-        unsigned okbits = 0u;
-        for (int b0 = 0, ch = 0; b0 < h; b0 += 64, ++ch) {
-            const int b = b0 + lane;
-            bool ok = false, inr = false;
-            if (b < h) {
-                const int f = cf[b];
-                const int *cb = rank + (int64_t)f * KR;
-                for (int c = 0; c < h; ++c) ok |= (cb[c] == cand);
-                inr = ok && ((Rmask[f >> 5] >> (f & 31)) & 1u);
+    // k_reciprocal_index: fwd[a] such that i is among the first K neighbours of fwd[a]; rank order kept (wave 0)
+    if (wave == 0) {
+        int nR = 0;
+        for (int a0 = 0; a0 < K; a0 += 64) {
+            const int a = a0 + lane;
+            bool f = false;
+            int c = -1;
+            if (a < K) {
+                c = fwd[a];
+                const int *br = rank + (int64_t)c * KR;
+                for (int b = 0; b < K; ++b) f |= (br[b] == i);
             }
-            nRc += __popcll(__ballot(ok));
-            inter += __popcll(__ballot(inr));
-            if (ok) okbits |= (1u << ch);
+            const unsigned long long m = __ballot(f);
+            if (f) {
+                const int pos = nR + __popcll(m & ((1ull << lane) - 1ull));
+                R[pos] = c;
+                atomicOr(&Rmask[c >> 5], 1u << (c & 31));
+                atomicOr(&Emask[c >> 5], 1u << (c & 31));
+            }
+            nR += __popcll(m);
         }
-        if ((double)inter > (2.0 / 3.0) * (double)nRc) {
-            for (int b0 = 0, ch = 0; b0 < h; b0 += 64, ++ch) {
-                const int b = b0 + lane;
-                if (b < h && ((okbits >> ch) & 1u)) {
+        if (lane == 0) {
+            s_nR = nR;
+            if (r_count) r_count[li] = nR;   // |R(i, k1)|, summed afterwards (statistics)
+        }
+    }
+    __syncthreads();
+    const int nR = s_nR;
+
+    // expansion: the k/2-reciprocal set of every candidate, accepted on > 2/3 overlap with R.  A half-wave (32
+    // lanes) per candidate; h <= 32 entries are tested in one step, larger h in chunks of 32.
+    {
+        const int half = tid >> 5, hl = tid & 31;          // 8 half-waves
+        const unsigned long long hmask = (hl == (lane & 31) && (lane & 32)) ? 0xffffffff00000000ull : 0x00000000ffffffffull;
+        for (int a0 = 0; a0 < nR; a0 += 8) {
+            const int a = a0 + half;
+            const bool live = a < nR;
+            const int cand = live ? R[a] : 0;
+            const int *cf = rank + (int64_t)cand * KR;
+            int nRc = 0, inter = 0;
+            unsigned okbits = 0u;
+            for (int b0 = 0, ch = 0; b0 < h; b0 += 32, ++ch) {
+                const int b = b0 + hl;
+                bool ok = false, inr = false;
+                if (live && b < h) {
                     const int f = cf[b];
-                    atomicOr(&Emask[f >> 5], 1u << (f & 31));
+                    const int *cb = rank + (int64_t)f * KR;
+                    for (int c = 0; c < h; ++c) ok |= (cb[c] == cand);
+                    inr = ok && ((Rmask[f >> 5] >> (f & 31)) & 1u);
+                }
+                nRc += __popcll(__ballot(ok) & hmask);
+                inter += __popcll(__ballot(inr) & hmask);
+                if (ok) okbits |= (1u << ch);
+            }
+            if (live && (double)inter > (2.0 / 3.0) * (double)nRc) {
+                for (int b0 = 0, ch = 0; b0 < h; b0 += 32, ++ch) {
+                    const int b = b0 + hl;
+                    if (b < h && ((okbits >> ch) & 1u)) {
+                        const int f = cf[b];
+                        atomicOr(&Emask[f >> 5], 1u << (f & 31));
+                    }
                 }
             }
         }
@@ -654,12 +799,45 @@ __global__ __launch_bounds__(64) void krecip_kernel(const float *__restrict__ MT
     __syncthreads();
 
     // np.unique(expansion index) == set bits of Emask in ascending order
-    const int nE = extract_bits_sorted(Emask, nw, Elist, lane);
+    if (wave == 0) {
+        const int n = extract_bits_sorted(Emask, nw, Elist, lane);
+        if (lane == 0) s_nE = n;
+    }
+    if (SPARSE)
+        for (int k = tid; k < d; k += 256) qrow[k] = feat[(int64_t)i * d + k];
     __syncthreads();
+    const int nE = s_nE;
     const float mx = rowmax[li];
-    const float *row = MT + (int64_t)li * ld;
-    for (int t = lane; t < nE; t += 64) wbuf[t] = mpreid_np_expf(-__fdiv_rn(row[Elist[t]], mx));
+    if (SPARSE) {
+        // entries among the first K neighbours (all of R, i.e. nearly everything) have their exact distance already;
+        // the others are evaluated now
+        for (int t = tid; t < nE; t += 256) {
+            const int j = Elist[t];
+            int pos = -1;
+            for (int a = 0; a < K; ++a) pos = (fwd[a] == j) ? a : pos;
+            if (pos >= 0) {
+                wbuf[t] = mpreid_np_expf(-__fdiv_rn(fdist[pos], mx));
+            } else {
+                miss[atomicAdd(&s_nmiss, 1)] = t;
+            }
+        }
+        __syncthreads();
+        const int nmiss = s_nmiss;
+        if (wave == 0 && nmiss > 0) {
+            const float ni = norms[i];
+            for (int t0 = 0; t0 < nmiss; t0 += 64) {
+                const int u = t0 + lane;
+                const int t = u < nmiss ? miss[u] : -1;
+                const float dij = wave_exact_dists(qrow, feat, d, t >= 0 ? Elist[t] : -1, ni, norms, xtile, lane);
+                if (t >= 0) wbuf[t] = mpreid_np_expf(-__fdiv_rn(dij, mx));
+            }
+        }
+    } else {
+        const float *row = MT + (int64_t)li * ld;
+        for (int t = tid; t < nE; t += 256) wbuf[t] = mpreid_np_expf(-__fdiv_rn(row[Elist[t]], mx));
+    }
     __syncthreads();
+    if (wave != 0) return;
     const float s = wave_pairwise_sum(wbuf, nE, lane);
     // V[i, E] = fp16(weight / sum); only non-zero halves are kept (V != 0 tests later)
     int out = 0;
@@ -845,6 +1023,79 @@ __global__ __launch_bounds__(256) void csc_fill_kernel(int64_t N, const int *__r
 }
 
 // ---------------------------------------------------------------------------------------------
+// Inverted index WITHOUT global atomics (the atomic-cursor build above ran at 1 % of HBM bandwidth: 25 M device-scope
+// atomics for 12.5 M entries).  Counting sort with the rows cut into CSC_B blocks:
+//   1. every block histograms the columns of its rows in LDS (LDS atomics) and writes its histogram row H[b][.]
+//   2. per column: exclusive scan of H[.][c] over the blocks (in place) and the column total -> ccnt[c];
+//      the existing single-workgroup scan turns ccnt into cptr
+//   3. every block re-walks its rows with LDS cursors cptr[c] + H[b][c] and writes (row, value) to its slots
+// Columns are processed in ranges of CSC_CR (LDS: 4 bytes per column) -- one range up to N = 36 864.
+// The order of the rows inside a column depends on LDS-atomic arrival order within a block; the Jaccard sum does
+// not (every row occurs once per column and owns its own accumulator).
+// ---------------------------------------------------------------------------------------------
+constexpr int CSC_B = 256, CSC_CR = 36864;
+static_assert(CSC_B == 256, "the workspace layouts reserve 256 block histograms");
+__global__ __launch_bounds__(1024) void csc2_hist_kernel(int64_t N, const int *__restrict__ qcnt, const int *__restrict__ qidx,
+                                                         int qcap, int rows_per_block, unsigned *__restrict__ H) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned *hist = (unsigned *)smem;
+    const int b = blockIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.y * CSC_CR;
+    const int cw = (int)((N - c0 < CSC_CR) ? N - c0 : CSC_CR);
+    for (int c = threadIdx.x; c < cw; c += 1024) hist[c] = 0u;
+    __syncthreads();
+    const int64_t r_lo = (int64_t)b * rows_per_block, r_hi = (r_lo + rows_per_block < N) ? r_lo + rows_per_block : N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t i = r_lo + wave; i < r_hi; i += 16) {
+        const int cnt = qcnt[i];
+        for (int a = lane; a < cnt; a += 64) {
+            const int64_t c = qidx[i * qcap + a] - c0;
+            if (c >= 0 && c < cw) atomicAdd(&hist[c], 1u);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < cw; c += 1024) H[(int64_t)b * N + c0 + c] = hist[c];
+}
+// per column: H[b][c] <- sum of H[b'][c] over b' < b; ccnt[c] = total
+__global__ __launch_bounds__(256) void csc2_colscan_kernel(int64_t N, unsigned *__restrict__ H, unsigned *__restrict__ ccnt) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    unsigned run = 0u;
+#pragma unroll 8
+    for (int b = 0; b < CSC_B; ++b) {
+        const unsigned v = H[(int64_t)b * N + c];
+        H[(int64_t)b * N + c] = run;
+        run += v;
+    }
+    ccnt[c] = run;
+}
+__global__ __launch_bounds__(1024) void csc2_fill_kernel(int64_t N, const int *__restrict__ qcnt, const int *__restrict__ qidx,
+                                                         const uint16_t *__restrict__ qval, int qcap, int rows_per_block,
+                                                         const unsigned *__restrict__ H, const long long *__restrict__ cptr,
+                                                         int *__restrict__ crow, uint16_t *__restrict__ cval) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned *cur = (unsigned *)smem;
+    const int b = blockIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.y * CSC_CR;
+    const int cw = (int)((N - c0 < CSC_CR) ? N - c0 : CSC_CR);
+    for (int c = threadIdx.x; c < cw; c += 1024) cur[c] = (unsigned)cptr[c0 + c] + H[(int64_t)b * N + c0 + c];
+    __syncthreads();
+    const int64_t r_lo = (int64_t)b * rows_per_block, r_hi = (r_lo + rows_per_block < N) ? r_lo + rows_per_block : N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t i = r_lo + wave; i < r_hi; i += 16) {
+        const int cnt = qcnt[i];
+        for (int a = lane; a < cnt; a += 64) {
+            const int64_t c = qidx[i * qcap + a] - c0;
+            if (c >= 0 && c < cw) {
+                const unsigned p = atomicAdd(&cur[c], 1u);
+                crow[p] = (int)i;
+                cval[p] = qval[i * qcap + a];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Jaccard min-sum with fp16 accumulation in ascending column order + final blend
 // (utils/reranking.py:84-100).  One 256-thread workgroup per query; t[] lives in LDS as fp16 bits,
 // r-space processed in chunks of rch entries so that any N fits.
@@ -966,6 +1217,343 @@ __global__ __launch_bounds__(JT) void jaccard_kernel(int64_t N, int64_t nq, cons
     }
 }
 
+// =============================================================================================
+// Candidate pipeline ("sparse" algorithm): initial_rank and the column maxima WITHOUT the N x N matrix.
+//
+//   1. feat -> fp16 (one rounding per element); every 16th row forms a sample.
+//   2. sample pass: d~ = one-pass fp16 distances of every row against the sample ([N][N/16] fp32, 1/16 of N x N);
+//      per row the r-th smallest and the largest sample value give two thresholds (rr2_threshold_kernel).
+//   3. fused pass: the full symmetric fp16 GEMM on the matrix cores with the GE_CAND epilogue (gemm_f16.hip):
+//      nothing is stored, entries with d~ <= tlo[i] or d~ >= thi[i] are appended to row i's candidate lists
+//      (~160 + ~16 of N entries).
+//   4. refinement (rr2_refine_kernel): the EXACT distance (exact_dist_chain = the oracle's fmaf chain) of the few
+//      candidates that can still be among the first KR neighbours / be the row maximum, then the exact selection by
+//      (O value, index).  Everything rests on one bound:   |d~ - d_exact| <= eps_i   (derivation at rr2_eps).
+//      A row whose candidate list cannot be PROVEN to contain the answer (too few / too many candidates, threshold
+//      closer than 2 eps to the KR-th candidate) is handed to the fallback: its whole distance row is computed
+//      exactly and selected by the dense kernel.  So the result is always the dense algorithm's, bit for bit;
+//      the thresholds only decide how much work that takes.
+//   5. k-reciprocal expansion with on-the-fly exact distances (krecip_kernel<true>), query expansion, inverted index
+//      as before; the Jaccard stage reads the exact distance rows of the QUERIES only ([nq][N]).
+// HBM traffic: N x N/16 fp32 once, instead of N x N fp32 written once and read ~5 times.
+// =============================================================================================
+
+// |fp16 one-pass distance - exact fp32-chain distance| for rows i, j with norms a = |f_i|, b = |f_j|, dimension D:
+//   inputs rounded to fp16: relative 2^-11 each  ->  |dot~ - dot| <= (2 * 2^-11 + 2^-22) * sum |x_k y_k| <= 2^-10 * 1.001 * a * b
+//   fp16 subnormals (|x_k| < 2^-14): absolute 2^-25 per element  ->  <= 2^-25 * sqrt(D) * (a + b)
+//   fp32 accumulation, either side, any order: <= D * 2^-24 * a * b each
+//   d = fmaf(-2, dot, a^2 + b^2): the dot errors double; the norm sum and the final rounding add 2^-23 * (a^2 + b^2 + 2ab)
+// eps_i uses b <= G = the largest row norm.
+__device__ __forceinline__ float rr2_eps(float a, float G, int D) {
+    const float ab = a * G;
+    return ab * (0.0019551f + 2.4e-7f * (float)D) + 1.2e-7f * sqrtf((float)D) * (a + G) + 2.4e-7f * (a + G) * (a + G);
+}
+
+// rows r*stride of x (fp32 [n][d]) -> fp16 [n_out_pad][d_pad], zero padded; norms gathered alongside (padded with 0)
+__global__ __launch_bounds__(256) void rr2_cast_rows_kernel(const float *__restrict__ x, const float *__restrict__ sqn,
+                                                            int64_t n, int d, int stride, _Float16 *__restrict__ y,
+                                                            int d_pad, float *__restrict__ sqn_out) {
+    const int64_t r = blockIdx.x, src = r * stride;
+    const bool ok = src < n;
+    for (int k = threadIdx.x; k < d_pad; k += 256) y[r * (int64_t)d_pad + k] = (ok && k < d) ? (_Float16)x[src * d + k] : (_Float16)0.0f;
+    if (sqn_out && threadIdx.x == 0) sqn_out[r] = ok ? sqn[src] : 0.0f;
+}
+
+// G = max row norm -> gstat[0]; gstat[1] = 1 if any norm is too large for fp16 operands (or not finite)
+__global__ __launch_bounds__(1024) void rr2_norm_stats_kernel(const float *__restrict__ sqn, int64_t n, float *__restrict__ gstat) {
+    __shared__ float red[16];
+    float m = 0.0f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, sqn[i]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+        const float G = sqrtf(m);
+        gstat[0] = G;
+        gstat[1] = (G < 3.0e4f) ? 0.0f : 1.0f;   // NaN compares false -> 1
+    }
+}
+
+// per row: thresholds from the sample distances.  tlo = r-th smallest sample value (about 16 r of the N entries of
+// the row lie below it), thi = sample maximum - 2 eps.  Padded rows get -inf / +inf.  256 threads per row.
+__global__ __launch_bounds__(256) void rr2_threshold_kernel(const float *__restrict__ S, int64_t ldS, int ns, int64_t N,
+                                                            int rsel, const float *__restrict__ sqn,
+                                                            const float *__restrict__ gstat, int D,
+                                                            float *__restrict__ tlo, float *__restrict__ thi,
+                                                            float *__restrict__ eps, unsigned *__restrict__ cnt_lo,
+                                                            unsigned *__restrict__ cnt_hi) {
+    __shared__ unsigned keys[512];
+    __shared__ float s_red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t i = blockIdx.x;
+    if (tid == 0) {
+        cnt_lo[i] = 0u;
+        cnt_hi[i] = 0u;
+    }
+    if (i >= N) {
+        if (tid == 0) {
+            tlo[i] = -__builtin_huge_valf();
+            thi[i] = __builtin_huge_valf();
+            eps[i] = 0.0f;
+        }
+        return;
+    }
+    const float *row = S + i * ldS;
+    // thread-local two smallest + maximum over a strided slice; the r-th smallest of the 512 survivors is an
+    // approximation of the row's r-th smallest (exact unless one thread holds three of the r smallest) -- it is
+    // only a threshold: correctness never depends on it
+    unsigned k0 = 0xffffffffu, k1 = 0xffffffffu;
+    float mx = -3.402823466e+38f;
+    for (int j = tid; j < ns; j += 256) {
+        const float v = row[j];
+        mx = fmaxf(mx, v);
+        const unsigned k = fkey(v);
+        if (k < k0) {
+            k1 = k0;
+            k0 = k;
+        } else if (k < k1)
+            k1 = k;
+    }
+    keys[tid] = k0;
+    keys[256 + tid] = k1;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if (lane == 0) s_red[wave] = mx;
+    __syncthreads();
+    for (int size = 2; size <= 512; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int e = tid + h * 256, partner = e ^ stride;
+                if (partner > e) {
+                    const unsigned a = keys[e], b = keys[partner];
+                    const bool up = ((e & size) == 0);
+                    if ((a > b) == up) {
+                        keys[e] = b;
+                        keys[partner] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    if (tid == 0) {
+        const int r = rsel < ns ? rsel : ns;
+        const unsigned kk = keys[r - 1];
+        const unsigned u = (kk & 0x80000000u) ? (kk & 0x7fffffffu) : ~kk;   // inverse of fkey
+        const float e = rr2_eps(sqrtf(sqn[i]), gstat[0], D);
+        tlo[i] = __uint_as_float(u);
+        thi[i] = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3])) - 2.0f * e;
+        eps[i] = e;
+    }
+}
+
+// Refinement of one row (256 threads): see the header of this section.  status[i]: 0 = certified, 1 = fallback.
+constexpr int RR2_MAXE = 128;   // exact evaluations per row on the `lo` side
+constexpr int RR2_MAXH = 32;    // ... and on the `hi` side
+template <int CAP_LO, int CAP_HI>
+__global__ __launch_bounds__(256) void rr2_refine_kernel(const float *__restrict__ feat, const float *__restrict__ sqn,
+                                                         int64_t N, int d, int KR, const unsigned *__restrict__ cnt_lo,
+                                                         const uint2 *__restrict__ list_lo,
+                                                         const unsigned *__restrict__ cnt_hi,
+                                                         const uint2 *__restrict__ list_hi,
+                                                         const float *__restrict__ tlo, const float *__restrict__ eps,
+                                                         float *__restrict__ rowmax, int *__restrict__ rank,
+                                                         float *__restrict__ rankd,
+                                                         unsigned *__restrict__ fb_count, int *__restrict__ fb_rows,
+                                                         unsigned fb_max) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    static_assert(CAP_LO <= 512 && CAP_HI <= 256, "list capacities");
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);   // [512]
+    unsigned long long *ekey = keys + 512;                                     // [RR2_MAXE] exact (O key, index)
+    int *hsel = reinterpret_cast<int *>(ekey + RR2_MAXE);                      // [RR2_MAXH]
+    float *hval = reinterpret_cast<float *>(hsel + RR2_MAXH);                  // [RR2_MAXH]
+    float *qrow = hval + RR2_MAXH;                                             // [d rounded up to 4]
+    float *xtile = qrow + ((d + 3) & ~3);                                      // [3 waves][64][WXD_STRIDE]
+    __shared__ float s_red[4];
+    __shared__ unsigned s_cnt;
+    __shared__ int s_fail;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t i = blockIdx.x;
+    const unsigned nlo = cnt_lo[i], nhi = cnt_hi[i];
+    const float e = eps[i];
+    if (tid == 0) {
+        s_cnt = 0u;
+        s_fail = (nlo > (unsigned)CAP_LO || nhi > (unsigned)CAP_HI || nlo < (unsigned)KR || nhi < 1u) ? 1 : 0;
+    }
+    for (int k = tid; k < d; k += 256) qrow[k] = feat[i * d + k];
+    // ---- lo side: sort the candidates by approximate distance ----
+    for (int t = tid; t < 512; t += 256) {
+        unsigned long long kv = ~0ull;
+        if (t < (int)nlo && t < CAP_LO) {
+            const uint2 c = list_lo[i * CAP_LO + t];
+            kv = ((unsigned long long)fkey(__uint_as_float(c.y)) << 32) | c.x;
+        }
+        keys[t] = kv;
+    }
+    __syncthreads();
+    const bool fail0 = s_fail != 0;
+    if (!fail0) {
+        for (int size = 2; size <= 512; size <<= 1)
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int a_i = tid + h * 256, partner = a_i ^ stride;
+                    if (partner > a_i) {
+                        const unsigned long long a = keys[a_i], b = keys[partner];
+                        const bool up = ((a_i & size) == 0);
+                        if ((a > b) == up) {
+                            keys[a_i] = b;
+                            keys[partner] = a;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+    }
+    // x~ = KR-th smallest approximate distance; every candidate up to x~ + 2 eps is evaluated exactly
+    float xt = 0.0f, cut = 0.0f;
+    int m = 0;
+    if (!fail0) {
+        const unsigned kx = (unsigned)(keys[KR - 1] >> 32);
+        xt = __uint_as_float((kx & 0x80000000u) ? (kx & 0x7fffffffu) : ~kx);
+        cut = xt + 2.0f * e;
+        const unsigned kcut = fkey(cut);
+        // count of keys <= cut (keys sorted ascending; nlo <= 512)
+        int c = 0;
+        for (int t = tid; t < (int)nlo; t += 256) c += ((unsigned)(keys[t] >> 32) <= kcut) ? 1 : 0;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+        if (lane == 0) atomicAdd(&s_cnt, (unsigned)c);
+    }
+    __syncthreads();
+    m = (int)s_cnt;
+    __syncthreads();
+    // certification 1: everything that was NOT a candidate has d~ > tlo, so exact > tlo - eps; it must lie above the
+    // exact KR-th, which is <= x~ + eps  ->  x~ + 2 eps <= tlo;  and the evaluation budget
+    if (tid == 0) {
+        if (!fail0 && (m > RR2_MAXE || !(xt + 2.0f * e <= tlo[i]))) s_fail = 1;
+        s_cnt = 0u;
+    }
+    // ---- hi side: approximate maximum, everything within 2 eps of it is evaluated exactly ----
+    float hm = -3.402823466e+38f;
+    if (!fail0)
+        for (int t = tid; t < (int)nhi; t += 256) hm = fmaxf(hm, __uint_as_float(list_hi[i * CAP_HI + t].y));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) hm = fmaxf(hm, __shfl_xor(hm, off, 64));
+    if (lane == 0) s_red[wave] = hm;
+    __syncthreads();
+    hm = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    if (!fail0)
+        for (int t = tid; t < (int)nhi; t += 256) {
+            const uint2 c = list_hi[i * CAP_HI + t];
+            if (__uint_as_float(c.y) >= hm - 2.0f * e) {
+                const unsigned p = atomicAdd(&s_cnt, 1u);
+                if (p < (unsigned)RR2_MAXH) hsel[p] = (int)c.x;
+            }
+        }
+    __syncthreads();
+    const int mh = (int)s_cnt;
+    if (tid == 0 && mh > RR2_MAXH) s_fail = 1;
+    __syncthreads();
+    if (s_fail) {
+        if (tid == 0) {
+            const unsigned p = atomicAdd(fb_count, 1u);
+            if (p < fb_max) fb_rows[p] = (int)i;
+        }
+        return;
+    }
+    // ---- exact distances: threads 0..m-1 the lo candidates, threads 128..128+mh-1 the hi candidates ----
+    const float ni = sqn[i];
+    float dex = 0.0f;
+    int jx = -1;
+    if (tid < m) jx = (int)(unsigned)(keys[tid] & 0xffffffffull);
+    else if (tid >= 128 && tid < 128 + mh) jx = hsel[tid - 128];
+    if (wave < 3 && (wave * 64 < m || wave == 2))   // wave-uniform: waves 0, 1 the lo candidates, wave 2 the hi ones
+        dex = wave_exact_dists(qrow, feat, d, jx, ni, sqn, xtile + wave * 64 * WXD_STRIDE, lane);
+    if (tid >= 128 && tid < 128 + mh) hval[tid - 128] = dex;
+    __syncthreads();
+    float mx = -3.402823466e+38f;
+    for (int t = 0; t < mh; ++t) mx = fmaxf(mx, hval[t]);   // exact row maximum (see the header: always certified)
+    // ---- exact selection by (O value, index) ----
+    if (tid < RR2_MAXE) ekey[tid] = (tid < m) ? (((unsigned long long)fkey(__fdiv_rn(dex, mx)) << 32) | (unsigned)jx) : ~0ull;
+    // the approximate keys are done with (every thread has read its jx before the barrier above): their memory now
+    // holds (index, exact distance) by slot, for the distances of the selected neighbours written out below
+    int *djx = reinterpret_cast<int *>(keys);
+    float *dlo = reinterpret_cast<float *>(keys + 64);
+    if (tid < m) {
+        djx[tid] = jx;
+        dlo[tid] = dex;
+    }
+    __syncthreads();
+    for (int size = 2; size <= RR2_MAXE; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (tid < RR2_MAXE) {
+                const int partner = tid ^ stride;
+                if (partner > tid) {
+                    const unsigned long long a = ekey[tid], b = ekey[partner];
+                    const bool up = ((tid & size) == 0);
+                    if ((a > b) == up) {
+                        ekey[tid] = b;
+                        ekey[partner] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    // certification 2 (ties after the division): whatever was not evaluated has exact distance > x~ + eps (the
+    // unevaluated candidates) or > tlo - eps >= x~ + eps (the rest); its O value is >= fdiv(x~ + eps, mx), which
+    // must be STRICTLY above the KR-th selected O value
+    const unsigned okx = (unsigned)(ekey[KR - 1] >> 32);
+    const bool ok = fkey(__fdiv_rn(xt + e, mx)) > okx;
+    if (!ok) {
+        if (tid == 0) {
+            const unsigned p = atomicAdd(fb_count, 1u);
+            if (p < fb_max) fb_rows[p] = (int)i;
+        }
+        return;
+    }
+    if (tid < KR) {
+        const int j = (int)(unsigned)(ekey[tid] & 0xffffffffull);
+        rank[i * KR + tid] = j;
+        float dj = 0.0f;   // D[i][j], exact: the expansion kernel weighs the neighbours with exp(-D / rowmax)
+        for (int sl = 0; sl < m; ++sl) dj = (djx[sl] == j) ? dlo[sl] : dj;
+        rankd[i * KR + tid] = dj;
+    }
+    if (tid == 0) rowmax[i] = mx;
+}
+
+// fallback rows: gather their features / norms, and scatter their dense results back
+__global__ __launch_bounds__(256) void rr2_fb_gather_kernel(const float *__restrict__ feat, const float *__restrict__ sqn, int d,
+                                                            const int *__restrict__ fb_rows,
+                                                            const unsigned *__restrict__ fb_count, unsigned fb_max,
+                                                            float *__restrict__ fb_feat, float *__restrict__ fb_sqn) {
+    const unsigned b = blockIdx.x;
+    const unsigned cnt = *fb_count < fb_max ? *fb_count : fb_max;
+    if (b >= cnt) return;
+    const int64_t i = fb_rows[b];
+    for (int k = threadIdx.x; k < d; k += 256) fb_feat[(int64_t)b * d + k] = feat[i * d + k];
+    if (threadIdx.x == 0) fb_sqn[b] = sqn[i];
+}
+__global__ __launch_bounds__(256) void rr2_fb_scatter_kernel(const int *__restrict__ fb_rows, const unsigned *__restrict__ fb_count,
+                                                             unsigned fb_max, const float *__restrict__ fb_rowmax,
+                                                             const int *__restrict__ fb_rank, int KR,
+                                                             const float *__restrict__ fb_D, int64_t ld,
+                                                             float *__restrict__ rowmax, int *__restrict__ rank,
+                                                             float *__restrict__ rankd) {
+    const unsigned b = blockIdx.x;
+    const unsigned cnt = *fb_count < fb_max ? *fb_count : fb_max;
+    if (b >= cnt) return;
+    const int64_t i = fb_rows[b];
+    for (int t = threadIdx.x; t < KR; t += 256) {
+        const int j = fb_rank[(int64_t)b * KR + t];
+        rank[i * KR + t] = j;
+        rankd[i * KR + t] = fb_D[(int64_t)b * ld + j];
+    }
+    if (threadIdx.x == 0) rowmax[i] = fb_rowmax[b];
+}
+
 // ---------------------------------------------------------------------------------------------
 // host driver
 // ---------------------------------------------------------------------------------------------
@@ -1021,7 +1609,166 @@ static int set_dyn_lds(F kernel, size_t bytes) {
     return MPREID_OK;
 }
 
-extern "C" int mpreid_rerank_f32(const float *q, const float *g, int64_t nq, int64_t ng, int d, int k1, int k2,
+// max of x[0..n) -> out[0] (one workgroup)
+__global__ __launch_bounds__(1024) void max_i32_kernel(const int *__restrict__ x, int64_t n, int *__restrict__ out) {
+    __shared__ int part[16];
+    int m = 0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) m = max(m, x[i]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) m = max(m, part[w]);
+        out[0] = m;
+    }
+}
+
+// Everything after the V rows (query expansion, inverted index, Jaccard + blend, statistics): shared by the dense and
+// the sparse algorithm.  MT = distance rows of (at least) the queries, row stride ld; rowmax indexed like MT's rows.
+// The ONE host round trip of the call is in here: 16 bytes (largest union size of the query expansion, which sizes
+// the ELL rows of V_qe and the LDS of the kernels that walk them, and nnz(V)); counts and sums are reduced on the GPU.
+struct TailArgs {
+    int64_t N, nq;
+    int k1, k2, KR, h, vcap;
+    int64_t qcap_bound;   // capacity the workspace was sized for (entries per row of V_qe / of the inverted index)
+    const int *rank;
+    int *vcnt, *vidx;
+    uint16_t *vval;
+    int *ucnt, *qcnt, *qidx;
+    uint16_t *qval;
+    unsigned *ccnt;
+    unsigned *chist;                // [CSC_B][N] block histograms of the atomics-free inverted-index build (or NULL)
+    long long *cptr;
+    int *crow;
+    uint16_t *cval;
+    unsigned long long *counters;   // [0] Jaccard pairs, [1] sum |R|, [2] nnz(V), [3] max union (int), [4] fallback rows, [5] candidates
+    const float *MT;
+    int64_t ld;
+    const float *rowmax;
+    float *out;
+    int64_t ldo;
+    double lambda_value;
+    int algo;
+};
+
+static int rerank_tail(const TailArgs &a, hipStream_t stream, StageTimer &tm, mpreid_rerank_stats *stats, int marks_so_far) {
+    const int64_t N = a.N;
+    const int nw = (int)((N + 31) >> 5);
+    const int k2e = (int)std::min<int64_t>(a.k2, N); // rows the query expansion really averages (numpy clamps the slice)
+    int qcap = a.vcap;
+    const int *fcnt = a.vcnt, *fidx = a.vidx;
+    const uint16_t *fval = a.vval;
+    // (7) query expansion
+    hipLaunchKernelGGL(sum_i32_kernel, dim3(1), dim3(1024), 0, stream, a.vcnt, N, a.counters + 2);
+    if (a.k2 != 1) {
+        {
+            const size_t lds = (size_t)nw * 4;
+            int rc = set_dyn_lds(qe_count_kernel, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL(qe_count_kernel, dim3((unsigned)N), dim3(64), lds, stream, N, a.rank, a.KR, k2e, a.vcnt, a.vidx,
+                               a.vcap, a.ucnt, 0);
+            hipLaunchKernelGGL(max_i32_kernel, dim3(1), dim3(1024), 0, stream, a.ucnt, N, (int *)(a.counters + 3));
+            LAUNCH_CHECK();
+        }
+        int mxu = 1;
+        HIP_TRY(hipMemcpyAsync(&mxu, a.counters + 3, 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        if (mxu < 1) mxu = 1;
+        qcap = (int)align_up((size_t)mxu, 8);
+        if ((int64_t)qcap > a.qcap_bound) {
+            if ((int64_t)mxu <= a.qcap_bound) {
+                qcap = (int)a.qcap_bound;
+            } else {
+                mpreid_set_error("query expansion: a row has %d entries, the workspace was sized for %lld; retry with "
+                                 "MPREID_RERANK_DENSE", mxu, (long long)a.qcap_bound);
+                return MPREID_ERR_RETRY_DENSE;
+            }
+        }
+        {
+            const size_t lds = (size_t)nw * 8 + (size_t)qcap * 8;
+            int rc = set_dyn_lds(qe_fill_kernel, lds);
+            if (rc) return rc;
+            hipLaunchKernelGGL(qe_fill_kernel, dim3((unsigned)N), dim3(64), lds, stream, N, a.rank, a.KR, k2e, a.vcnt, a.vidx,
+                               a.vval, a.vcap, qcap, a.qcnt, a.qidx, a.qval, 0);
+            LAUNCH_CHECK();
+        }
+        fcnt = a.qcnt;
+        fidx = a.qidx;
+        fval = a.qval;
+    }
+    tm.mark(); // +1
+    // inverted index
+    static const bool csc_atomic = getenv("MPREID_CSC_ATOMIC") != nullptr;   // A/B switch: the round-1 atomic build
+    if (a.chist && !csc_atomic && (uint64_t)N * (uint64_t)qcap < (1ull << 32)) {
+        const int rpb = (int)((N + CSC_B - 1) / CSC_B);
+        const int nranges = (int)((N + CSC_CR - 1) / CSC_CR);
+        const size_t lds = (size_t)std::min<int64_t>(N, CSC_CR) * 4;
+        int rc = set_dyn_lds(csc2_hist_kernel, lds);
+        if (rc) return rc;
+        rc = set_dyn_lds(csc2_fill_kernel, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(csc2_hist_kernel, dim3(CSC_B, nranges), dim3(1024), lds, stream, N, fcnt, fidx, qcap, rpb, a.chist);
+        hipLaunchKernelGGL(csc2_colscan_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, N, a.chist, a.ccnt);
+        hipLaunchKernelGGL(csc_scan_kernel, dim3(1), dim3(1024), 0, stream, N, a.ccnt, a.cptr);
+        hipLaunchKernelGGL(csc2_fill_kernel, dim3(CSC_B, nranges), dim3(1024), lds, stream, N, fcnt, fidx, fval, qcap, rpb,
+                           a.chist, a.cptr, a.crow, a.cval);
+    } else {
+        HIP_TRY(hipMemsetAsync(a.ccnt, 0, (size_t)(N + 1) * 4, stream));
+        hipLaunchKernelGGL(csc_count_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, N, fcnt, fidx, qcap,
+                           a.ccnt);
+        hipLaunchKernelGGL(csc_scan_kernel, dim3(1), dim3(1024), 0, stream, N, a.ccnt, a.cptr);
+        hipLaunchKernelGGL(csc_fill_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, N, fcnt, fidx, fval, qcap,
+                           a.cptr, a.ccnt, a.crow, a.cval);
+    }
+    LAUNCH_CHECK();
+    tm.mark(); // +2
+    // (8)-(11) Jaccard + blend
+    {
+        const uint16_t oml = f64_to_f16_host(1.0 - a.lambda_value);
+        const float lam32 = (float)a.lambda_value;
+        int rch = (int)std::min<int64_t>(N, 49152);
+        rch = (int)align_up((size_t)rch, 8);
+        const size_t lds = align_up((size_t)rch * 2, 16) + (size_t)qcap * (8 + 4 + 2) + 16;
+        int rc = set_dyn_lds(jaccard_kernel, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(jaccard_kernel, dim3((unsigned)a.nq), dim3(JT), lds, stream, N, a.nq, a.MT, a.ld, a.rowmax, fcnt,
+                           fidx, fval, qcap, a.cptr, a.crow, a.cval, rch, oml, lam32, a.out, a.ldo, a.counters, 0);
+        LAUNCH_CHECK();
+    }
+    tm.mark(); // +3
+    unsigned long long cnt[6] = {0, 0, 0, 0, 0, 0};
+    long long nnz_total = 0;
+    HIP_TRY(hipMemcpyAsync(cnt, a.counters, sizeof(cnt), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(&nnz_total, a.cptr + N, 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (stats) {
+        const int m = marks_so_far;   // index of the mark taken after the V rows
+        stats->n = N;
+        stats->k1 = a.k1;
+        stats->k2 = a.k2;
+        stats->half_k1 = a.h;
+        stats->v_cap = a.vcap;
+        stats->vqe_cap = qcap;
+        stats->v_nnz = (int64_t)cnt[2];
+        stats->vqe_nnz = nnz_total;
+        stats->jaccard_pairs = (int64_t)cnt[0];
+        stats->krecip_r_sum = (int64_t)cnt[1];
+        stats->fallback_rows = (int64_t)(cnt[4] & 0xffffffffull);
+        stats->cand_total = (int64_t)cnt[5];
+        stats->algo = a.algo;
+        stats->ms_gemm = tm.ms(0, 1);
+        stats->ms_topk = tm.ms(1, 2);
+        stats->ms_krecip = tm.ms(2, 3);
+        stats->ms_qe = tm.ms(m, m + 1);
+        stats->ms_csc = tm.ms(m + 1, m + 2);
+        stats->ms_jaccard = tm.ms(m + 2, m + 3);
+        stats->ms_total = tm.ms(0, m + 3);
+    }
+    return MPREID_OK;
+}
+
+static int rerank_dense(const float *q, const float *g, int64_t nq, int64_t ng, int d, int k1, int k2,
                                  double lambda_value, const float *local, int only_local, float *out, int64_t ldo,
                                  void *ws, size_t ws_bytes, mpreid_stream_t stream_, mpreid_rerank_stats *stats,
                                  int timing) {
@@ -1085,108 +1832,303 @@ extern "C" int mpreid_rerank_f32(const float *q, const float *g, int64_t nq, int
     // (4)-(6) V rows
     {
         const size_t lds = (size_t)nw * 8 + (size_t)L.K * 8 + (size_t)L.vcap * 8;
-        int rc = set_dyn_lds(krecip_kernel, lds);
+        int rc = set_dyn_lds(krecip_kernel<false>, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(krecip_kernel, dim3((unsigned)N), dim3(64), lds, stream, MT, L.ld, N, rowmax, rank, L.K,
-                           L.KR, L.h, L.vcap, vcnt, vidx, vval, 0, counters + 1);
+        hipLaunchKernelGGL(krecip_kernel<false>, dim3((unsigned)N), dim3(256), lds, stream, MT, L.ld, N, rowmax, rank, L.K,
+                           L.KR, L.h, L.vcap, vcnt, vidx, vval, 0, ucnt, (const float *)nullptr,
+                           (const float *)nullptr, 0, (const float *)nullptr);
+        hipLaunchKernelGGL(sum_i32_kernel, dim3(1), dim3(1024), 0, stream, ucnt, N, counters + 1);
         LAUNCH_CHECK();
     }
     tm.mark(); // 3
-    // (7) query expansion
-    std::vector<int> host_cnt((size_t)N);
-    int64_t v_nnz = 0, q_nnz = 0;
-    const int k2e = (int)std::min<int64_t>(k2, N); // rows the query expansion really averages (numpy clamps the slice)
-    int qcap = L.vcap;
-    const int *fcnt = vcnt, *fidx = vidx;
-    const uint16_t *fval = vval;
-    HIP_TRY(hipMemcpyAsync(host_cnt.data(), vcnt, (size_t)N * 4, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    for (int64_t i = 0; i < N; ++i) v_nnz += host_cnt[(size_t)i];
-    if (k2 != 1) {
-        {
-            const size_t lds = (size_t)nw * 4;
-            int rc = set_dyn_lds(qe_count_kernel, lds);
-            if (rc) return rc;
-            hipLaunchKernelGGL(qe_count_kernel, dim3((unsigned)N), dim3(64), lds, stream, N, rank, L.KR, k2e, vcnt, vidx,
-                               L.vcap, ucnt, 0);
-            LAUNCH_CHECK();
-        }
-        HIP_TRY(hipMemcpyAsync(host_cnt.data(), ucnt, (size_t)N * 4, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        int mxu = 1;
-        for (int64_t i = 0; i < N; ++i) mxu = std::max(mxu, host_cnt[(size_t)i]);
-        qcap = (int)std::min<int64_t>(L.qcap_bound, (int64_t)align_up((size_t)mxu, 8));
-        if (qcap < mxu) qcap = mxu;
-        {
-            const size_t lds = (size_t)nw * 8 + (size_t)qcap * 8;
-            int rc = set_dyn_lds(qe_fill_kernel, lds);
-            if (rc) return rc;
-            hipLaunchKernelGGL(qe_fill_kernel, dim3((unsigned)N), dim3(64), lds, stream, N, rank, L.KR, k2e, vcnt, vidx,
-                               vval, L.vcap, qcap, qcnt, qidx, qval, 0);
-            LAUNCH_CHECK();
-        }
-        fcnt = qcnt;
-        fidx = qidx;
-        fval = qval;
+    TailArgs ta{};
+    ta.N = N; ta.nq = nq; ta.k1 = k1; ta.k2 = k2; ta.KR = L.KR; ta.h = L.h; ta.vcap = L.vcap; ta.qcap_bound = L.qcap_bound;
+    ta.rank = rank; ta.vcnt = vcnt; ta.vidx = vidx; ta.vval = vval; ta.ucnt = ucnt; ta.qcnt = qcnt; ta.qidx = qidx;
+    ta.qval = qval; ta.ccnt = ccnt; ta.cptr = cptr; ta.crow = crow; ta.cval = cval; ta.counters = counters;
+    ta.chist = (unsigned *)(base + L.chist);
+    ta.MT = MT; ta.ld = L.ld; ta.rowmax = rowmax; ta.out = out; ta.ldo = ldo; ta.lambda_value = lambda_value;
+    ta.algo = MPREID_RERANK_DENSE;
+    return rerank_tail(ta, stream, tm, stats, 3);
+}
+
+// ---------------------------------------------------------------------------------------------
+// sparse algorithm: host driver (kernels: the "Candidate pipeline" section above)
+// ---------------------------------------------------------------------------------------------
+constexpr int RR2_CAP_LO = 384, RR2_CAP_HI = 128, RR2_SAMPLE_STRIDE = 16, RR2_RSEL = 10, RR2_QCAP = 4096;
+
+struct Rerank2Layout {
+    int64_t N, Np, Nsp, ld, fb_max;
+    int dp, K, KR, h, vcap;
+    int64_t qcap_bound;
+    size_t feat, sqn, feat16, samp16, sampn, sampD, tlo, thi, eps, cnt_lo, cnt_hi, list_lo, list_hi, gstat, rowmax, rank, rankd,
+        fb_count, fb_rows, fb_feat, fb_sqn, fb_D, fb_rowmax, fb_rank, vcnt, vidx, vval, ucnt, qcnt, qidx, qval, ccnt, chist,
+        cptr, crow, cval, dq, counters, total;
+};
+
+static Rerank2Layout make_layout2(int64_t nq, int64_t ng, int d, int k1, int k2) {
+    Rerank2Layout L{};
+    L.N = nq + ng;
+    L.Np = (int64_t)align_up((size_t)L.N, 256);
+    const int64_t ns = (L.N + RR2_SAMPLE_STRIDE - 1) / RR2_SAMPLE_STRIDE;
+    L.Nsp = (int64_t)align_up((size_t)ns, 256);
+    L.ld = (int64_t)align_up((size_t)L.N, 64);
+    L.dp = (int)align_up((size_t)d, 64);
+    L.fb_max = std::max<int64_t>(256, L.N / 16);
+    L.K = (int)std::min<int64_t>(k1 + 1, L.N);
+    L.KR = std::max(L.K, (int)std::min<int64_t>(k2, L.N));
+    L.h = (int)std::min<int64_t>(mpreid_half_k1(k1), L.N);
+    L.vcap = (int)std::min<int64_t>((int64_t)L.K * (1 + L.h), L.N);
+    L.qcap_bound = std::min<int64_t>(std::min<int64_t>(L.N, (int64_t)std::max(k2, 1) * L.vcap), RR2_QCAP);
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += align_up(bytes, 256);
+        return o;
+    };
+    const size_t N = (size_t)L.N, Np = (size_t)L.Np, F = (size_t)L.fb_max;
+    L.feat = take(N * (size_t)d * 4);
+    L.sqn = take(Np * 4);
+    L.feat16 = take(Np * (size_t)L.dp * 2);
+    L.samp16 = take((size_t)L.Nsp * L.dp * 2);
+    L.sampn = take((size_t)L.Nsp * 4);
+    L.sampD = take(Np * (size_t)L.Nsp * 4);
+    L.tlo = take(Np * 4);
+    L.thi = take(Np * 4);
+    L.eps = take(Np * 4);
+    L.cnt_lo = take(Np * 4);
+    L.cnt_hi = take(Np * 4);
+    L.list_lo = take(Np * (size_t)RR2_CAP_LO * 8);
+    L.list_hi = take(Np * (size_t)RR2_CAP_HI * 8);
+    L.gstat = take(64);
+    L.rowmax = take(N * 4);
+    L.rank = take(N * (size_t)L.KR * 4);
+    L.rankd = take(N * (size_t)L.KR * 4);
+    L.fb_count = take(64);
+    L.fb_rows = take(F * 4);
+    L.fb_feat = take(F * (size_t)d * 4);
+    L.fb_sqn = take(F * 4);
+    L.fb_D = take(F * (size_t)L.ld * 4);
+    L.fb_rowmax = take(F * 4);
+    L.fb_rank = take(F * (size_t)L.KR * 4);
+    L.vcnt = take(N * 4);
+    L.vidx = take(N * (size_t)L.vcap * 4);
+    L.vval = take(N * (size_t)L.vcap * 2);
+    L.ucnt = take(N * 4);
+    L.qcnt = take(N * 4);
+    L.qidx = take(N * (size_t)L.qcap_bound * 4);
+    L.qval = take(N * (size_t)L.qcap_bound * 2);
+    L.ccnt = take((N + 1) * 4);
+    L.chist = take(N * (size_t)256 * 4);   // CSC_B block histograms
+    L.cptr = take((N + 1) * 8);
+    L.crow = take(N * (size_t)L.qcap_bound * 4);
+    L.cval = take(N * (size_t)L.qcap_bound * 2);
+    L.dq = take((size_t)nq * L.ld * 4);
+    L.counters = take(64);
+    L.total = off;
+    return L;
+}
+
+// the sparse algorithm applies when there is no local_distmat, the problem is large enough for the sample to mean
+// something, and the neighbour count fits the refinement kernel's evaluation budget
+static bool sparse_eligible(int64_t nq, int64_t ng, int k1, int k2, const float *local) {
+    const int64_t N = nq + ng;
+    const int64_t KR = std::max<int64_t>(std::min<int64_t>(k1 + 1, N), std::min<int64_t>(k2, N));
+    return local == nullptr && N >= 2048 && KR <= 64;
+}
+
+static int rerank_sparse(const float *q, const float *g, int64_t nq, int64_t ng, int d, int k1, int k2, double lambda_value,
+                         float *out, int64_t ldo, void *ws, size_t ws_bytes, mpreid_stream_t stream_,
+                         mpreid_rerank_stats *stats, int timing) {
+    ARG_CHECK(q && g && out && nq > 0 && ng > 0 && d > 0 && k1 >= 0 && k2 >= 1 && ldo >= ng);
+    const Rerank2Layout L = make_layout2(nq, ng, d, k1, k2);
+    const int64_t N = L.N;
+    if (N >= (1ll << 28) - 512) {
+        mpreid_set_error("N too large for the sparse algorithm");
+        return MPREID_ERR_UNSUPPORTED;
     }
-    tm.mark(); // 4
-    // inverted index
-    HIP_TRY(hipMemsetAsync(ccnt, 0, (size_t)(N + 1) * 4, stream));
-    hipLaunchKernelGGL(csc_count_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, N, fcnt, fidx, qcap,
-                       ccnt);
-    hipLaunchKernelGGL(csc_scan_kernel, dim3(1), dim3(1024), 0, stream, N, ccnt, cptr);
-    hipLaunchKernelGGL(csc_fill_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, N, fcnt, fidx, fval, qcap,
-                       cptr, ccnt, crow, cval);
+    if (!ws || ws_bytes < L.total) {
+        mpreid_set_error("rerank workspace too small: %zu < %zu", ws_bytes, L.total);
+        return MPREID_ERR_WORKSPACE;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    char *base = (char *)ws;
+    float *feat = (float *)(base + L.feat), *sqn = (float *)(base + L.sqn);
+    _Float16 *feat16 = (_Float16 *)(base + L.feat16), *samp16 = (_Float16 *)(base + L.samp16);
+    float *sampn = (float *)(base + L.sampn), *sampD = (float *)(base + L.sampD);
+    float *tlo = (float *)(base + L.tlo), *thi = (float *)(base + L.thi), *eps = (float *)(base + L.eps);
+    unsigned *cnt_lo = (unsigned *)(base + L.cnt_lo), *cnt_hi = (unsigned *)(base + L.cnt_hi);
+    uint2 *list_lo = (uint2 *)(base + L.list_lo), *list_hi = (uint2 *)(base + L.list_hi);
+    float *gstat = (float *)(base + L.gstat), *rowmax = (float *)(base + L.rowmax);
+    int *rank = (int *)(base + L.rank);
+    float *rankd = (float *)(base + L.rankd);
+    unsigned *fb_count = (unsigned *)(base + L.fb_count);
+    int *fb_rows = (int *)(base + L.fb_rows);
+    float *fb_feat = (float *)(base + L.fb_feat), *fb_sqn = (float *)(base + L.fb_sqn), *fb_D = (float *)(base + L.fb_D),
+          *fb_rowmax = (float *)(base + L.fb_rowmax);
+    int *fb_rank = (int *)(base + L.fb_rank);
+    int *vcnt = (int *)(base + L.vcnt), *vidx = (int *)(base + L.vidx);
+    uint16_t *vval = (uint16_t *)(base + L.vval);
+    int *ucnt = (int *)(base + L.ucnt);
+    float *dq = (float *)(base + L.dq);
+    unsigned long long *counters = (unsigned long long *)(base + L.counters);
+    const int nw = (int)((N + 31) >> 5);
+    const int ns = (int)((N + RR2_SAMPLE_STRIDE - 1) / RR2_SAMPLE_STRIDE);
+
+    StageTimer tm(timing != 0, stream);
+    HIP_TRY(hipMemsetAsync(counters, 0, 64, stream));
+    HIP_TRY(hipMemsetAsync(fb_count, 0, 64, stream));
+    // rows that need the fallback but do not fit its buffer keep these values: the call then ends with
+    // MPREID_ERR_RETRY_DENSE, but every kernel on the way must still see valid neighbour indices
+    HIP_TRY(hipMemsetAsync(rank, 0, (size_t)N * L.KR * 4, stream));
+    HIP_TRY(hipMemsetAsync(rankd, 0, (size_t)N * L.KR * 4, stream));
+    HIP_TRY(hipMemsetAsync(rowmax, 0, (size_t)N * 4, stream));
+    tm.mark(); // 0
+    // features, exact squared norms (padded with zeros), fp16 operands, sample
+    HIP_TRY(hipMemcpyAsync(feat, q, (size_t)nq * d * 4, hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(feat + (size_t)nq * d, g, (size_t)ng * d * 4, hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemsetAsync(sqn, 0, (size_t)L.Np * 4, stream));
+    int rc = mpreid_sqnorm_f32(feat, N, d, sqn, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(rr2_norm_stats_kernel, dim3(1), dim3(1024), 0, stream, sqn, N, gstat);
+    hipLaunchKernelGGL(rr2_cast_rows_kernel, dim3((unsigned)L.Np), dim3(256), 0, stream, feat, sqn, N, d, 1, feat16, L.dp,
+                       (float *)nullptr);
+    hipLaunchKernelGGL(rr2_cast_rows_kernel, dim3((unsigned)L.Nsp), dim3(256), 0, stream, feat, sqn, N, d,
+                       RR2_SAMPLE_STRIDE, samp16, L.dp, sampn);
     LAUNCH_CHECK();
-    tm.mark(); // 5
-    // (8)-(11) Jaccard + blend
-    {
-        const uint16_t oml = f64_to_f16_host(1.0 - lambda_value);
-        const float lam32 = (float)lambda_value;
-        int rch = (int)std::min<int64_t>(N, 49152);
-        rch = (int)align_up((size_t)rch, 8);
-        const size_t lds = align_up((size_t)rch * 2, 16) + (size_t)qcap * (8 + 4 + 2) + 16;
-        int rc = set_dyn_lds(jaccard_kernel, lds);
+    {   // sample pass: [Np] x [Nsp] one-pass fp16 distances, stored
+        GemmArgs a{};
+        a.A = feat16; a.W = samp16; a.M = (int)L.Np; a.N = (int)L.Nsp; a.K = L.dp;
+        a.out = sampD; a.ldo = L.Nsp; a.aux = sqn; a.aux2 = sampn; a.m_valid = (int)N; a.n_valid = ns;
+        rc = launch_gemm_f16(a, GE_EUCLID, stream);
         if (rc) return rc;
-        hipLaunchKernelGGL(jaccard_kernel, dim3((unsigned)nq), dim3(JT), lds, stream, N, nq, MT, L.ld, rowmax, fcnt,
-                           fidx, fval, qcap, cptr, crow, cval, rch, oml, lam32, out, ldo, counters, 0);
+    }
+    hipLaunchKernelGGL(rr2_threshold_kernel, dim3((unsigned)L.Np), dim3(256), 0, stream, sampD, L.Nsp, ns, N, RR2_RSEL, sqn,
+                       gstat, d, tlo, thi, eps, cnt_lo, cnt_hi);
+    LAUNCH_CHECK();
+    {   // fused pass: symmetric N x N on the matrix cores, candidates only
+        GemmArgs a{};
+        a.A = feat16; a.W = feat16; a.M = (int)L.Np; a.N = (int)L.Np; a.K = L.dp;
+        a.aux = sqn; a.aux2 = sqn; a.m_valid = (int)N; a.n_valid = (int)N;
+        a.tlo = tlo; a.thi = thi; a.cnt_lo = cnt_lo; a.cnt_hi = cnt_hi; a.list_lo = list_lo; a.list_hi = list_hi;
+        a.cap_lo = RR2_CAP_LO; a.cap_hi = RR2_CAP_HI; a.sym = 1;
+        rc = launch_gemm_f16(a, GE_CAND, stream);
+        if (rc) return rc;
+    }
+    tm.mark(); // 1
+    {   // refinement + fallback rows
+        const size_t lds = 512 * 8 + RR2_MAXE * 8 + RR2_MAXH * 8 + (size_t)((d + 3) & ~3) * 4 + 3 * 64 * WXD_STRIDE * 4;
+        rc = set_dyn_lds(rr2_refine_kernel<RR2_CAP_LO, RR2_CAP_HI>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((rr2_refine_kernel<RR2_CAP_LO, RR2_CAP_HI>), dim3((unsigned)N), dim3(256), lds, stream, feat, sqn, N,
+                           d, L.KR, cnt_lo, list_lo, cnt_hi, list_hi, tlo, eps, rowmax, rank, rankd, fb_count, fb_rows,
+                           (unsigned)L.fb_max);
+        hipLaunchKernelGGL(rr2_fb_gather_kernel, dim3((unsigned)L.fb_max), dim3(256), 0, stream, feat, sqn, d, fb_rows,
+                           fb_count, (unsigned)L.fb_max, fb_feat, fb_sqn);
+        LAUNCH_CHECK();
+        rc = mpreid_distance_launch(fb_feat, feat, L.fb_max, N, d, fb_sqn, sqn, fb_D, L.ld, 0, stream, fb_count);
+        if (rc) return rc;
+        rc = launch_rowmax_topk(fb_D, L.ld, N, L.KR, L.fb_max, fb_rowmax, fb_rank, stream, fb_count);
+        if (rc) return rc;
+        hipLaunchKernelGGL(rr2_fb_scatter_kernel, dim3((unsigned)L.fb_max), dim3(256), 0, stream, fb_rows, fb_count,
+                           (unsigned)L.fb_max, fb_rowmax, fb_rank, L.KR, fb_D, L.ld, rowmax, rank, rankd);
+        hipLaunchKernelGGL(sum_i32_kernel, dim3(1), dim3(1024), 0, stream, (const int *)cnt_lo, N, counters + 5);
+        HIP_TRY(hipMemcpyAsync(counters + 4, fb_count, 4, hipMemcpyDeviceToDevice, stream));
         LAUNCH_CHECK();
     }
-    tm.mark(); // 6
-    unsigned long long pairs = 0, r_sum = 0;
-    long long nnz_total = 0;
-    HIP_TRY(hipMemcpyAsync(&pairs, counters, 8, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(&r_sum, counters + 1, 8, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipMemcpyAsync(&nnz_total, cptr + N, 8, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    q_nnz = nnz_total;
-    if (stats) {
-        stats->n = N;
-        stats->k1 = k1;
-        stats->k2 = k2;
-        stats->half_k1 = L.h;
-        stats->v_cap = L.vcap;
-        stats->vqe_cap = qcap;
-        stats->v_nnz = v_nnz;
-        stats->vqe_nnz = q_nnz;
-        stats->jaccard_pairs = (int64_t)pairs;
-        stats->krecip_r_sum = (int64_t)r_sum;
-        stats->ms_gemm = tm.ms(0, 1);
-        stats->ms_topk = tm.ms(1, 2);
-        stats->ms_krecip = tm.ms(2, 3);
-        stats->ms_qe = tm.ms(3, 4);
-        stats->ms_csc = tm.ms(4, 5);
-        stats->ms_jaccard = tm.ms(5, 6);
-        stats->ms_total = tm.ms(0, 6);
+    tm.mark(); // 2
+    {   // V rows, distances on the fly
+        const size_t lds = (size_t)nw * 8 + (size_t)L.K * 12 + (size_t)L.vcap * 12 + 16 + (size_t)((d + 3) & ~3) * 4 +
+                           64 * WXD_STRIDE * 4;
+        rc = set_dyn_lds(krecip_kernel<true>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(krecip_kernel<true>, dim3((unsigned)N), dim3(256), lds, stream, (const float *)nullptr, L.ld, N,
+                           rowmax, rank, L.K, L.KR, L.h, L.vcap, vcnt, vidx, vval, 0, ucnt, feat, sqn, d, rankd);
+        hipLaunchKernelGGL(sum_i32_kernel, dim3(1), dim3(1024), 0, stream, ucnt, N, counters + 1);
+        LAUNCH_CHECK();
+    }
+    tm.mark(); // 3
+    // exact distance rows of the queries (what the Jaccard blend reads)
+    rc = mpreid_distance_launch(feat, feat, nq, N, d, sqn, sqn, dq, L.ld, 0, stream);
+    if (rc) return rc;
+    TailArgs ta{};
+    ta.N = N; ta.nq = nq; ta.k1 = k1; ta.k2 = k2; ta.KR = L.KR; ta.h = L.h; ta.vcap = L.vcap; ta.qcap_bound = L.qcap_bound;
+    ta.rank = rank; ta.vcnt = vcnt; ta.vidx = vidx; ta.vval = vval; ta.ucnt = ucnt; ta.qcnt = (int *)(base + L.qcnt);
+    ta.qidx = (int *)(base + L.qidx); ta.qval = (uint16_t *)(base + L.qval); ta.ccnt = (unsigned *)(base + L.ccnt);
+    ta.cptr = (long long *)(base + L.cptr); ta.crow = (int *)(base + L.crow); ta.cval = (uint16_t *)(base + L.cval);
+    ta.chist = (unsigned *)(base + L.chist);
+    ta.counters = counters; ta.MT = dq; ta.ld = L.ld; ta.rowmax = rowmax; ta.out = out; ta.ldo = ldo;
+    ta.lambda_value = lambda_value; ta.algo = MPREID_RERANK_SPARSE;
+    rc = rerank_tail(ta, stream, tm, stats, 3);
+    if (rc) return rc;
+    // status of the data-dependent capacities (read with the statistics, after the fact): the fp16 operands must
+    // not have overflowed and the fallback rows must have fitted their buffer -- otherwise the result above is not
+    // valid and the caller repeats the call with the dense algorithm
+    float gs[2] = {0.f, 0.f};
+    unsigned fbc = 0;
+    HIP_TRY(hipMemcpy(gs, gstat, 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&fbc, fb_count, 4, hipMemcpyDeviceToHost));
+    if (gs[1] != 0.0f || fbc > (unsigned)L.fb_max) {
+        mpreid_set_error("sparse re-ranking: %s; retry with MPREID_RERANK_DENSE",
+                         gs[1] != 0.0f ? "row norms too large for fp16 operands" : "too many rows needed the dense fallback");
+        return MPREID_ERR_RETRY_DENSE;
     }
     return MPREID_OK;
+}
+
+extern "C" size_t mpreid_rerank_workspace_bytes_ex(int64_t nq, int64_t ng, int d, int k1, int k2, int has_local, int algo) {
+    if (nq < 0 || ng < 0 || d <= 0 || k1 < 0 || k2 < 1) return 0;
+    const bool sparse = algo == MPREID_RERANK_SPARSE ||
+                        (algo == MPREID_RERANK_AUTO && sparse_eligible(nq, ng, k1, k2, has_local ? (const float *)1 : nullptr));
+    return sparse ? make_layout2(nq, ng, d, k1, k2).total : make_layout(nq, ng, d, k1, k2, has_local).total;
+}
+extern "C" size_t mpreid_rerank_workspace_bytes(int64_t nq, int64_t ng, int d, int k1, int k2, int has_local) {
+    return mpreid_rerank_workspace_bytes_ex(nq, ng, d, k1, k2, has_local, MPREID_RERANK_AUTO);
+}
+
+extern "C" int mpreid_rerank_f32_ex(const float *q, const float *g, int64_t nq, int64_t ng, int d, int k1, int k2,
+                                    double lambda_value, const float *local, int only_local, float *out, int64_t ldo,
+                                    void *ws, size_t ws_bytes, mpreid_stream_t stream, mpreid_rerank_stats *stats,
+                                    int timing, int algo) {
+    ARG_CHECK(algo == MPREID_RERANK_AUTO || algo == MPREID_RERANK_DENSE || algo == MPREID_RERANK_SPARSE);
+    const bool eligible = sparse_eligible(nq, ng, k1, k2, local);
+    if (algo == MPREID_RERANK_SPARSE && !eligible) {
+        mpreid_set_error("the sparse re-ranking algorithm needs N >= 2048, max(k1+1, k2) <= 64 and no local_distmat");
+        return MPREID_ERR_UNSUPPORTED;
+    }
+    if (algo == MPREID_RERANK_SPARSE || (algo == MPREID_RERANK_AUTO && eligible))
+        return rerank_sparse(q, g, nq, ng, d, k1, k2, lambda_value, out, ldo, ws, ws_bytes, stream, stats, timing);
+    return rerank_dense(q, g, nq, ng, d, k1, k2, lambda_value, local, only_local, out, ldo, ws, ws_bytes, stream, stats,
+                        timing);
+}
+extern "C" int mpreid_rerank_f32(const float *q, const float *g, int64_t nq, int64_t ng, int d, int k1, int k2,
+                                 double lambda_value, const float *local, int only_local, float *out, int64_t ldo,
+                                 void *ws, size_t ws_bytes, mpreid_stream_t stream, mpreid_rerank_stats *stats,
+                                 int timing) {
+    return mpreid_rerank_f32_ex(q, g, nq, ng, d, k1, k2, lambda_value, local, only_local, out, ldo, ws, ws_bytes, stream,
+                                stats, timing, MPREID_RERANK_AUTO);
 }
 
 extern "C" int mpreid_rerank_debug_copy(const void *ws, int64_t nq, int64_t ng, int d, int k1, int k2, int has_local,
                                         int32_t *rank_out, int32_t *v_cnt, int32_t *vqe_cnt,
                                         mpreid_stream_t stream_) {
-    ARG_CHECK(ws);
-    const RerankLayout L = make_layout(nq, ng, d, k1, k2, has_local);
+    return mpreid_rerank_debug_copy_ex(ws, nq, ng, d, k1, k2, has_local, rank_out, v_cnt, vqe_cnt, stream_,
+                                       sparse_eligible(nq, ng, k1, k2, has_local ? (const float *)1 : nullptr)
+                                           ? MPREID_RERANK_SPARSE : MPREID_RERANK_DENSE);
+}
+
+extern "C" int mpreid_rerank_debug_copy_ex(const void *ws, int64_t nq, int64_t ng, int d, int k1, int k2, int has_local,
+                                           int32_t *rank_out, int32_t *v_cnt, int32_t *vqe_cnt,
+                                           mpreid_stream_t stream_, int algo) {
+    ARG_CHECK(ws && (algo == MPREID_RERANK_DENSE || algo == MPREID_RERANK_SPARSE));
+    // the fields the taps read, from whichever layout the call used
+    struct { int64_t N; int K, KR; size_t rank, vcnt, qcnt; } L;
+    if (algo == MPREID_RERANK_SPARSE) {
+        const Rerank2Layout s2 = make_layout2(nq, ng, d, k1, k2);
+        L.N = s2.N; L.K = s2.K; L.KR = s2.KR; L.rank = s2.rank; L.vcnt = s2.vcnt; L.qcnt = s2.qcnt;
+    } else {
+        const RerankLayout s1 = make_layout(nq, ng, d, k1, k2, has_local);
+        L.N = s1.N; L.K = s1.K; L.KR = s1.KR; L.rank = s1.rank; L.vcnt = s1.vcnt; L.qcnt = s1.qcnt;
+    }
     hipStream_t stream = (hipStream_t)stream_;
     const char *base = (const char *)ws;
     if (rank_out) { // [N][k1+1]; columns past min(k1+1, N) are -1
@@ -1275,11 +2217,11 @@ extern "C" int mpreid_rr_krecip(const float *d_local, int64_t ld, int64_t n, con
     ARG_CHECK(d_local && rowmax_local && rank_all && vcnt && vidx && vval && rows > 0 && kr >= K);
     const int nw = (int)((n + 31) >> 5);
     const size_t lds = (size_t)nw * 8 + (size_t)K * 8 + (size_t)vcap * 8;
-    int rc = set_dyn_lds(krecip_kernel, lds);
+    int rc = set_dyn_lds(krecip_kernel<false>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(krecip_kernel, dim3((unsigned)rows), dim3(64), lds, (hipStream_t)stream_, d_local, ld, n,
+    hipLaunchKernelGGL(krecip_kernel<false>, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream_, d_local, ld, n,
                        rowmax_local, rank_all, K, kr, h, vcap, vcnt, vidx, vval, (int)r_lo,
-                       (unsigned long long *)nullptr);
+                       (int *)nullptr, (const float *)nullptr, (const float *)nullptr, 0, (const float *)nullptr);
     LAUNCH_CHECK();
     return MPREID_OK;
 }

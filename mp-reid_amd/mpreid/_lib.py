@@ -15,6 +15,8 @@ LIB_PATH = os.environ.get("MPREID_LIB") or os.path.join(_HERE, "libmpreid_hip.so
 GEMM_F32_EXACT = 0
 GEMM_F16_FAST = 1
 GEMM_F16_SPLIT3 = 2
+RERANK_AUTO, RERANK_DENSE, RERANK_SPARSE = 0, 1, 2
+ERR_RETRY_DENSE = -5
 
 #: every symbol include/mpreid.h declares (tests check the library exports all of them)
 SYMBOLS = [
@@ -22,6 +24,7 @@ SYMBOLS = [
     "mpreid_sqnorm_f32", "mpreid_l2_normalize_f32", "mpreid_distance_workspace_bytes",
     "mpreid_euclidean_distance_f32", "mpreid_cosine_similarity_f32",
     "mpreid_rerank_workspace_bytes", "mpreid_rerank_f32", "mpreid_rerank_debug_copy",
+    "mpreid_rerank_workspace_bytes_ex", "mpreid_rerank_f32_ex", "mpreid_rerank_debug_copy_ex",
     "mpreid_eval_rank_positions", "mpreid_rr_dist_rows", "mpreid_rr_vcap", "mpreid_rr_krecip", "mpreid_rr_pack_rows", "mpreid_rr_qe_count",
     "mpreid_rr_qe_fill", "mpreid_rr_jaccard",
     "mpreid_vit_workspace_bytes", "mpreid_vit_forward", "mpreid_vit_forward_u8", "mpreid_vit_forward_view",
@@ -35,7 +38,8 @@ SYMBOLS = [
 class RerankStats(C.Structure):
     _fields_ = [("n", C.c_int64), ("k1", C.c_int32), ("k2", C.c_int32), ("half_k1", C.c_int32),
                 ("v_cap", C.c_int32), ("vqe_cap", C.c_int32), ("v_nnz", C.c_int64), ("vqe_nnz", C.c_int64),
-                ("jaccard_pairs", C.c_int64), ("krecip_r_sum", C.c_int64), ("ms_gemm", C.c_float), ("ms_topk", C.c_float),
+                ("jaccard_pairs", C.c_int64), ("krecip_r_sum", C.c_int64), ("fallback_rows", C.c_int64),
+                ("cand_total", C.c_int64), ("algo", C.c_int32), ("ms_gemm", C.c_float), ("ms_topk", C.c_float),
                 ("ms_krecip", C.c_float), ("ms_qe", C.c_float), ("ms_csc", C.c_float),
                 ("ms_jaccard", C.c_float), ("ms_total", C.c_float)]
 
@@ -126,6 +130,13 @@ def load():
                                     C.POINTER(RerankStats), i32]
     L.mpreid_rerank_debug_copy.restype = i32
     L.mpreid_rerank_debug_copy.argtypes = [vp, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp]
+    L.mpreid_rerank_workspace_bytes_ex.restype = sz
+    L.mpreid_rerank_workspace_bytes_ex.argtypes = [i64, i64, i32, i32, i32, i32, i32]
+    L.mpreid_rerank_f32_ex.restype = i32
+    L.mpreid_rerank_f32_ex.argtypes = [vp, vp, i64, i64, i32, i32, i32, f64, vp, i32, vp, i64, vp, sz, vp,
+                                       C.POINTER(RerankStats), i32, i32]
+    L.mpreid_rerank_debug_copy_ex.restype = i32
+    L.mpreid_rerank_debug_copy_ex.argtypes = [vp, i64, i64, i32, i32, i32, i32, vp, vp, vp, vp, i32]
     L.mpreid_eval_rank_positions.restype = i32
     L.mpreid_eval_rank_positions.argtypes = [vp, i64, i32, i32, vp, vp, i32, vp, vp, vp]
     L.mpreid_rr_dist_rows.restype = i32

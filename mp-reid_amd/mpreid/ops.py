@@ -12,6 +12,7 @@ import torch
 
 from . import _lib
 from ._lib import GEMM_F16_FAST, GEMM_F16_SPLIT3, GEMM_F32_EXACT  # noqa: F401  (re-exported)
+from ._lib import RERANK_AUTO, RERANK_DENSE, RERANK_SPARSE  # noqa: F401
 
 _ws_cache: Dict[tuple, torch.Tensor] = {}
 
@@ -99,9 +100,11 @@ def cosine_similarity(q, g, mode: int = GEMM_F32_EXACT, out: Optional[torch.Tens
 
 
 def re_ranking(q, g, k1: int, k2: int, lambda_value: float, local_distmat=None, only_local: bool = False,
-               timing: bool = False, debug: bool = False):
+               timing: bool = False, debug: bool = False, algo: int = _lib.RERANK_AUTO):
     """utils/reranking.py:29-100 on the GPU.  Returns (device tensor [nq, ng] fp32, stats dict)
-    and, with debug=True, additionally (initial_rank[:, :k1+1], nnz(V) per row, nnz(V_qe) per row)."""
+    and, with debug=True, additionally (initial_rank[:, :k1+1], nnz(V) per row, nnz(V_qe) per row).
+    algo: RERANK_AUTO (the candidate pipeline without the N x N matrix when it applies, else the dense one; a sparse
+    call that hits a data-dependent capacity is repeated densely), RERANK_DENSE, RERANK_SPARSE -- same bits."""
     dev = _lib.require_gpu()
     L = _lib.load()
     q, g = _dev_f32(q, dev), _dev_f32(g, dev)
@@ -111,22 +114,28 @@ def re_ranking(q, g, k1: int, k2: int, lambda_value: float, local_distmat=None, 
     if local_distmat is not None:
         loc = _dev_f32(local_distmat, dev)
         assert tuple(loc.shape) == (N, N)
-    wsb = L.mpreid_rerank_workspace_bytes(nq, ng, d, int(k1), int(k2), int(loc is not None))
-    ws = _workspace("rerank", wsb, dev)
     out = torch.empty((nq, ng), dtype=torch.float32, device=dev)
     st = _lib.RerankStats()
-    _lib.check(L.mpreid_rerank_f32(_ptr(q), _ptr(g), nq, ng, d, int(k1), int(k2), float(lambda_value), _ptr(loc),
-                                   int(bool(only_local)), _ptr(out), ng, _ptr(ws), ws.numel(), _lib.stream_ptr(),
-                                   C.byref(st), int(bool(timing))), "mpreid_rerank_f32")
+    for attempt in (algo, _lib.RERANK_DENSE):
+        wsb = L.mpreid_rerank_workspace_bytes_ex(nq, ng, d, int(k1), int(k2), int(loc is not None), int(attempt))
+        ws = _workspace("rerank", wsb, dev)
+        rc = L.mpreid_rerank_f32_ex(_ptr(q), _ptr(g), nq, ng, d, int(k1), int(k2), float(lambda_value), _ptr(loc),
+                                    int(bool(only_local)), _ptr(out), ng, _ptr(ws), ws.numel(), _lib.stream_ptr(),
+                                    C.byref(st), int(bool(timing)), int(attempt))
+        if rc == _lib.ERR_RETRY_DENSE and attempt != _lib.RERANK_DENSE and algo == _lib.RERANK_AUTO:
+            continue
+        _lib.check(rc, "mpreid_rerank_f32_ex")
+        break
     stats = st.as_dict()
     if not debug:
         return out, stats
     rank = np.empty((N, k1 + 1), np.int32)
     vc = np.empty(N, np.int32)
     vq = np.empty(N, np.int32)
-    _lib.check(L.mpreid_rerank_debug_copy(_ptr(ws), nq, ng, d, int(k1), int(k2), int(loc is not None),
-                                          C.c_void_p(rank.ctypes.data), C.c_void_p(vc.ctypes.data),
-                                          C.c_void_p(vq.ctypes.data), _lib.stream_ptr()), "mpreid_rerank_debug_copy")
+    _lib.check(L.mpreid_rerank_debug_copy_ex(_ptr(ws), nq, ng, d, int(k1), int(k2), int(loc is not None),
+                                             C.c_void_p(rank.ctypes.data), C.c_void_p(vc.ctypes.data),
+                                             C.c_void_p(vq.ctypes.data), _lib.stream_ptr(), int(stats["algo"])),
+               "mpreid_rerank_debug_copy_ex")
     return out, stats, rank, vc, vq
 
 

@@ -20,11 +20,14 @@ def ops():
     return o
 
 
-def _check_vs_oracle(ops, f, nq, k1, k2, lam, local=None, only_local=False):
+def _check_vs_oracle(ops, f, nq, k1, k2, lam, local=None, only_local=False, algo=0, want_all=None):
     q, g = torch.from_numpy(f[:nq]), torch.from_numpy(f[nq:])
-    got, st, rank, vc, vq = ops.re_ranking(q, g, k1, k2, lam, local_distmat=local, only_local=only_local, debug=True)
-    want, orank, ovc, ovq = orc.re_ranking(f[:nq], f[nq:], k1, k2, lam, local_distmat=local, only_local=only_local,
-                                           debug=True)
+    got, st, rank, vc, vq = ops.re_ranking(q, g, k1, k2, lam, local_distmat=local, only_local=only_local, debug=True,
+                                           algo=algo)
+    if algo:
+        assert st["algo"] == algo
+    want, orank, ovc, ovq = want_all if want_all is not None else orc.re_ranking(
+        f[:nq], f[nq:], k1, k2, lam, local_distmat=local, only_local=only_local, debug=True)
     assert np.array_equal(rank, orank), "initial_rank differs"
     assert np.array_equal(vc, ovc), "nnz(V) differs"
     assert np.array_equal(vq, ovq), "nnz(V_qe) differs"
@@ -100,6 +103,64 @@ def test_rerank_unselected_seeds(ops, golden, row):
     got2 = got2.cpu().numpy()
     assert np.array_equal(got2.reshape(-1)[idx], g[f"{tag}_sameD_val"]), tag
     assert hashlib.sha256(np.ascontiguousarray(got2).tobytes()).hexdigest() == str(g[f"{tag}_sameD_sha"]), tag
+
+
+@pytest.mark.parametrize("n,nq,d,k1,k2,sigma,per_id", [(2048, 400, 256, 50, 15, 2.5, 20), (4096, 500, 768, 50, 15, 3.0, 20),
+                                                        (5000, 1000, 1280, 50, 15, 3.5, 20), (6001, 77, 100, 20, 6, 2.0, 10),
+                                                        (8000, 1600, 768, 30, 10, 3.0, 40), (3000, 600, 64, 10, 1, 1.5, 8),
+                                                        (7000, 1400, 768, 50, 15, 6.0, 20)])
+def test_rerank_sparse_equals_dense_equals_oracle(ops, n, nq, d, k1, k2, sigma, per_id):
+    """the candidate pipeline (no N x N matrix: fp16 GEMM -> thresholded candidates -> exact refinement, fallback rows)
+    against the dense algorithm and the oracle: neighbour table, nnz(V), nnz(V_qe) and every output bit"""
+    from mpreid import synth
+    f, _ = synth.clustered_features(n, d, sigma, seed=3 * n + k1, per_id=per_id)
+    want_all = orc.re_ranking(f[:nq], f[nq:], k1, k2, 0.3, debug=True)
+    _check_vs_oracle(ops, f, nq, k1, k2, 0.3, algo=ops.RERANK_SPARSE, want_all=want_all)
+    _check_vs_oracle(ops, f, nq, k1, k2, 0.3, algo=ops.RERANK_DENSE, want_all=want_all)
+    _, st = ops.re_ranking(torch.from_numpy(f[:nq]), torch.from_numpy(f[nq:]), k1, k2, 0.3, timing=True)
+    assert st["algo"] == ops.RERANK_SPARSE and st["cand_total"] >= n * max(k1 + 1, k2)
+    print("sparse stats", {k: st[k] for k in ("n", "fallback_rows", "cand_total", "v_nnz", "vqe_nnz")})
+
+
+def test_rerank_sparse_hard_cases(ops):
+    """data that stresses the certification: exact duplicates (ties at every cut), unnormalised rows of very
+    different norms, a tight cluster larger than the candidate capacity (those rows must take the dense fallback),
+    and a degenerate set on which the sparse algorithm gives up (AUTO then repeats the call densely)"""
+    from mpreid import synth
+    f, _ = synth.clustered_features(4200, 128, 2.0, seed=77, per_id=10)
+    f[1000:1060] = f[40:100]                 # 60 exact duplicates
+    f[3000:3010] = f[0]                      # 10 copies of one row
+    _check_vs_oracle(ops, f, 800, 20, 6, 0.3, algo=ops.RERANK_SPARSE)
+    _check_vs_oracle(ops, f, 800, 50, 15, 0.3, algo=ops.RERANK_SPARSE)
+    raw, _ = synth.clustered_features(4500, 256, 3.0, seed=5, per_id=15, normalize=False)
+    rng0 = np.random.default_rng(4)
+    mild = raw * rng0.uniform(0.7, 1.4, raw.shape[0]).astype(np.float32)[:, None]   # norms ~35 .. ~70, unnormalised
+    _check_vs_oracle(ops, mild, 900, 50, 15, 0.3, algo=ops.RERANK_SPARSE)
+    # norms from ~2 to ~2000: the nearest neighbours of a large row are the smallest rows, far closer together than
+    # the fp16 error bound of that row -> (almost) nothing can be certified, the sparse algorithm reports it and
+    # AUTO repeats the call densely; nothing may crash on the way
+    wild = raw * np.linspace(0.05, 40.0, raw.shape[0], dtype=np.float32)[:, None]
+    with pytest.raises(RuntimeError, match="RERANK_DENSE"):
+        ops.re_ranking(torch.from_numpy(wild[:900]), torch.from_numpy(wild[900:]), 50, 15, 0.3, algo=ops.RERANK_SPARSE)
+    _check_vs_oracle(ops, wild, 900, 50, 15, 0.3)
+    # 150 near-identical rows: their mutual distances (~1e-7) drown in the fp16 error, nothing about their order can
+    # be certified -> each of them takes the dense fallback (buffer: max(256, N/16) = 312 rows)
+    g, _ = synth.clustered_features(5000, 96, 2.5, seed=9, per_id=10)
+    rng = np.random.default_rng(1)
+    g[2000:2150] = g[1999] + 1e-4 * rng.standard_normal((150, 96)).astype(np.float32)
+    g = orc.l2_normalize(g)
+    got, st, *_ = ops.re_ranking(torch.from_numpy(g[:1000]), torch.from_numpy(g[1000:]), 50, 15, 0.3, debug=True,
+                                 algo=ops.RERANK_SPARSE)
+    assert 150 <= st["fallback_rows"] <= 312, st["fallback_rows"]
+    assert np.array_equal(got.cpu().numpy(), orc.re_ranking(g[:1000], g[1000:], 50, 15, 0.3))
+    # all rows (nearly) identical: more fallback rows than the buffer holds -> RETRY_DENSE, handled by AUTO
+    h = np.tile(g[:1], (2500, 1)) + 1e-5 * rng.standard_normal((2500, 96)).astype(np.float32)
+    h = orc.l2_normalize(h)
+    with pytest.raises(RuntimeError, match="RERANK_DENSE"):
+        ops.re_ranking(torch.from_numpy(h[:300]), torch.from_numpy(h[300:]), 20, 6, 0.3, algo=ops.RERANK_SPARSE)
+    got, st = ops.re_ranking(torch.from_numpy(h[:300]), torch.from_numpy(h[300:]), 20, 6, 0.3)
+    assert st["algo"] == ops.RERANK_DENSE
+    assert np.array_equal(got.cpu().numpy(), orc.re_ranking(h[:300], h[300:], 20, 6, 0.3), equal_nan=True)
 
 
 def test_rerank_with_exact_ties(ops):

@@ -86,8 +86,12 @@ def test_rerank_full_size_properties(ops, name, nq, ng, d, sigma):
         assert torch.equal(r1[s:e], want), s
     del r1, want
     ra, st = ops.re_ranking(q, g, 50, 15, 0.3, timing=True)
+    assert st["algo"] == ops.RERANK_SPARSE and st["fallback_rows"] < N // 16
     rb, _ = ops.re_ranking(q, g, 50, 15, 0.3)
     assert torch.equal(ra, rb)                                   # idempotent / run-to-run deterministic
+    rb, std = ops.re_ranking(q, g, 50, 15, 0.3, timing=True, algo=ops.RERANK_DENSE)   # the N x N algorithm (35-40 GB)
+    assert torch.equal(ra, rb), "sparse and dense algorithms differ"
+    print(name, "dense stats", std)
     del rb
     assert st["vqe_nnz"] > st["v_nnz"] > N * 10 and st["jaccard_pairs"] > 0
     print(name, "re-rank stats", st)
