@@ -150,9 +150,11 @@ int mpreid_rr_dist_rows(const float *feat_all_dev, const float *norms_all_dev, i
 /* ELL row capacity of V before query expansion: min(N, (k1+1)*(1+half_k1)) */
 int mpreid_rr_vcap(int64_t n, int k1);
 /* phase 2: V rows (ELL, row stride mpreid_rr_vcap) of the local rows from the global rank table [N][kr] */
+/* scratch_dev: mpreid_rr_krecip_scratch_bytes(n) bytes (reciprocity bits of all n rows of the table) */
+size_t mpreid_rr_krecip_scratch_bytes(int64_t n);
 int mpreid_rr_krecip(const float *d_local_dev, int64_t ld, int64_t n, const float *rowmax_local_dev,
                      const int32_t *rank_all_dev, int k1, int kr, int64_t r_lo, int64_t rows, int32_t *vcnt_dev,
-                     int32_t *vidx_dev, uint16_t *vval_dev, mpreid_stream_t stream);
+                     int32_t *vidx_dev, uint16_t *vval_dev, void *scratch_dev, mpreid_stream_t stream);
 /* re-stride ELL rows (for the all-gather: common width = global max count) */
 int mpreid_rr_pack_rows(const int32_t *cnt_dev, const int32_t *idx_dev, const uint16_t *val_dev, int64_t rows,
                         int src_stride, int dst_stride, int32_t *idx_out_dev, uint16_t *val_out_dev,

@@ -370,7 +370,27 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
     const int pos_step = owned ? per_xcd : (blocked ? 1 : nb);
     auto tile_at_raw = [&](int p) -> int { // -1 when the list is exhausted, -2 for an unused slot of an edge block
         if (blocked) {
-            const int b = p * 8 + xcd, br = b / nbc, bcol = b - br * nbc;
+            int b = p * 8 + xcd, br, bcol;
+            if (EPI == GE_CAND && g.sym) {
+                // symmetric problem: only blocks with a tile on or above the diagonal are enumerated (block row br
+                // starts at block column ceil((8 br - bc_w + 1) / bc_w)), so the eight XCDs get the same number of
+                // blocks to within one
+                br = 0;
+                for (;; ++br) {
+                    if (br >= nbr) return -1;
+                    int fb = (br * 8 - bc_w + 1 + bc_w - 1) / bc_w;
+                    fb = fb < 0 ? 0 : fb;
+                    const int cnt = nbc - fb;
+                    if (cnt > 0 && b < cnt) {
+                        bcol = fb + b;
+                        break;
+                    }
+                    b -= cnt > 0 ? cnt : 0;
+                }
+            } else {
+                br = b / nbc;
+                bcol = b - br * nbc;
+            }
             if (br >= nbr) return -1;
             const int slot = (int)(blockIdx.x >> 3);
             const int tm = br * 8 + (slot & 7), tn = bcol * bc_w + (slot >> 3);
@@ -460,6 +480,9 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // (tried: all slot reservations of a flush issued before the first is consumed -- fewer round trips, but
+            // the 30 extra live registers spill the accumulators and the replicated body triples the kernel's ISA:
+            // 727 us instead of 540 at N = 20 000)
             for (int e = lane; e < cl_n; e += 64) {
                 const unsigned rw = cl_row[e], cw = cl_col[e], dv = cl_d[e];
                 const unsigned fl = rw >> 28, row = rw & 0x0fffffffu;
@@ -605,24 +628,46 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
         float *tp = reinterpret_cast<float *>(smem + wave * 16384);   // patch in the idle k-loop ring
         const int rb = cur_m0 + wr * 128, cb = cur_n0 + wc * 64;
         const float NEG = -__builtin_huge_valf(), POS = __builtin_huge_valf();
+        // the wave's 128 rows x (norm, tlo, thi) and 64 columns x (norm, tlo, thi) are fetched ONCE per tile into a
+        // wave-private LDS table (one global round trip instead of one per 16-row pass); arrays are padded to M
+        // entries (0 / -inf / +inf past m_valid)
+        float *rt = tp + 1024;                 // [3][128] rows, then [3][64] columns (2304 B, behind the 4 KB patch)
+        float *ct = rt + 384;
+        {
+            const float a0 = g.aux[rb + lane], a1 = g.aux[rb + 64 + lane];
+            const float l0 = g.tlo[rb + lane], l1 = g.tlo[rb + 64 + lane];
+            const float h0 = g.thi[rb + lane], h1 = g.thi[rb + 64 + lane];
+            const int c = cb + lane;
+            const bool cv = c < g.n_valid;
+            const float cn = cv ? g.aux2[c] : 0.f;
+            const float cl = (mirror && cv) ? g.tlo[c] : NEG, chh = (mirror && cv) ? g.thi[c] : POS;
+            rt[lane] = a0; rt[64 + lane] = a1;
+            rt[128 + lane] = l0; rt[192 + lane] = l1;
+            rt[256 + lane] = h0; rt[320 + lane] = h1;
+            ct[lane] = cn; ct[64 + lane] = cl; ct[128 + lane] = chh;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         float bnv[4], tlc[4], thc[4];
         unsigned cvm = 0u;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int c = cb + j * 16 + frow;
-            const bool cv = c < g.n_valid;
-            cvm |= cv ? (0xfu << (4 * j)) : 0u;
-            bnv[j] = cv ? g.aux2[c] : 0.f;
-            tlc[j] = (mirror && cv) ? g.tlo[c] : NEG;
-            thc[j] = (mirror && cv) ? g.thi[c] : POS;
+            const int cl_ = j * 16 + frow;
+            cvm |= (cb + cl_ < g.n_valid) ? (0xfu << (4 * j)) : 0u;
+            bnv[j] = ct[cl_];
+            tlc[j] = ct[64 + cl_];
+            thc[j] = ct[128 + cl_];
         }
+        // (tried: the eight passes rolled into one copy of the code, accumulators moved into place by a switch -- the
+        // ISA shrinks from 6 k to 5.6 k lines but 40-80 VGPRs spill and the kernel is slower, 592 vs 540 us)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int r0 = rb + i * 16 + fq * 4;
-            // arrays are padded to M entries (0 / -inf / +inf past m_valid)
-            const float4 an4 = *reinterpret_cast<const float4 *>(g.aux + r0);
-            const float4 tl4 = *reinterpret_cast<const float4 *>(g.tlo + r0);
-            const float4 th4 = *reinterpret_cast<const float4 *>(g.thi + r0);
+            const int rl = i * 16 + fq * 4;
+            const int r0 = rb + rl;
+            const float4 an4 = *reinterpret_cast<const float4 *>(rt + rl);
+            const float4 tl4 = *reinterpret_cast<const float4 *>(rt + 128 + rl);
+            const float4 th4 = *reinterpret_cast<const float4 *>(rt + 256 + rl);
             const float anr[4] = {an4.x, an4.y, an4.z, an4.w}, tlr[4] = {tl4.x, tl4.y, tl4.z, tl4.w},
                         thr[4] = {th4.x, th4.y, th4.z, th4.w};
             unsigned rvm = 0u;   // rows inside the problem (the mirrored tests need it: a padded row has d = |g|^2)
@@ -644,6 +689,7 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             unsigned long long bal = __ballot(hit != 0u);
+            if (g.stagger & 2) bal = 0;   // (timing experiment only: no appends)
             while (bal) {
                 const int add = __popcll(bal);
                 if (cl_n + add > CL_CAP) cl_flush();

@@ -55,7 +55,7 @@ struct RerankLayout {
     int64_t N, ld;
     int K, KR, h, vcap;
     int64_t qcap_bound;
-    size_t feat, norms, D, MT, rowmax, rank, vcnt, vidx, vval, ucnt, qcnt, qidx, qval, ccnt, chist, cptr, crow, cval,
+    size_t feat, norms, D, MT, rowmax, rank, rbits, vcnt, vidx, vval, ucnt, qcnt, qidx, qval, ccnt, chist, cptr, crow, cval,
         counters, total;
 };
 
@@ -84,6 +84,7 @@ static RerankLayout make_layout(int64_t nq, int64_t ng, int d, int k1, int k2, i
     L.MT = has_local ? take(N * (size_t)L.ld * 4) : L.D;
     L.rowmax = take(N * 4);
     L.rank = take(N * (size_t)L.KR * 4);
+    L.rbits = take(N * (size_t)8 * 4 * 2);  // RB_WORDS words per row, two masks
     L.vcnt = take(N * 4);
     L.vidx = take(N * (size_t)L.vcap * 4);
     L.vval = take(N * (size_t)L.vcap * 2);
@@ -689,6 +690,48 @@ __device__ __forceinline__ float wave_exact_dists(const float *qrow, const float
 // row0 the global index of local row 0 (0 on a single GPU; the rank's first row when rows are sharded).
 // SPARSE (candidate pipeline, no N x N matrix): the distances of row i to its expansion set are evaluated on the fly
 // from the features (exact_dist_chain); MT is unused, feat [N][d] / norms [N] are the inputs.
+// ---------------------------------------------------------------------------------------------
+// Reciprocity bits of the neighbour table, once per row (they depend on the table only, not on which row's
+// expansion asks): for row c and position a < K with n = rank[c][a], p = position of c in rank[n][0..K) or none;
+//   bit a of rk[c]  <=>  p exists            (n is a k-reciprocal neighbour of c:        R(c, k1))
+//   bit a of rh[c]  <=>  a < h and p < h     (n is a k1/2-reciprocal neighbour of c:     R(c, k1/2))
+// utils/reranking.py:53-58 and :61-66 evaluate exactly these with np.where per (row, candidate) pair; done per pair
+// on the GPU that was 47 x 26 x 26 scattered 4-byte loads per row and the kernel ran at the texture unit's request
+// rate.  RB_WORDS 32-bit words per row and mask (K <= 256).  One wave per row, neighbour rows read 16 bytes per load.
+// ---------------------------------------------------------------------------------------------
+constexpr int RB_WORDS = 8;
+struct __attribute__((packed, aligned(4))) int4u { int v[4]; };   // 16-byte load from a 4-byte aligned address
+__global__ __launch_bounds__(256) void recip_bits_kernel(const int *__restrict__ rank, int64_t N, int K, int KR, int h,
+                                                         unsigned *__restrict__ rk, unsigned *__restrict__ rh) {
+    const int lane = threadIdx.x & 63;
+    const int64_t c = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= N) return;
+    for (int a0 = 0; a0 < K; a0 += 64) {
+        const int a = a0 + lane;
+        int p = -1;
+        if (a < K) {
+            const int n = rank[c * KR + a];
+            const int *row = rank + (int64_t)n * KR;
+            int b = 0;
+            for (; b + 3 < K; b += 4) {
+                const int4u q = *reinterpret_cast<const int4u *>(row + b);
+#pragma unroll
+                for (int e = 3; e >= 0; --e) p = (q.v[e] == (int)c) ? b + e : p;   // rows hold distinct indices
+            }
+            for (; b < K; ++b) p = (row[b] == (int)c) ? b : p;
+        }
+        const unsigned long long mk = __ballot(p >= 0), mh = __ballot(p >= 0 && p < h && a < h);
+        if (lane == 0) {
+            rk[c * RB_WORDS + (a0 >> 5)] = (unsigned)mk;
+            rh[c * RB_WORDS + (a0 >> 5)] = (unsigned)mh;
+            if (a0 + 32 < RB_WORDS * 32) {
+                rk[c * RB_WORDS + (a0 >> 5) + 1] = (unsigned)(mk >> 32);
+                rh[c * RB_WORDS + (a0 >> 5) + 1] = (unsigned)(mh >> 32);
+            }
+        }
+    }
+}
+
 // One 256-thread workgroup per row.  (First version: one wave per row walking the expansion candidates one after the
 // other -- ~47 iterations of two dependent global loads with 26 active lanes, 130 us per row.  Now a half-wave per
 // candidate, eight candidates per iteration.)  Wave 0 keeps the ordered steps (rank-order compaction of R, bitmap
@@ -700,7 +743,8 @@ __global__ __launch_bounds__(256) void krecip_kernel(const float *__restrict__ M
                                                      int *__restrict__ vidx, uint16_t *__restrict__ vval, int row0,
                                                      int *__restrict__ r_count,
                                                      const float *__restrict__ feat, const float *__restrict__ norms,
-                                                     int d, const float *__restrict__ rankd) {
+                                                     int d, const float *__restrict__ rankd,
+                                                     const unsigned *__restrict__ rk, const unsigned *__restrict__ rh) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nw = (int)((N + 31) >> 5);
     unsigned *Rmask = (unsigned *)smem;
@@ -740,8 +784,7 @@ __global__ __launch_bounds__(256) void krecip_kernel(const float *__restrict__ M
             int c = -1;
             if (a < K) {
                 c = fwd[a];
-                const int *br = rank + (int64_t)c * KR;
-                for (int b = 0; b < K; ++b) f |= (br[b] == i);
+                f = (rk[(int64_t)i * RB_WORDS + (a >> 5)] >> (a & 31)) & 1u;
             }
             const unsigned long long m = __ballot(f);
             if (f) {
@@ -776,10 +819,11 @@ __global__ __launch_bounds__(256) void krecip_kernel(const float *__restrict__ M
                 const int b = b0 + hl;
                 bool ok = false, inr = false;
                 if (live && b < h) {
-                    const int f = cf[b];
-                    const int *cb = rank + (int64_t)f * KR;
-                    for (int c = 0; c < h; ++c) ok |= (cb[c] == cand);
-                    inr = ok && ((Rmask[f >> 5] >> (f & 31)) & 1u);
+                    ok = (rh[(int64_t)cand * RB_WORDS + (b >> 5)] >> (b & 31)) & 1u;
+                    if (ok) {
+                        const int f = cf[b];
+                        inr = (Rmask[f >> 5] >> (f & 31)) & 1u;
+                    }
                 }
                 nRc += __popcll(__ballot(ok) & hmask);
                 inter += __popcll(__ballot(inr) & hmask);
@@ -1301,45 +1345,47 @@ __global__ __launch_bounds__(256) void rr2_threshold_kernel(const float *__restr
         return;
     }
     const float *row = S + i * ldS;
-    // thread-local two smallest + maximum over a strided slice; the r-th smallest of the 512 survivors is an
-    // approximation of the row's r-th smallest (exact unless one thread holds three of the r smallest) -- it is
-    // only a threshold: correctness never depends on it
-    unsigned k0 = 0xffffffffu, k1 = 0xffffffffu;
+    // A threshold is all this has to produce (correctness never depends on it), so the selection is approximate and
+    // cheap: every thread keeps the minimum of its strided slice, each wave sorts its 64 minima with a shuffle-only
+    // bitonic network, and the r-th smallest of the four waves' r smallest is taken.  It is >= the row's true r-th
+    // smallest sample value (two of the r smallest in one thread's slice hide one of them), which only adds candidates.
+    unsigned k0 = 0xffffffffu;
     float mx = -3.402823466e+38f;
     for (int j = tid; j < ns; j += 256) {
         const float v = row[j];
         mx = fmaxf(mx, v);
         const unsigned k = fkey(v);
-        if (k < k0) {
-            k1 = k0;
-            k0 = k;
-        } else if (k < k1)
-            k1 = k;
+        k0 = k < k0 ? k : k0;
     }
-    keys[tid] = k0;
-    keys[256 + tid] = k1;
+#pragma unroll
+    for (int size = 2; size <= 64; size <<= 1)
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const unsigned y = __shfl_xor(k0, stride, 64);
+            const bool keep_min = (((lane & stride) == 0) == ((lane & size) == 0));
+            k0 = keep_min ? (k0 < y ? k0 : y) : (k0 > y ? k0 : y);
+        }
+    if (lane < 16) keys[wave * 16 + lane] = k0;          // the wave's 16 smallest minima, ascending
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
     if (lane == 0) s_red[wave] = mx;
     __syncthreads();
-    for (int size = 2; size <= 512; size <<= 1)
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+    if (wave == 0) {
+        unsigned x = keys[lane];                          // 4 x 16 keys
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int e = tid + h * 256, partner = e ^ stride;
-                if (partner > e) {
-                    const unsigned a = keys[e], b = keys[partner];
-                    const bool up = ((e & size) == 0);
-                    if ((a > b) == up) {
-                        keys[e] = b;
-                        keys[partner] = a;
-                    }
-                }
+        for (int size = 2; size <= 64; size <<= 1)
+#pragma unroll
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                const unsigned y = __shfl_xor(x, stride, 64);
+                const bool keep_min = (((lane & stride) == 0) == ((lane & size) == 0));
+                x = keep_min ? (x < y ? x : y) : (x > y ? x : y);
             }
-            __syncthreads();
-        }
+        keys[lane] = x;
+    }
+    __syncthreads();
     if (tid == 0) {
-        const int r = rsel < ns ? rsel : ns;
+        int r = rsel < ns ? rsel : ns;
+        r = r < 16 ? r : 16;
         const unsigned kk = keys[r - 1];
         const unsigned u = (kk & 0x80000000u) ? (kk & 0x7fffffffu) : ~kk;   // inverse of fkey
         const float e = rr2_eps(sqrtf(sqn[i]), gstat[0], D);
@@ -1834,9 +1880,12 @@ static int rerank_dense(const float *q, const float *g, int64_t nq, int64_t ng, 
         const size_t lds = (size_t)nw * 8 + (size_t)L.K * 8 + (size_t)L.vcap * 8;
         int rc = set_dyn_lds(krecip_kernel<false>, lds);
         if (rc) return rc;
+        unsigned *rk = (unsigned *)(base + L.rbits);
+        hipLaunchKernelGGL(recip_bits_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, rank, N, L.K, L.KR, L.h, rk,
+                           rk + (size_t)N * RB_WORDS);
         hipLaunchKernelGGL(krecip_kernel<false>, dim3((unsigned)N), dim3(256), lds, stream, MT, L.ld, N, rowmax, rank, L.K,
                            L.KR, L.h, L.vcap, vcnt, vidx, vval, 0, ucnt, (const float *)nullptr,
-                           (const float *)nullptr, 0, (const float *)nullptr);
+                           (const float *)nullptr, 0, (const float *)nullptr, rk, rk + (size_t)N * RB_WORDS);
         hipLaunchKernelGGL(sum_i32_kernel, dim3(1), dim3(1024), 0, stream, ucnt, N, counters + 1);
         LAUNCH_CHECK();
     }
@@ -1860,7 +1909,7 @@ struct Rerank2Layout {
     int64_t N, Np, Nsp, ld, fb_max;
     int dp, K, KR, h, vcap;
     int64_t qcap_bound;
-    size_t feat, sqn, feat16, samp16, sampn, sampD, tlo, thi, eps, cnt_lo, cnt_hi, list_lo, list_hi, gstat, rowmax, rank, rankd,
+    size_t feat, sqn, feat16, samp16, sampn, sampD, tlo, thi, eps, cnt_lo, cnt_hi, list_lo, list_hi, gstat, rowmax, rank, rankd, rbits,
         fb_count, fb_rows, fb_feat, fb_sqn, fb_D, fb_rowmax, fb_rank, vcnt, vidx, vval, ucnt, qcnt, qidx, qval, ccnt, chist,
         cptr, crow, cval, dq, counters, total;
 };
@@ -1903,6 +1952,7 @@ static Rerank2Layout make_layout2(int64_t nq, int64_t ng, int d, int k1, int k2)
     L.rowmax = take(N * 4);
     L.rank = take(N * (size_t)L.KR * 4);
     L.rankd = take(N * (size_t)L.KR * 4);
+    L.rbits = take(N * (size_t)8 * 4 * 2);
     L.fb_count = take(64);
     L.fb_rows = take(F * 4);
     L.fb_feat = take(F * (size_t)d * 4);
@@ -2011,6 +2061,9 @@ static int rerank_sparse(const float *q, const float *g, int64_t nq, int64_t ng,
         a.aux = sqn; a.aux2 = sqn; a.m_valid = (int)N; a.n_valid = (int)N;
         a.tlo = tlo; a.thi = thi; a.cnt_lo = cnt_lo; a.cnt_hi = cnt_hi; a.list_lo = list_lo; a.list_hi = list_hi;
         a.cap_lo = RR2_CAP_LO; a.cap_hi = RR2_CAP_HI; a.sym = 1;
+        static const int cand_dbg = getenv("MPREID_CAND_DBG") ? atoi(getenv("MPREID_CAND_DBG")) : 0;   // timing experiments
+        if (cand_dbg & 1) a.sym = 0;
+        if (cand_dbg & 2) a.stagger = 2;
         rc = launch_gemm_f16(a, GE_CAND, stream);
         if (rc) return rc;
     }
@@ -2041,8 +2094,12 @@ static int rerank_sparse(const float *q, const float *g, int64_t nq, int64_t ng,
                            64 * WXD_STRIDE * 4;
         rc = set_dyn_lds(krecip_kernel<true>, lds);
         if (rc) return rc;
+        unsigned *rk = (unsigned *)(base + L.rbits);
+        hipLaunchKernelGGL(recip_bits_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, rank, N, L.K, L.KR, L.h, rk,
+                           rk + (size_t)N * RB_WORDS);
         hipLaunchKernelGGL(krecip_kernel<true>, dim3((unsigned)N), dim3(256), lds, stream, (const float *)nullptr, L.ld, N,
-                           rowmax, rank, L.K, L.KR, L.h, L.vcap, vcnt, vidx, vval, 0, ucnt, feat, sqn, d, rankd);
+                           rowmax, rank, L.K, L.KR, L.h, L.vcap, vcnt, vidx, vval, 0, ucnt, feat, sqn, d, rankd, rk,
+                           rk + (size_t)N * RB_WORDS);
         hipLaunchKernelGGL(sum_i32_kernel, dim3(1), dim3(1024), 0, stream, ucnt, N, counters + 1);
         LAUNCH_CHECK();
     }
@@ -2209,19 +2266,27 @@ extern "C" int mpreid_rr_vcap(int64_t n, int k1) {
     return (int)(cap < n ? cap : n);
 }
 
+extern "C" size_t mpreid_rr_krecip_scratch_bytes(int64_t n) { return (size_t)n * RB_WORDS * 4 * 2; }
+
 extern "C" int mpreid_rr_krecip(const float *d_local, int64_t ld, int64_t n, const float *rowmax_local,
                                 const int32_t *rank_all, int k1, int kr, int64_t r_lo, int64_t rows, int32_t *vcnt,
-                                int32_t *vidx, uint16_t *vval, mpreid_stream_t stream_) {
+                                int32_t *vidx, uint16_t *vval, void *scratch, mpreid_stream_t stream_) {
     const int K = (int)std::min<int64_t>(k1 + 1, n), h = (int)std::min<int64_t>(mpreid_half_k1(k1), n);
     const int vcap = mpreid_rr_vcap(n, k1);
-    ARG_CHECK(d_local && rowmax_local && rank_all && vcnt && vidx && vval && rows > 0 && kr >= K);
+    ARG_CHECK(d_local && rowmax_local && rank_all && vcnt && vidx && vval && scratch && rows > 0 && kr >= K);
     const int nw = (int)((n + 31) >> 5);
     const size_t lds = (size_t)nw * 8 + (size_t)K * 8 + (size_t)vcap * 8;
     int rc = set_dyn_lds(krecip_kernel<false>, lds);
     if (rc) return rc;
+    // reciprocity bits of ALL rows (candidates of a local row live anywhere): recomputed by every rank from the
+    // all-gathered table -- N x K membership tests, cheaper than another exchange
+    unsigned *rk = (unsigned *)scratch;
+    hipLaunchKernelGGL(recip_bits_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, rank_all, n, K, kr,
+                       h, rk, rk + (size_t)n * RB_WORDS);
     hipLaunchKernelGGL(krecip_kernel<false>, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream_, d_local, ld, n,
                        rowmax_local, rank_all, K, kr, h, vcap, vcnt, vidx, vval, (int)r_lo,
-                       (int *)nullptr, (const float *)nullptr, (const float *)nullptr, 0, (const float *)nullptr);
+                       (int *)nullptr, (const float *)nullptr, (const float *)nullptr, 0, (const float *)nullptr, rk,
+                       rk + (size_t)n * RB_WORDS);
     LAUNCH_CHECK();
     return MPREID_OK;
 }

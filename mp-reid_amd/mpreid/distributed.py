@@ -142,10 +142,11 @@ class _RerankShard:
         self.vidx = t.empty((max(self.rows, 1), self.vcap), dtype=t.int32, device=dev)
         self.vval = t.empty((max(self.rows, 1), self.vcap), dtype=t.int16, device=dev)
         if self.rows:
+            scratch = t.empty(self.L.mpreid_rr_krecip_scratch_bytes(self.N), dtype=t.uint8, device=dev)
             self.lib.check(self.L.mpreid_rr_krecip(_rr_ptr(self.D), self.ld, self.N, _rr_ptr(self.rowmax),
                                                    _rr_ptr(rank_all), self.k1, self.KR, self.r_lo, self.rows,
                                                    _rr_ptr(self.vcnt), _rr_ptr(self.vidx), _rr_ptr(self.vval),
-                                                   self.lib.stream_ptr()), "mpreid_rr_krecip")
+                                                   _rr_ptr(scratch), self.lib.stream_ptr()), "mpreid_rr_krecip")
         return int(self.vcnt.max().item()) if self.rows else 0
 
     def _pack(self, cnt, idx, val, width):
