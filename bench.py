@@ -218,16 +218,25 @@ def rerank_roofline(st):
         rows.append(e)
 
     d = st.get("d", 0)
-    gemm_kind = st.get("gemm_kind", "exact")
-    if gemm_kind == "exact":
+    if st.get("algo", 1) == 2:
+        # sparse algorithm: no N x N matrix.  fp16 MFMA: symmetric candidate GEMM (N*N*D executed) + sample pass
+        add("rerank.candidates", "gemm_f16_big_kernel<cand> (+ cast, sample pass, thresholds)", st["ms_gemm"], "mfma_f16",
+            1.0 * N * N * d + 2.0 * N * (N / 16.0) * d,
+            "executed FLOPs: upper-triangular tiles of the symmetric N x N problem + the N x N/16 sample pass; nothing stored")
+        add("rerank.refine", "rr2_refine_kernel (+ fallback rows)", st["ms_topk"], "hbm",
+            4.0 * d * kr * N + 8.0 * st.get("cand_total", 0),
+            "algorithmic: the KR exact neighbour rows of every row (4*D*KR*N) + the candidate lists; the kernel evaluates "
+            "~1.5 KR rows per row (everything within 2 eps of the KR-th candidate)")
+        add("rerank.krecip", "recip_bits_kernel + krecip_kernel<sparse>", st["ms_krecip"], "hbm",
+            4.0 * N * ((k1 + 1) ** 2 + rbar * (h + h * h)), f"mean |R| = {rbar:.1f}")
+        add("rerank.query_rows", "gemm_f32_exact_kernel", st.get("ms_dq", 0.0), "mfma_f32", 2.0 * nq * N * d,
+            "exact fp32 distance rows of the queries only ([nq][N]): what the Jaccard blend reads")
+    else:
         add("rerank.distance", "gemm_f32_exact_kernel<SYM>", st["ms_gemm"], "mfma_f32", 1.0 * N * N * d,
             "executed FLOPs: the symmetric kernel computes the upper-triangular tiles only (2*N*N*D/2)")
-    else:
-        add("rerank.distance", "gemm_f16_big_kernel<split3>", st["ms_gemm"], "mfma_f16", 6.0 * N * N * d,
-            "3-term fp16 split: 3 x 2*N*N*D executed")
-    add("rerank.topk", "rowmax_topk_kernel", st["ms_topk"], "hbm", 4.0 * N * N + 4.0 * N * kr)
-    add("rerank.krecip", "krecip_kernel", st["ms_krecip"], "hbm", 4.0 * N * ((k1 + 1) ** 2 + rbar * (h + h * h)),
-        f"mean |R| = {rbar:.1f}")
+        add("rerank.topk", "rowmax_topk_kernel", st["ms_topk"], "hbm", 4.0 * N * N + 4.0 * N * kr)
+        add("rerank.krecip", "recip_bits_kernel + krecip_kernel", st["ms_krecip"], "hbm",
+            4.0 * N * ((k1 + 1) ** 2 + rbar * (h + h * h)), f"mean |R| = {rbar:.1f}")
     add("rerank.qe", "qe_count/fill_kernel", st["ms_qe"], "hbm", 6.0 * st["v_nnz"] * (1 + k2))
     add("rerank.csc", "csc_*", st["ms_csc"], "hbm", 12.0 * st["vqe_nnz"])
     add("rerank.jaccard", "jaccard_kernel", st["ms_jaccard"], "hbm", 6.0 * st["jaccard_pairs"] + 8.0 * nq * ng)
@@ -278,7 +287,14 @@ def extras(ops, dev, with_widened=True):
     out["rerank_N20000_nq4000_d768_k50_15_ms"] = round(st["ms_total"], 3)
     out["rerank_stages_ms"] = {k[3:]: round(v, 3) for k, v in st.items() if k.startswith("ms_") and k != "ms_total"}
     out["rerank_nnz"] = {"v": st["v_nnz"], "vqe": st["vqe_nnz"], "jaccard_pairs": st["jaccard_pairs"]}
+    out["rerank_algo"] = {1: "dense", 2: "sparse"}.get(st["algo"], st["algo"])
+    out["rerank_fallback_rows"] = st["fallback_rows"]
+    out["rerank_candidates"] = st["cand_total"]
     roofs += rerank_roofline(st)
+    _, sd = ops.re_ranking(ft[:4000], ft[4000:], 50, 15, 0.3, timing=True, algo=ops.RERANK_DENSE)
+    sd.update(nq=4000, d=768)
+    out["rerank_dense_algorithm_ms"] = round(sd["ms_total"], 3)
+    out["rerank_dense_stages_ms"] = {k[3:]: round(v, 3) for k, v in sd.items() if k.startswith("ms_") and k != "ms_total"}
     ms = timed_ms(lambda: ops.re_ranking(ft[:4000], ft[4000:], 50, 15, 0.3), 3)
     out["rerank_N20000_untimed_stages_ms"] = round(ms, 3)
     out["distmat_plus_rerank_20kx20k_ms"] = round(ms, 3)   # the re-rank computes its own all-pairs distance matrix

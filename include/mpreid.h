@@ -75,7 +75,10 @@ typedef struct {
     int64_t fallback_rows;/* sparse algorithm: rows whose candidate list could not be certified (done densely) */
     int64_t cand_total;   /* sparse algorithm: neighbour candidates emitted by the fused GEMM (sum over rows) */
     int32_t algo;         /* MPREID_RERANK_DENSE or MPREID_RERANK_SPARSE: what the call actually ran */
-    float ms_gemm, ms_topk, ms_krecip, ms_qe, ms_csc, ms_jaccard, ms_total; /* filled when timing != 0 */
+    /* filled when timing != 0 (hipEvents on the stream).  DENSE: gemm = N x N exact distances, topk = row maxima +
+     * neighbour selection.  SPARSE: gemm = fp16 operands + sample pass + thresholds + fused candidate GEMM, topk =
+     * exact refinement + fallback rows, dq = exact distance rows of the queries. */
+    float ms_gemm, ms_topk, ms_krecip, ms_qe, ms_csc, ms_jaccard, ms_total, ms_dq;
 } mpreid_rerank_stats;
 
 /* Two algorithms, the same bits out (tests/test_gpu_rerank.py):

@@ -1806,6 +1806,7 @@ static int rerank_tail(const TailArgs &a, hipStream_t stream, StageTimer &tm, mp
         stats->ms_gemm = tm.ms(0, 1);
         stats->ms_topk = tm.ms(1, 2);
         stats->ms_krecip = tm.ms(2, 3);
+        stats->ms_dq = (m == 4) ? tm.ms(3, 4) : 0.0f;
         stats->ms_qe = tm.ms(m, m + 1);
         stats->ms_csc = tm.ms(m + 1, m + 2);
         stats->ms_jaccard = tm.ms(m + 2, m + 3);
@@ -2107,6 +2108,7 @@ static int rerank_sparse(const float *q, const float *g, int64_t nq, int64_t ng,
     // exact distance rows of the queries (what the Jaccard blend reads)
     rc = mpreid_distance_launch(feat, feat, nq, N, d, sqn, sqn, dq, L.ld, 0, stream);
     if (rc) return rc;
+    tm.mark(); // 4
     TailArgs ta{};
     ta.N = N; ta.nq = nq; ta.k1 = k1; ta.k2 = k2; ta.KR = L.KR; ta.h = L.h; ta.vcap = L.vcap; ta.qcap_bound = L.qcap_bound;
     ta.rank = rank; ta.vcnt = vcnt; ta.vidx = vidx; ta.vval = vval; ta.ucnt = ucnt; ta.qcnt = (int *)(base + L.qcnt);
@@ -2115,7 +2117,7 @@ static int rerank_sparse(const float *q, const float *g, int64_t nq, int64_t ng,
     ta.chist = (unsigned *)(base + L.chist);
     ta.counters = counters; ta.MT = dq; ta.ld = L.ld; ta.rowmax = rowmax; ta.out = out; ta.ldo = ldo;
     ta.lambda_value = lambda_value; ta.algo = MPREID_RERANK_SPARSE;
-    rc = rerank_tail(ta, stream, tm, stats, 3);
+    rc = rerank_tail(ta, stream, tm, stats, 4);
     if (rc) return rc;
     // status of the data-dependent capacities (read with the statistics, after the fact): the fp16 operands must
     // not have overflowed and the fallback rows must have fitted their buffer -- otherwise the result above is not

@@ -41,7 +41,7 @@ class RerankStats(C.Structure):
                 ("jaccard_pairs", C.c_int64), ("krecip_r_sum", C.c_int64), ("fallback_rows", C.c_int64),
                 ("cand_total", C.c_int64), ("algo", C.c_int32), ("ms_gemm", C.c_float), ("ms_topk", C.c_float),
                 ("ms_krecip", C.c_float), ("ms_qe", C.c_float), ("ms_csc", C.c_float),
-                ("ms_jaccard", C.c_float), ("ms_total", C.c_float)]
+                ("ms_jaccard", C.c_float), ("ms_total", C.c_float), ("ms_dq", C.c_float)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
