@@ -219,6 +219,15 @@ int mpreid_vit_forward(const mpreid_vit_cfg *cfg, const mpreid_vit_weights *w, c
                        const float *cv_emb_dev, float *out_dev, void *ws_dev, size_t ws_bytes,
                        mpreid_stream_t stream);
 
+/* All-fp32 mode of the same encoder (parity / debugging; SURVEY.md section 7 hard part 5): activations and weights
+ * fp32, linear layers on the exact fp32 matrix instruction, attention on fp32 vector FMAs -- relative feature error
+ * ~1e-6 against the fp32 CPU path instead of ~4e-4, at ~1/8 of the throughput.  The structs are the ones above,
+ * but conv_w and every layer's *_w point to FP32 [out][in] matrices.  Head dimension 64 only. */
+size_t mpreid_vit_workspace_bytes_f32(const mpreid_vit_cfg *cfg, int batch);
+int mpreid_vit_forward_f32(const mpreid_vit_cfg *cfg, const mpreid_vit_weights *w_f32, const float *img_dev, int batch,
+                           const float *cv_emb_dev, float *out_dev, void *ws_dev, size_t ws_bytes,
+                           mpreid_stream_t stream);
+
 /* same, from uint8 images [B][img_h][img_w][3] (HWC, after Resize): ToTensor (x/255) and Normalize
  * ((x - pixel_mean)/pixel_std, host arrays of 3 floats: INPUT.PIXEL_MEAN / PIXEL_STD) of the reference's
  * val_transforms (datasets/make_dataloader.py:57-61) are fused into the patch gather; 4x fewer input bytes. */

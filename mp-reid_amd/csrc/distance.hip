@@ -53,7 +53,11 @@ __global__ __launch_bounds__(256) void l2_normalize_kernel(const float *__restri
 // ---------------------------------------------------------------------------------------------
 // exact fp32 MFMA GEMM with distance epilogues
 // ---------------------------------------------------------------------------------------------
-enum { EPI_EUCLID = 0, EPI_COSINE = 1 };
+enum { EPI_EUCLID = 0, EPI_COSINE = 1,
+       // linear layers of the all-fp32 encoder mode (vit.hip): bn = bias[n] (or NULL), C = out
+       EPI_LIN = 2,        // C = acc + bias
+       EPI_LIN_GELU = 3,   // C = quickgelu(acc + bias)
+       EPI_LIN_RES = 4 };  // C += acc + bias
 
 constexpr int XBM = 128, XBN = 128, XBK = 16, XLD = 132;
 
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(256) void gemm_f32_exact_kernel(const float *__rest
     for (int j = 0; j < 2; ++j) {
         const int64_t col = n0 + wn * 64 + j * 32 + li;
         if (col >= N) continue;
-        const float bnv = bn[col];
+        const float bnv = (EPI >= EPI_LIN && bn == nullptr) ? 0.0f : bn[col];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -182,6 +186,13 @@ __global__ __launch_bounds__(256) void gemm_f32_exact_kernel(const float *__rest
                 float v;
                 if (EPI == EPI_EUCLID) {
                     v = fmaf(-2.0f, dot, an[row] + bnv);
+                } else if (EPI == EPI_LIN) {
+                    v = dot + bnv;
+                } else if (EPI == EPI_LIN_GELU) {
+                    const float t = dot + bnv;   // model/clip/model.py:159-161  x * sigmoid(1.702 x), IEEE divide, accurate exp
+                    v = __fdiv_rn(t, 1.0f + expf(-1.702f * t));
+                } else if (EPI == EPI_LIN_RES) {
+                    v = C[row * ldc + col] + (dot + bnv);
                 } else {
                     float c = dot * __fdiv_rn(1.0f, an[row] * bnv);
                     const float lo = (float)(-1.0 + 0.00001), hi = (float)(1.0 - 0.00001);
@@ -280,6 +291,36 @@ int mpreid_distance_launch(const float *q, const float *g, int64_t nq, int64_t n
     else
         hipLaunchKernelGGL((gemm_f32_exact_kernel<EPI_COSINE, false>), grid, dim3(256), 0, stream, q, g, nq, ng, d, qn,
                            gn, out, ldo, tiles_m, tiles_n, vec_ok, m_count);
+    LAUNCH_CHECK();
+    return MPREID_OK;
+}
+
+// C[M][N] (row stride ldc) = A[M][K] x W[N][K]^T (+ bias[N]) with a linear-layer epilogue (EPI_LIN*); exact fp32 MFMA
+// (k-ascending fmaf chains), any M, N, K: the GEMM of the all-fp32 encoder mode
+int mpreid_gemm_f32_linear(const float *A, const float *Wt, int64_t M, int64_t N, int K, const float *bias, float *C,
+                           int64_t ldc, int epi, hipStream_t stream) {
+    const int tiles_m = (int)((M + XBM - 1) / XBM), tiles_n = (int)((N + XBN - 1) / XBN);
+    const int vec_ok = (K % 4 == 0) && (((uintptr_t)A | (uintptr_t)Wt) % 16 == 0);
+    const dim3 grid((unsigned)tiles_m * (unsigned)tiles_n);
+    const float *none = nullptr;
+    const unsigned *nocount = nullptr;
+    switch (epi) {
+    case EPI_LIN:
+        hipLaunchKernelGGL((gemm_f32_exact_kernel<EPI_LIN, false>), grid, dim3(256), 0, stream, A, Wt, M, N, K, none, bias, C,
+                           ldc, tiles_m, tiles_n, vec_ok, nocount);
+        break;
+    case EPI_LIN_GELU:
+        hipLaunchKernelGGL((gemm_f32_exact_kernel<EPI_LIN_GELU, false>), grid, dim3(256), 0, stream, A, Wt, M, N, K, none, bias,
+                           C, ldc, tiles_m, tiles_n, vec_ok, nocount);
+        break;
+    case EPI_LIN_RES:
+        hipLaunchKernelGGL((gemm_f32_exact_kernel<EPI_LIN_RES, false>), grid, dim3(256), 0, stream, A, Wt, M, N, K, none, bias,
+                           C, ldc, tiles_m, tiles_n, vec_ok, nocount);
+        break;
+    default:
+        mpreid_set_error("gemm_f32_linear: unknown epilogue %d", epi);
+        return MPREID_ERR_ARG;
+    }
     LAUNCH_CHECK();
     return MPREID_OK;
 }

@@ -717,6 +717,182 @@ static int vit_forward_impl(const mpreid_vit_cfg *cfg, const mpreid_vit_weights 
     return MPREID_OK;
 }
 
+// =============================================================================================
+// All-fp32 encoder mode (SURVEY.md section 7 hard part 5: "expose an all-fp32 debug mode").
+// The fp16-MFMA path above carries a relative feature error of ~4e-4 (operand rounding), which moves mAP by ~1e-4
+// on hard data (tests/test_gpu_map_parity.py); this mode keeps every activation and weight in fp32 and runs the
+// linear layers on the exact fp32 matrix instruction (gemm_f32_exact_kernel, k-ascending fmaf chains, ~100 TFLOP/s),
+// the attention on fp32 vector FMAs.  ~4-5 k images/s: a parity / debugging mode, not the throughput path.
+// Same structs as the fp16 entry points, but every *_w / conv_w pointer is an fp32 [out][in] matrix.
+// =============================================================================================
+int mpreid_gemm_f32_linear(const float *A, const float *Wt, int64_t M, int64_t N, int K, const float *bias, float *C,
+                           int64_t ldc, int epi, hipStream_t stream);
+enum { F32_LIN = 2, F32_LIN_GELU = 3, F32_LIN_RES = 4 };   // distance.hip: EPI_LIN*
+
+// img [B][3][H][W] fp32 -> patches [B*P][3*p*p] fp32, inner order (c, kh, kw)
+__global__ __launch_bounds__(256) void im2col_f32_kernel(const float *__restrict__ img, int B, int H, int Wd, int p, int stride,
+                                                         int h_res, int w_res, float *__restrict__ out) {
+    const int Kp = 3 * p * p, P = h_res * w_res;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (int64_t)B * P * Kp) return;
+    const int m = (int)(gid / Kp), k = (int)(gid % Kp);
+    const int b = m / P, pi = m % P, ph = pi / w_res, pw = pi % w_res;
+    const int c = k / (p * p), kh = (k % (p * p)) / p, kw = k % p;
+    out[gid] = img[(((int64_t)b * 3 + c) * H + (ph * stride + kh)) * Wd + pw * stride + kw];
+}
+
+// x[b*L + 1 + p][:] = tok[b*P + p][:] + pos[1 + p][:]
+__global__ __launch_bounds__(256) void patch_scatter_f32_kernel(const float *__restrict__ tok, const float *__restrict__ pos, int B,
+                                                                int P, int L, int W, float *__restrict__ x) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (int64_t)B * P * W) return;
+    const int m = (int)(gid / W), k = (int)(gid % W);
+    const int b = m / P, pp = m % P;
+    x[((int64_t)b * L + 1 + pp) * W + k] = tok[gid] + pos[(int64_t)(1 + pp) * W + k];
+}
+
+// softmax(q k^T / sqrt(64)) v per (image, head), fp32 throughout: K and V of the head in LDS, one thread per query
+// row, online softmax.  qkv [B*L][3W] (q | k | v column blocks, head h = columns [64h, 64h + 64)), out [B*L][W].
+__global__ __launch_bounds__(256) void attention_f32_kernel(const float *__restrict__ qkv, int L, int W, int heads,
+                                                            float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *Ks = reinterpret_cast<float *>(smem), *Vs = Ks + (size_t)L * 64;
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads, tid = threadIdx.x;
+    const float *base = qkv + (int64_t)b * L * 3 * W + h * 64;
+    for (int idx = tid; idx < L * 16; idx += 256) {
+        const int row = idx >> 4, c4 = (idx & 15) * 4;
+        *reinterpret_cast<float4 *>(Ks + row * 64 + c4) = *reinterpret_cast<const float4 *>(base + (int64_t)row * 3 * W + W + c4);
+        *reinterpret_cast<float4 *>(Vs + row * 64 + c4) = *reinterpret_cast<const float4 *>(base + (int64_t)row * 3 * W + 2 * W + c4);
+    }
+    __syncthreads();
+    for (int t = tid; t < L; t += 256) {
+        float q[64], acc[64];
+#pragma unroll
+        for (int c = 0; c < 64; c += 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(base + (int64_t)t * 3 * W + c);
+            q[c] = v.x * 0.125f; q[c + 1] = v.y * 0.125f; q[c + 2] = v.z * 0.125f; q[c + 3] = v.w * 0.125f;   // 64^-0.5, exact
+            acc[c] = acc[c + 1] = acc[c + 2] = acc[c + 3] = 0.0f;
+        }
+        float m = -3.402823466e+38f, l = 0.0f;
+        for (int j = 0; j < L; ++j) {
+            const float *kr = Ks + j * 64, *vr = Vs + j * 64;
+            float s = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 64; ++c) s = fmaf(q[c], kr[c], s);
+            const float mn = fmaxf(m, s);
+            const float corr = expf(m - mn), pj = expf(s - mn);
+            l = l * corr + pj;
+#pragma unroll
+            for (int c = 0; c < 64; ++c) acc[c] = fmaf(pj, vr[c], acc[c] * corr);
+            m = mn;
+        }
+        float *o = out + ((int64_t)b * L + t) * W + h * 64;
+#pragma unroll
+        for (int c = 0; c < 64; ++c) o[c] = __fdiv_rn(acc[c], l);
+    }
+}
+
+struct VitLayoutF32 {
+    int L, P, M, Kp;
+    size_t patches, x, a, qkv, hbuf, y_cls, total;
+};
+static VitLayoutF32 vit_layout_f32(const mpreid_vit_cfg *c, int B) {
+    VitLayoutF32 v{};
+    v.P = c->h_res * c->w_res;
+    v.L = v.P + 1;
+    v.M = B * v.L;
+    v.Kp = 3 * c->patch * c->patch;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += align_up(bytes, 256);
+        return o;
+    };
+    v.patches = take((size_t)B * v.P * v.Kp * 4);
+    v.x = take((size_t)v.M * c->width * 4);
+    v.a = take((size_t)v.M * c->width * 4);
+    v.qkv = take((size_t)v.M * 3 * c->width * 4);
+    v.hbuf = take((size_t)v.M * 4 * c->width * 4);
+    v.y_cls = take((size_t)B * c->width * 4);
+    v.total = off;
+    return v;
+}
+
+extern "C" size_t mpreid_vit_workspace_bytes_f32(const mpreid_vit_cfg *cfg, int batch) {
+    if (!cfg || batch <= 0) return 0;
+    return vit_layout_f32(cfg, batch).total;
+}
+
+extern "C" int mpreid_vit_forward_f32(const mpreid_vit_cfg *cfg, const mpreid_vit_weights *w, const float *img, int B,
+                                      const float *cv_emb, float *out, void *ws, size_t ws_bytes, mpreid_stream_t stream_) {
+    int rc = vit_check_cfg(cfg);
+    if (rc) return rc;
+    ARG_CHECK(w && img && out && B > 0 && w->layers);
+    if (cfg->width / cfg->heads != 64) {
+        mpreid_set_error("fp32 attention: head dimension %d != 64", cfg->width / cfg->heads);
+        return MPREID_ERR_UNSUPPORTED;
+    }
+    const VitLayoutF32 v = vit_layout_f32(cfg, B);
+    if (!ws || ws_bytes < v.total) {
+        mpreid_set_error("vit fp32 workspace too small: %zu < %zu", ws_bytes, v.total);
+        return MPREID_ERR_WORKSPACE;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    const int W = cfg->width, L = v.L;
+    char *base = (char *)ws;
+    float *patches = (float *)(base + v.patches), *x = (float *)(base + v.x), *a = (float *)(base + v.a);
+    float *qkv = (float *)(base + v.qkv), *hbuf = (float *)(base + v.hbuf), *y_cls = (float *)(base + v.y_cls);
+    {
+        const int64_t n = (int64_t)B * v.P * v.Kp;
+        hipLaunchKernelGGL(im2col_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, img, B, cfg->img_h,
+                           cfg->img_w, cfg->patch, cfg->stride, cfg->h_res, cfg->w_res, patches);
+        LAUNCH_CHECK();
+        if ((rc = mpreid_gemm_f32_linear(patches, (const float *)w->conv_w, (int64_t)B * v.P, W, v.Kp, nullptr, a, W, F32_LIN,
+                                         stream)))
+            return rc;
+        const int64_t n2 = (int64_t)B * v.P * W;
+        hipLaunchKernelGGL(patch_scatter_f32_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, stream, a, w->pos_emb, B,
+                           v.P, L, W, x);
+        hipLaunchKernelGGL(cls_token_kernel, dim3((unsigned)B), dim3(256), 0, stream, w->class_emb, w->pos_emb, cv_emb, B, L, W,
+                           x);
+        hipLaunchKernelGGL(layernorm_kernel<false>, dim3((unsigned)((v.M + 3) / 4)), dim3(256), 0, stream, x, (int64_t)v.M, W,
+                           w->ln_pre_g, w->ln_pre_b, (void *)x, (int64_t)W);
+        LAUNCH_CHECK();
+    }
+    const size_t att_lds = (size_t)L * 64 * 4 * 2;
+    if (att_lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_f32_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)att_lds));
+    for (int l = 0; l < cfg->layers; ++l) {
+        const mpreid_vit_layer &ly = w->layers[l];
+        hipLaunchKernelGGL(layernorm_kernel<false>, dim3((unsigned)((v.M + 3) / 4)), dim3(256), 0, stream, x, (int64_t)v.M, W,
+                           ly.ln1_g, ly.ln1_b, (void *)a, (int64_t)W);
+        LAUNCH_CHECK();
+        if ((rc = mpreid_gemm_f32_linear(a, (const float *)ly.in_proj_w, v.M, 3 * W, W, ly.in_proj_b, qkv, 3 * W, F32_LIN, stream)))
+            return rc;
+        hipLaunchKernelGGL(attention_f32_kernel, dim3((unsigned)(B * cfg->heads)), dim3(256), att_lds, stream, qkv, L, W,
+                           cfg->heads, a);
+        LAUNCH_CHECK();
+        if ((rc = mpreid_gemm_f32_linear(a, (const float *)ly.out_proj_w, v.M, W, W, ly.out_proj_b, x, W, F32_LIN_RES, stream)))
+            return rc;
+        hipLaunchKernelGGL(layernorm_kernel<false>, dim3((unsigned)((v.M + 3) / 4)), dim3(256), 0, stream, x, (int64_t)v.M, W,
+                           ly.ln2_g, ly.ln2_b, (void *)a, (int64_t)W);
+        LAUNCH_CHECK();
+        if ((rc = mpreid_gemm_f32_linear(a, (const float *)ly.fc_w, v.M, 4 * W, W, ly.fc_b, hbuf, 4 * W, F32_LIN_GELU, stream)))
+            return rc;
+        if ((rc = mpreid_gemm_f32_linear(hbuf, (const float *)ly.proj_w, v.M, W, 4 * W, ly.proj_b, x, W, F32_LIN_RES, stream)))
+            return rc;
+    }
+    const bool neck = cfg->neck_after != 0 && w->bn_scale && w->bn_proj_scale;
+    hipLaunchKernelGGL(cls_ln_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, x, (int64_t)L * W, B, W, cfg->out_dim,
+                       w->ln_post_g, w->ln_post_b, neck ? w->bn_scale : nullptr, neck ? w->bn_shift : nullptr, y_cls, out);
+    hipLaunchKernelGGL(cls_proj_kernel, dim3((unsigned)((B + HEAD_IMGS - 1) / HEAD_IMGS), (unsigned)((cfg->out_dim + 255) / 256)),
+                       dim3(256), (size_t)HEAD_IMGS * W * 4, stream, y_cls, B, W, cfg->out_dim, w->proj,
+                       neck ? w->bn_proj_scale : nullptr, neck ? w->bn_proj_shift : nullptr, out);
+    LAUNCH_CHECK();
+    return MPREID_OK;
+}
+
 extern "C" int mpreid_vit_forward(const mpreid_vit_cfg *cfg, const mpreid_vit_weights *w, const float *img, int B,
                                   const float *cv_emb, float *out, void *ws, size_t ws_bytes, mpreid_stream_t stream) {
     ARG_CHECK(img);

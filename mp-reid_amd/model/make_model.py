@@ -37,6 +37,9 @@ class build_transformer(nn.Module):
         if self.model_name not in ('ViT-B-16', 'RN50'):
             raise NotImplementedError(f"MODEL.NAME {self.model_name!r}: the reference knows 'ViT-B-16' and 'RN50'")
         self.neck_feat = cfg.TEST.NECK_FEAT
+        # MODEL.ENCODER_PRECISION (not a reference key): 'fp16' = fp16 MFMA operands (throughput path), 'fp32' = the
+        # all-fp32 parity mode of the ViT encoder (mpreid_vit_forward_f32)
+        self.precision = str(getattr(cfg.MODEL, "ENCODER_PRECISION", "fp16"))
         self.in_planes, self.in_planes_proj = (768, 512) if self.model_name == 'ViT-B-16' else (2048, 1024)
         self.num_classes, self.camera_num, self.view_num = num_classes, camera_num, view_num
         self.sie_coe = cfg.MODEL.SIE_COE
@@ -101,7 +104,7 @@ class build_transformer(nn.Module):
         kw = {} if ws_tag is None else {"ws_tag": ws_tag}
         if self.model_name == 'RN50':
             return _ops.Rn50Encoder(self.rn_cfg, sd, self.img_hw, neck_after=neck_after, bn=bn, **kw)
-        return _ops.VitEncoder(self.vit_cfg, sd, self.img_hw, neck_after=neck_after, bn=bn, **kw)
+        return _ops.VitEncoder(self.vit_cfg, sd, self.img_hw, neck_after=neck_after, bn=bn, precision=self.precision, **kw)
 
     def _get_encoder(self):
         if self._encoder is None:

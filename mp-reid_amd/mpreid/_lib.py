@@ -28,6 +28,7 @@ SYMBOLS = [
     "mpreid_eval_rank_positions", "mpreid_rr_dist_rows", "mpreid_rr_vcap", "mpreid_rr_krecip", "mpreid_rr_krecip_scratch_bytes", "mpreid_rr_pack_rows", "mpreid_rr_qe_count",
     "mpreid_rr_qe_fill", "mpreid_rr_jaccard",
     "mpreid_vit_workspace_bytes", "mpreid_vit_forward", "mpreid_vit_forward_u8", "mpreid_vit_forward_view",
+    "mpreid_vit_workspace_bytes_f32", "mpreid_vit_forward_f32",
     "mpreid_tta_mean_f32", "mpreid_resize_workspace_bytes", "mpreid_resize_bilinear_u8", "mpreid_conv_f16_nhwc",
     "mpreid_rn50_workspace_bytes", "mpreid_rn50_forward",
     "mpreid_gemm_f16_nt", "mpreid_gemm_f16_nt_ex",
@@ -159,6 +160,10 @@ def load():
     L.mpreid_vit_workspace_bytes.argtypes = [C.POINTER(VitCfg), i32]
     L.mpreid_vit_forward.restype = i32
     L.mpreid_vit_forward.argtypes = [C.POINTER(VitCfg), C.POINTER(VitWeights), vp, i32, vp, vp, vp, sz, vp]
+    L.mpreid_vit_workspace_bytes_f32.restype = sz
+    L.mpreid_vit_workspace_bytes_f32.argtypes = [C.POINTER(VitCfg), i32]
+    L.mpreid_vit_forward_f32.restype = i32
+    L.mpreid_vit_forward_f32.argtypes = [C.POINTER(VitCfg), C.POINTER(VitWeights), vp, i32, vp, vp, vp, sz, vp]
     L.mpreid_vit_forward_u8.restype = i32
     L.mpreid_vit_forward_u8.argtypes = [C.POINTER(VitCfg), C.POINTER(VitWeights), vp, C.POINTER(C.c_float),
                                         C.POINTER(C.c_float), i32, vp, vp, vp, sz, vp]

@@ -232,7 +232,12 @@ class VitEncoder:
     """
 
     def __init__(self, cfg: dict, state_dict: dict, img_hw, neck_after: bool = False, bn: Optional[dict] = None,
-                 device=None, cls_only_last: bool = True, ws_tag: str = "vit"):
+                 device=None, cls_only_last: bool = True, ws_tag: str = "vit", precision: str = "fp16"):
+        """precision: 'fp16' = fp16 MFMA operands, fp32 accumulate / residual stream (the throughput path, relative
+        feature error ~4e-4); 'fp32' = every weight and activation fp32, exact fp32 matrix instruction (parity mode,
+        ~1e-6, ~1/8 of the throughput; mpreid_vit_forward_f32)."""
+        assert precision in ("fp16", "fp32"), precision
+        self.precision = precision
         self.device = device or _lib.require_gpu()
         self.ws_tag = ws_tag   # encoders that run concurrently on different streams need distinct workspaces
         self.cfg = dict(cfg)
@@ -249,11 +254,11 @@ class VitEncoder:
         def f32(name):
             return get(name).to(device=dev, dtype=torch.float32).contiguous()
 
-        def f16(name, shape=None):
+        def f16(name, shape=None):   # a GEMM weight: fp16 for the MFMA path, fp32 in the all-fp32 mode
             t = get(name).to(device=dev, dtype=torch.float32)
             if shape is not None:
                 t = t.reshape(shape)
-            return t.to(torch.float16).contiguous()
+            return t.contiguous() if precision == "fp32" else t.to(torch.float16).contiguous()
 
         w = cfg["width"]
         self._keep = []  # owns every device tensor referenced by the C structs
@@ -310,6 +315,15 @@ class VitEncoder:
         if out is None:
             out = torch.empty((B, self.feat_dim), dtype=torch.float32, device=self.device)
         assert out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (B, self.feat_dim)
+        if self.precision == "fp32":
+            step = 64   # fp32 activations: 4x the bytes per token
+            for s in range(0, B, step):
+                e = min(B, s + step)
+                ws = _workspace(self.ws_tag + "_f32", L.mpreid_vit_workspace_bytes_f32(C.byref(self.c_cfg), e - s), self.device)
+                _lib.check(L.mpreid_vit_forward_f32(C.byref(self.c_cfg), C.byref(self.c_w), _ptr(img[s:e]), e - s,
+                                                    _ptr(None if cv is None else cv[s:e].contiguous()), _ptr(out[s:e]), _ptr(ws),
+                                                    ws.numel(), _lib.stream_ptr()), "mpreid_vit_forward_f32")
+            return out
         wsb = L.mpreid_vit_workspace_bytes(C.byref(self.c_cfg), B)
         ws = _workspace(self.ws_tag, wsb, self.device)
         _lib.check(L.mpreid_vit_forward(C.byref(self.c_cfg), C.byref(self.c_w), _ptr(img), B, _ptr(cv), _ptr(out),
@@ -318,10 +332,19 @@ class VitEncoder:
 
     __call__ = forward
 
+    def _to_f32_images(self, img_hwc, pixel_mean, pixel_std):
+        """ToTensor + Normalize of val_transforms (datasets/make_dataloader.py:59-60) with torch ops: fp32 mode only"""
+        t = img_hwc.detach().to(device=self.device).permute(0, 3, 1, 2).to(torch.float32).div(255)
+        mean = torch.tensor(pixel_mean, dtype=torch.float32, device=self.device)[None, :, None, None]
+        std = torch.tensor(pixel_std, dtype=torch.float32, device=self.device)[None, :, None, None]
+        return ((t - mean) / std).contiguous()
+
     @torch.no_grad()
     def forward_u8(self, img_hwc: torch.Tensor, pixel_mean=(0.5, 0.5, 0.5), pixel_std=(0.5, 0.5, 0.5),
                    cv_emb: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """uint8 images [B, H, W, 3] (after Resize); ToTensor + Normalize run inside the patch-gather kernel."""
+        if self.precision == "fp32":
+            return self.forward(self._to_f32_images(img_hwc, pixel_mean, pixel_std), cv_emb, out)
         L = _lib.load()
         img = img_hwc.detach().to(device=self.device, dtype=torch.uint8).contiguous()
         B = img.shape[0]
@@ -345,6 +368,15 @@ class VitEncoder:
         img is either fp32 [B,3,H,W] (already normalised) or uint8 [B,H,W,3].  The view transform of
         processor/processor_uniprompt_stage2.py:605-633 happens inside the patch gather."""
         L = _lib.load()
+        if self.precision == "fp32":   # the views as the reference materialises them (tensor ops), then the fp32 encoder
+            t = self._to_f32_images(img, pixel_mean, pixel_std) if img.dtype == torch.uint8 else _dev_f32(img, self.device)
+            if view == VIEW_FLIP:
+                t = torch.flip(t, [3])
+            elif view == VIEW_PSEUDO_IR:
+                t = t.mean(dim=1, keepdim=True).repeat(1, 3, 1, 1)
+            elif view == VIEW_PSEUDO_RGB:
+                t = t[:, 0:1].repeat(1, 3, 1, 1)
+            return self.forward(t.contiguous(), cv_emb, out)
         u8 = img.dtype == torch.uint8
         if u8:
             img = img.detach().to(device=self.device).contiguous()
