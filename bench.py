@@ -516,7 +516,7 @@ def run_rank(a):
         roof = None
         traffic = None
         try:  # HBM bytes per launch of the dominant kernel: committed rocprofv3 PMC passes (profiles/)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_gemm_pmc_traffic.json")))
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r02_gemm_pmc_traffic.json")))
             e0 = ents[0]
             key = f"{_lib.GEMM_EPILOGUE_NAMES.get(e0.epilogue)}:{e0.n}:{e0.k}"
             traffic = tj["classes"].get(key, {}).get("hbm_bytes_per_launch")
@@ -528,7 +528,7 @@ def run_rank(a):
                     "achieved": top["tflops"], "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                     "algorithmic_gflop_per_launch": top["gflop_per_launch"],
                     "frac": round(top["tflops"] / PEAK_F16_TFLOPS, 4), "traffic": traffic,
-                    "traffic_source": "profiles/r01_gemm_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate "
+                    "traffic_source": "profiles/r02_gemm_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate "
                                       "passes), bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, same kernel and shape at M=65536",
                     "avg_launch_ms": top["avg_ms"], "launches": top["launches"],
                     "measured": "hipEvents around every launch, on the launch stream, " +
