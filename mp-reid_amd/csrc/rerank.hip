@@ -1153,7 +1153,14 @@ __global__ __launch_bounds__(JT) void jaccard_kernel(int64_t N, int64_t nq, cons
                                                       const int *__restrict__ crow, const uint16_t *__restrict__ cval,
                                                       int rch, uint16_t one_minus_lam_h, float lam32,
                                                       float *__restrict__ out, int64_t ldo,
-                                                      unsigned long long *__restrict__ pair_counter, int q0) {
+                                                      unsigned long long *__restrict__ pair_counter, int q0,
+                                                      const unsigned *__restrict__ H, int rows_per_block,
+                                                      int blocks_per_chunk) {
+    // H != NULL (inverted index built by csc2_*: the entries of a column are grouped by row block, and
+    // H[b][c] = number of entries of column c in the row blocks below b): blockIdx.y selects a chunk of
+    // blocks_per_chunk row blocks = rch rows, and the workgroup gathers exactly the sub-range of every column that
+    // lies in it.  (Round 1 walked the r-space chunk by chunk inside one workgroup and re-read every column in
+    // full for every chunk: 3x the gather traffic at N = 100 000, at one workgroup per CU.)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t *t = (uint16_t *)smem;                                   // [rch]
     long long *cp0 = (long long *)(smem + align_up((size_t)rch * 2, 16)); // [cnt]
@@ -1164,9 +1171,15 @@ __global__ __launch_bounds__(JT) void jaccard_kernel(int64_t N, int64_t nq, cons
     const int64_t ig = (int64_t)q0 + i;        // global row: the sparse V rows are indexed by it
     const int cnt = qcnt[ig];
     unsigned long long pairs = 0;
+    const int b_lo = H ? (int)blockIdx.y * blocks_per_chunk : 0;
+    const int b_hi = b_lo + blocks_per_chunk;   // >= CSC_B for the last chunk
     for (int a = tid; a < cnt; a += JT) {
         const int c = qidx[ig * qcap + a];
-        const long long p0 = cptr[c], p1 = cptr[c + 1];
+        long long p0 = cptr[c], p1 = cptr[c + 1];
+        if (H) {
+            if (b_hi < CSC_B) p1 = p0 + H[(int64_t)b_hi * N + c];
+            p0 += H[(int64_t)b_lo * N + c];
+        }
         cp0[a] = p0;
         clen[a] = (int)(p1 - p0);
         vi[a] = qval[ig * qcap + a];
@@ -1180,8 +1193,11 @@ __global__ __launch_bounds__(JT) void jaccard_kernel(int64_t N, int64_t nq, cons
     const float mx = rowmax[i];
     const float *row = MT + i * ld;
     const uint16_t H1 = 0x3c00u, H2 = 0x4000u;
-    for (int64_t r0 = 0; r0 < N; r0 += rch) {
-        const int64_t r1 = (r0 + rch < N) ? r0 + rch : N;
+    const int64_t r_first = H ? (int64_t)b_lo * rows_per_block : 0;
+    const int64_t r_end = (int64_t)b_hi * rows_per_block;
+    const int64_t r_last = H ? (r_end < N ? r_end : N) : N;   // (rch, the LDS size, may be rounded up past it)
+    for (int64_t r0 = r_first; r0 < r_last; r0 += rch) {
+        const int64_t r1 = (r0 + rch < r_last) ? r0 + rch : r_last;
         for (int r = tid; r < rch; r += JT) t[r] = 0;
         __syncthreads();
         // ascending column; rows of one column are distinct, so the threads of a column never collide and
@@ -1746,7 +1762,8 @@ static int rerank_tail(const TailArgs &a, hipStream_t stream, StageTimer &tm, mp
     tm.mark(); // +1
     // inverted index
     static const bool csc_atomic = getenv("MPREID_CSC_ATOMIC") != nullptr;   // A/B switch: the round-1 atomic build
-    if (a.chist && !csc_atomic && (uint64_t)N * (uint64_t)qcap < (1ull << 32)) {
+    const bool blocked_csc = a.chist && !csc_atomic && (uint64_t)N * (uint64_t)qcap < (1ull << 32);
+    if (blocked_csc) {
         const int rpb = (int)((N + CSC_B - 1) / CSC_B);
         const int nranges = (int)((N + CSC_CR - 1) / CSC_CR);
         const size_t lds = (size_t)std::min<int64_t>(N, CSC_CR) * 4;
@@ -1775,11 +1792,23 @@ static int rerank_tail(const TailArgs &a, hipStream_t stream, StageTimer &tm, mp
         const float lam32 = (float)a.lambda_value;
         int rch = (int)std::min<int64_t>(N, 49152);
         rch = (int)align_up((size_t)rch, 8);
+        const unsigned *Hp = nullptr;
+        int rpb = 0, bpc = 0, nchunks = 1;
+        if (blocked_csc) {
+            // chunks of whole row blocks of the inverted index, at most ~24 K rows (48 KB of fp16 accumulators: two or
+            // three workgroups per CU beside the column tables)
+            rpb = (int)((N + CSC_B - 1) / CSC_B);
+            bpc = std::max(1, std::min(CSC_B, 24576 / rpb));
+            nchunks = (CSC_B + bpc - 1) / bpc;
+            rch = (int)align_up((size_t)std::min<int64_t>(N, (int64_t)bpc * rpb), 8);
+            Hp = a.chist;
+        }
         const size_t lds = align_up((size_t)rch * 2, 16) + (size_t)qcap * (8 + 4 + 2) + 16;
         int rc = set_dyn_lds(jaccard_kernel, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(jaccard_kernel, dim3((unsigned)a.nq), dim3(JT), lds, stream, N, a.nq, a.MT, a.ld, a.rowmax, fcnt,
-                           fidx, fval, qcap, a.cptr, a.crow, a.cval, rch, oml, lam32, a.out, a.ldo, a.counters, 0);
+        hipLaunchKernelGGL(jaccard_kernel, dim3((unsigned)a.nq, (unsigned)nchunks), dim3(JT), lds, stream, N, a.nq, a.MT, a.ld,
+                           a.rowmax, fcnt, fidx, fval, qcap, a.cptr, a.crow, a.cval, rch, oml, lam32, a.out, a.ldo,
+                           a.counters, 0, Hp, rpb, bpc);
         LAUNCH_CHECK();
     }
     tm.mark(); // +3
@@ -2360,7 +2389,7 @@ extern "C" int mpreid_rr_jaccard(int64_t n, int64_t nq, int64_t q_lo, int64_t qr
     if (rc) return rc;
     hipLaunchKernelGGL(jaccard_kernel, dim3((unsigned)qrows), dim3(JT), lds, stream, n, nq, d_q, ld, rowmax_q, qcnt_all,
                        qidx_all, qval_all, qstride, cptr, crow, cval, rch, oml, lam32, out, ldo,
-                       (unsigned long long *)nullptr, (int)q_lo);
+                       (unsigned long long *)nullptr, (int)q_lo, (const unsigned *)nullptr, 0, 0);
     LAUNCH_CHECK();
     return MPREID_OK;
 }

@@ -30,8 +30,13 @@ def _workspace(tag: str, nbytes: int, device) -> torch.Tensor:
     return buf
 
 
-def release_workspaces():
-    _ws_cache.clear()
+def release_workspaces(tag: Optional[str] = None):
+    """drop the cached workspace buffers (all of them, or those of one tag on every device)"""
+    if tag is None:
+        _ws_cache.clear()
+        return
+    for key in [k for k in _ws_cache if k[1] == tag]:
+        del _ws_cache[key]
 
 
 def _dev_f32(t, device) -> torch.Tensor:

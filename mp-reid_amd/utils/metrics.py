@@ -152,6 +152,9 @@ class R1_mAP_eval():
         if self.reranking:
             print('=> Enter reranking')
             dist, self.last_rerank_stats = re_ranking_device(qf, gf, k1=50, k2=15, lambda_value=0.3)
+            # the evaluator is called once per run: do not keep the re-ranking workspace (GBs at MSMT17 scale)
+            # pinned beside the encoder's for the rest of the process
+            _ops.release_workspaces("rerank")
         else:
             print('=> Computing DistMat with euclidean_distance')
             dist = _ops.euclidean_distance(qf, gf, mode=self.distance_mode)
