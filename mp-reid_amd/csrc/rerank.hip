@@ -18,6 +18,7 @@
 // All kernels here are HBM/L2-bound integer+fp16 work (no MFMA); the GEMM is in distance.hip.
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 #include "common.h"
@@ -1712,6 +1713,7 @@ struct TailArgs {
     int64_t ldo;
     double lambda_value;
     int algo;
+    hipEvent_t join;   // (sparse) the distance rows MT are produced on a side stream: the Jaccard stage waits for this
 };
 
 static int rerank_tail(const TailArgs &a, hipStream_t stream, StageTimer &tm, mpreid_rerank_stats *stats, int marks_so_far) {
@@ -1787,6 +1789,7 @@ static int rerank_tail(const TailArgs &a, hipStream_t stream, StageTimer &tm, mp
     LAUNCH_CHECK();
     tm.mark(); // +2
     // (8)-(11) Jaccard + blend
+    if (a.join) HIP_TRY(hipStreamWaitEvent(stream, a.join, 0));
     {
         const uint16_t oml = f64_to_f16_host(1.0 - a.lambda_value);
         const float lam32 = (float)a.lambda_value;
@@ -2016,6 +2019,32 @@ static bool sparse_eligible(int64_t nq, int64_t ng, int k1, int k2, const float 
     return local == nullptr && N >= 2048 && KR <= 64;
 }
 
+// A second HIP stream (per device, created once) for work that is independent of the main chain: the exact distance
+// rows of the queries depend only on the features, so the fp32 matrix pipe computes them while the candidate
+// refinement / expansion / inverted-index kernels (gathers, LDS, no MFMA) run on the caller's stream.  Fork and join
+// with events; to the caller the call is still ordered on `stream`.
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr, t0 = nullptr, t1 = nullptr;
+};
+static int side_stream(SideStream **out) {
+    static std::mutex mu;
+    static SideStream table[64];
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    SideStream &ss = table[(dev >= 0 && dev < 64) ? dev : 0];
+    if (!ss.s) {
+        HIP_TRY(hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ss.join, hipEventDisableTiming));
+        HIP_TRY(hipEventCreate(&ss.t0));
+        HIP_TRY(hipEventCreate(&ss.t1));
+    }
+    *out = &ss;
+    return MPREID_OK;
+}
+
 static int rerank_sparse(const float *q, const float *g, int64_t nq, int64_t ng, int d, int k1, int k2, double lambda_value,
                          float *out, int64_t ldo, void *ws, size_t ws_bytes, mpreid_stream_t stream_,
                          mpreid_rerank_stats *stats, int timing) {
@@ -2031,6 +2060,10 @@ static int rerank_sparse(const float *q, const float *g, int64_t nq, int64_t ng,
         return MPREID_ERR_WORKSPACE;
     }
     hipStream_t stream = (hipStream_t)stream_;
+    // one sparse call at a time per process: the side stream and its events are shared state (calls on different
+    // devices of one process serialise here too; a call is a few ms)
+    static std::mutex call_mu;
+    std::lock_guard<std::mutex> call_lock(call_mu);
     char *base = (char *)ws;
     float *feat = (float *)(base + L.feat), *sqn = (float *)(base + L.sqn);
     _Float16 *feat16 = (_Float16 *)(base + L.feat16), *samp16 = (_Float16 *)(base + L.samp16);
@@ -2098,6 +2131,22 @@ static int rerank_sparse(const float *q, const float *g, int64_t nq, int64_t ng,
         if (rc) return rc;
     }
     tm.mark(); // 1
+    // fork: exact distance rows of the queries (what the Jaccard blend reads) on the side stream.  Forked AFTER the
+    // fused GEMM (a persistent kernel that owns every CU's LDS: forked before it, the two GEMMs only take turns):
+    // the fp32 matrix work then runs beside the refinement / expansion / inverted-index kernels, which gather
+    // measured: N = 20 000 no gain (6.06 vs 6.04 ms: either side saturates the chip), N = 100 000 116 -> 113 ms
+    static const char *ov_env = getenv("MPREID_RERANK_OVERLAP");   // A/B switch: "0" / "1" force it off / on
+    const bool no_overlap = ov_env ? (atoi(ov_env) == 0) : (N < 50000);
+    SideStream *ss = nullptr;
+    if (!no_overlap) {
+        if ((rc = side_stream(&ss))) return rc;
+        HIP_TRY(hipEventRecord(ss->fork, stream));
+        HIP_TRY(hipStreamWaitEvent(ss->s, ss->fork, 0));
+        if (timing) HIP_TRY(hipEventRecord(ss->t0, ss->s));
+        if ((rc = mpreid_distance_launch(feat, feat, nq, N, d, sqn, sqn, dq, L.ld, 0, ss->s))) return rc;
+        if (timing) HIP_TRY(hipEventRecord(ss->t1, ss->s));
+        HIP_TRY(hipEventRecord(ss->join, ss->s));
+    }
     {   // refinement + fallback rows
         const size_t lds = 512 * 8 + RR2_MAXE * 8 + RR2_MAXH * 8 + (size_t)((d + 3) & ~3) * 4 + 3 * 64 * WXD_STRIDE * 4;
         rc = set_dyn_lds(rr2_refine_kernel<RR2_CAP_LO, RR2_CAP_HI>, lds);
@@ -2134,9 +2183,10 @@ static int rerank_sparse(const float *q, const float *g, int64_t nq, int64_t ng,
         LAUNCH_CHECK();
     }
     tm.mark(); // 3
-    // exact distance rows of the queries (what the Jaccard blend reads)
-    rc = mpreid_distance_launch(feat, feat, nq, N, d, sqn, sqn, dq, L.ld, 0, stream);
-    if (rc) return rc;
+    if (no_overlap) {   // exact distance rows of the queries, in line
+        rc = mpreid_distance_launch(feat, feat, nq, N, d, sqn, sqn, dq, L.ld, 0, stream);
+        if (rc) return rc;
+    }
     tm.mark(); // 4
     TailArgs ta{};
     ta.N = N; ta.nq = nq; ta.k1 = k1; ta.k2 = k2; ta.KR = L.KR; ta.h = L.h; ta.vcap = L.vcap; ta.qcap_bound = L.qcap_bound;
@@ -2146,8 +2196,13 @@ static int rerank_sparse(const float *q, const float *g, int64_t nq, int64_t ng,
     ta.chist = (unsigned *)(base + L.chist);
     ta.counters = counters; ta.MT = dq; ta.ld = L.ld; ta.rowmax = rowmax; ta.out = out; ta.ldo = ldo;
     ta.lambda_value = lambda_value; ta.algo = MPREID_RERANK_SPARSE;
+    ta.join = ss ? ss->join : nullptr;
     rc = rerank_tail(ta, stream, tm, stats, 4);
     if (rc) return rc;
+    if (ss && timing && stats) {   // the side stream's own duration (it overlaps the main chain)
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ss->t0, ss->t1) == hipSuccess) stats->ms_dq = ms;
+    }
     // status of the data-dependent capacities (read with the statistics, after the fact): the fp16 operands must
     // not have overflowed and the fallback rows must have fitted their buffer -- otherwise the result above is not
     // valid and the caller repeats the call with the dense algorithm
