@@ -591,6 +591,11 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
         }
         mfma32(fa, fb);
     };
+    // (tried in round 2: waves 4-7 half a stage late -- MI355X_MICROARCH.md "Two waves per SIMD" item 9 -- by moving
+    // their MFMA groups across the barrier: rows 4-7 of stage t after barrier t, rows 0-3 of stage t+1 before barrier
+    // t+1; LDS traffic unchanged, same bits.  Both formulations that hipcc accepts -- two copies of the loop selected
+    // by the wave number, or one copy with a wave-uniform branch per MFMA group -- make the register allocator spill
+    // 300-1000 VGPRs around the accumulators; it needs an assembly k-loop.)
     int t = 0;
     for (; t + 4 < nst; t += 2) {
         step_steady(t, fa0, fb0, fa1, fb1);
