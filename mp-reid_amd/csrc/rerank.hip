@@ -1433,7 +1433,7 @@ __global__ __launch_bounds__(256) void rr2_refine_kernel(const float *__restrict
     int *hsel = reinterpret_cast<int *>(ekey + RR2_MAXE);                      // [RR2_MAXH]
     float *hval = reinterpret_cast<float *>(hsel + RR2_MAXH);                  // [RR2_MAXH]
     float *qrow = hval + RR2_MAXH;                                             // [d rounded up to 4]
-    float *xtile = qrow + ((d + 3) & ~3);                                      // [3 waves][64][WXD_STRIDE]
+    float *xtile = qrow + ((d + 3) & ~3);                                      // [2 waves][64][WXD_STRIDE]
     __shared__ float s_red[4];
     __shared__ unsigned s_cnt;
     __shared__ int s_fail;
@@ -1458,12 +1458,13 @@ __global__ __launch_bounds__(256) void rr2_refine_kernel(const float *__restrict
     __syncthreads();
     const bool fail0 = s_fail != 0;
     if (!fail0) {
-        for (int size = 2; size <= 512; size <<= 1)
+        const int sort_n = nlo <= 256u ? 256 : 512;   // (most rows have ~160 candidates)
+        for (int size = 2; size <= sort_n; size <<= 1)
             for (int stride = size >> 1; stride > 0; stride >>= 1) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int a_i = tid + h * 256, partner = a_i ^ stride;
-                    if (partner > a_i) {
+                    if (a_i < sort_n && partner > a_i) {
                         const unsigned long long a = keys[a_i], b = keys[partner];
                         const bool up = ((a_i & size) == 0);
                         if ((a > b) == up) {
@@ -1518,7 +1519,7 @@ __global__ __launch_bounds__(256) void rr2_refine_kernel(const float *__restrict
         }
     __syncthreads();
     const int mh = (int)s_cnt;
-    if (tid == 0 && mh > RR2_MAXH) s_fail = 1;
+    if (tid == 0 && (mh > RR2_MAXH || m + mh > RR2_MAXE)) s_fail = 1;   // lo and hi evaluations share 128 lanes
     __syncthreads();
     if (s_fail) {
         if (tid == 0) {
@@ -1527,15 +1528,15 @@ __global__ __launch_bounds__(256) void rr2_refine_kernel(const float *__restrict
         }
         return;
     }
-    // ---- exact distances: threads 0..m-1 the lo candidates, threads 128..128+mh-1 the hi candidates ----
+    // ---- exact distances: threads 0..m-1 the lo candidates, threads m..m+mh-1 the hi candidates (two waves) ----
     const float ni = sqn[i];
     float dex = 0.0f;
     int jx = -1;
     if (tid < m) jx = (int)(unsigned)(keys[tid] & 0xffffffffull);
-    else if (tid >= 128 && tid < 128 + mh) jx = hsel[tid - 128];
-    if (wave < 3 && (wave * 64 < m || wave == 2))   // wave-uniform: waves 0, 1 the lo candidates, wave 2 the hi ones
+    else if (tid < m + mh) jx = hsel[tid - m];
+    if (wave < 2 && wave * 64 < m + mh)   // wave-uniform
         dex = wave_exact_dists(qrow, feat, d, jx, ni, sqn, xtile + wave * 64 * WXD_STRIDE, lane);
-    if (tid >= 128 && tid < 128 + mh) hval[tid - 128] = dex;
+    if (tid >= m && tid < m + mh) hval[tid - m] = dex;
     __syncthreads();
     float mx = -3.402823466e+38f;
     for (int t = 0; t < mh; ++t) mx = fmaxf(mx, hval[t]);   // exact row maximum (see the header: always certified)
@@ -2148,7 +2149,7 @@ static int rerank_sparse(const float *q, const float *g, int64_t nq, int64_t ng,
         HIP_TRY(hipEventRecord(ss->join, ss->s));
     }
     {   // refinement + fallback rows
-        const size_t lds = 512 * 8 + RR2_MAXE * 8 + RR2_MAXH * 8 + (size_t)((d + 3) & ~3) * 4 + 3 * 64 * WXD_STRIDE * 4;
+        const size_t lds = 512 * 8 + RR2_MAXE * 8 + RR2_MAXH * 8 + (size_t)((d + 3) & ~3) * 4 + 2 * 64 * WXD_STRIDE * 4;
         rc = set_dyn_lds(rr2_refine_kernel<RR2_CAP_LO, RR2_CAP_HI>, lds);
         if (rc) return rc;
         hipLaunchKernelGGL((rr2_refine_kernel<RR2_CAP_LO, RR2_CAP_HI>), dim3((unsigned)N), dim3(256), lds, stream, feat, sqn, N,
