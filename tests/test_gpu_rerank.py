@@ -109,7 +109,8 @@ def test_rerank_unselected_seeds(ops, golden, row):
                                                         (5000, 1000, 1280, 50, 15, 3.5, 20), (6001, 77, 100, 20, 6, 2.0, 10),
                                                         (8000, 1600, 768, 30, 10, 3.0, 40), (3000, 600, 64, 10, 1, 1.5, 8),
                                                         (7000, 1400, 768, 50, 15, 6.0, 20), (2100, 1, 2048, 50, 15, 3.0, 20),
-                                                        (2500, 2499, 36, 20, 6, 1.5, 10), (2048, 300, 130, 5, 1, 2.0, 6)])
+                                                        (2500, 2499, 36, 20, 6, 1.5, 10), (2048, 300, 130, 5, 1, 2.0, 6),
+                                                        (3000, 500, 96, 30, 40, 2.0, 25), (4500, 900, 512, 62, 64, 2.6, 30)])
 def test_rerank_sparse_equals_dense_equals_oracle(ops, n, nq, d, k1, k2, sigma, per_id):
     """the candidate pipeline (no N x N matrix: fp16 GEMM -> thresholded candidates -> exact refinement, fallback rows)
     against the dense algorithm and the oracle: neighbour table, nnz(V), nnz(V_qe) and every output bit"""
