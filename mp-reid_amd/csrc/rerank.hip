@@ -1145,6 +1145,8 @@ __global__ __launch_bounds__(1024) void csc2_fill_kernel(int64_t N, const int *_
 // (utils/reranking.py:84-100).  One 256-thread workgroup per query; t[] lives in LDS as fp16 bits,
 // r-space processed in chunks of rch entries so that any N fits.
 // ---------------------------------------------------------------------------------------------
+// (tried for N > 49 152: 8 K-row chunks with ONE wave per (query, chunk) instead of 24 K rows and 512 threads --
+// 45.4 -> 41.3 ms at N = 100 000 but 19.9 -> 24.6 ms at the MSMT17 shape: not kept)
 constexpr int JT = 512; // threads per query workgroup
 __global__ __launch_bounds__(JT) void jaccard_kernel(int64_t N, int64_t nq, const float *__restrict__ MT, int64_t ld,
                                                       const float *__restrict__ rowmax,
