@@ -158,6 +158,18 @@ size_t mpreid_rr_krecip_scratch_bytes(int64_t n);
 int mpreid_rr_krecip(const float *d_local_dev, int64_t ld, int64_t n, const float *rowmax_local_dev,
                      const int32_t *rank_all_dev, int k1, int kr, int64_t r_lo, int64_t rows, int32_t *vcnt_dev,
                      int32_t *vidx_dev, uint16_t *vval_dev, void *scratch_dev, mpreid_stream_t stream);
+/* SPARSE forms of phases 1 and 2 (no [rows][n] distance block; n >= 2048, kr <= 64): phase 1 returns the first kr
+ * neighbours, the row maxima and the exact distances of the neighbours of the local rows; MPREID_ERR_RETRY_DENSE
+ * (degenerate data) means "use mpreid_rr_dist_rows + mpreid_rr_krecip for this row block" -- every rank may decide
+ * for itself, the bits are the same.  The Jaccard phase is mpreid_rr_jaccard as before. */
+size_t mpreid_rr_sparse_workspace_bytes(int64_t n, int d, int64_t rows, int kr);
+int mpreid_rr_neighbours_sparse(const float *feat_all_dev, const float *norms_all_dev, int64_t n, int d, int64_t r_lo,
+                                int64_t rows, int kr, int32_t *rank_local_dev, float *rowmax_local_dev,
+                                float *rankd_local_dev, void *ws_dev, size_t ws_bytes, mpreid_stream_t stream);
+int mpreid_rr_krecip_sparse(const float *feat_all_dev, const float *norms_all_dev, int64_t n, int d,
+                            const float *rowmax_local_dev, const int32_t *rank_all_dev, const float *rankd_local_dev,
+                            int k1, int kr, int64_t r_lo, int64_t rows, int32_t *vcnt_dev, int32_t *vidx_dev,
+                            uint16_t *vval_dev, void *scratch_dev, mpreid_stream_t stream);
 /* re-stride ELL rows (for the all-gather: common width = global max count) */
 int mpreid_rr_pack_rows(const int32_t *cnt_dev, const int32_t *idx_dev, const uint16_t *val_dev, int64_t rows,
                         int src_stride, int dst_stride, int32_t *idx_out_dev, uint16_t *val_out_dev,

@@ -1427,7 +1427,9 @@ __global__ __launch_bounds__(256) void rr2_refine_kernel(const float *__restrict
                                                          float *__restrict__ rowmax, int *__restrict__ rank,
                                                          float *__restrict__ rankd,
                                                          unsigned *__restrict__ fb_count, int *__restrict__ fb_rows,
-                                                         unsigned fb_max) {
+                                                         unsigned fb_max, int64_t row0) {
+    // lists, thresholds, rank / rankd / rowmax and the fallback list are indexed by the LOCAL row (blockIdx.x); feat
+    // and sqn are the global arrays and row0 the global index of local row 0 (0 unless the rows are sharded)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     static_assert(CAP_LO <= 512 && CAP_HI <= 256, "list capacities");
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);   // [512]
@@ -1447,7 +1449,7 @@ __global__ __launch_bounds__(256) void rr2_refine_kernel(const float *__restrict
         s_cnt = 0u;
         s_fail = (nlo > (unsigned)CAP_LO || nhi > (unsigned)CAP_HI || nlo < (unsigned)KR || nhi < 1u) ? 1 : 0;
     }
-    for (int k = tid; k < d; k += 256) qrow[k] = feat[i * d + k];
+    for (int k = tid; k < d; k += 256) qrow[k] = feat[(row0 + i) * d + k];
     // ---- lo side: sort the candidates by approximate distance ----
     for (int t = tid; t < 512; t += 256) {
         unsigned long long kv = ~0ull;
@@ -1531,7 +1533,7 @@ __global__ __launch_bounds__(256) void rr2_refine_kernel(const float *__restrict
         return;
     }
     // ---- exact distances: threads 0..m-1 the lo candidates, threads m..m+mh-1 the hi candidates (two waves) ----
-    const float ni = sqn[i];
+    const float ni = sqn[row0 + i];
     float dex = 0.0f;
     int jx = -1;
     if (tid < m) jx = (int)(unsigned)(keys[tid] & 0xffffffffull);
@@ -1594,11 +1596,12 @@ __global__ __launch_bounds__(256) void rr2_refine_kernel(const float *__restrict
 __global__ __launch_bounds__(256) void rr2_fb_gather_kernel(const float *__restrict__ feat, const float *__restrict__ sqn, int d,
                                                             const int *__restrict__ fb_rows,
                                                             const unsigned *__restrict__ fb_count, unsigned fb_max,
-                                                            float *__restrict__ fb_feat, float *__restrict__ fb_sqn) {
+                                                            float *__restrict__ fb_feat, float *__restrict__ fb_sqn,
+                                                            int64_t row0) {
     const unsigned b = blockIdx.x;
     const unsigned cnt = *fb_count < fb_max ? *fb_count : fb_max;
     if (b >= cnt) return;
-    const int64_t i = fb_rows[b];
+    const int64_t i = row0 + fb_rows[b];
     for (int k = threadIdx.x; k < d; k += 256) fb_feat[(int64_t)b * d + k] = feat[i * d + k];
     if (threadIdx.x == 0) fb_sqn[b] = sqn[i];
 }
@@ -2156,9 +2159,9 @@ static int rerank_sparse(const float *q, const float *g, int64_t nq, int64_t ng,
         if (rc) return rc;
         hipLaunchKernelGGL((rr2_refine_kernel<RR2_CAP_LO, RR2_CAP_HI>), dim3((unsigned)N), dim3(256), lds, stream, feat, sqn, N,
                            d, L.KR, cnt_lo, list_lo, cnt_hi, list_hi, tlo, eps, rowmax, rank, rankd, fb_count, fb_rows,
-                           (unsigned)L.fb_max);
+                           (unsigned)L.fb_max, (int64_t)0);
         hipLaunchKernelGGL(rr2_fb_gather_kernel, dim3((unsigned)L.fb_max), dim3(256), 0, stream, feat, sqn, d, fb_rows,
-                           fb_count, (unsigned)L.fb_max, fb_feat, fb_sqn);
+                           fb_count, (unsigned)L.fb_max, fb_feat, fb_sqn, (int64_t)0);
         LAUNCH_CHECK();
         rc = mpreid_distance_launch(fb_feat, feat, L.fb_max, N, d, fb_sqn, sqn, fb_D, L.ld, 0, stream, fb_count);
         if (rc) return rc;
@@ -2376,6 +2379,174 @@ extern "C" int mpreid_rr_krecip(const float *d_local, int64_t ld, int64_t n, con
                        rowmax_local, rank_all, K, kr, h, vcap, vcnt, vidx, vval, (int)r_lo,
                        (int *)nullptr, (const float *)nullptr, (const float *)nullptr, 0, (const float *)nullptr, rk,
                        rk + (size_t)n * RB_WORDS);
+    LAUNCH_CHECK();
+    return MPREID_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row-sharded SPARSE phases (the multi-GPU form of the candidate pipeline): a rank's rows [r_lo, r_lo + rows) of the
+// N x N problem without its [rows][N] distance block.
+//   mpreid_rr_neighbours_sparse   phase 1: fp16 operands of all rows (every rank needs all columns), sample pass and
+//                                 thresholds for the local rows, candidate GEMM local rows x all columns (no symmetry
+//                                 to exploit inside a row block), exact refinement + fallback rows
+//                                 -> rank_local [rows][kr], rowmax_local [rows], rankd_local [rows][kr]
+//   mpreid_rr_krecip_sparse       phase 2 with on-the-fly exact distances (no D rows)
+// Phases 3 and 4 are the existing ones (the Jaccard phase computes the exact rows of the LOCAL QUERIES only).  Same
+// bits as the dense phases and the single-GPU call.  MPREID_ERR_RETRY_DENSE: use mpreid_rr_dist_rows for this rank.
+// ---------------------------------------------------------------------------------------------
+struct RrSparseLayout {
+    int64_t Np, Nsp, Mp, ld, fb_max;
+    int dp;
+    size_t sqn, feat16, samp16, sampn, sampD, tlo, thi, eps, cnt_lo, cnt_hi, list_lo, list_hi, gstat, fb_count, fb_rows, fb_feat,
+        fb_sqn, fb_D, fb_rowmax, fb_rank, total;
+};
+static RrSparseLayout rr_sparse_layout(int64_t n, int d, int64_t rows, int kr) {
+    RrSparseLayout L{};
+    L.Np = (int64_t)align_up((size_t)n, 256);
+    L.Nsp = (int64_t)align_up((size_t)((n + RR2_SAMPLE_STRIDE - 1) / RR2_SAMPLE_STRIDE), 256);
+    L.Mp = (int64_t)align_up((size_t)rows, 256);
+    L.ld = (int64_t)align_up((size_t)n, 64);
+    L.dp = (int)align_up((size_t)d, 64);
+    L.fb_max = std::max<int64_t>(256, rows / 16);
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off += align_up(bytes, 256);
+        return o;
+    };
+    const size_t Np = (size_t)L.Np, Mp = (size_t)L.Mp, F = (size_t)L.fb_max;
+    L.sqn = take((Np + 256) * 4);                      // + slack: the local row block is read in whole 256-row tiles
+    L.feat16 = take((Np + 256) * (size_t)L.dp * 2);
+    L.samp16 = take((size_t)L.Nsp * L.dp * 2);
+    L.sampn = take((size_t)L.Nsp * 4);
+    L.sampD = take(Mp * (size_t)L.Nsp * 4);
+    L.tlo = take(Mp * 4);
+    L.thi = take(Mp * 4);
+    L.eps = take(Mp * 4);
+    L.cnt_lo = take(Mp * 4);
+    L.cnt_hi = take(Mp * 4);
+    L.list_lo = take(Mp * (size_t)RR2_CAP_LO * 8);
+    L.list_hi = take(Mp * (size_t)RR2_CAP_HI * 8);
+    L.gstat = take(64);
+    L.fb_count = take(64);
+    L.fb_rows = take(F * 4);
+    L.fb_feat = take(F * (size_t)d * 4);
+    L.fb_sqn = take(F * 4);
+    L.fb_D = take(F * (size_t)L.ld * 4);
+    L.fb_rowmax = take(F * 4);
+    L.fb_rank = take(F * (size_t)kr * 4);
+    L.total = off;
+    return L;
+}
+
+extern "C" size_t mpreid_rr_sparse_workspace_bytes(int64_t n, int d, int64_t rows, int kr) {
+    if (n <= 0 || d <= 0 || rows <= 0 || kr <= 0) return 0;
+    return rr_sparse_layout(n, d, rows, kr).total;
+}
+
+extern "C" int mpreid_rr_neighbours_sparse(const float *feat_all, const float *norms_all, int64_t n, int d, int64_t r_lo,
+                                           int64_t rows, int kr, int32_t *rank_local, float *rowmax_local, float *rankd_local,
+                                           void *ws, size_t ws_bytes, mpreid_stream_t stream_) {
+    ARG_CHECK(feat_all && norms_all && rank_local && rowmax_local && rankd_local && n >= 2048 && d > 0 && rows > 0 && r_lo >= 0 &&
+              r_lo + rows <= n && kr >= 1 && kr <= 64 && kr <= n);
+    const RrSparseLayout L = rr_sparse_layout(n, d, rows, kr);
+    if (!ws || ws_bytes < L.total) {
+        mpreid_set_error("sparse phase-1 workspace too small: %zu < %zu", ws_bytes, L.total);
+        return MPREID_ERR_WORKSPACE;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    char *base = (char *)ws;
+    float *sqn = (float *)(base + L.sqn);
+    _Float16 *feat16 = (_Float16 *)(base + L.feat16), *samp16 = (_Float16 *)(base + L.samp16);
+    float *sampn = (float *)(base + L.sampn), *sampD = (float *)(base + L.sampD);
+    float *tlo = (float *)(base + L.tlo), *thi = (float *)(base + L.thi), *eps = (float *)(base + L.eps);
+    unsigned *cnt_lo = (unsigned *)(base + L.cnt_lo), *cnt_hi = (unsigned *)(base + L.cnt_hi);
+    uint2 *list_lo = (uint2 *)(base + L.list_lo), *list_hi = (uint2 *)(base + L.list_hi);
+    float *gstat = (float *)(base + L.gstat);
+    unsigned *fb_count = (unsigned *)(base + L.fb_count);
+    int *fb_rows = (int *)(base + L.fb_rows);
+    float *fb_feat = (float *)(base + L.fb_feat), *fb_sqn = (float *)(base + L.fb_sqn), *fb_D = (float *)(base + L.fb_D),
+          *fb_rowmax = (float *)(base + L.fb_rowmax);
+    int *fb_rank = (int *)(base + L.fb_rank);
+    const int ns = (int)((n + RR2_SAMPLE_STRIDE - 1) / RR2_SAMPLE_STRIDE);
+
+    HIP_TRY(hipMemsetAsync(fb_count, 0, 64, stream));
+    HIP_TRY(hipMemsetAsync(rank_local, 0, (size_t)rows * kr * 4, stream));
+    HIP_TRY(hipMemsetAsync(rankd_local, 0, (size_t)rows * kr * 4, stream));
+    HIP_TRY(hipMemsetAsync(rowmax_local, 0, (size_t)rows * 4, stream));
+    HIP_TRY(hipMemsetAsync(sqn, 0, (size_t)(L.Np + 256) * 4, stream));
+    HIP_TRY(hipMemcpyAsync(sqn, norms_all, (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
+    hipLaunchKernelGGL(rr2_norm_stats_kernel, dim3(1), dim3(1024), 0, stream, sqn, n, gstat);
+    hipLaunchKernelGGL(rr2_cast_rows_kernel, dim3((unsigned)(L.Np + 256)), dim3(256), 0, stream, feat_all, sqn, n, d, 1, feat16,
+                       L.dp, (float *)nullptr);
+    hipLaunchKernelGGL(rr2_cast_rows_kernel, dim3((unsigned)L.Nsp), dim3(256), 0, stream, feat_all, sqn, n, d, RR2_SAMPLE_STRIDE,
+                       samp16, L.dp, sampn);
+    LAUNCH_CHECK();
+    int rc;
+    {   // sample pass for the local rows
+        GemmArgs a{};
+        a.A = feat16 + (size_t)r_lo * L.dp; a.W = samp16; a.M = (int)L.Mp; a.N = (int)L.Nsp; a.K = L.dp;
+        a.out = sampD; a.ldo = L.Nsp; a.aux = sqn + r_lo; a.aux2 = sampn; a.m_valid = (int)rows; a.n_valid = ns;
+        if ((rc = launch_gemm_f16(a, GE_EUCLID, stream))) return rc;
+    }
+    hipLaunchKernelGGL(rr2_threshold_kernel, dim3((unsigned)L.Mp), dim3(256), 0, stream, sampD, L.Nsp, ns, rows, RR2_RSEL,
+                       sqn + r_lo, gstat, d, tlo, thi, eps, cnt_lo, cnt_hi);
+    LAUNCH_CHECK();
+    {   // candidates: local rows x all columns
+        GemmArgs a{};
+        a.A = feat16 + (size_t)r_lo * L.dp; a.W = feat16; a.M = (int)L.Mp; a.N = (int)L.Np; a.K = L.dp;
+        a.aux = sqn + r_lo; a.aux2 = sqn; a.m_valid = (int)rows; a.n_valid = (int)n;
+        a.tlo = tlo; a.thi = thi; a.cnt_lo = cnt_lo; a.cnt_hi = cnt_hi; a.list_lo = list_lo; a.list_hi = list_hi;
+        a.cap_lo = RR2_CAP_LO; a.cap_hi = RR2_CAP_HI; a.sym = 0;
+        if ((rc = launch_gemm_f16(a, GE_CAND, stream))) return rc;
+    }
+    {
+        const size_t lds = 512 * 8 + RR2_MAXE * 8 + RR2_MAXH * 8 + (size_t)((d + 3) & ~3) * 4 + 2 * 64 * WXD_STRIDE * 4;
+        if ((rc = set_dyn_lds(rr2_refine_kernel<RR2_CAP_LO, RR2_CAP_HI>, lds))) return rc;
+        hipLaunchKernelGGL((rr2_refine_kernel<RR2_CAP_LO, RR2_CAP_HI>), dim3((unsigned)rows), dim3(256), lds, stream, feat_all, sqn,
+                           n, d, kr, cnt_lo, list_lo, cnt_hi, list_hi, tlo, eps, rowmax_local, rank_local, rankd_local, fb_count,
+                           fb_rows, (unsigned)L.fb_max, r_lo);
+        hipLaunchKernelGGL(rr2_fb_gather_kernel, dim3((unsigned)L.fb_max), dim3(256), 0, stream, feat_all, sqn, d, fb_rows, fb_count,
+                           (unsigned)L.fb_max, fb_feat, fb_sqn, r_lo);
+        LAUNCH_CHECK();
+        if ((rc = mpreid_distance_launch(fb_feat, feat_all, L.fb_max, n, d, fb_sqn, sqn, fb_D, L.ld, 0, stream, fb_count))) return rc;
+        if ((rc = launch_rowmax_topk(fb_D, L.ld, n, kr, L.fb_max, fb_rowmax, fb_rank, stream, fb_count))) return rc;
+        hipLaunchKernelGGL(rr2_fb_scatter_kernel, dim3((unsigned)L.fb_max), dim3(256), 0, stream, fb_rows, fb_count,
+                           (unsigned)L.fb_max, fb_rowmax, fb_rank, kr, fb_D, L.ld, rowmax_local, rank_local, rankd_local);
+        LAUNCH_CHECK();
+    }
+    float gs[2] = {0.f, 0.f};
+    unsigned fbc = 0;
+    HIP_TRY(hipMemcpyAsync(gs, gstat, 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(&fbc, fb_count, 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (gs[1] != 0.0f || fbc > (unsigned)L.fb_max) {
+        mpreid_set_error("sparse phase 1: %s; use mpreid_rr_dist_rows for this row block",
+                         gs[1] != 0.0f ? "row norms too large for fp16 operands" : "too many rows needed the dense fallback");
+        return MPREID_ERR_RETRY_DENSE;
+    }
+    return MPREID_OK;
+}
+
+extern "C" int mpreid_rr_krecip_sparse(const float *feat_all, const float *norms_all, int64_t n, int d,
+                                       const float *rowmax_local, const int32_t *rank_all, const float *rankd_local, int k1,
+                                       int kr, int64_t r_lo, int64_t rows, int32_t *vcnt, int32_t *vidx, uint16_t *vval,
+                                       void *scratch, mpreid_stream_t stream_) {
+    const int K = (int)std::min<int64_t>(k1 + 1, n), h = (int)std::min<int64_t>(mpreid_half_k1(k1), n);
+    const int vcap = mpreid_rr_vcap(n, k1);
+    ARG_CHECK(feat_all && norms_all && rowmax_local && rank_all && rankd_local && vcnt && vidx && vval && scratch && rows > 0 &&
+              kr >= K);
+    const int nw = (int)((n + 31) >> 5);
+    const size_t lds = (size_t)nw * 8 + (size_t)K * 12 + (size_t)vcap * 12 + 16 + (size_t)((d + 3) & ~3) * 4 + 64 * WXD_STRIDE * 4;
+    int rc = set_dyn_lds(krecip_kernel<true>, lds);
+    if (rc) return rc;
+    unsigned *rk = (unsigned *)scratch;
+    hipLaunchKernelGGL(recip_bits_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, rank_all, n, K, kr,
+                       h, rk, rk + (size_t)n * RB_WORDS);
+    // rankd is indexed by the global row inside the kernel: shift the local table's base accordingly
+    hipLaunchKernelGGL(krecip_kernel<true>, dim3((unsigned)rows), dim3(256), lds, (hipStream_t)stream_, (const float *)nullptr,
+                       (int64_t)0, n, rowmax_local, rank_all, K, kr, h, vcap, vcnt, vidx, vval, (int)r_lo, (int *)nullptr, feat_all,
+                       norms_all, d, rankd_local - (int64_t)r_lo * kr, rk, rk + (size_t)n * RB_WORDS);
     LAUNCH_CHECK();
     return MPREID_OK;
 }

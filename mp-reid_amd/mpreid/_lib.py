@@ -25,7 +25,8 @@ SYMBOLS = [
     "mpreid_euclidean_distance_f32", "mpreid_cosine_similarity_f32",
     "mpreid_rerank_workspace_bytes", "mpreid_rerank_f32", "mpreid_rerank_debug_copy",
     "mpreid_rerank_workspace_bytes_ex", "mpreid_rerank_f32_ex", "mpreid_rerank_debug_copy_ex",
-    "mpreid_eval_rank_positions", "mpreid_rr_dist_rows", "mpreid_rr_vcap", "mpreid_rr_krecip", "mpreid_rr_krecip_scratch_bytes", "mpreid_rr_pack_rows", "mpreid_rr_qe_count",
+    "mpreid_eval_rank_positions", "mpreid_rr_dist_rows", "mpreid_rr_vcap", "mpreid_rr_krecip", "mpreid_rr_krecip_scratch_bytes",
+    "mpreid_rr_sparse_workspace_bytes", "mpreid_rr_neighbours_sparse", "mpreid_rr_krecip_sparse", "mpreid_rr_pack_rows", "mpreid_rr_qe_count",
     "mpreid_rr_qe_fill", "mpreid_rr_jaccard",
     "mpreid_vit_workspace_bytes", "mpreid_vit_forward", "mpreid_vit_forward_u8", "mpreid_vit_forward_view",
     "mpreid_vit_workspace_bytes_f32", "mpreid_vit_forward_f32",
@@ -148,6 +149,12 @@ def load():
     L.mpreid_rr_krecip_scratch_bytes.argtypes = [i64]
     L.mpreid_rr_krecip.restype = i32
     L.mpreid_rr_krecip.argtypes = [vp, i64, i64, vp, vp, i32, i32, i64, i64, vp, vp, vp, vp, vp]
+    L.mpreid_rr_sparse_workspace_bytes.restype = sz
+    L.mpreid_rr_sparse_workspace_bytes.argtypes = [i64, i32, i64, i32]
+    L.mpreid_rr_neighbours_sparse.restype = i32
+    L.mpreid_rr_neighbours_sparse.argtypes = [vp, vp, i64, i32, i64, i64, i32, vp, vp, vp, vp, sz, vp]
+    L.mpreid_rr_krecip_sparse.restype = i32
+    L.mpreid_rr_krecip_sparse.argtypes = [vp, vp, i64, i32, vp, vp, vp, i32, i32, i64, i64, vp, vp, vp, vp, vp]
     L.mpreid_rr_pack_rows.restype = i32
     L.mpreid_rr_pack_rows.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp]
     L.mpreid_rr_qe_count.restype = i32

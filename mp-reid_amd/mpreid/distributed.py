@@ -95,6 +95,10 @@ def gather_column_blocks_to_host(block: torch.Tensor, dst: int = 0):
 #   phase 4  queries sharded nq/P: distance rows of the local queries, inverted index of V_qe, Jaccard + blend
 #            -> each rank owns final_dist[q_lo:q_hi, nq:]; row blocks are concatenated on the host
 #
+# Phases 1-2 have a SPARSE form (default when N >= 2048 and max(k1+1, k2) <= 64): no [N/P][N] distance block per rank --
+# fp16 candidate GEMM of the local rows against all columns, certified exact refinement, on-the-fly distances in the
+# expansion (csrc/rerank.hip); a rank whose rows cannot be certified uses the dense form by itself.
+#
 # Every row is produced by the same instruction sequence as in the single-GPU call and no floating-point
 # reduction crosses ranks, so the result is bit-identical for any number of ranks
 # (tests/test_gpu_rerank.py::test_sharded_rerank_is_rank_count_independent).
@@ -107,8 +111,10 @@ def _rr_ptr(t):
 class _RerankShard:
     """state of one (real or virtual) rank"""
 
-    def __init__(self, feat_all, norms_all, nq, k1, k2, lam, rank, world):
+    def __init__(self, feat_all, norms_all, nq, k1, k2, lam, rank, world, algo=0):
         from . import _lib
+        self.algo = algo          # _lib.RERANK_AUTO / RERANK_DENSE / RERANK_SPARSE for phases 1-2 of this rank
+        self.sparse = False
         self.L = _lib.load()
         self.lib = _lib
         self.feat, self.norms = feat_all, norms_all
@@ -125,9 +131,28 @@ class _RerankShard:
 
     def phase1(self):
         t, dev = torch, self.dev
-        self.D = t.empty((max(self.rows, 1), self.ld), dtype=t.float32, device=dev)
         self.rowmax = t.empty(max(self.rows, 1), dtype=t.float32, device=dev)
         rank_local = t.empty((self.rows, self.KR), dtype=t.int32, device=dev)
+        lib = self.lib
+        eligible = self.N >= 2048 and self.KR <= 64 and self.rows > 0
+        if self.algo == lib.RERANK_SPARSE and not eligible:
+            raise RuntimeError("the sparse phases need N >= 2048 and max(k1+1, k2) <= 64")
+        if eligible and self.algo != lib.RERANK_DENSE:
+            # sparse phase 1: no [rows][N] distance block; a rank whose rows cannot be certified falls back to the
+            # dense phases by itself (same bits either way)
+            self.rankd = t.empty((self.rows, self.KR), dtype=t.float32, device=dev)
+            wsb = self.L.mpreid_rr_sparse_workspace_bytes(self.N, self.d, self.rows, self.KR)
+            ws = t.empty(wsb, dtype=t.uint8, device=dev)
+            rc = self.L.mpreid_rr_neighbours_sparse(_rr_ptr(self.feat), _rr_ptr(self.norms), self.N, self.d, self.r_lo,
+                                                    self.rows, self.KR, _rr_ptr(rank_local), _rr_ptr(self.rowmax),
+                                                    _rr_ptr(self.rankd), _rr_ptr(ws), ws.numel(), lib.stream_ptr())
+            del ws
+            if rc == 0:
+                self.sparse = True
+                return rank_local
+            if rc != lib.ERR_RETRY_DENSE or self.algo == lib.RERANK_SPARSE:
+                lib.check(rc, "mpreid_rr_neighbours_sparse")
+        self.D = t.empty((max(self.rows, 1), self.ld), dtype=t.float32, device=dev)
         if self.rows:
             self.lib.check(self.L.mpreid_rr_dist_rows(_rr_ptr(self.feat), _rr_ptr(self.norms), self.N, self.d, self.r_lo,
                                                       self.rows, _rr_ptr(self.D), self.ld, _rr_ptr(self.rowmax),
@@ -141,7 +166,14 @@ class _RerankShard:
         self.vcnt = t.zeros(self.rows, dtype=t.int32, device=dev)
         self.vidx = t.empty((max(self.rows, 1), self.vcap), dtype=t.int32, device=dev)
         self.vval = t.empty((max(self.rows, 1), self.vcap), dtype=t.int16, device=dev)
-        if self.rows:
+        if self.rows and self.sparse:
+            scratch = t.empty(self.L.mpreid_rr_krecip_scratch_bytes(self.N), dtype=t.uint8, device=dev)
+            self.lib.check(self.L.mpreid_rr_krecip_sparse(_rr_ptr(self.feat), _rr_ptr(self.norms), self.N, self.d,
+                                                          _rr_ptr(self.rowmax), _rr_ptr(rank_all), _rr_ptr(self.rankd),
+                                                          self.k1, self.KR, self.r_lo, self.rows, _rr_ptr(self.vcnt),
+                                                          _rr_ptr(self.vidx), _rr_ptr(self.vval), _rr_ptr(scratch),
+                                                          self.lib.stream_ptr()), "mpreid_rr_krecip_sparse")
+        elif self.rows:
             scratch = t.empty(self.L.mpreid_rr_krecip_scratch_bytes(self.N), dtype=t.uint8, device=dev)
             self.lib.check(self.L.mpreid_rr_krecip(_rr_ptr(self.D), self.ld, self.N, _rr_ptr(self.rowmax),
                                                    _rr_ptr(rank_all), self.k1, self.KR, self.r_lo, self.rows,
@@ -192,7 +224,7 @@ class _RerankShard:
         out = t.empty((qrows, ng), dtype=t.float32, device=dev)
         if qrows == 0:
             return out
-        del self.D  # the row block of phase 1 is no longer needed
+        self.D = None  # the row block of phase 1 (dense phases) is no longer needed
         dq = t.empty((qrows, self.ld), dtype=t.float32, device=dev)
         rmq = t.empty(qrows, dtype=t.float32, device=dev)
         self.lib.check(self.L.mpreid_rr_dist_rows(_rr_ptr(self.feat), _rr_ptr(self.norms), self.N, self.d, self.q_lo, qrows,
@@ -218,7 +250,7 @@ def _rr_prepare(qf, gf):
     return feat, ops.sqnorm(feat)
 
 
-def re_ranking_sharded(qf_all, gf_all, k1, k2, lambda_value):
+def re_ranking_sharded(qf_all, gf_all, k1, k2, lambda_value, algo=0):
     """Re-ranking with the rows of the N x N problem sharded over the ranks of the default process group
     (every rank passes the full, all-gathered query and gallery features).  Returns this rank's
     final_dist[q_lo:q_hi, nq:] block on the GPU; use gather_row_blocks_to_host() for the full matrix."""
@@ -228,10 +260,10 @@ def re_ranking_sharded(qf_all, gf_all, k1, k2, lambda_value):
         # one GPU: the single call (symmetric distance GEMM: half the tiles) gives the same bits as the phases below
         # (tests/test_gpu_rerank.py::test_sharded_rerank_is_rank_count_independent)
         from . import ops
-        return ops.re_ranking(qf_all, gf_all, k1, k2, lambda_value)[0]
+        return ops.re_ranking(qf_all, gf_all, k1, k2, lambda_value, algo=algo)[0]
     feat, norms = _rr_prepare(qf_all, gf_all)
     N, nq = feat.shape[0], qf_all.shape[0]
-    sh = _RerankShard(feat, norms, nq, int(k1), int(k2), float(lambda_value), rank, world)
+    sh = _RerankShard(feat, norms, nq, int(k1), int(k2), float(lambda_value), rank, world, algo)
 
     def gmax(v):
         if world == 1:
@@ -251,12 +283,12 @@ def re_ranking_sharded(qf_all, gf_all, k1, k2, lambda_value):
     return sh.phase4(vc, vi, vv)
 
 
-def re_ranking_virtual(qf_all, gf_all, k1, k2, lambda_value, world):
+def re_ranking_virtual(qf_all, gf_all, k1, k2, lambda_value, world, algo=0):
     """The same phases for `world` VIRTUAL ranks executed one after the other on the current GPU (no process
     group): the all-gathers become concatenations.  Used to test rank-count independence on one GPU."""
     feat, norms = _rr_prepare(qf_all, gf_all)
     nq = qf_all.shape[0]
-    shards = [_RerankShard(feat, norms, nq, int(k1), int(k2), float(lambda_value), r, world) for r in range(world)]
+    shards = [_RerankShard(feat, norms, nq, int(k1), int(k2), float(lambda_value), r, world, algo) for r in range(world)]
     rank_all = torch.cat([s.phase1() for s in shards], dim=0)
     w = max(max(s.phase2(rank_all) for s in shards), 1)
     packs = [s.pack_v(w) for s in shards]

@@ -51,7 +51,8 @@ WORKER = textwrap.dedent("""
     dist.barrier(); dist.destroy_process_group()
 """)
 
-CASES = [(1500, 300, 256, 50, 15, 0.3), (901, 7, 64, 20, 6, 0.3), (700, 101, 128, 10, 1, 0.5)]
+CASES = [(1500, 300, 256, 50, 15, 0.3), (901, 7, 64, 20, 6, 0.3), (700, 101, 128, 10, 1, 0.5),
+         (2600, 500, 128, 50, 15, 0.3)]   # the last one is large enough for the SPARSE sharded phases
 
 
 def _spawn(script, args, world, tmp_path, extra_env=None):

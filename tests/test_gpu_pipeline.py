@@ -140,6 +140,35 @@ def test_sie_camera_embedding():
     assert np.abs(got[1] - got[3]).max() > 0  # same camera, different images
 
 
+@pytest.mark.parametrize("cam,view", [(False, True), (True, True)])
+def test_sie_view_and_camera_view_index(cam, view):
+    """MODEL.SIE_VIEW alone (index = view) and SIE_CAMERA + SIE_VIEW (index = cam * view_num + view; the table has
+    camera_num * view_num rows): model/make_model.py:65-77, 89-96"""
+    from config import cfg_base
+    from mpreid import synth
+    from model.make_model import make_model
+    cfg = cfg_base.clone()
+    cfg.defrost()
+    cfg.merge_from_list(["MODEL.SIE_CAMERA", cam, "MODEL.SIE_VIEW", view, "MODEL.SIE_COE", 1.5])
+    cfg.freeze()
+    camera_num, view_num = 4, 3
+    m = make_model(cfg, num_class=5, camera_num=camera_num, view_num=view_num)
+    assert m.cv_embed.shape[0] == (camera_num * view_num if cam else view_num)
+    imgs = torch.from_numpy(synth.synthetic_images(5, 256, 128, seed=4))
+    cams, views = torch.tensor([0, 3, 1, 3, 2]), torch.tensor([2, 0, 1, 2, 2])
+    got = m(imgs.cuda(), cam_label=cams.cuda() if cam else None, view_label=views.cuda()).cpu().numpy()
+    idx = cams * view_num + views if cam else views
+    cv = (1.5 * m.cv_embed[idx]).detach().cpu().numpy()
+    sd = {k[len("image_encoder."):]: v.cpu().numpy() for k, v in m.state_dict().items()
+          if k.startswith("image_encoder.")}
+    want = orc.vit_features(sd, m.vit_cfg, imgs.numpy(), cv_emb=cv)
+    rel = np.linalg.norm(got - want) / np.linalg.norm(want)
+    assert rel < 4e-3, rel
+    # a different view index gives a different feature for the same image
+    other = m(imgs.cuda(), cam_label=cams.cuda() if cam else None, view_label=((views + 1) % view_num).cuda()).cpu().numpy()
+    assert np.abs(other - got).max() > 1e-4
+
+
 def _raw_cfg(nq, ng, batch, **extra):
     from config import cfg
     c = cfg.clone()

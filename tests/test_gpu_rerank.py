@@ -248,6 +248,22 @@ def test_sharded_rerank_is_rank_count_independent(ops, n, nq, d, k1, k2, world):
         assert torch.equal(real, single)
 
 
+@pytest.mark.parametrize("n,nq,d,k1,k2,world", [(4100, 800, 256, 50, 15, 3), (2500, 300, 100, 20, 6, 8), (6000, 1200, 768, 50, 15, 2),
+                                                 (3000, 2999, 64, 30, 40, 5)])
+def test_sharded_sparse_phases_equal_single_call(ops, n, nq, d, k1, k2, world):
+    """the row-sharded phases in their SPARSE form (mpreid_rr_neighbours_sparse / mpreid_rr_krecip_sparse: no
+    [rows][N] distance block per rank), executed for `world` virtual ranks == the dense sharded phases == the single
+    call == the oracle, bit for bit"""
+    from mpreid import distributed as D, synth
+    f, _ = synth.clustered_features(n, d, 2.5, seed=n + world, per_id=20)
+    q, g = torch.from_numpy(f[:nq]).cuda(), torch.from_numpy(f[nq:]).cuda()
+    want = orc.re_ranking(f[:nq], f[nq:], k1, k2, 0.3)
+    sparse = D.re_ranking_virtual(q, g, k1, k2, 0.3, world, algo=ops.RERANK_SPARSE)
+    assert np.array_equal(sparse.cpu().numpy(), want)
+    dense = D.re_ranking_virtual(q, g, k1, k2, 0.3, world, algo=ops.RERANK_DENSE)
+    assert torch.equal(sparse, dense)
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_rerank_small_n_clamped_like_reference(ops, golden, tag):
     """N < k1+1 / N < k2 (the reference's slices clamp): HIP == oracle bit for bit, both within tolerance of the
