@@ -185,11 +185,14 @@ int mpreid_rr_qe_fill(int64_t n, const int32_t *rank_all_dev, int kr, int k2, in
 /* phase 4: inverted index of the global V_qe + Jaccard / blend for query rows [q_lo, q_lo+qrows);
  * out [qrows][ldo] = final_dist[q_lo : q_lo+qrows, nq:].  Scratch: ccnt [N+1] u32, cptr [N+1] i64,
  * crow / cval [sum of qcnt_all]. */
+/* chist_dev: NULL (atomic build of the inverted index) or mpreid_rr_jaccard_hist_bytes(n) bytes: block histograms of the
+ * atomics-free build, which also lets the Jaccard kernel gather exact column sub-ranges per row chunk */
+size_t mpreid_rr_jaccard_hist_bytes(int64_t n);
 int mpreid_rr_jaccard(int64_t n, int64_t nq, int64_t q_lo, int64_t qrows, const float *d_q_dev, int64_t ld,
                       const float *rowmax_q_dev, const int32_t *qcnt_all_dev, const int32_t *qidx_all_dev,
                       const uint16_t *qval_all_dev, int qstride, double lambda_value, uint32_t *ccnt_dev,
-                      long long *cptr_dev, int32_t *crow_dev, uint16_t *cval_dev, float *out_dev, int64_t ldo,
-                      mpreid_stream_t stream);
+                      long long *cptr_dev, int32_t *crow_dev, uint16_t *cval_dev, uint32_t *chist_dev, float *out_dev,
+                      int64_t ldo, mpreid_stream_t stream);
 
 /* ---- CLIP ViT-B/16 image encoder, model/clip/model.py:415-479 + model/make_model.py:81-115 -- */
 typedef struct {

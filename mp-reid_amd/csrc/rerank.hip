@@ -1693,6 +1693,67 @@ __global__ __launch_bounds__(1024) void max_i32_kernel(const int *__restrict__ x
     }
 }
 
+// inverted index of the ELL rows (fcnt, fidx, fval; row stride qcap) -> cptr / crow / cval.  With a block-histogram
+// buffer (chist, [CSC_B][N] u32) the atomics-free counting sort is used (and *blocked = true: the Jaccard stage may
+// then gather exact sub-ranges per row chunk); otherwise the round-1 atomic build.
+static int launch_csc(int64_t N, const int *fcnt, const int *fidx, const uint16_t *fval, int qcap, unsigned *ccnt,
+                      unsigned *chist, long long *cptr, int *crow, uint16_t *cval, hipStream_t stream, bool *blocked) {
+    static const bool csc_atomic = getenv("MPREID_CSC_ATOMIC") != nullptr;   // A/B switch: the round-1 atomic build
+    const bool blocked_csc = chist && !csc_atomic && (uint64_t)N * (uint64_t)qcap < (1ull << 32);
+    *blocked = blocked_csc;
+    if (blocked_csc) {
+        const int rpb = (int)((N + CSC_B - 1) / CSC_B);
+        const int nranges = (int)((N + CSC_CR - 1) / CSC_CR);
+        const size_t lds = (size_t)std::min<int64_t>(N, CSC_CR) * 4;
+        int rc = set_dyn_lds(csc2_hist_kernel, lds);
+        if (rc) return rc;
+        rc = set_dyn_lds(csc2_fill_kernel, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(csc2_hist_kernel, dim3(CSC_B, nranges), dim3(1024), lds, stream, N, fcnt, fidx, qcap, rpb, chist);
+        hipLaunchKernelGGL(csc2_colscan_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, N, chist, ccnt);
+        hipLaunchKernelGGL(csc_scan_kernel, dim3(1), dim3(1024), 0, stream, N, ccnt, cptr);
+        hipLaunchKernelGGL(csc2_fill_kernel, dim3(CSC_B, nranges), dim3(1024), lds, stream, N, fcnt, fidx, fval, qcap, rpb,
+                           chist, cptr, crow, cval);
+    } else {
+        HIP_TRY(hipMemsetAsync(ccnt, 0, (size_t)(N + 1) * 4, stream));
+        hipLaunchKernelGGL(csc_count_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, N, fcnt, fidx, qcap, ccnt);
+        hipLaunchKernelGGL(csc_scan_kernel, dim3(1), dim3(1024), 0, stream, N, ccnt, cptr);
+        hipLaunchKernelGGL(csc_fill_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, N, fcnt, fidx, fval, qcap,
+                           cptr, ccnt, crow, cval);
+    }
+    LAUNCH_CHECK();
+    return MPREID_OK;
+}
+
+// Jaccard + blend for the query rows [q0, q0 + qrows): MT / rowmax / out indexed by the local row
+static int launch_jaccard(int64_t N, int64_t nq, int q0, int64_t qrows, const float *MT, int64_t ld, const float *rowmax,
+                          const int *fcnt, const int *fidx, const uint16_t *fval, int qcap, const long long *cptr,
+                          const int *crow, const uint16_t *cval, const unsigned *chist, bool blocked, double lambda_value,
+                          float *out, int64_t ldo, unsigned long long *pair_counter, hipStream_t stream) {
+    const uint16_t oml = f64_to_f16_host(1.0 - lambda_value);
+    const float lam32 = (float)lambda_value;
+    int rch = (int)std::min<int64_t>(N, 49152);
+    rch = (int)align_up((size_t)rch, 8);
+    const unsigned *Hp = nullptr;
+    int rpb = 0, bpc = 0, nchunks = 1;
+    if (blocked) {
+        // chunks of whole row blocks of the inverted index, at most ~24 K rows (48 KB of fp16 accumulators: two or
+        // three workgroups per CU beside the column tables)
+        rpb = (int)((N + CSC_B - 1) / CSC_B);
+        bpc = std::max(1, std::min(CSC_B, 24576 / rpb));
+        nchunks = (CSC_B + bpc - 1) / bpc;
+        rch = (int)align_up((size_t)std::min<int64_t>(N, (int64_t)bpc * rpb), 8);
+        Hp = chist;
+    }
+    const size_t lds = align_up((size_t)rch * 2, 16) + (size_t)qcap * (8 + 4 + 2) + 16;
+    int rc = set_dyn_lds(jaccard_kernel, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(jaccard_kernel, dim3((unsigned)qrows, (unsigned)nchunks), dim3(JT), lds, stream, N, nq, MT, ld, rowmax,
+                       fcnt, fidx, fval, qcap, cptr, crow, cval, rch, oml, lam32, out, ldo, pair_counter, q0, Hp, rpb, bpc);
+    LAUNCH_CHECK();
+    return MPREID_OK;
+}
+
 // Everything after the V rows (query expansion, inverted index, Jaccard + blend, statistics): shared by the dense and
 // the sparse algorithm.  MT = distance rows of (at least) the queries, row stride ld; rowmax indexed like MT's rows.
 // The ONE host round trip of the call is in here: 16 bytes (largest union size of the query expansion, which sizes
@@ -1769,56 +1830,18 @@ static int rerank_tail(const TailArgs &a, hipStream_t stream, StageTimer &tm, mp
     }
     tm.mark(); // +1
     // inverted index
-    static const bool csc_atomic = getenv("MPREID_CSC_ATOMIC") != nullptr;   // A/B switch: the round-1 atomic build
-    const bool blocked_csc = a.chist && !csc_atomic && (uint64_t)N * (uint64_t)qcap < (1ull << 32);
-    if (blocked_csc) {
-        const int rpb = (int)((N + CSC_B - 1) / CSC_B);
-        const int nranges = (int)((N + CSC_CR - 1) / CSC_CR);
-        const size_t lds = (size_t)std::min<int64_t>(N, CSC_CR) * 4;
-        int rc = set_dyn_lds(csc2_hist_kernel, lds);
+    bool blocked_csc = false;
+    {
+        int rc = launch_csc(N, fcnt, fidx, fval, qcap, a.ccnt, a.chist, a.cptr, a.crow, a.cval, stream, &blocked_csc);
         if (rc) return rc;
-        rc = set_dyn_lds(csc2_fill_kernel, lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL(csc2_hist_kernel, dim3(CSC_B, nranges), dim3(1024), lds, stream, N, fcnt, fidx, qcap, rpb, a.chist);
-        hipLaunchKernelGGL(csc2_colscan_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, N, a.chist, a.ccnt);
-        hipLaunchKernelGGL(csc_scan_kernel, dim3(1), dim3(1024), 0, stream, N, a.ccnt, a.cptr);
-        hipLaunchKernelGGL(csc2_fill_kernel, dim3(CSC_B, nranges), dim3(1024), lds, stream, N, fcnt, fidx, fval, qcap, rpb,
-                           a.chist, a.cptr, a.crow, a.cval);
-    } else {
-        HIP_TRY(hipMemsetAsync(a.ccnt, 0, (size_t)(N + 1) * 4, stream));
-        hipLaunchKernelGGL(csc_count_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, N, fcnt, fidx, qcap,
-                           a.ccnt);
-        hipLaunchKernelGGL(csc_scan_kernel, dim3(1), dim3(1024), 0, stream, N, a.ccnt, a.cptr);
-        hipLaunchKernelGGL(csc_fill_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, N, fcnt, fidx, fval, qcap,
-                           a.cptr, a.ccnt, a.crow, a.cval);
     }
-    LAUNCH_CHECK();
     tm.mark(); // +2
     // (8)-(11) Jaccard + blend
     if (a.join) HIP_TRY(hipStreamWaitEvent(stream, a.join, 0));
     {
-        const uint16_t oml = f64_to_f16_host(1.0 - a.lambda_value);
-        const float lam32 = (float)a.lambda_value;
-        int rch = (int)std::min<int64_t>(N, 49152);
-        rch = (int)align_up((size_t)rch, 8);
-        const unsigned *Hp = nullptr;
-        int rpb = 0, bpc = 0, nchunks = 1;
-        if (blocked_csc) {
-            // chunks of whole row blocks of the inverted index, at most ~24 K rows (48 KB of fp16 accumulators: two or
-            // three workgroups per CU beside the column tables)
-            rpb = (int)((N + CSC_B - 1) / CSC_B);
-            bpc = std::max(1, std::min(CSC_B, 24576 / rpb));
-            nchunks = (CSC_B + bpc - 1) / bpc;
-            rch = (int)align_up((size_t)std::min<int64_t>(N, (int64_t)bpc * rpb), 8);
-            Hp = a.chist;
-        }
-        const size_t lds = align_up((size_t)rch * 2, 16) + (size_t)qcap * (8 + 4 + 2) + 16;
-        int rc = set_dyn_lds(jaccard_kernel, lds);
+        int rc = launch_jaccard(N, a.nq, 0, a.nq, a.MT, a.ld, a.rowmax, fcnt, fidx, fval, qcap, a.cptr, a.crow, a.cval, a.chist,
+                                blocked_csc, a.lambda_value, a.out, a.ldo, a.counters, stream);
         if (rc) return rc;
-        hipLaunchKernelGGL(jaccard_kernel, dim3((unsigned)a.nq, (unsigned)nchunks), dim3(JT), lds, stream, N, a.nq, a.MT, a.ld,
-                           a.rowmax, fcnt, fidx, fval, qcap, a.cptr, a.crow, a.cval, rch, oml, lam32, a.out, a.ldo,
-                           a.counters, 0, Hp, rpb, bpc);
-        LAUNCH_CHECK();
     }
     tm.mark(); // +3
     unsigned long long cnt[6] = {0, 0, 0, 0, 0, 0};
@@ -2594,31 +2617,19 @@ extern "C" int mpreid_rr_qe_fill(int64_t n, const int32_t *rank_all, int kr, int
 // phase 4: inverted index of the GLOBAL V_qe (row stride qstride) + Jaccard / blend for the query rows
 // [q_lo, q_lo + qrows): d_q [qrows][ld] and rowmax_q from mpreid_rr_dist_rows on that range.
 // Scratch: ccnt [N+1] u32, cptr [N+1] i64, crow [nnz] i32, cval [nnz] u16 (nnz = sum of qcnt_all).
+extern "C" size_t mpreid_rr_jaccard_hist_bytes(int64_t n) { return (size_t)n * CSC_B * 4; }
+
 extern "C" int mpreid_rr_jaccard(int64_t n, int64_t nq, int64_t q_lo, int64_t qrows, const float *d_q, int64_t ld,
                                  const float *rowmax_q, const int32_t *qcnt_all, const int32_t *qidx_all,
                                  const uint16_t *qval_all, int qstride, double lambda_value, uint32_t *ccnt,
-                                 long long *cptr, int32_t *crow, uint16_t *cval, float *out, int64_t ldo,
+                                 long long *cptr, int32_t *crow, uint16_t *cval, uint32_t *chist, float *out, int64_t ldo,
                                  mpreid_stream_t stream_) {
     ARG_CHECK(d_q && rowmax_q && qcnt_all && qidx_all && qval_all && ccnt && cptr && crow && cval && out && qrows > 0 &&
               q_lo >= 0 && q_lo + qrows <= nq && ldo >= n - nq);
     hipStream_t stream = (hipStream_t)stream_;
-    HIP_TRY(hipMemsetAsync(ccnt, 0, (size_t)(n + 1) * 4, stream));
-    hipLaunchKernelGGL(csc_count_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, n, qcnt_all, qidx_all,
-                       qstride, ccnt);
-    hipLaunchKernelGGL(csc_scan_kernel, dim3(1), dim3(1024), 0, stream, n, ccnt, cptr);
-    hipLaunchKernelGGL(csc_fill_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, n, qcnt_all, qidx_all,
-                       qval_all, qstride, cptr, ccnt, crow, cval);
-    LAUNCH_CHECK();
-    const uint16_t oml = f64_to_f16_host(1.0 - lambda_value);
-    const float lam32 = (float)lambda_value;
-    int rch = (int)std::min<int64_t>(n, 49152);
-    rch = (int)align_up((size_t)rch, 8);
-    const size_t lds = align_up((size_t)rch * 2, 16) + (size_t)qstride * (8 + 4 + 2) + 16;
-    int rc = set_dyn_lds(jaccard_kernel, lds);
+    bool blocked = false;
+    int rc = launch_csc(n, qcnt_all, qidx_all, qval_all, qstride, ccnt, chist, cptr, crow, cval, stream, &blocked);
     if (rc) return rc;
-    hipLaunchKernelGGL(jaccard_kernel, dim3((unsigned)qrows), dim3(JT), lds, stream, n, nq, d_q, ld, rowmax_q, qcnt_all,
-                       qidx_all, qval_all, qstride, cptr, crow, cval, rch, oml, lam32, out, ldo,
-                       (unsigned long long *)nullptr, (int)q_lo, (const unsigned *)nullptr, 0, 0);
-    LAUNCH_CHECK();
-    return MPREID_OK;
+    return launch_jaccard(n, nq, (int)q_lo, qrows, d_q, ld, rowmax_q, qcnt_all, qidx_all, qval_all, qstride, cptr, crow, cval,
+                          chist, blocked, lambda_value, out, ldo, nullptr, stream);
 }

@@ -235,11 +235,12 @@ class _RerankShard:
         cptr = t.empty(self.N + 1, dtype=t.int64, device=dev)
         crow = t.empty(max(nnz, 1), dtype=t.int32, device=dev)
         cval = t.empty(max(nnz, 1), dtype=t.int16, device=dev)
+        chist = t.empty(self.L.mpreid_rr_jaccard_hist_bytes(self.N), dtype=t.uint8, device=dev)
         self.lib.check(self.L.mpreid_rr_jaccard(self.N, self.nq, self.q_lo, qrows, _rr_ptr(dq), self.ld, _rr_ptr(rmq),
                                                 _rr_ptr(qcnt_all), _rr_ptr(qidx_all), _rr_ptr(qval_all),
                                                 qidx_all.shape[1], float(self.lam), _rr_ptr(ccnt), _rr_ptr(cptr),
-                                                _rr_ptr(crow), _rr_ptr(cval), _rr_ptr(out), ng, self.lib.stream_ptr()),
-                       "mpreid_rr_jaccard")
+                                                _rr_ptr(crow), _rr_ptr(cval), _rr_ptr(chist), _rr_ptr(out), ng,
+                                                self.lib.stream_ptr()), "mpreid_rr_jaccard")
         return out
 
 
@@ -283,21 +284,41 @@ def re_ranking_sharded(qf_all, gf_all, k1, k2, lambda_value, algo=0):
     return sh.phase4(vc, vi, vv)
 
 
-def re_ranking_virtual(qf_all, gf_all, k1, k2, lambda_value, world, algo=0):
+def re_ranking_virtual(qf_all, gf_all, k1, k2, lambda_value, world, algo=0, timings=None):
     """The same phases for `world` VIRTUAL ranks executed one after the other on the current GPU (no process
-    group): the all-gathers become concatenations.  Used to test rank-count independence on one GPU."""
+    group): the all-gathers become concatenations.  Used to test rank-count independence on one GPU.
+    timings: optional dict that receives, per phase, the list of per-rank wall times in ms (synchronised) and the
+    bytes each all-gather would move -- the compute side of a `world`-GPU run, measured on one GPU."""
+    import time
+
+    def timed(name, fn):
+        if timings is None:
+            return fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        timings.setdefault(name, []).append((time.perf_counter() - t0) * 1e3)
+        return out
+
     feat, norms = _rr_prepare(qf_all, gf_all)
     nq = qf_all.shape[0]
     shards = [_RerankShard(feat, norms, nq, int(k1), int(k2), float(lambda_value), r, world, algo) for r in range(world)]
-    rank_all = torch.cat([s.phase1() for s in shards], dim=0)
-    w = max(max(s.phase2(rank_all) for s in shards), 1)
+    rank_all = torch.cat([timed("phase1_neighbours", s.phase1) for s in shards], dim=0)
+    w = max(max(timed("phase2_krecip", lambda s=s: s.phase2(rank_all)) for s in shards), 1)
     packs = [s.pack_v(w) for s in shards]
     vc, vi, vv = (torch.cat([p[i] for p in packs], dim=0) for i in range(3))
+    gathers = {"rank_table": rank_all.numel() * 4, "V": vc.numel() * 4 + vi.numel() * 4 + vv.numel() * 2}
     if k2 != 1:
-        qcap = max(max(s.phase3_count(vc, vi, vv) for s in shards), 1)
-        fills = [s.phase3_fill(qcap) for s in shards]
+        qcap = max(max(timed("phase3_qe_count", lambda s=s: s.phase3_count(vc, vi, vv)) for s in shards), 1)
+        fills = [timed("phase3_qe_fill", lambda s=s: s.phase3_fill(qcap)) for s in shards]
         vc, vi, vv = (torch.cat([f[i] for f in fills], dim=0) for i in range(3))
-    return torch.cat([s.phase4(vc, vi, vv) for s in shards], dim=0)
+        gathers["V_qe"] = vc.numel() * 4 + vi.numel() * 4 + vv.numel() * 2
+    out = torch.cat([timed("phase4_jaccard", lambda s=s: s.phase4(vc, vi, vv)) for s in shards], dim=0)
+    if timings is not None:
+        timings["all_gather_bytes"] = gathers
+        timings["sparse_ranks"] = sum(1 for s in shards if s.sparse)
+    return out
 
 
 def gather_row_blocks_to_host(block: torch.Tensor, dst: int = 0):
