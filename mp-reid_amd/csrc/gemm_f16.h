@@ -66,6 +66,7 @@ struct GemmArgs {
     int stagger;          // persistent kernel: workgroup b starts (b mod 256) / 256 * stagger ticks of the 100 MHz
                           // real-time counter late, so that the CUs reach their store-heavy epilogues at different
                           // times instead of all at once (0 = off)
+    int stagger_mode;     // 1: eight phases by the CU's slot inside its XCD instead ((b >> 3) mod 8) / 8
 };
 
 int launch_gemm_f16(const GemmArgs &a, int epi, hipStream_t stream);

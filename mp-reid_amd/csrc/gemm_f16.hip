@@ -512,7 +512,8 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
     if (tile < 0) return;
     if (g.stagger > 0) {
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        const unsigned long long wait = (unsigned long long)g.stagger * (blockIdx.x & 255u) / 256u;
+        const unsigned long long wait = g.stagger_mode ? (unsigned long long)g.stagger * ((blockIdx.x >> 3) & 7u) / 8u
+                                                       : (unsigned long long)g.stagger * (blockIdx.x & 255u) / 256u;
         while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
     }
     set_tile(tile);
@@ -1069,7 +1070,8 @@ extern "C" int mpreid_profile_query(mpreid_profile_entry *out, int cap) {
 }
 
 template <int EPI>
-static int launch_one(const GemmArgs &a, hipStream_t stream) {
+static int launch_one(const GemmArgs &a_in, hipStream_t stream) {
+    const GemmArgs &a = a_in;
     static PerDeviceOnce attr_once;
     {
         const int rc = attr_once.run([]() -> int {
@@ -1120,6 +1122,12 @@ static int launch_one(const GemmArgs &a, hipStream_t stream) {
                 if (cus_of[slot] == 0 || slot != dev)
                     HIP_TRY(hipDeviceGetAttribute(&cus_of[slot], hipDeviceAttributeMultiprocessorCount, dev));
                 big_cus = cus_of[slot];
+            }
+            static const int stag_all = getenv("MPREID_GEMM_STAGGER_ALL") ? atoi(getenv("MPREID_GEMM_STAGGER_ALL")) : 0;
+            GemmArgs a = a_in;
+            if (stag_all > 0) {
+                a.stagger = stag_all;
+                a.stagger_mode = 1;
             }
             const unsigned total_tiles = (unsigned)tiles_m * (unsigned)tiles_n;
             const dim3 grid(total_tiles < (unsigned)big_cus ? total_tiles : (unsigned)big_cus);

@@ -52,6 +52,35 @@ __device__ __forceinline__ uint16_t h_add_native(uint16_t a, uint16_t b) {
 // ---------------------------------------------------------------------------------------------
 // workspace layout
 // ---------------------------------------------------------------------------------------------
+// How the Jaccard stage cuts the row space of the blocked inverted index (256 row blocks of rows_per_block rows): a
+// workgroup accumulates one chunk of blocks_per_chunk blocks (rch rows of fp16 accumulators in LDS).  A function of N
+// only, so that the workspace layouts can reserve the chunk-boundary table ([N][nchunks + 1] u32) the build writes.
+struct JaccardPlan {
+    int rpb, bpc, nchunks, rch;
+    bool wave_form;   // one 64-thread workgroup per (query, chunk) instead of 512 threads
+};
+static JaccardPlan jaccard_plan(int64_t N) {
+    constexpr int B = 256;   // = CSC_B
+    static const int jwave = getenv("MPREID_JACCARD_WAVE") ? atoi(getenv("MPREID_JACCARD_WAVE")) : -1;
+    static const int jrows = getenv("MPREID_JACCARD_WAVE_ROWS") ? atoi(getenv("MPREID_JACCARD_WAVE_ROWS")) : 8192;
+    JaccardPlan p;
+    p.rpb = (int)((N + B - 1) / B);
+    // 512-thread form: at most ~24 K rows per chunk (48 KB of accumulators: two workgroups per CU beside the tables)
+    p.bpc = std::max(1, std::min(B, 24576 / p.rpb));
+    p.nchunks = (B + p.bpc - 1) / p.bpc;
+    // more than one chunk: ONE wave per (query, chunk of ~8 K rows) -- no barriers at all (the LDS operations of a wave
+    // execute in order, which is all the fp16 accumulation order needs) and six workgroups per CU
+    p.wave_form = jwave < 0 ? p.nchunks > 1 : jwave > 0;
+    if (p.wave_form) {
+        p.bpc = std::max(1, std::min(B, jrows / p.rpb));
+        p.nchunks = (B + p.bpc - 1) / p.bpc;
+    }
+    p.rch = (int)align_up((size_t)std::min<int64_t>(N, (int64_t)p.bpc * p.rpb), 8);
+    return p;
+}
+// bytes of the block histograms [256][N] + the chunk-boundary table [N][nchunks + 1]
+static size_t csc_hist_bytes(int64_t N) { return ((size_t)N * 256 + (size_t)N * (size_t)(jaccard_plan(N).nchunks + 1)) * 4; }
+
 struct RerankLayout {
     int64_t N, ld;
     int K, KR, h, vcap;
@@ -94,7 +123,7 @@ static RerankLayout make_layout(int64_t nq, int64_t ng, int d, int k1, int k2, i
     L.qidx = take(N * (size_t)L.qcap_bound * 4);
     L.qval = take(N * (size_t)L.qcap_bound * 2);
     L.ccnt = take((N + 1) * 4);
-    L.chist = take(N * (size_t)256 * 4);   // CSC_B block histograms
+    L.chist = take(csc_hist_bytes((int64_t)N));   // CSC_B block histograms + chunk bounds
     L.cptr = take((N + 1) * 8);
     L.crow = take(N * (size_t)L.qcap_bound * 4);
     L.cval = take(N * (size_t)L.qcap_bound * 2);
@@ -1114,6 +1143,17 @@ __global__ __launch_bounds__(256) void csc2_colscan_kernel(int64_t N, unsigned *
     }
     ccnt[c] = run;
 }
+// chunk-boundary table of the Jaccard stage: HB[c][k] = absolute position (in crow / cval) of the first entry of column c
+// that lies in row chunk k (= row block k * bpc), HB[c][nchunks] = end of the column.  One 8-byte read per (query,
+// chunk, column) from a table of a few MB instead of four scattered reads of cptr and the [256][N] histograms.
+__global__ __launch_bounds__(256) void csc2_bounds_kernel(int64_t N, int nchunks, int bpc, const unsigned *__restrict__ H,
+                                                          const long long *__restrict__ cptr, unsigned *__restrict__ HB) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    const unsigned base = (unsigned)cptr[c];
+    for (int k = 0; k < nchunks; ++k) HB[c * (nchunks + 1) + k] = base + H[(int64_t)k * bpc * N + c];
+    HB[c * (nchunks + 1) + nchunks] = (unsigned)cptr[c + 1];
+}
 __global__ __launch_bounds__(1024) void csc2_fill_kernel(int64_t N, const int *__restrict__ qcnt, const int *__restrict__ qidx,
                                                          const uint16_t *__restrict__ qval, int qcap, int rows_per_block,
                                                          const unsigned *__restrict__ H, const long long *__restrict__ cptr,
@@ -1145,10 +1185,16 @@ __global__ __launch_bounds__(1024) void csc2_fill_kernel(int64_t N, const int *_
 // (utils/reranking.py:84-100).  One 256-thread workgroup per query; t[] lives in LDS as fp16 bits,
 // r-space processed in chunks of rch entries so that any N fits.
 // ---------------------------------------------------------------------------------------------
-// (tried for N > 49 152: 8 K-row chunks with ONE wave per (query, chunk) instead of 24 K rows and 512 threads --
-// 45.4 -> 41.3 ms at N = 100 000 but 19.9 -> 24.6 ms at the MSMT17 shape: not kept)
+// Two forms (jaccard_plan): 512 threads per (query, chunk of <= 24 K rows) with one barrier per column -- whole columns
+// when N <= 24 576 -- and ONE wave per (query, chunk of ~8 K rows) without barriers when the 512-thread form would need
+// several chunks (N = 100 000: 45.5 -> 33.8 ms, MSMT17 shape 21.8 -> 18.6 ms, with the counted waits, the register-held
+// column table and the branch-free accumulation below; the same one-wave split measured 41 / 25 ms before those).
 constexpr int JT = 512; // threads per query workgroup
-__global__ __launch_bounds__(JT) void jaccard_kernel(int64_t N, int64_t nq, const float *__restrict__ MT, int64_t ld,
+// NPF entries per thread and column are held in registers (columns up to NPF * JT entries; longer ones take the direct
+// path below), the gathers of PD columns are in flight.  <2, 4> suits whole columns (~600 entries: 43 KB in flight per CU
+// at three workgroups); at large N a workgroup sees ~130-entry sub-ranges and <1, 12> keeps as many bytes in flight.
+template <int JT_, int NPF, int PD>
+__global__ __launch_bounds__(JT_) void jaccard_kernel(int64_t N, int64_t nq, const float *__restrict__ MT, int64_t ld,
                                                       const float *__restrict__ rowmax,
                                                       const int *__restrict__ qcnt, const int *__restrict__ qidx,
                                                       const uint16_t *__restrict__ qval, int qcap,
@@ -1158,15 +1204,14 @@ __global__ __launch_bounds__(JT) void jaccard_kernel(int64_t N, int64_t nq, cons
                                                       float *__restrict__ out, int64_t ldo,
                                                       unsigned long long *__restrict__ pair_counter, int q0,
                                                       const unsigned *__restrict__ H, int rows_per_block,
-                                                      int blocks_per_chunk) {
-    // H != NULL (inverted index built by csc2_*: the entries of a column are grouped by row block, and
-    // H[b][c] = number of entries of column c in the row blocks below b): blockIdx.y selects a chunk of
-    // blocks_per_chunk row blocks = rch rows, and the workgroup gathers exactly the sub-range of every column that
-    // lies in it.  (Round 1 walked the r-space chunk by chunk inside one workgroup and re-read every column in
+                                                      int blocks_per_chunk, int dbg) {
+    // H != NULL (inverted index built by csc2_*: the entries of a column are grouped by row block; H = the chunk
+    // boundaries of every column): blockIdx.y selects a chunk of blocks_per_chunk row blocks = rch rows, and the
+    // workgroup gathers exactly the sub-range of every column that lies in it.  (Round 1 walked the r-space chunk by chunk inside one workgroup and re-read every column in
     // full for every chunk: 3x the gather traffic at N = 100 000, at one workgroup per CU.)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t *t = (uint16_t *)smem;                                   // [rch]
-    long long *cp0 = (long long *)(smem + align_up((size_t)rch * 2, 16)); // [cnt]
+    long long *cp0 = (long long *)(smem + align_up((size_t)rch * 2 + 16, 16)); // [cnt]  (t[rch] = dummy slot)
     int *clen = (int *)(cp0 + qcap);                                  // [cnt]
     uint16_t *vi = (uint16_t *)(clen + qcap);                         // [cnt]
     const int tid = threadIdx.x;
@@ -1176,12 +1221,16 @@ __global__ __launch_bounds__(JT) void jaccard_kernel(int64_t N, int64_t nq, cons
     unsigned long long pairs = 0;
     const int b_lo = H ? (int)blockIdx.y * blocks_per_chunk : 0;
     const int b_hi = b_lo + blocks_per_chunk;   // >= CSC_B for the last chunk
-    for (int a = tid; a < cnt; a += JT) {
+    const int nb1 = (int)gridDim.y + 1;
+    for (int a = tid; a < cnt; a += JT_) {
         const int c = qidx[ig * qcap + a];
-        long long p0 = cptr[c], p1 = cptr[c + 1];
-        if (H) {
-            if (b_hi < CSC_B) p1 = p0 + H[(int64_t)b_hi * N + c];
-            p0 += H[(int64_t)b_lo * N + c];
+        long long p0, p1;
+        if (H) {   // H = chunk-boundary table [N][nchunks + 1] (csc2_bounds_kernel)
+            p0 = H[(int64_t)c * nb1 + blockIdx.y];
+            p1 = H[(int64_t)c * nb1 + blockIdx.y + 1];
+        } else {
+            p0 = cptr[c];
+            p1 = cptr[c + 1];
         }
         cp0[a] = p0;
         clen[a] = (int)(p1 - p0);
@@ -1196,85 +1245,131 @@ __global__ __launch_bounds__(JT) void jaccard_kernel(int64_t N, int64_t nq, cons
     const float mx = rowmax[i];
     const float *row = MT + i * ld;
     const uint16_t H1 = 0x3c00u, H2 = 0x4000u;
+    const unsigned long long last = cnt > 0 ? (unsigned long long)(cptr[N] - 1) : 0ull;   // cnt > 0: the index is not empty
     const int64_t r_first = H ? (int64_t)b_lo * rows_per_block : 0;
     const int64_t r_end = (int64_t)b_hi * rows_per_block;
     const int64_t r_last = H ? (r_end < N ? r_end : N) : N;   // (rch, the LDS size, may be rounded up past it)
     for (int64_t r0 = r_first; r0 < r_last; r0 += rch) {
         const int64_t r1 = (r0 + rch < r_last) ? r0 + rch : r_last;
-        for (int r = tid; r < rch; r += JT) t[r] = 0;
+        for (int r = tid; r < rch; r += JT_) t[r] = 0;
         __syncthreads();
+        const int r0i = (int)r0;
+        const unsigned span = (unsigned)(r1 - r0);
         // ascending column; rows of one column are distinct, so the threads of a column never collide and
         // one barrier per column keeps the fp16 accumulation order of the reference.  The (row, value)
         // pairs of column a+1 are requested into registers before column a is applied, so the L2/HBM
         // latency of the gathers is paid once per pipeline fill instead of once per column.
-        constexpr int NPF = 2; // entries per thread held in registers (columns up to 1024 entries)
-        constexpr int PD = 4;  // columns of gathers in flight: the (row, value) pairs of columns a+1 .. a+PD are
-                               // requested before column a is applied (one column ahead left ~1.6 us per column
-                               // exposed: a barrier plus most of an L2 / HBM round trip)
+        // the (row, value) pairs of columns a+1 .. a+PD are requested before column a is applied (one column ahead
+        // left ~1.6 us per column exposed: a barrier plus most of an L2 / HBM round trip)
+        // Every gather is UNCONDITIONAL (clamped column index, entry 0 for the lanes past the column's end) and a
+        // column's registers are refilled only after it has been applied: hipcc then counts the loads in flight exactly
+        // and waits with vmcnt((PD - 1) * 2 * NPF).  (With the loads under `if (e < len)` / `if (a + PD < cnt)` it could
+        // not know how many younger loads exist, and with the refill issued before the apply it rotated the registers
+        // by moves at the loop end: both forms drained to vmcnt(0) once per PD columns -- a full HBM round trip per
+        // group, ~0.8 us per column.)
+        // The column table (start, length, V[i][c]) is NOT read from LDS per column -- four dependent LDS round trips per
+        // step were most of a step's time at one or two waves per SIMD -- but once per 64 columns: lane l keeps the
+        // entries of column 64 b + l in registers (one set for the column being applied, one for the column being
+        // prefetched, PD columns ahead) and a step picks its column with v_readlane.
+        static_assert(64 % PD == 0, "batch boundaries must fall on group boundaries");
         int pr[PD][NPF];
         uint16_t pv[PD][NPF];
-        auto fetch = [&](int a, int (&er)[NPF], uint16_t (&ev)[NPF]) {
-            const long long p0 = cp0[a];
-            const int len = clen[a];
+        const int lane = tid & 63;
+        unsigned f_lo = 0, f_hi = 0;
+        int f_len = 0, a_len = 0, a_vi = 0;
+        auto load_fetch_batch = [&](int base) {
+            int idx = base + lane;
+            idx = idx < cnt ? idx : cnt - 1;
+            const unsigned long long p0 = (unsigned long long)cp0[idx];
+            f_lo = (unsigned)p0;
+            f_hi = (unsigned)(p0 >> 32);
+            f_len = clen[idx];
+        };
+        auto load_apply_batch = [&](int base) {
+            int idx = base + lane;
+            idx = idx < cnt ? idx : cnt - 1;
+            a_len = clen[idx];
+            a_vi = vi[idx];
+        };
+        // (the loads use a wave-uniform base + a 32-bit lane offset; lanes past the column's end read its first entry
+        // -- `last` keeps that in bounds for an empty column at the very end of the index -- and are masked when applied)
+        auto fetch = [&](int a, int (&er)[NPF], uint16_t (&ev)[NPF]) {   // a >= cnt: the batch entry is a clamped copy
+            const int sl = a & 63;
+            unsigned long long p0 = (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)f_lo, sl) |
+                                    ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)f_hi, sl) << 32);
+            p0 = p0 < last ? p0 : last;
+            const int len = __builtin_amdgcn_readlane(f_len, sl);
+            const int *cb = crow + p0;
+            const uint16_t *vb = cval + p0;
 #pragma unroll
             for (int k = 0; k < NPF; ++k) {
-                const int e = tid + k * JT;
-                er[k] = -1;
-                ev[k] = 0;
-                if (e < len) {
-                    er[k] = crow[p0 + e];
-                    ev[k] = cval[p0 + e];
-                }
+                const unsigned e = (unsigned)(tid + k * JT_);
+                const unsigned off = e < (unsigned)len ? e : 0u;
+                er[k] = cb[off];
+                ev[k] = vb[off];
             }
         };
+        if (cnt > 0) {
+            load_fetch_batch(0);
 #pragma unroll
-        for (int d = 0; d < PD; ++d)
-            if (d < cnt) fetch(d, pr[d], pv[d]);
+            for (int d = 0; d < PD; ++d) fetch(d, pr[d], pv[d]);
+        }
         for (int a0 = 0; a0 < cnt; a0 += PD) {
+            if ((a0 & 63) == 0) load_apply_batch(a0);
+            if (((a0 + PD) & 63) == 0) load_fetch_batch(a0 + PD);
 #pragma unroll
             for (int d = 0; d < PD; ++d) {
                 const int a = a0 + d;
-                if (a >= cnt) break;
-                int cr[NPF];
-                uint16_t cv[NPF];
+                if (a < cnt) {
+                    const uint16_t vic = (uint16_t)__builtin_amdgcn_readlane(a_vi, a & 63);
+                    const int len = __builtin_amdgcn_readlane(a_len, a & 63);
+                    // branch free: lanes without an entry in this chunk add into a dummy slot behind the accumulators
 #pragma unroll
-                for (int k = 0; k < NPF; ++k) {
-                    cr[k] = pr[d][k];
-                    cv[k] = pv[d][k];
-                }
-                if (a + PD < cnt) fetch(a + PD, pr[d], pv[d]);
-                const uint16_t vic = vi[a];
-#pragma unroll
-                for (int k = 0; k < NPF; ++k) {
-                    const int r = cr[k];
-                    if (r >= r0 && r < r1) { // r == -1 (no entry) fails r >= r0
-                        const uint16_t m = mpreid_h_min_nonneg(vic, cv[k]);
-                        t[r - r0] = h_add_native(t[r - r0], m);
+                    for (int k = 0; k < NPF; ++k) {
+                        const unsigned rl = (unsigned)(pr[d][k] - r0i);
+                        const bool ok = (tid + k * JT_ < len) && rl < span && !(dbg & 1);
+                        const unsigned idx = ok ? rl : (unsigned)rch;
+                        const uint16_t m = mpreid_h_min_nonneg(vic, pv[d][k]);
+                        t[idx] = h_add_native(t[idx], m);
                     }
-                }
-                const int len = clen[a];
-                if (len > NPF * JT) { // rare long column: the tail is gathered directly
-                    const long long p0 = cp0[a];
-                    for (int e = tid + NPF * JT; e < len; e += JT) {
-                        const int r = crow[p0 + e];
-                        if (r >= r0 && r < r1) {
-                            const uint16_t m = mpreid_h_min_nonneg(vic, cval[p0 + e]);
-                            t[r - r0] = h_add_native(t[r - r0], m);
+                    if (len > NPF * JT_ && !(dbg & 8)) { // rare long column: the tail is gathered directly
+                        const long long p0 = cp0[a];
+                        for (int e = tid + NPF * JT_; e < len; e += JT_) {
+                            const int r = crow[p0 + e];
+                            if (r >= r0 && r < r1) {
+                                const uint16_t m = mpreid_h_min_nonneg(vic, cval[p0 + e]);
+                                t[r - r0] = h_add_native(t[r - r0], m);
+                            }
                         }
                     }
                 }
+                fetch(a + PD, pr[d], pv[d]);
                 __syncthreads();
             }
         }
         const int64_t jlo = (r0 > nq) ? r0 : nq;
-        for (int64_t j = jlo + tid; j < r1; j += JT) {
-            const uint16_t tv = t[j - r0];
-            const uint16_t den = h_sub_native(H2, tv);
-            const uint16_t qt = h_div_native(tv, den);
-            const uint16_t jac = h_sub_native(H1, qt);
-            const uint16_t jl = h_mul_native(jac, one_minus_lam_h);
-            const float o = __fdiv_rn(row[j], mx);
-            out[i * ldo + (j - nq)] = h_to_f32(jl) + o * lam32;
+        // eight independent loads per thread and trip (a one-wave workgroup would otherwise pay a memory round trip per
+        // 64 elements)
+        for (int64_t jb = jlo; jb < ((dbg & 4) ? jlo : r1); jb += 8 * JT_) {
+            float dv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t j = jb + u * JT_ + tid;
+                dv[u] = row[j < r1 ? j : r1 - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t j = jb + u * JT_ + tid;
+                if (j < r1) {
+                    const uint16_t tv = t[j - r0];
+                    const uint16_t den = h_sub_native(H2, tv);
+                    const uint16_t qt = h_div_native(tv, den);
+                    const uint16_t jac = h_sub_native(H1, qt);
+                    const uint16_t jl = h_mul_native(jac, one_minus_lam_h);
+                    const float o = __fdiv_rn(dv[u], mx);
+                    out[i * ldo + (j - nq)] = h_to_f32(jl) + o * lam32;
+                }
+            }
         }
         __syncthreads();
     }
@@ -1714,6 +1809,9 @@ static int launch_csc(int64_t N, const int *fcnt, const int *fidx, const uint16_
         hipLaunchKernelGGL(csc_scan_kernel, dim3(1), dim3(1024), 0, stream, N, ccnt, cptr);
         hipLaunchKernelGGL(csc2_fill_kernel, dim3(CSC_B, nranges), dim3(1024), lds, stream, N, fcnt, fidx, fval, qcap, rpb,
                            chist, cptr, crow, cval);
+        const JaccardPlan jp = jaccard_plan(N);
+        hipLaunchKernelGGL(csc2_bounds_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, N, jp.nchunks, jp.bpc,
+                           chist, cptr, chist + (size_t)N * CSC_B);
     } else {
         HIP_TRY(hipMemsetAsync(ccnt, 0, (size_t)(N + 1) * 4, stream));
         hipLaunchKernelGGL(csc_count_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, N, fcnt, fidx, qcap, ccnt);
@@ -1735,21 +1833,28 @@ static int launch_jaccard(int64_t N, int64_t nq, int q0, int64_t qrows, const fl
     int rch = (int)std::min<int64_t>(N, 49152);
     rch = (int)align_up((size_t)rch, 8);
     const unsigned *Hp = nullptr;
-    int rpb = 0, bpc = 0, nchunks = 1;
+    int rpb = 0, bpc = 0, nchunks = 1, threads = JT;
     if (blocked) {
-        // chunks of whole row blocks of the inverted index, at most ~24 K rows (48 KB of fp16 accumulators: two or
-        // three workgroups per CU beside the column tables)
-        rpb = (int)((N + CSC_B - 1) / CSC_B);
-        bpc = std::max(1, std::min(CSC_B, 24576 / rpb));
-        nchunks = (CSC_B + bpc - 1) / bpc;
-        rch = (int)align_up((size_t)std::min<int64_t>(N, (int64_t)bpc * rpb), 8);
-        Hp = chist;
+        const JaccardPlan jp = jaccard_plan(N);
+        rpb = jp.rpb; bpc = jp.bpc; nchunks = jp.nchunks; rch = jp.rch;
+        threads = jp.wave_form ? 64 : JT;
+        Hp = chist + (size_t)N * CSC_B;   // the chunk-boundary table
     }
-    const size_t lds = align_up((size_t)rch * 2, 16) + (size_t)qcap * (8 + 4 + 2) + 16;
-    int rc = set_dyn_lds(jaccard_kernel, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL(jaccard_kernel, dim3((unsigned)qrows, (unsigned)nchunks), dim3(JT), lds, stream, N, nq, MT, ld, rowmax,
-                       fcnt, fidx, fval, qcap, cptr, crow, cval, rch, oml, lam32, out, ldo, pair_counter, q0, Hp, rpb, bpc);
+    // timing ablations (wrong results): 1 nothing is accumulated, 4 no output pass, 8 no direct path for long columns.
+    // (An ablation that points every gather at ONE address measures an L2 hot spot, not the loop: removed.)
+    static const int jdbg = getenv("MPREID_JACCARD_DBG") ? atoi(getenv("MPREID_JACCARD_DBG")) : 0;
+    const size_t lds = align_up((size_t)rch * 2 + 16, 16) + (size_t)qcap * (8 + 4 + 2) + 16;
+#define MPREID_JACCARD_LAUNCH(JT_, NPF_, PD_)                                                                            \
+    {                                                                                                                    \
+        int rc = set_dyn_lds(jaccard_kernel<JT_, NPF_, PD_>, lds);                                                       \
+        if (rc) return rc;                                                                                               \
+        hipLaunchKernelGGL((jaccard_kernel<JT_, NPF_, PD_>), dim3((unsigned)qrows, (unsigned)nchunks), dim3(JT_), lds,   \
+                           stream, N, nq, MT, ld, rowmax, fcnt, fidx, fval, qcap, cptr, crow, cval, rch, oml, lam32, out, \
+                           ldo, pair_counter, q0, Hp, rpb, bpc, jdbg);                                                   \
+    }
+    if (threads == 64) MPREID_JACCARD_LAUNCH(64, 2, 8)
+    else MPREID_JACCARD_LAUNCH(JT, 2, 4)
+#undef MPREID_JACCARD_LAUNCH
     LAUNCH_CHECK();
     return MPREID_OK;
 }
@@ -2030,7 +2135,7 @@ static Rerank2Layout make_layout2(int64_t nq, int64_t ng, int d, int k1, int k2)
     L.qidx = take(N * (size_t)L.qcap_bound * 4);
     L.qval = take(N * (size_t)L.qcap_bound * 2);
     L.ccnt = take((N + 1) * 4);
-    L.chist = take(N * (size_t)256 * 4);   // CSC_B block histograms
+    L.chist = take(csc_hist_bytes((int64_t)N));   // CSC_B block histograms + chunk bounds
     L.cptr = take((N + 1) * 8);
     L.crow = take(N * (size_t)L.qcap_bound * 4);
     L.cval = take(N * (size_t)L.qcap_bound * 2);
@@ -2617,7 +2722,7 @@ extern "C" int mpreid_rr_qe_fill(int64_t n, const int32_t *rank_all, int kr, int
 // phase 4: inverted index of the GLOBAL V_qe (row stride qstride) + Jaccard / blend for the query rows
 // [q_lo, q_lo + qrows): d_q [qrows][ld] and rowmax_q from mpreid_rr_dist_rows on that range.
 // Scratch: ccnt [N+1] u32, cptr [N+1] i64, crow [nnz] i32, cval [nnz] u16 (nnz = sum of qcnt_all).
-extern "C" size_t mpreid_rr_jaccard_hist_bytes(int64_t n) { return (size_t)n * CSC_B * 4; }
+extern "C" size_t mpreid_rr_jaccard_hist_bytes(int64_t n) { return csc_hist_bytes(n); }
 
 extern "C" int mpreid_rr_jaccard(int64_t n, int64_t nq, int64_t q_lo, int64_t qrows, const float *d_q, int64_t ld,
                                  const float *rowmax_q, const int32_t *qcnt_all, const int32_t *qidx_all,
