@@ -1886,6 +1886,7 @@ struct TailArgs {
     double lambda_value;
     int algo;
     hipEvent_t join;   // (sparse) the distance rows MT are produced on a side stream: the Jaccard stage waits for this
+
 };
 
 static int rerank_tail(const TailArgs &a, hipStream_t stream, StageTimer &tm, mpreid_rerank_stats *stats, int marks_so_far) {
@@ -2265,19 +2266,33 @@ static int rerank_sparse(const float *q, const float *g, int64_t nq, int64_t ng,
         if (rc) return rc;
     }
     tm.mark(); // 1
-    // fork: exact distance rows of the queries (what the Jaccard blend reads) on the side stream.  Forked AFTER the
-    // fused GEMM (a persistent kernel that owns every CU's LDS: forked before it, the two GEMMs only take turns):
-    // the fp32 matrix work then runs beside the refinement / expansion / inverted-index kernels, which gather
-    // measured: N = 20 000 no gain (6.06 vs 6.04 ms: either side saturates the chip), N = 100 000 116 -> 113 ms
-    static const char *ov_env = getenv("MPREID_RERANK_OVERLAP");   // A/B switch: "0" / "1" force it off / on
-    const bool no_overlap = ov_env ? (atoi(ov_env) == 0) : (N < 50000);
+    // exact distance rows of the queries (what the Jaccard blend reads): only the GALLERY columns [nq, N) of the query rows are ever read (the blend of final_dist[:nq, nq:]): the first
+    // nq columns of dq stay unwritten (20 % of the fp32 matrix work at nq = N / 5)
+    auto launch_dq = [&](hipStream_t s, int64_t q0, int64_t rows) -> int {
+        if (N == nq || rows <= 0) return MPREID_OK;
+        return mpreid_distance_launch(feat + (size_t)q0 * d, feat + (size_t)nq * d, rows, N - nq, d, sqn + q0, sqn + nq,
+                                      dq + (size_t)q0 * L.ld + nq, L.ld, 0, s);
+    };
+    // Overlap of the fp32 matrix work with the rest (MPREID_RERANK_OVERLAP = 0 / 1 forces it off / on): one launch on
+    // the side stream, forked AFTER the fused GEMM (a persistent kernel that owns every CU's LDS: forked before it, the
+    // two GEMMs only take turns).  Nearly zero-sum wherever it was measured: N = 20 000 6.06 vs 6.04 ms, N = 100 000
+    // 87.7 -> 86.2 ms, MSMT17 shape 77.7 -> 76.7 ms (on by default only from N = 50 000).  Also measured at N = 100 000
+    // and NOT kept: the rows in four query blocks forked after the V rows so that the Jaccard stage of block b runs
+    // beside the rows of block b + 1 -- 87.0 ms as launched (the GEMM's workgroups take every slot that frees up and
+    // the partner starves), 90.2 ms against 90.7 in line with the GEMM made persistent at two workgroups per CU so that
+    // both kernels are resident (both then run at half speed: they share each CU's load path and LDS).
+    static const char *ov_env = getenv("MPREID_RERANK_OVERLAP");
+    const int ov_mode = ov_env ? (atoi(ov_env) != 0) : (N < 50000 ? 0 : 1);
+    const bool no_overlap = ov_mode == 0;
     SideStream *ss = nullptr;
-    if (!no_overlap) {
+    if (ov_mode != 0) {
         if ((rc = side_stream(&ss))) return rc;
+    }
+    if (ov_mode == 1) {
         HIP_TRY(hipEventRecord(ss->fork, stream));
         HIP_TRY(hipStreamWaitEvent(ss->s, ss->fork, 0));
         if (timing) HIP_TRY(hipEventRecord(ss->t0, ss->s));
-        if ((rc = mpreid_distance_launch(feat, feat, nq, N, d, sqn, sqn, dq, L.ld, 0, ss->s))) return rc;
+        if ((rc = launch_dq(ss->s, 0, nq))) return rc;
         if (timing) HIP_TRY(hipEventRecord(ss->t1, ss->s));
         HIP_TRY(hipEventRecord(ss->join, ss->s));
     }
@@ -2318,7 +2333,7 @@ static int rerank_sparse(const float *q, const float *g, int64_t nq, int64_t ng,
     }
     tm.mark(); // 3
     if (no_overlap) {   // exact distance rows of the queries, in line
-        rc = mpreid_distance_launch(feat, feat, nq, N, d, sqn, sqn, dq, L.ld, 0, stream);
+        rc = launch_dq(stream, 0, nq);
         if (rc) return rc;
     }
     tm.mark(); // 4
