@@ -60,6 +60,8 @@ enum { EPI_EUCLID = 0, EPI_COSINE = 1,
        EPI_LIN_RES = 4 };  // C += acc + bias
 
 constexpr int XBM = 128, XBN = 128, XBK = 16, XLD = 132;
+constexpr int XKC = XBK / 4;            // float4 chunks per row of a k tile
+constexpr int XNR = XBM * XKC / 256;    // float4 per thread, operand and k tile
 
 __device__ __forceinline__ float4 load_k4(const float *__restrict__ base, int64_t row, int64_t nrows, int k, int K,
                                           bool vec_ok) {
@@ -82,6 +84,8 @@ __device__ __forceinline__ float4 load_k4(const float *__restrict__ base, int64_
 // (i,j) and (j,i), commutative norm sum), so only tiles with tn >= tm are computed; off-diagonal tiles
 // are also written mirrored, transposed through LDS so that the mirrored rows leave as 128-byte pieces.
 template <int EPI, bool SYM>
+// (measured: k tile 32 -- half the barriers, two workgroups per CU -- 104 TF; forced to four waves per SIMD 112 TF;
+// as is, three waves per SIMD, 115 TF on 20 000 x 80 000 x 768)
 __global__ __launch_bounds__(256) void gemm_f32_exact_kernel(const float *__restrict__ A, const float *__restrict__ B,
                                                              int64_t M, int64_t N, int K,
                                                              const float *__restrict__ an,
@@ -114,23 +118,42 @@ __global__ __launch_bounds__(256) void gemm_f32_exact_kernel(const float *__rest
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
 
-    // staging map: each thread moves 2 float4 of A and 2 of B per K tile; idx -> (row, kc)
-    const int r0 = tid >> 2, kc = tid & 3; // rows r0 and r0 + 64
-    float4 ra[2], rb[2];
+    // staging map: each thread moves XNR float4 of A and of B per K tile; idx -> (row, kc)
+    constexpr int RSTEP = 256 / XKC;   // rows r0, r0 + RSTEP, ...
+    const int r0 = tid / XKC, kc = tid % XKC;
+    float4 ra[XNR], rb[XNR];
     const int nkt = (K + XBK - 1) / XBK;
 
+    // fast staging (16-byte aligned rows, K a multiple of the k tile): unconditional 16-byte loads from row pointers
+    // clamped to the last valid row (the padded rows' results are never stored); otherwise element-wise with bounds
+    const bool fast = vec_ok != 0 && K % XBK == 0;
+    const float *arow[XNR], *brow[XNR];
+#pragma unroll
+    for (int r = 0; r < XNR; ++r) {
+        const int64_t ar = m0 + r0 + RSTEP * r, br = n0 + r0 + RSTEP * r;
+        arow[r] = A + (ar < M ? ar : M - 1) * (int64_t)K + kc * 4;
+        brow[r] = B + (br < N ? br : N - 1) * (int64_t)K + kc * 4;
+    }
     auto gload = [&](int kt) {
+        if (fast) {
+#pragma unroll
+            for (int r = 0; r < XNR; ++r) {
+                ra[r] = *reinterpret_cast<const float4 *>(arow[r] + kt * XBK);
+                rb[r] = *reinterpret_cast<const float4 *>(brow[r] + kt * XBK);
+            }
+            return;
+        }
         const int k = kt * XBK + kc * 4;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            ra[r] = load_k4(A, m0 + r0 + 64 * r, M, k, K, vec_ok != 0);
-            rb[r] = load_k4(B, n0 + r0 + 64 * r, N, k, K, vec_ok != 0);
+        for (int r = 0; r < XNR; ++r) {
+            ra[r] = load_k4(A, m0 + r0 + RSTEP * r, M, k, K, vec_ok != 0);
+            rb[r] = load_k4(B, n0 + r0 + RSTEP * r, N, k, K, vec_ok != 0);
         }
     };
     auto sstore = [&](int buf) {
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int row = r0 + 64 * r;
+        for (int r = 0; r < XNR; ++r) {
+            const int row = r0 + RSTEP * r;
             As[buf][kc * 4 + 0][row] = ra[r].x;
             As[buf][kc * 4 + 1][row] = ra[r].y;
             As[buf][kc * 4 + 2][row] = ra[r].z;
@@ -157,17 +180,27 @@ __global__ __launch_bounds__(256) void gemm_f32_exact_kernel(const float *__rest
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nkt) gload(kt + 1);
+        // lane l holds A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; k ascends across MFMAs.  The operands of k pair
+        // kp + 1 are read from LDS before the MFMAs of pair kp are issued (hipcc otherwise re-uses the operand registers
+        // and exposes one LDS round trip per four MFMAs)
+        float a0 = As[buf][lh][wm * 64 + li], a1 = As[buf][lh][wm * 64 + 32 + li];
+        float b0 = Bs[buf][lh][wn * 64 + li], b1 = Bs[buf][lh][wn * 64 + 32 + li];
 #pragma unroll
         for (int kp = 0; kp < XBK / 2; ++kp) {
-            // lane l holds A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; k ascends across MFMAs
-            const float a0 = As[buf][2 * kp + lh][wm * 64 + li];
-            const float a1 = As[buf][2 * kp + lh][wm * 64 + 32 + li];
-            const float b0 = Bs[buf][2 * kp + lh][wn * 64 + li];
-            const float b1 = Bs[buf][2 * kp + lh][wn * 64 + 32 + li];
+            float a0n = 0.f, a1n = 0.f, b0n = 0.f, b1n = 0.f;
+            if (kp + 1 < XBK / 2) {
+                a0n = As[buf][2 * kp + 2 + lh][wm * 64 + li];
+                a1n = As[buf][2 * kp + 2 + lh][wm * 64 + 32 + li];
+                b0n = Bs[buf][2 * kp + 2 + lh][wn * 64 + li];
+                b1n = Bs[buf][2 * kp + 2 + lh][wn * 64 + 32 + li];
+            }
+            __builtin_amdgcn_sched_barrier(0);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = a0n; a1 = a1n; b0 = b0n; b1 = b1n;
         }
         if (kt + 1 < nkt) sstore(buf ^ 1);
         __syncthreads();
