@@ -19,6 +19,8 @@ g.manual_seed(4321)
 cent = torch.randn((N // 20, d), generator=g, device="cuda")
 pid = torch.randint(0, N // 20, (N,), generator=g, device="cuda")
 f = ops.l2_normalize(cent[pid] + sigma * torch.randn((N, d), generator=g, device="cuda"))
+if os.environ.get("BENCH_SORT_BY_PID"):   # locality experiment: rows of one identity adjacent (as in a file-name-sorted dataset)
+    f = f[torch.argsort(pid, stable=True)].contiguous()
 best = None
 for _ in range(4):
     out, st = ops.re_ranking(f[:nq], f[nq:], 50, 15, 0.3, timing=True)
