@@ -279,3 +279,49 @@ def test_rerank_small_n_clamped_like_reference(ops, golden, tag):
         assert d.max() <= RR_MAX and (d > 1e-5).mean() <= 0.01
         q, ga = torch.from_numpy(feat[:nq]).cuda(), torch.from_numpy(feat[nq:]).cuda()
         assert np.array_equal(D.re_ranking_virtual(q, ga, k1, k2, lam, 3).cpu().numpy(), got)
+
+
+_FORM_WORKER = """
+import os, sys, hashlib
+import numpy as np, torch
+sys.path[:0] = [{root!r}, os.path.join({root!r}, "mp-reid_amd")]
+from mpreid import ops, synth
+res = {{}}
+for n, nq, d, k1, k2, algo in {cases!r}:
+    f, _ = synth.clustered_features(n, d, 2.5, seed=77 + n, per_id=10)
+    ft = torch.from_numpy(f).cuda()
+    out, st = ops.re_ranking(ft[:nq], ft[nq:], k1, k2, 0.3, algo=algo)
+    res[f"{{n}}_{{algo}}"] = out.cpu().numpy()
+np.savez(sys.argv[1], **res)
+"""
+
+
+@pytest.mark.parametrize("env", [
+    {"MPREID_JACCARD_WAVE": "1", "MPREID_JACCARD_WAVE_ROWS": "1024"},   # one-wave Jaccard form, 3-4 row chunks
+    {"MPREID_JACCARD_WAVE": "1", "MPREID_JACCARD_WAVE_ROWS": "256"},    # ... 12-16 chunks of ~250 rows
+    {"MPREID_JACCARD_WAVE": "0"},                                         # 512-thread form
+    {"MPREID_CSC_ATOMIC": "1"},                                           # round-1 atomic inverted index + unchunked Jaccard
+    {"MPREID_RERANK_OVERLAP": "1"},                                       # exact query rows on the side stream
+])
+def test_rerank_kernel_forms_against_oracle(tmp_path, env):
+    """The large-N forms of the Jaccard stage (and the A/B switches of the inverted index / the side stream) are
+    selected by environment variables read once per process: each runs in a child process on problems small enough
+    for the oracle, for both algorithms, bit for bit."""
+    import os
+    import subprocess
+    import sys
+    from mpreid import ops as o, synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = [(3100, 600, 128, 50, 15, o.RERANK_SPARSE), (3100, 600, 128, 50, 15, o.RERANK_DENSE),
+             (2333, 211, 64, 20, 6, o.RERANK_SPARSE)]
+    script = tmp_path / "w.py"
+    script.write_text(_FORM_WORKER.format(root=root, cases=cases))
+    out = tmp_path / "out.npz"
+    r = subprocess.run([sys.executable, str(script), str(out)], env=dict(os.environ, **env), capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.load(out)
+    for n, nq, d, k1, k2, algo in cases:
+        f, _ = synth.clustered_features(n, d, 2.5, seed=77 + n, per_id=10)
+        want = orc.re_ranking(f[:nq], f[nq:], k1, k2, 0.3)
+        assert np.array_equal(got[f"{n}_{algo}"], want), (env, n, algo)
