@@ -59,7 +59,7 @@ struct JaccardPlan {
     int rpb, bpc, nchunks, rch;
     bool wave_form;   // one 64-thread workgroup per (query, chunk) instead of 512 threads
 };
-static JaccardPlan jaccard_plan(int64_t N) {
+static JaccardPlan jaccard_plan(int64_t N) {   // N = number of INDEXED rows (the gallery rows)
     constexpr int B = 256;   // = CSC_B
     static const int jwave = getenv("MPREID_JACCARD_WAVE") ? atoi(getenv("MPREID_JACCARD_WAVE")) : -1;
     static const int jrows = getenv("MPREID_JACCARD_WAVE_ROWS") ? atoi(getenv("MPREID_JACCARD_WAVE_ROWS")) : 8192;
@@ -79,7 +79,8 @@ static JaccardPlan jaccard_plan(int64_t N) {
     return p;
 }
 // bytes of the block histograms [256][N] + the chunk-boundary table [N][nchunks + 1]
-static size_t csc_hist_bytes(int64_t N) { return ((size_t)N * 256 + (size_t)N * (size_t)(jaccard_plan(N).nchunks + 1)) * 4; }
+// (sized for the worst case over the number of indexed rows: nchunks <= 256)
+static size_t csc_hist_bytes(int64_t N) { return ((size_t)N * 256 + (size_t)N * 257) * 4; }
 
 struct RerankLayout {
     int64_t N, ld;
@@ -1060,9 +1061,9 @@ __global__ __launch_bounds__(64) void qe_fill_kernel(int64_t N, const int *__res
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void csc_count_kernel(int64_t N, const int *__restrict__ qcnt,
                                                         const int *__restrict__ qidx, int qcap,
-                                                        unsigned *__restrict__ ccnt) {
+                                                        unsigned *__restrict__ ccnt, int64_t row_lo) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t i = row_lo + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= N) return;
     const int cnt = qcnt[i];
     for (int a = lane; a < cnt; a += 64) atomicAdd(&ccnt[qidx[i * qcap + a]], 1u);
@@ -1102,9 +1103,9 @@ __global__ __launch_bounds__(256) void csc_fill_kernel(int64_t N, const int *__r
                                                        const uint16_t *__restrict__ qval, int qcap,
                                                        const long long *__restrict__ cptr,
                                                        unsigned *__restrict__ cursor, int *__restrict__ crow,
-                                                       uint16_t *__restrict__ cval) {
+                                                       uint16_t *__restrict__ cval, int64_t row_lo) {
     const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t i = row_lo + (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= N) return;
     const int cnt = qcnt[i];
     for (int a = lane; a < cnt; a += 64) {
@@ -1129,7 +1130,8 @@ __global__ __launch_bounds__(256) void csc_fill_kernel(int64_t N, const int *__r
 constexpr int CSC_B = 256, CSC_CR = 36864;
 static_assert(CSC_B == 256, "the workspace layouts reserve 256 block histograms");
 __global__ __launch_bounds__(1024) void csc2_hist_kernel(int64_t N, const int *__restrict__ qcnt, const int *__restrict__ qidx,
-                                                         int qcap, int rows_per_block, unsigned *__restrict__ H) {
+                                                         int qcap, int rows_per_block, unsigned *__restrict__ H,
+                                                         int64_t row_lo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned *hist = (unsigned *)smem;
     const int b = blockIdx.x;
@@ -1137,7 +1139,7 @@ __global__ __launch_bounds__(1024) void csc2_hist_kernel(int64_t N, const int *_
     const int cw = (int)((N - c0 < CSC_CR) ? N - c0 : CSC_CR);
     for (int c = threadIdx.x; c < cw; c += 1024) hist[c] = 0u;
     __syncthreads();
-    const int64_t r_lo = (int64_t)b * rows_per_block, r_hi = (r_lo + rows_per_block < N) ? r_lo + rows_per_block : N;
+    const int64_t r_lo = row_lo + (int64_t)b * rows_per_block, r_hi = (r_lo + rows_per_block < N) ? r_lo + rows_per_block : N;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int64_t i = r_lo + wave; i < r_hi; i += 16) {
         const int cnt = qcnt[i];
@@ -1176,7 +1178,7 @@ __global__ __launch_bounds__(256) void csc2_bounds_kernel(int64_t N, int nchunks
 __global__ __launch_bounds__(1024) void csc2_fill_kernel(int64_t N, const int *__restrict__ qcnt, const int *__restrict__ qidx,
                                                          const uint16_t *__restrict__ qval, int qcap, int rows_per_block,
                                                          const unsigned *__restrict__ H, const long long *__restrict__ cptr,
-                                                         int *__restrict__ crow, uint16_t *__restrict__ cval) {
+                                                         int *__restrict__ crow, uint16_t *__restrict__ cval, int64_t row_lo) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned *cur = (unsigned *)smem;
     const int b = blockIdx.x;
@@ -1184,7 +1186,7 @@ __global__ __launch_bounds__(1024) void csc2_fill_kernel(int64_t N, const int *_
     const int cw = (int)((N - c0 < CSC_CR) ? N - c0 : CSC_CR);
     for (int c = threadIdx.x; c < cw; c += 1024) cur[c] = (unsigned)cptr[c0 + c] + H[(int64_t)b * N + c0 + c];
     __syncthreads();
-    const int64_t r_lo = (int64_t)b * rows_per_block, r_hi = (r_lo + rows_per_block < N) ? r_lo + rows_per_block : N;
+    const int64_t r_lo = row_lo + (int64_t)b * rows_per_block, r_hi = (r_lo + rows_per_block < N) ? r_lo + rows_per_block : N;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int64_t i = r_lo + wave; i < r_hi; i += 16) {
         const int cnt = qcnt[i];
@@ -1265,8 +1267,9 @@ __global__ __launch_bounds__(JT_) void jaccard_kernel(int64_t N, int64_t nq, con
     const float *row = MT + i * ld;
     const uint16_t H1 = 0x3c00u, H2 = 0x4000u;
     const unsigned long long last = cnt > 0 ? (unsigned long long)(cptr[N] - 1) : 0ull;   // cnt > 0: the index is not empty
-    const int64_t r_first = H ? (int64_t)b_lo * rows_per_block : 0;
-    const int64_t r_end = (int64_t)b_hi * rows_per_block;
+    // the inverted index holds the rows [nq, N) only (launch_csc): the accumulators start at row nq
+    const int64_t r_first = nq + (H ? (int64_t)b_lo * rows_per_block : 0);
+    const int64_t r_end = nq + (int64_t)b_hi * rows_per_block;
     const int64_t r_last = H ? (r_end < N ? r_end : N) : N;   // (rch, the LDS size, may be rounded up past it)
     for (int64_t r0 = r_first; r0 < r_last; r0 += rch) {
         const int64_t r1 = (r0 + rch < r_last) ? r0 + rch : r_last;
@@ -1812,36 +1815,40 @@ __global__ __launch_bounds__(1024) void max_i32_kernel(const int *__restrict__ x
     }
 }
 
-// inverted index of the ELL rows (fcnt, fidx, fval; row stride qcap) -> cptr / crow / cval.  With a block-histogram
-// buffer (chist, [CSC_B][N] u32) the atomics-free counting sort is used (and *blocked = true: the Jaccard stage may
-// then gather exact sub-ranges per row chunk); otherwise the round-1 atomic build.
-static int launch_csc(int64_t N, const int *fcnt, const int *fidx, const uint16_t *fval, int qcap, unsigned *ccnt,
+// inverted index of the ELL rows (fcnt, fidx, fval; row stride qcap) -> cptr / crow / cval, over the rows [nq, N) ONLY:
+// the Jaccard stage produces final_dist[:nq, nq:], i.e. the accumulators of the first nq rows are never read (the
+// reference computes and discards them, utils/reranking.py:84-100) -- a fifth of the entries, gathers and accumulator
+// rows at nq = N / 5.  With a block-histogram buffer (chist: [CSC_B][N] u32 + the chunk-boundary table) the atomics-free
+// counting sort over CSC_B blocks of the indexed rows is used (and *blocked = true: the Jaccard stage then gathers
+// exact sub-ranges per row chunk); otherwise the round-1 atomic build.
+static int launch_csc(int64_t N, int64_t nq, const int *fcnt, const int *fidx, const uint16_t *fval, int qcap, unsigned *ccnt,
                       unsigned *chist, long long *cptr, int *crow, uint16_t *cval, hipStream_t stream, bool *blocked) {
     static const bool csc_atomic = getenv("MPREID_CSC_ATOMIC") != nullptr;   // A/B switch: the round-1 atomic build
     const bool blocked_csc = chist && !csc_atomic && (uint64_t)N * (uint64_t)qcap < (1ull << 32);
     *blocked = blocked_csc;
+    const int64_t M = N - nq;   // indexed rows
     if (blocked_csc) {
-        const int rpb = (int)((N + CSC_B - 1) / CSC_B);
+        const JaccardPlan jp = jaccard_plan(M);
         const int nranges = (int)((N + CSC_CR - 1) / CSC_CR);
         const size_t lds = (size_t)std::min<int64_t>(N, CSC_CR) * 4;
         int rc = set_dyn_lds(csc2_hist_kernel, lds);
         if (rc) return rc;
         rc = set_dyn_lds(csc2_fill_kernel, lds);
         if (rc) return rc;
-        hipLaunchKernelGGL(csc2_hist_kernel, dim3(CSC_B, nranges), dim3(1024), lds, stream, N, fcnt, fidx, qcap, rpb, chist);
+        hipLaunchKernelGGL(csc2_hist_kernel, dim3(CSC_B, nranges), dim3(1024), lds, stream, N, fcnt, fidx, qcap, jp.rpb, chist,
+                           nq);
         hipLaunchKernelGGL(csc2_colscan_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, N, chist, ccnt);
         hipLaunchKernelGGL(csc_scan_kernel, dim3(1), dim3(1024), 0, stream, N, ccnt, cptr);
-        hipLaunchKernelGGL(csc2_fill_kernel, dim3(CSC_B, nranges), dim3(1024), lds, stream, N, fcnt, fidx, fval, qcap, rpb,
-                           chist, cptr, crow, cval);
-        const JaccardPlan jp = jaccard_plan(N);
+        hipLaunchKernelGGL(csc2_fill_kernel, dim3(CSC_B, nranges), dim3(1024), lds, stream, N, fcnt, fidx, fval, qcap, jp.rpb,
+                           chist, cptr, crow, cval, nq);
         hipLaunchKernelGGL(csc2_bounds_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, N, jp.nchunks, jp.bpc,
                            chist, cptr, chist + (size_t)N * CSC_B);
     } else {
         HIP_TRY(hipMemsetAsync(ccnt, 0, (size_t)(N + 1) * 4, stream));
-        hipLaunchKernelGGL(csc_count_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, N, fcnt, fidx, qcap, ccnt);
+        hipLaunchKernelGGL(csc_count_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, N, fcnt, fidx, qcap, ccnt, nq);
         hipLaunchKernelGGL(csc_scan_kernel, dim3(1), dim3(1024), 0, stream, N, ccnt, cptr);
-        hipLaunchKernelGGL(csc_fill_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, N, fcnt, fidx, fval, qcap,
-                           cptr, ccnt, crow, cval);
+        hipLaunchKernelGGL(csc_fill_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, N, fcnt, fidx, fval, qcap,
+                           cptr, ccnt, crow, cval, nq);
     }
     LAUNCH_CHECK();
     return MPREID_OK;
@@ -1854,12 +1861,12 @@ static int launch_jaccard(int64_t N, int64_t nq, int q0, int64_t qrows, const fl
                           float *out, int64_t ldo, unsigned long long *pair_counter, hipStream_t stream) {
     const uint16_t oml = f64_to_f16_host(1.0 - lambda_value);
     const float lam32 = (float)lambda_value;
-    int rch = (int)std::min<int64_t>(N, 49152);
+    int rch = (int)std::min<int64_t>(N - nq, 49152);
     rch = (int)align_up((size_t)rch, 8);
     const unsigned *Hp = nullptr;
     int rpb = 0, bpc = 0, nchunks = 1, threads = JT;
     if (blocked) {
-        const JaccardPlan jp = jaccard_plan(N);
+        const JaccardPlan jp = jaccard_plan(N - nq);
         rpb = jp.rpb; bpc = jp.bpc; nchunks = jp.nchunks; rch = jp.rch;
         threads = jp.wave_form ? 64 : JT;
         Hp = chist + (size_t)N * CSC_B;   // the chunk-boundary table
@@ -1904,7 +1911,7 @@ struct TailArgs {
     long long *cptr;
     int *crow;
     uint16_t *cval;
-    unsigned long long *counters;   // [0] Jaccard pairs, [1] sum |R|, [2] nnz(V), [3] max union (int), [4] fallback rows, [5] candidates
+    unsigned long long *counters;   // [0] Jaccard pairs, [1] sum |R|, [2] nnz(V), [3] max union (int), [4] fallback rows, [5] candidates, [6] nnz(V_qe)
     const float *MT;
     int64_t ld;
     const float *rowmax;
@@ -1961,11 +1968,12 @@ static int rerank_tail(const TailArgs &a, hipStream_t stream, StageTimer &tm, mp
         fidx = a.qidx;
         fval = a.qval;
     }
+    hipLaunchKernelGGL(sum_i32_kernel, dim3(1), dim3(1024), 0, stream, fcnt, N, a.counters + 6);   // nnz(V_qe), all rows
     tm.mark(); // +1
     // inverted index
     bool blocked_csc = false;
     {
-        int rc = launch_csc(N, fcnt, fidx, fval, qcap, a.ccnt, a.chist, a.cptr, a.crow, a.cval, stream, &blocked_csc);
+        int rc = launch_csc(N, a.nq, fcnt, fidx, fval, qcap, a.ccnt, a.chist, a.cptr, a.crow, a.cval, stream, &blocked_csc);
         if (rc) return rc;
     }
     tm.mark(); // +2
@@ -1977,7 +1985,7 @@ static int rerank_tail(const TailArgs &a, hipStream_t stream, StageTimer &tm, mp
         if (rc) return rc;
     }
     tm.mark(); // +3
-    unsigned long long cnt[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long cnt[7] = {0, 0, 0, 0, 0, 0, 0};
     long long nnz_total = 0;
     HIP_TRY(hipMemcpyAsync(cnt, a.counters, sizeof(cnt), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipMemcpyAsync(&nnz_total, a.cptr + N, 8, hipMemcpyDeviceToHost, stream));
@@ -1991,7 +1999,7 @@ static int rerank_tail(const TailArgs &a, hipStream_t stream, StageTimer &tm, mp
         stats->v_cap = a.vcap;
         stats->vqe_cap = qcap;
         stats->v_nnz = (int64_t)cnt[2];
-        stats->vqe_nnz = nnz_total;
+        stats->vqe_nnz = (int64_t)cnt[6];   // (nnz_total = entries of the inverted index: gallery rows only)
         stats->jaccard_pairs = (int64_t)cnt[0];
         stats->krecip_r_sum = (int64_t)cnt[1];
         stats->fallback_rows = (int64_t)(cnt[4] & 0xffffffffull);
@@ -2775,7 +2783,7 @@ extern "C" int mpreid_rr_jaccard(int64_t n, int64_t nq, int64_t q_lo, int64_t qr
               q_lo >= 0 && q_lo + qrows <= nq && ldo >= n - nq);
     hipStream_t stream = (hipStream_t)stream_;
     bool blocked = false;
-    int rc = launch_csc(n, qcnt_all, qidx_all, qval_all, qstride, ccnt, chist, cptr, crow, cval, stream, &blocked);
+    int rc = launch_csc(n, nq, qcnt_all, qidx_all, qval_all, qstride, ccnt, chist, cptr, crow, cval, stream, &blocked);
     if (rc) return rc;
     return launch_jaccard(n, nq, (int)q_lo, qrows, d_q, ld, rowmax_q, qcnt_all, qidx_all, qval_all, qstride, cptr, crow, cval,
                           chist, blocked, lambda_value, out, ldo, nullptr, stream);
