@@ -229,8 +229,8 @@ def rerank_roofline(st):
             "~1.5 KR rows per row (everything within 2 eps of the KR-th candidate)")
         add("rerank.krecip", "recip_bits_kernel + krecip_kernel<sparse>", st["ms_krecip"], "hbm",
             4.0 * N * ((k1 + 1) ** 2 + rbar * (h + h * h)), f"mean |R| = {rbar:.1f}")
-        add("rerank.query_rows", "gemm_f32_exact_kernel", st.get("ms_dq", 0.0), "mfma_f32", 2.0 * nq * N * d,
-            "exact fp32 distance rows of the queries only ([nq][N]): what the Jaccard blend reads")
+        add("rerank.query_rows", "gemm_f32_exact_kernel", st.get("ms_dq", 0.0), "mfma_f32", 2.0 * nq * ng * d,
+            "exact fp32 distance rows of the queries over the gallery columns only ([nq][ng]): what the Jaccard blend reads")
     else:
         add("rerank.distance", "gemm_f32_exact_kernel<SYM>", st["ms_gemm"], "mfma_f32", 1.0 * N * N * d,
             "executed FLOPs: the symmetric kernel computes the upper-triangular tiles only (2*N*N*D/2)")
@@ -238,7 +238,9 @@ def rerank_roofline(st):
         add("rerank.krecip", "recip_bits_kernel + krecip_kernel", st["ms_krecip"], "hbm",
             4.0 * N * ((k1 + 1) ** 2 + rbar * (h + h * h)), f"mean |R| = {rbar:.1f}")
     add("rerank.qe", "qe_count/fill_kernel", st["ms_qe"], "hbm", 6.0 * st["v_nnz"] * (1 + k2))
-    add("rerank.csc", "csc_*", st["ms_csc"], "hbm", 12.0 * st["vqe_nnz"])
+    # the inverted index holds the gallery rows only: ~ng/N of the V_qe entries are read (6 B) and written (6 B)
+    add("rerank.csc", "csc2_*", st["ms_csc"], "hbm", 12.0 * st["vqe_nnz"] * (ng / max(N, 1)),
+        "inverted index of the gallery rows (the accumulators of the query rows are never read)")
     add("rerank.jaccard", "jaccard_kernel", st["ms_jaccard"], "hbm", 6.0 * st["jaccard_pairs"] + 8.0 * nq * ng)
     return rows
 
