@@ -57,7 +57,7 @@ __device__ __forceinline__ uint16_t h_add_native(uint16_t a, uint16_t b) {
 // only, so that the workspace layouts can reserve the chunk-boundary table ([N][nchunks + 1] u32) the build writes.
 struct JaccardPlan {
     int rpb, bpc, nchunks, rch;
-    bool wave_form;   // one 64-thread workgroup per (query, chunk) instead of 512 threads
+    bool wave_form;   // one 64-thread workgroup per (query, chunk) instead of 256 threads
 };
 static JaccardPlan jaccard_plan(int64_t N) {   // N = number of INDEXED rows (the gallery rows)
     constexpr int B = 256;   // = CSC_B
@@ -65,7 +65,7 @@ static JaccardPlan jaccard_plan(int64_t N) {   // N = number of INDEXED rows (th
     static const int jrows = getenv("MPREID_JACCARD_WAVE_ROWS") ? atoi(getenv("MPREID_JACCARD_WAVE_ROWS")) : 8192;
     JaccardPlan p;
     p.rpb = (int)((N + B - 1) / B);
-    // 512-thread form: at most ~24 K rows per chunk (48 KB of accumulators: two workgroups per CU beside the tables)
+    // 256-thread form: at most ~24 K rows per chunk (48 KB of accumulators: two workgroups per CU beside the tables)
     p.bpc = std::max(1, std::min(B, 24576 / p.rpb));
     p.nchunks = (B + p.bpc - 1) / p.bpc;
     // more than one chunk: ONE wave per (query, chunk of ~8 K rows) -- no barriers at all (the LDS operations of a wave
@@ -1206,11 +1206,11 @@ __global__ __launch_bounds__(1024) void csc2_fill_kernel(int64_t N, const int *_
 // (utils/reranking.py:84-100).  One 256-thread workgroup per query; t[] lives in LDS as fp16 bits,
 // r-space processed in chunks of rch entries so that any N fits.
 // ---------------------------------------------------------------------------------------------
-// Two forms (jaccard_plan): 512 threads per (query, chunk of <= 24 K rows) with one barrier per column -- whole columns
-// when N <= 24 576 -- and ONE wave per (query, chunk of ~8 K rows) without barriers when the 512-thread form would need
+// Two forms (jaccard_plan): 256 threads per (query, chunk of <= 24 K rows) with one barrier per column -- whole columns
+// when N - nq <= 24 576 -- and ONE wave per (query, chunk of ~8 K rows) without barriers when the 256-thread form would need
 // several chunks (N = 100 000: 45.5 -> 33.8 ms, MSMT17 shape 21.8 -> 18.6 ms, with the counted waits, the register-held
 // column table and the branch-free accumulation below; the same one-wave split measured 41 / 25 ms before those).
-constexpr int JT = 512; // threads per query workgroup
+constexpr int JT = 256; // threads per query workgroup (multi-wave form)
 // NPF entries per thread and column are held in registers (columns up to NPF * JT entries; longer ones take the direct
 // path below), the gathers of PD columns are in flight.  <2, 4> suits whole columns (~600 entries: 43 KB in flight per CU
 // at three workgroups); at large N a workgroup sees ~130-entry sub-ranges and <1, 12> keeps as many bytes in flight.
@@ -1886,8 +1886,10 @@ static int launch_jaccard(int64_t N, int64_t nq, int q0, int64_t qrows, const fl
     // (one-wave form measured at N = 100 000 with 8 / 16 / 32 columns of gathers in flight: 32.3 / 32.4 / 32.1 ms, and with
     // the rows sorted by identity so that neighbouring queries share their columns in L2: 32.3 ms -- neither the memory
     // latency nor the hit rate is what bounds it; 4 K-row chunks 45.8 ms, 12 K-row chunks 44 ms)
+    // (multi-wave form, N = 20 000 / Market shape: 512 threads <2, 4> 1.58 / 1.42 ms, 256 threads <3, 4> 1.36 / 1.21,
+    // <3, 8> the same, <2, 4> 2.05 (columns longer than 512 entries take the direct path), 128 threads <5, 4> 1.72 / 1.50)
     if (threads == 64) MPREID_JACCARD_LAUNCH(64, 2, 8)
-    else MPREID_JACCARD_LAUNCH(JT, 2, 4)
+    else MPREID_JACCARD_LAUNCH(JT, 3, 4)
 #undef MPREID_JACCARD_LAUNCH
     LAUNCH_CHECK();
     return MPREID_OK;
