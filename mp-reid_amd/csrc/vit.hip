@@ -399,7 +399,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && KTP <= 10) ? 4 : 2) void atten
 // head: ln_post on the CLS row, CLS @ proj, optional eval-BN necks, concat -> [B][W + out_dim]
 // model/clip/model.py:471-474, model/make_model.py:98-115
 // ---------------------------------------------------------------------------------------------
-constexpr int HEAD_IMGS = 8;
+constexpr int HEAD_IMGS = 2;   // (8 images per workgroup: 128 workgroups, 90 us at B = 508; 2: 508 workgroups)
 // ln_post of the CLS rows (one wave per row): y[b][:] (fp32, for the projection) and out[b][0:W]
 __global__ __launch_bounds__(256) void cls_ln_kernel(const float *__restrict__ x, int64_t row_stride, int B, int W,
                                                      int out_dim, const float *__restrict__ g,
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256) void cls_proj_kernel(const float *__restrict__
     float acc[HEAD_IMGS];
 #pragma unroll
     for (int i = 0; i < HEAD_IMGS; ++i) acc[i] = 0.f;
-#pragma unroll 4
+#pragma unroll 8
     for (int k = 0; k < W; ++k) {
         const float pw = proj[(int64_t)k * out_dim + o];
 #pragma unroll
