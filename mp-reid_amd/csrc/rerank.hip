@@ -1178,7 +1178,10 @@ __global__ __launch_bounds__(256) void csc2_bounds_kernel(int64_t N, int nchunks
 __global__ __launch_bounds__(1024) void csc2_fill_kernel(int64_t N, const int *__restrict__ qcnt, const int *__restrict__ qidx,
                                                          const uint16_t *__restrict__ qval, int qcap, int rows_per_block,
                                                          const unsigned *__restrict__ H, const long long *__restrict__ cptr,
-                                                         int *__restrict__ crow, uint16_t *__restrict__ cval, int64_t row_lo) {
+                                                         unsigned *__restrict__ cpk, int64_t row_lo, int blocks_per_chunk) {
+    // entries are PACKED: (row - first row of the Jaccard chunk the row block belongs to) << 16 | fp16 bits of V_qe
+    // (a chunk has at most 24 K rows): 4 bytes per entry in ONE array instead of 4 + 2 in two -- a third fewer bytes
+    // and, at large N, ~40 % fewer 128-byte lines per gathered sub-range
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned *cur = (unsigned *)smem;
     const int b = blockIdx.x;
@@ -1187,6 +1190,7 @@ __global__ __launch_bounds__(1024) void csc2_fill_kernel(int64_t N, const int *_
     for (int c = threadIdx.x; c < cw; c += 1024) cur[c] = (unsigned)cptr[c0 + c] + H[(int64_t)b * N + c0 + c];
     __syncthreads();
     const int64_t r_lo = row_lo + (int64_t)b * rows_per_block, r_hi = (r_lo + rows_per_block < N) ? r_lo + rows_per_block : N;
+    const int64_t chunk_row0 = row_lo + (int64_t)(b / blocks_per_chunk) * blocks_per_chunk * rows_per_block;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int64_t i = r_lo + wave; i < r_hi; i += 16) {
         const int cnt = qcnt[i];
@@ -1194,8 +1198,7 @@ __global__ __launch_bounds__(1024) void csc2_fill_kernel(int64_t N, const int *_
             const int64_t c = qidx[i * qcap + a] - c0;
             if (c >= 0 && c < cw) {
                 const unsigned p = atomicAdd(&cur[c], 1u);
-                crow[p] = (int)i;
-                cval[p] = qval[i * qcap + a];
+                cpk[p] = ((unsigned)(i - chunk_row0) << 16) | (unsigned)qval[i * qcap + a];
             }
         }
     }
@@ -1214,7 +1217,7 @@ constexpr int JT = 256; // threads per query workgroup (multi-wave form)
 // NPF entries per thread and column are held in registers (columns up to NPF * JT entries; longer ones take the direct
 // path below), the gathers of PD columns are in flight.  <2, 4> suits whole columns (~600 entries: 43 KB in flight per CU
 // at three workgroups); at large N a workgroup sees ~130-entry sub-ranges and <1, 12> keeps as many bytes in flight.
-template <int JT_, int NPF, int PD>
+template <int JT_, int NPF, int PD, bool PACKED>
 __global__ __launch_bounds__(JT_) void jaccard_kernel(int64_t N, int64_t nq, const float *__restrict__ MT, int64_t ld,
                                                       const float *__restrict__ rowmax,
                                                       const int *__restrict__ qcnt, const int *__restrict__ qidx,
@@ -1328,7 +1331,7 @@ __global__ __launch_bounds__(JT_) void jaccard_kernel(int64_t N, int64_t nq, con
                 const unsigned e = (unsigned)(tid + k * JT_);
                 const unsigned off = e < (unsigned)len ? e : 0u;
                 er[k] = cb[off];
-                ev[k] = vb[off];
+                if (!PACKED) ev[k] = vb[off];
             }
         };
         if (cnt > 0) {
@@ -1352,20 +1355,30 @@ __global__ __launch_bounds__(JT_) void jaccard_kernel(int64_t N, int64_t nq, con
                     uint16_t tv[NPF];
 #pragma unroll
                     for (int k = 0; k < NPF; ++k) {
-                        const unsigned rl = (unsigned)(pr[d][k] - r0i);
-                        const bool ok = (tid + k * JT_ < len) && rl < span && !(dbg & 1);
+                        // PACKED: chunk-relative row in the high half (every entry of the sub-range lies in the chunk)
+                        const unsigned rl = PACKED ? ((unsigned)pr[d][k] >> 16) : (unsigned)(pr[d][k] - r0i);
+                        const bool ok = (tid + k * JT_ < len) && (PACKED || rl < span) && !(dbg & 1);
                         idx[k] = ok ? rl : (unsigned)(rch + k);   // NPF dummy slots
                         tv[k] = t[idx[k]];
                     }
 #pragma unroll
-                    for (int k = 0; k < NPF; ++k) t[idx[k]] = h_add_native(tv[k], mpreid_h_min_nonneg(vic, pv[d][k]));
+                    for (int k = 0; k < NPF; ++k) {
+                        const uint16_t vv = PACKED ? (uint16_t)((unsigned)pr[d][k] & 0xffffu) : pv[d][k];
+                        t[idx[k]] = h_add_native(tv[k], mpreid_h_min_nonneg(vic, vv));
+                    }
                     if (len > NPF * JT_ && !(dbg & 8)) { // rare long column: the tail is gathered directly
                         const long long p0 = cp0[a];
                         for (int e = tid + NPF * JT_; e < len; e += JT_) {
-                            const int r = crow[p0 + e];
-                            if (r >= r0 && r < r1) {
-                                const uint16_t m = mpreid_h_min_nonneg(vic, cval[p0 + e]);
-                                t[r - r0] = h_add_native(t[r - r0], m);
+                            if (PACKED) {
+                                const unsigned pe = (unsigned)crow[p0 + e];
+                                const uint16_t m = mpreid_h_min_nonneg(vic, (uint16_t)(pe & 0xffffu));
+                                t[pe >> 16] = h_add_native(t[pe >> 16], m);
+                            } else {
+                                const int r = crow[p0 + e];
+                                if (r >= r0 && r < r1) {
+                                    const uint16_t m = mpreid_h_min_nonneg(vic, cval[p0 + e]);
+                                    t[r - r0] = h_add_native(t[r - r0], m);
+                                }
                             }
                         }
                     }
@@ -1840,7 +1853,7 @@ static int launch_csc(int64_t N, int64_t nq, const int *fcnt, const int *fidx, c
         hipLaunchKernelGGL(csc2_colscan_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, N, chist, ccnt);
         hipLaunchKernelGGL(csc_scan_kernel, dim3(1), dim3(1024), 0, stream, N, ccnt, cptr);
         hipLaunchKernelGGL(csc2_fill_kernel, dim3(CSC_B, nranges), dim3(1024), lds, stream, N, fcnt, fidx, fval, qcap, jp.rpb,
-                           chist, cptr, crow, cval, nq);
+                           chist, cptr, (unsigned *)crow, nq, jp.bpc);   // packed entries live in the crow buffer
         hipLaunchKernelGGL(csc2_bounds_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, N, jp.nchunks, jp.bpc,
                            chist, cptr, chist + (size_t)N * CSC_B);
     } else {
@@ -1875,21 +1888,20 @@ static int launch_jaccard(int64_t N, int64_t nq, int q0, int64_t qrows, const fl
     // (An ablation that points every gather at ONE address measures an L2 hot spot, not the loop: removed.)
     static const int jdbg = getenv("MPREID_JACCARD_DBG") ? atoi(getenv("MPREID_JACCARD_DBG")) : 0;
     const size_t lds = align_up((size_t)rch * 2 + 16, 16) + (size_t)qcap * (8 + 4 + 2) + 16;
-#define MPREID_JACCARD_LAUNCH(JT_, NPF_, PD_)                                                                            \
+#define MPREID_JACCARD_LAUNCH(JT_, NPF_, PD_, PK_)                                                                       \
     {                                                                                                                    \
-        int rc = set_dyn_lds(jaccard_kernel<JT_, NPF_, PD_>, lds);                                                       \
+        int rc = set_dyn_lds(jaccard_kernel<JT_, NPF_, PD_, PK_>, lds);                                                  \
         if (rc) return rc;                                                                                               \
-        hipLaunchKernelGGL((jaccard_kernel<JT_, NPF_, PD_>), dim3((unsigned)qrows, (unsigned)nchunks), dim3(JT_), lds,   \
-                           stream, N, nq, MT, ld, rowmax, fcnt, fidx, fval, qcap, cptr, crow, cval, rch, oml, lam32, out, \
-                           ldo, pair_counter, q0, Hp, rpb, bpc, jdbg);                                                   \
+        hipLaunchKernelGGL((jaccard_kernel<JT_, NPF_, PD_, PK_>), dim3((unsigned)qrows, (unsigned)nchunks), dim3(JT_),   \
+                           lds, stream, N, nq, MT, ld, rowmax, fcnt, fidx, fval, qcap, cptr, crow, cval, rch, oml, lam32, \
+                           out, ldo, pair_counter, q0, Hp, rpb, bpc, jdbg);                                              \
     }
-    // (one-wave form measured at N = 100 000 with 8 / 16 / 32 columns of gathers in flight: 32.3 / 32.4 / 32.1 ms, and with
-    // the rows sorted by identity so that neighbouring queries share their columns in L2: 32.3 ms -- neither the memory
-    // latency nor the hit rate is what bounds it; 4 K-row chunks 45.8 ms, 12 K-row chunks 44 ms)
     // (multi-wave form, N = 20 000 / Market shape: 512 threads <2, 4> 1.58 / 1.42 ms, 256 threads <3, 4> 1.36 / 1.21,
     // <3, 8> the same, <2, 4> 2.05 (columns longer than 512 entries take the direct path), 128 threads <5, 4> 1.72 / 1.50)
-    if (threads == 64) MPREID_JACCARD_LAUNCH(64, 2, 8)
-    else MPREID_JACCARD_LAUNCH(JT, 3, 4)
+    // blocked index = packed entries (csc2_fill_kernel); the atomic build keeps (row, value) in two arrays
+    if (threads == 64) MPREID_JACCARD_LAUNCH(64, 2, 8, true)
+    else if (blocked) MPREID_JACCARD_LAUNCH(JT, 3, 4, true)
+    else MPREID_JACCARD_LAUNCH(JT, 3, 4, false)
 #undef MPREID_JACCARD_LAUNCH
     LAUNCH_CHECK();
     return MPREID_OK;
