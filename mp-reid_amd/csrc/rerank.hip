@@ -138,14 +138,25 @@ static RerankLayout make_layout(int64_t nq, int64_t ng, int d, int k1, int k2, i
 // ---------------------------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
+// Inclusive scan over the 64 lanes with DPP moves (row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes, then row_bcast:15
+// into rows 1 and 3 and row_bcast:31 into rows 2 and 3): six VALU operations.  The __shfl_up formulation compiles to
+// ds_bpermute_b32 -- an LDS crossbar round trip per step, ~850 cycles per scan measured with in-kernel stamps: the ten
+// scans of extract_bits_sorted were a third of a k-reciprocal row at N = 20 000, the 49 of the query expansion most of it
+// at N = 100 000.
+__device__ __forceinline__ int wave_incl_scan(int v) {
     int x = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int y = __shfl_up(x, off, 64);
-        if (lane >= off) x += y;
-    }
-    total = __shfl(x, 63, 64);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);    // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);    // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);    // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);    // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return x;
+}
+__device__ __forceinline__ int wave_excl_scan(int v, int lane, int &total) {
+    (void)lane;
+    const int x = wave_incl_scan(v);
+    total = __builtin_amdgcn_readlane(x, 63);
     return x - v;
 }
 
