@@ -63,14 +63,16 @@ struct JaccardPlan {
 static JaccardPlan jaccard_plan(int64_t N) {   // N = number of INDEXED rows (the gallery rows)
     constexpr int B = 256;   // = CSC_B
     static const int jwave = getenv("MPREID_JACCARD_WAVE") ? atoi(getenv("MPREID_JACCARD_WAVE")) : -1;
-    static const int jrows = getenv("MPREID_JACCARD_WAVE_ROWS") ? atoi(getenv("MPREID_JACCARD_WAVE_ROWS")) : 8192;
+    static const int jrows = getenv("MPREID_JACCARD_WAVE_ROWS") ? atoi(getenv("MPREID_JACCARD_WAVE_ROWS")) : 10240;
     JaccardPlan p;
     p.rpb = (int)((N + B - 1) / B);
     // 256-thread form: at most ~24 K rows per chunk (48 KB of accumulators: two workgroups per CU beside the tables)
     p.bpc = std::max(1, std::min(B, 24576 / p.rpb));
     p.nchunks = (B + p.bpc - 1) / p.bpc;
-    // more than one chunk: ONE wave per (query, chunk of ~8 K rows) -- no barriers at all (the LDS operations of a wave
-    // execute in order, which is all the fp16 accumulation order needs) and six workgroups per CU
+    // more than one chunk: ONE wave per (query, chunk of ~10 K rows) -- no barriers at all (the LDS operations of a wave
+    // execute in order, which is all the fp16 accumulation order needs), LDS = the accumulators only (jaccard_wave_kernel;
+    // measured at N = 100 000 / MSMT17 shape: 4 K rows 15.6 / 10.2 ms, 6 K 14.6 / 8.6, 8 K 14.1 / 8.9, 10 K 13.4 / 8.6,
+    // 12 K 15.6 / 9.2, 16 K 19.2 / 14.4)
     p.wave_form = jwave < 0 ? p.nchunks > 1 : jwave > 0;
     if (p.wave_form) {
         p.bpc = std::max(1, std::min(B, jrows / p.rpb));
@@ -1506,6 +1508,158 @@ __global__ __launch_bounds__(JT_) void jaccard_kernel(int64_t N, int64_t nq, con
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// One-wave form of the Jaccard stage WITHOUT a column table in LDS (blocked + packed index only): the workgroup's LDS is
+// the fp16 accumulators of its row chunk and nothing else (16 KB at 8 K rows: nine workgroups per CU instead of six), and
+// the per-column data (start of the sub-range, its length, V[i][c]) live in lane registers, 64 columns at a time:
+//   cur  = the batch the column being applied is in, nxt = the following batch (the prefetch stream, PD columns ahead,
+//   may already be there), both fully resolved (position / length from the chunk-boundary table HB);
+//   c2 / v2 = column indices and values of the batch after that, loaded one batch early so that resolving them at the
+//   next rotation is one round trip that nothing waits for.
+// In-kernel stamps of the table form at N = 100 000 (per (query, chunk) workgroup, cycles): table set-up 29 k, zeroing
+// 9 k, column loop 325 k (489 per column at 1.5 waves per SIMD), output pass 69 k.
+// ---------------------------------------------------------------------------------------------
+template <int NPF, int PD>
+__global__ __launch_bounds__(64) void jaccard_wave_kernel(int64_t N, int64_t nq, const float *__restrict__ MT, int64_t ld,
+                                                          const float *__restrict__ rowmax, const int *__restrict__ qcnt,
+                                                          const int *__restrict__ qidx, const uint16_t *__restrict__ qval,
+                                                          int qcap, const long long *__restrict__ cptr,
+                                                          const unsigned *__restrict__ cpk, int rch,
+                                                          uint16_t one_minus_lam_h, float lam32, float *__restrict__ out,
+                                                          int64_t ldo, unsigned long long *__restrict__ pair_counter, int q0,
+                                                          const unsigned *__restrict__ HB, int rows_per_block,
+                                                          int blocks_per_chunk) {
+    static_assert(64 % PD == 0, "batch boundaries must fall on group boundaries");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t *t = (uint16_t *)smem;            // [rch] + NPF dummy slots
+    const int lane = threadIdx.x;
+    const int64_t i = blockIdx.x;              // local query row: MT / rowmax / out are indexed by it
+    const int64_t ig = (int64_t)q0 + i;        // global row: the sparse V rows are indexed by it
+    const int y = (int)blockIdx.y, nb1 = (int)gridDim.y + 1;
+    const int cnt = qcnt[ig];
+    const int64_t r0 = nq + (int64_t)y * blocks_per_chunk * rows_per_block;
+    const int64_t r_end = r0 + (int64_t)blocks_per_chunk * rows_per_block;
+    const int64_t r1 = r_end < N ? r_end : N;
+    for (int r = lane; r < rch + 8; r += 64) t[r] = 0;
+    const unsigned last = cnt > 0 ? (unsigned)(cptr[N] - 1) : 0u;   // cnt > 0: the index is not empty
+    unsigned pairs = 0;
+    // column indices / values of a batch (lanes past the end: a copy of the last column, marked by v >> 31)
+    auto load_cols = [&](int base, int &c, unsigned &v) {
+        const int idx = base + lane;
+        const int ic = idx < cnt ? idx : cnt - 1;
+        c = qidx[ig * qcap + ic];
+        v = (unsigned)qval[ig * qcap + ic] | (idx < cnt ? 0u : 0x80000000u);
+    };
+    // start (clamped into the index) and (length << 16 | V[i][c]) of the chunk's sub-range of every column of a batch
+    auto resolve = [&](int c, unsigned v, unsigned &p0, unsigned &lenvi) {
+        const unsigned a = HB[(int64_t)c * nb1 + y], b = HB[(int64_t)c * nb1 + y + 1];
+        const unsigned len = (v >> 31) ? 0u : b - a;
+        p0 = a < last ? a : last;
+        lenvi = (len << 16) | (v & 0xffffu);
+        pairs += len;
+    };
+    if (cnt > 0) {
+        unsigned cur_p0, cur_lv, nxt_p0, nxt_lv, v2;
+        int c2;
+        {
+            int c0, c1;
+            unsigned v0, v1;
+            load_cols(0, c0, v0);
+            load_cols(64, c1, v1);
+            load_cols(128, c2, v2);
+            resolve(c0, v0, cur_p0, cur_lv);
+            resolve(c1, v1, nxt_p0, nxt_lv);
+        }
+        unsigned pr[PD][NPF];
+        // (wave-uniform base + 32-bit lane offset; lanes past the column's end read its first entry and are masked when
+        // applied; every gather is unconditional so that hipcc counts the loads in flight exactly)
+        auto fetch = [&](unsigned p0v, unsigned lvv, int a, unsigned (&er)[NPF]) {
+            const int sl = a & 63;
+            const unsigned p0 = (unsigned)__builtin_amdgcn_readlane((int)p0v, sl);
+            const unsigned len = (unsigned)__builtin_amdgcn_readlane((int)lvv, sl) >> 16;
+            const unsigned *cb = cpk + p0;
+#pragma unroll
+            for (int k = 0; k < NPF; ++k) {
+                const unsigned e = (unsigned)(lane + k * 64);
+                er[k] = cb[e < len ? e : 0u];
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < PD; ++d) fetch(cur_p0, cur_lv, d, pr[d]);
+        for (int a0 = 0; a0 < cnt; a0 += PD) {
+            if ((a0 & 63) == 0 && a0 > 0) {   // the apply stream enters the next batch
+                cur_p0 = nxt_p0;
+                cur_lv = nxt_lv;
+                resolve(c2, v2, nxt_p0, nxt_lv);
+                load_cols(a0 + 128, c2, v2);
+            }
+            // the prefetch stream (columns a0 + PD ...) is in the next batch during the last group of a batch
+            const bool f_nxt = ((a0 + PD) >> 6) != (a0 >> 6);
+            const unsigned f_p0 = f_nxt ? nxt_p0 : cur_p0, f_lv = f_nxt ? nxt_lv : cur_lv;
+#pragma unroll
+            for (int d = 0; d < PD; ++d) {
+                const int a = a0 + d;
+                if (a < cnt) {
+                    const unsigned lv = (unsigned)__builtin_amdgcn_readlane((int)cur_lv, a & 63);
+                    const uint16_t vic = (uint16_t)(lv & 0xffffu);
+                    const unsigned len = lv >> 16;
+                    // branch free: lanes without an entry add into a dummy slot behind the accumulators; the NPF entries of
+                    // a lane belong to one column, i.e. to different rows: read all accumulators, add, write
+                    unsigned idx[NPF];
+                    uint16_t tv[NPF];
+#pragma unroll
+                    for (int k = 0; k < NPF; ++k) {
+                        idx[k] = ((unsigned)(lane + k * 64) < len) ? (pr[d][k] >> 16) : (unsigned)(rch + k);
+                        tv[k] = t[idx[k]];
+                    }
+#pragma unroll
+                    for (int k = 0; k < NPF; ++k)
+                        t[idx[k]] = h_add_native(tv[k], mpreid_h_min_nonneg(vic, (uint16_t)(pr[d][k] & 0xffffu)));
+                    if (len > (unsigned)(NPF * 64)) {   // long sub-range: the tail is gathered directly
+                        const unsigned p0 = (unsigned)__builtin_amdgcn_readlane((int)cur_p0, a & 63);
+                        for (unsigned e = (unsigned)(lane + NPF * 64); e < len; e += 64) {
+                            const unsigned pe = cpk[p0 + e];
+                            t[pe >> 16] = h_add_native(t[pe >> 16], mpreid_h_min_nonneg(vic, (uint16_t)(pe & 0xffffu)));
+                        }
+                    }
+                }
+                fetch(f_p0, f_lv, a + PD, pr[d]);
+            }
+        }
+    }
+    if (pair_counter) {
+        unsigned long long ps = pairs;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) ps += __shfl_xor(ps, off, 64);
+        if (lane == 0 && ps) atomicAdd(pair_counter, ps);
+    }
+    // blend: final = fp32(fp16(J * fp16(1 - lambda))) + O[i][j] * lambda for the chunk's gallery columns
+    const float mx = rowmax[i];
+    const float *row = MT + i * ld;
+    const uint16_t H1 = 0x3c00u, H2 = 0x4000u;
+    for (int64_t jb = r0; jb < r1; jb += 8 * 64) {
+        float dv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t j = jb + u * 64 + lane;
+            dv[u] = row[j < r1 ? j : r1 - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t j = jb + u * 64 + lane;
+            if (j < r1) {
+                const uint16_t tv = t[j - r0];
+                const uint16_t den = h_sub_native(H2, tv);
+                const uint16_t qt = h_div_native(tv, den);
+                const uint16_t jac = h_sub_native(H1, qt);
+                const uint16_t jl = h_mul_native(jac, one_minus_lam_h);
+                const float o = __fdiv_rn(dv[u], mx);
+                out[i * ldo + (j - nq)] = h_to_f32(jl) + o * lam32;
+            }
+        }
+    }
+}
+
 // =============================================================================================
 // Candidate pipeline ("sparse" algorithm): initial_rank and the column maxima WITHOUT the N x N matrix.
 //
@@ -1996,7 +2150,15 @@ static int launch_jaccard(int64_t N, int64_t nq, int q0, int64_t qrows, const fl
     // (multi-wave form, N = 20 000 / Market shape: 512 threads <2, 4> 1.58 / 1.42 ms, 256 threads <3, 4> 1.36 / 1.21,
     // <3, 8> the same, <2, 4> 2.05 (columns longer than 512 entries take the direct path), 128 threads <5, 4> 1.72 / 1.50)
     // blocked index = packed entries (csc2_fill_kernel); the atomic build keeps (row, value) in two arrays
-    if (threads == 64) MPREID_JACCARD_LAUNCH(64, 2, 8, true)
+    static const int jtab = getenv("MPREID_JACCARD_TABLE") ? atoi(getenv("MPREID_JACCARD_TABLE")) : 0;   // A/B: LDS table form
+    if (threads == 64 && !jtab) {
+        const size_t wl = align_up((size_t)rch * 2 + 16, 16);
+        int rc = set_dyn_lds(jaccard_wave_kernel<2, 8>, wl);
+        if (rc) return rc;
+        hipLaunchKernelGGL((jaccard_wave_kernel<2, 8>), dim3((unsigned)qrows, (unsigned)nchunks), dim3(64), wl, stream, N, nq, MT,
+                           ld, rowmax, fcnt, fidx, fval, qcap, cptr, (const unsigned *)crow, rch, oml, lam32, out, ldo,
+                           pair_counter, q0, Hp, rpb, bpc);
+    } else if (threads == 64) MPREID_JACCARD_LAUNCH(64, 2, 8, true)
     else if (blocked) MPREID_JACCARD_LAUNCH(JT, 3, 4, true)
     else MPREID_JACCARD_LAUNCH(JT, 3, 4, false)
 #undef MPREID_JACCARD_LAUNCH

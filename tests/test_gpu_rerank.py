@@ -299,7 +299,8 @@ np.savez(sys.argv[1], **res)
 @pytest.mark.parametrize("env", [
     {"MPREID_JACCARD_WAVE": "1", "MPREID_JACCARD_WAVE_ROWS": "1024"},   # one-wave Jaccard form, 3-4 row chunks
     {"MPREID_JACCARD_WAVE": "1", "MPREID_JACCARD_WAVE_ROWS": "256"},    # ... 12-16 chunks of ~250 rows
-    {"MPREID_JACCARD_WAVE": "0"},                                         # 512-thread form
+    {"MPREID_JACCARD_WAVE": "1", "MPREID_JACCARD_WAVE_ROWS": "512", "MPREID_JACCARD_TABLE": "1"},   # ... with the LDS table
+    {"MPREID_JACCARD_WAVE": "0"},                                         # 256-thread form
     {"MPREID_CSC_ATOMIC": "1"},                                           # round-1 atomic inverted index + unchunked Jaccard
     {"MPREID_RERANK_OVERLAP": "1"},                                       # exact query rows on the side stream
 ])
