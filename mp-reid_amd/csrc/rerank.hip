@@ -1519,8 +1519,8 @@ __global__ __launch_bounds__(JT_) void jaccard_kernel(int64_t N, int64_t nq, con
 // In-kernel stamps of the table form at N = 100 000 (per (query, chunk) workgroup, cycles): table set-up 29 k, zeroing
 // 9 k, column loop 325 k (489 per column at 1.5 waves per SIMD), output pass 69 k.
 // ---------------------------------------------------------------------------------------------
-template <int NPF, int PD>
-__global__ __launch_bounds__(64) void jaccard_wave_kernel(int64_t N, int64_t nq, const float *__restrict__ MT, int64_t ld,
+template <int JT_, int NPF, int PD>
+__global__ __launch_bounds__(JT_) void jaccard_wave_kernel(int64_t N, int64_t nq, const float *__restrict__ MT, int64_t ld,
                                                           const float *__restrict__ rowmax, const int *__restrict__ qcnt,
                                                           const int *__restrict__ qidx, const uint16_t *__restrict__ qval,
                                                           int qcap, const long long *__restrict__ cptr,
@@ -1532,7 +1532,8 @@ __global__ __launch_bounds__(64) void jaccard_wave_kernel(int64_t N, int64_t nq,
     static_assert(64 % PD == 0, "batch boundaries must fall on group boundaries");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t *t = (uint16_t *)smem;            // [rch] + NPF dummy slots
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    constexpr bool MULTI = JT_ > 64;   // several waves: one barrier per column keeps the accumulation order
     const int64_t i = blockIdx.x;              // local query row: MT / rowmax / out are indexed by it
     const int64_t ig = (int64_t)q0 + i;        // global row: the sparse V rows are indexed by it
     const int y = (int)blockIdx.y, nb1 = (int)gridDim.y + 1;
@@ -1540,7 +1541,8 @@ __global__ __launch_bounds__(64) void jaccard_wave_kernel(int64_t N, int64_t nq,
     const int64_t r0 = nq + (int64_t)y * blocks_per_chunk * rows_per_block;
     const int64_t r_end = r0 + (int64_t)blocks_per_chunk * rows_per_block;
     const int64_t r1 = r_end < N ? r_end : N;
-    for (int r = lane; r < rch + 8; r += 64) t[r] = 0;
+    for (int r = tid; r < rch + 8; r += JT_) t[r] = 0;
+    if (MULTI) __syncthreads();
     const unsigned last = cnt > 0 ? (unsigned)(cptr[N] - 1) : 0u;   // cnt > 0: the index is not empty
     unsigned pairs = 0;
     // column indices / values of a batch (lanes past the end: a copy of the last column, marked by v >> 31)
@@ -1580,7 +1582,7 @@ __global__ __launch_bounds__(64) void jaccard_wave_kernel(int64_t N, int64_t nq,
             const unsigned *cb = cpk + p0;
 #pragma unroll
             for (int k = 0; k < NPF; ++k) {
-                const unsigned e = (unsigned)(lane + k * 64);
+                const unsigned e = (unsigned)(tid + k * JT_);
                 er[k] = cb[e < len ? e : 0u];
             }
         };
@@ -1609,25 +1611,27 @@ __global__ __launch_bounds__(64) void jaccard_wave_kernel(int64_t N, int64_t nq,
                     uint16_t tv[NPF];
 #pragma unroll
                     for (int k = 0; k < NPF; ++k) {
-                        idx[k] = ((unsigned)(lane + k * 64) < len) ? (pr[d][k] >> 16) : (unsigned)(rch + k);
+                        idx[k] = ((unsigned)(tid + k * JT_) < len) ? (pr[d][k] >> 16) : (unsigned)(rch + k);
                         tv[k] = t[idx[k]];
                     }
 #pragma unroll
                     for (int k = 0; k < NPF; ++k)
                         t[idx[k]] = h_add_native(tv[k], mpreid_h_min_nonneg(vic, (uint16_t)(pr[d][k] & 0xffffu)));
-                    if (len > (unsigned)(NPF * 64)) {   // long sub-range: the tail is gathered directly
+                    if (len > (unsigned)(NPF * JT_)) {   // long sub-range: the tail is gathered directly
                         const unsigned p0 = (unsigned)__builtin_amdgcn_readlane((int)cur_p0, a & 63);
-                        for (unsigned e = (unsigned)(lane + NPF * 64); e < len; e += 64) {
+                        for (unsigned e = (unsigned)(tid + NPF * JT_); e < len; e += JT_) {
                             const unsigned pe = cpk[p0 + e];
                             t[pe >> 16] = h_add_native(t[pe >> 16], mpreid_h_min_nonneg(vic, (uint16_t)(pe & 0xffffu)));
                         }
                     }
                 }
                 fetch(f_p0, f_lv, a + PD, pr[d]);
+                if (MULTI) __syncthreads();
             }
         }
     }
-    if (pair_counter) {
+    if (MULTI) __syncthreads();
+    if (pair_counter && tid < 64) {   // (every wave resolves the same columns: wave 0 reports)
         unsigned long long ps = pairs;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) ps += __shfl_xor(ps, off, 64);
@@ -1637,16 +1641,16 @@ __global__ __launch_bounds__(64) void jaccard_wave_kernel(int64_t N, int64_t nq,
     const float mx = rowmax[i];
     const float *row = MT + i * ld;
     const uint16_t H1 = 0x3c00u, H2 = 0x4000u;
-    for (int64_t jb = r0; jb < r1; jb += 8 * 64) {
+    for (int64_t jb = r0; jb < r1; jb += 8 * JT_) {
         float dv[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int64_t j = jb + u * 64 + lane;
+            const int64_t j = jb + u * JT_ + tid;
             dv[u] = row[j < r1 ? j : r1 - 1];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int64_t j = jb + u * 64 + lane;
+            const int64_t j = jb + u * JT_ + tid;
             if (j < r1) {
                 const uint16_t tv = t[j - r0];
                 const uint16_t den = h_sub_native(H2, tv);
@@ -2151,14 +2155,21 @@ static int launch_jaccard(int64_t N, int64_t nq, int q0, int64_t qrows, const fl
     // <3, 8> the same, <2, 4> 2.05 (columns longer than 512 entries take the direct path), 128 threads <5, 4> 1.72 / 1.50)
     // blocked index = packed entries (csc2_fill_kernel); the atomic build keeps (row, value) in two arrays
     static const int jtab = getenv("MPREID_JACCARD_TABLE") ? atoi(getenv("MPREID_JACCARD_TABLE")) : 0;   // A/B: LDS table form
+    const size_t wl = align_up((size_t)rch * 2 + 16, 16);   // table-free kernels: the accumulators only
     if (threads == 64 && !jtab) {
-        const size_t wl = align_up((size_t)rch * 2 + 16, 16);
-        int rc = set_dyn_lds(jaccard_wave_kernel<2, 8>, wl);
+        int rc = set_dyn_lds(jaccard_wave_kernel<64, 2, 8>, wl);
         if (rc) return rc;
-        hipLaunchKernelGGL((jaccard_wave_kernel<2, 8>), dim3((unsigned)qrows, (unsigned)nchunks), dim3(64), wl, stream, N, nq, MT,
-                           ld, rowmax, fcnt, fidx, fval, qcap, cptr, (const unsigned *)crow, rch, oml, lam32, out, ldo,
+        hipLaunchKernelGGL((jaccard_wave_kernel<64, 2, 8>), dim3((unsigned)qrows, (unsigned)nchunks), dim3(64), wl, stream, N, nq,
+                           MT, ld, rowmax, fcnt, fidx, fval, qcap, cptr, (const unsigned *)crow, rch, oml, lam32, out, ldo,
                            pair_counter, q0, Hp, rpb, bpc);
     } else if (threads == 64) MPREID_JACCARD_LAUNCH(64, 2, 8, true)
+    else if (blocked && !jtab) {
+        int rc = set_dyn_lds(jaccard_wave_kernel<JT, 3, 4>, wl);
+        if (rc) return rc;
+        hipLaunchKernelGGL((jaccard_wave_kernel<JT, 3, 4>), dim3((unsigned)qrows, (unsigned)nchunks), dim3(JT), wl, stream, N, nq,
+                           MT, ld, rowmax, fcnt, fidx, fval, qcap, cptr, (const unsigned *)crow, rch, oml, lam32, out, ldo,
+                           pair_counter, q0, Hp, rpb, bpc);
+    }
     else if (blocked) MPREID_JACCARD_LAUNCH(JT, 3, 4, true)
     else MPREID_JACCARD_LAUNCH(JT, 3, 4, false)
 #undef MPREID_JACCARD_LAUNCH
