@@ -781,8 +781,17 @@ __global__ __launch_bounds__(256) void recip_bits_kernel(const int *__restrict__
 // other -- ~47 iterations of two dependent global loads with 26 active lanes, 130 us per row.  Now a half-wave per
 // candidate, eight candidates per iteration.)  Wave 0 keeps the ordered steps (rank-order compaction of R, bitmap
 // extraction, numpy-order pairwise sum, ordered write of the V row).
+constexpr int KR_HASH_BITS = 9, KR_HASH = 1 << KR_HASH_BITS;   // >= 2 x the largest K (256)
+// dynamic LDS of krecip_kernel (the layout at the top of the kernel)
+static size_t krecip_lds_bytes(bool sparse, int nw, int K, int vcap, int d) {
+    size_t b = (size_t)nw * 4 + KR_HASH * 4 + (size_t)K * 8 + (size_t)vcap * 8;
+    if (sparse) b += (size_t)K * 4 + (size_t)vcap * 2 + 16 + (size_t)((d + 3) & ~3) * 4 + 64 * WXD_STRIDE * 4;
+    return b;
+}
+// (launch bound: four workgroups per CU = at most 128 VGPRs; unconstrained hipcc took 222 for the rarely taken exact-
+// distance path and two workgroups per CU -- 0.53 -> 0.35 ms at N = 20 000 with the bound, 240 B of scratch per lane)
 template <bool SPARSE>
-__global__ __launch_bounds__(256) void krecip_kernel(const float *__restrict__ MT, int64_t ld, int64_t N,
+__global__ __launch_bounds__(256, 4) void krecip_kernel(const float *__restrict__ MT, int64_t ld, int64_t N,
                                                      const float *__restrict__ rowmax, const int *__restrict__ rank,
                                                      int K, int KR, int h, int vcap, int *__restrict__ vcnt,
                                                      int *__restrict__ vidx, uint16_t *__restrict__ vval, int row0,
@@ -792,27 +801,28 @@ __global__ __launch_bounds__(256) void krecip_kernel(const float *__restrict__ M
                                                      const unsigned *__restrict__ rk, const unsigned *__restrict__ rh) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nw = (int)((N + 31) >> 5);
-    unsigned *Rmask = (unsigned *)smem;
-    unsigned *Emask = Rmask + nw;
-    int *fwd = (int *)(Emask + nw);
+    // LDS (krecip_lds_bytes): the expansion bit mask over all N rows, a 512-slot hash set of R (membership tests of the
+    // expansion; a second N-bit mask cost two workgroups per CU at N = 100 000), the lists
+    unsigned *Emask = (unsigned *)smem;
+    int *Rhash = (int *)(Emask + nw);          // [KR_HASH] open addressing, -1 = empty
+    int *fwd = Rhash + KR_HASH;
     int *R = fwd + K;
     int *Elist = R + K;
     float *wbuf = (float *)(Elist + vcap);
     // SPARSE only: exact distances of the first K neighbours (from the refinement), the indices of expansion entries
     // that are not among them, row i of feat and the wave_exact_dists tile (16-byte aligned)
     float *fdist = wbuf + vcap;
-    int *miss = (int *)(fdist + K);
+    uint16_t *miss = (uint16_t *)(fdist + K);  // positions in Elist (< vcap < 65536)
     float *qrow = reinterpret_cast<float *>((reinterpret_cast<uintptr_t>(miss + vcap) + 15) & ~(uintptr_t)15);
     float *xtile = qrow + ((d + 3) & ~3);
+    auto rh_slot = [](int f) -> unsigned { return ((unsigned)f * 2654435761u) >> (32 - KR_HASH_BITS); };
     __shared__ int s_nR, s_nE, s_nmiss;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = blockIdx.x;      // local row
     const int i = row0 + li;        // global row
 
-    for (int w = tid; w < nw; w += 256) {
-        Rmask[w] = 0u;
-        Emask[w] = 0u;
-    }
+    for (int w = tid; w < nw; w += 256) Emask[w] = 0u;
+    for (int w = tid; w < KR_HASH; w += 256) Rhash[w] = -1;
     for (int a = tid; a < K; a += 256) {
         fwd[a] = rank[(int64_t)i * KR + a];
         if (SPARSE) fdist[a] = rankd[(int64_t)i * KR + a];
@@ -835,7 +845,9 @@ __global__ __launch_bounds__(256) void krecip_kernel(const float *__restrict__ M
             if (f) {
                 const int pos = nR + __popcll(m & ((1ull << lane) - 1ull));
                 R[pos] = c;
-                atomicOr(&Rmask[c >> 5], 1u << (c & 31));
+                for (unsigned sl = rh_slot(c);; sl = (sl + 1) & (KR_HASH - 1)) {   // (the entries of a rank row are distinct)
+                    if (atomicCAS(&Rhash[sl], -1, c) == -1) break;
+                }
                 atomicOr(&Emask[c >> 5], 1u << (c & 31));
             }
             nR += __popcll(m);
@@ -867,7 +879,11 @@ __global__ __launch_bounds__(256) void krecip_kernel(const float *__restrict__ M
                     ok = (rh[(int64_t)cand * RB_WORDS + (b >> 5)] >> (b & 31)) & 1u;
                     if (ok) {
                         const int f = cf[b];
-                        inr = (Rmask[f >> 5] >> (f & 31)) & 1u;
+                        for (unsigned sl = rh_slot(f);; sl = (sl + 1) & (KR_HASH - 1)) {
+                            const int hv = Rhash[sl];
+                            if (hv == f) inr = true;
+                            if (hv == f || hv == -1) break;
+                        }
                     }
                 }
                 nRc += __popcll(__ballot(ok) & hmask);
@@ -907,7 +923,7 @@ __global__ __launch_bounds__(256) void krecip_kernel(const float *__restrict__ M
             if (pos >= 0) {
                 wbuf[t] = mpreid_np_expf(-__fdiv_rn(fdist[pos], mx));
             } else {
-                miss[atomicAdd(&s_nmiss, 1)] = t;
+                miss[atomicAdd(&s_nmiss, 1)] = (uint16_t)t;
             }
         }
         __syncthreads();
@@ -916,7 +932,7 @@ __global__ __launch_bounds__(256) void krecip_kernel(const float *__restrict__ M
             const float ni = norms[i];
             for (int t0 = 0; t0 < nmiss; t0 += 64) {
                 const int u = t0 + lane;
-                const int t = u < nmiss ? miss[u] : -1;
+                const int t = u < nmiss ? (int)miss[u] : -1;
                 const float dij = wave_exact_dists(qrow, feat, d, t >= 0 ? Elist[t] : -1, ni, norms, xtile, lane);
                 if (t >= 0) wbuf[t] = mpreid_np_expf(-__fdiv_rn(dij, mx));
             }
@@ -2389,7 +2405,7 @@ static int rerank_dense(const float *q, const float *g, int64_t nq, int64_t ng, 
     tm.mark(); // 2
     // (4)-(6) V rows
     {
-        const size_t lds = (size_t)nw * 8 + (size_t)L.K * 8 + (size_t)L.vcap * 8;
+        const size_t lds = krecip_lds_bytes(false, nw, L.K, L.vcap, 0);
         int rc = set_dyn_lds(krecip_kernel<false>, lds);
         if (rc) return rc;
         unsigned *rk = (unsigned *)(base + L.rbits);
@@ -2662,8 +2678,7 @@ static int rerank_sparse(const float *q, const float *g, int64_t nq, int64_t ng,
     }
     tm.mark(); // 2
     {   // V rows, distances on the fly
-        const size_t lds = (size_t)nw * 8 + (size_t)L.K * 12 + (size_t)L.vcap * 12 + 16 + (size_t)((d + 3) & ~3) * 4 +
-                           64 * WXD_STRIDE * 4;
+        const size_t lds = krecip_lds_bytes(true, nw, L.K, L.vcap, d);
         rc = set_dyn_lds(krecip_kernel<true>, lds);
         if (rc) return rc;
         unsigned *rk = (unsigned *)(base + L.rbits);
@@ -2855,7 +2870,7 @@ extern "C" int mpreid_rr_krecip(const float *d_local, int64_t ld, int64_t n, con
     const int vcap = mpreid_rr_vcap(n, k1);
     ARG_CHECK(d_local && rowmax_local && rank_all && vcnt && vidx && vval && scratch && rows > 0 && kr >= K);
     const int nw = (int)((n + 31) >> 5);
-    const size_t lds = (size_t)nw * 8 + (size_t)K * 8 + (size_t)vcap * 8;
+    const size_t lds = krecip_lds_bytes(false, nw, K, vcap, 0);
     int rc = set_dyn_lds(krecip_kernel<false>, lds);
     if (rc) return rc;
     // reciprocity bits of ALL rows (candidates of a local row live anywhere): recomputed by every rank from the
@@ -3025,7 +3040,7 @@ extern "C" int mpreid_rr_krecip_sparse(const float *feat_all, const float *norms
     ARG_CHECK(feat_all && norms_all && rowmax_local && rank_all && rankd_local && vcnt && vidx && vval && scratch && rows > 0 &&
               kr >= K);
     const int nw = (int)((n + 31) >> 5);
-    const size_t lds = (size_t)nw * 8 + (size_t)K * 12 + (size_t)vcap * 12 + 16 + (size_t)((d + 3) & ~3) * 4 + 64 * WXD_STRIDE * 4;
+    const size_t lds = krecip_lds_bytes(true, nw, K, vcap, d);
     int rc = set_dyn_lds(krecip_kernel<true>, lds);
     if (rc) return rc;
     unsigned *rk = (unsigned *)scratch;
