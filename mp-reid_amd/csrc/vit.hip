@@ -592,9 +592,9 @@ static int attention_dispatch(const _Float16 *qkv, int B, int L, int W, int head
         // (L = 129 = nine query tiles: nine waves, one tile each, measured 123 us against 111 for eight waves with wave 0
         // taking tile 8 as well.  Ablations of the 8-wave kernel, same run: loads + LDS staging alone 61 us, compute on
         // stale LDS alone 80 us, stores 5 us)
-        if (nqt > 4) // 8 waves: two workgroups per CU under the 4-waves/SIMD register bound (wave 0 takes tile 8 too)
-            return exact ? launch_attention<10, 8, true>(qkv, B, L, W, heads, out, q_tiles, stream)
-                         : launch_attention<10, 8, false>(qkv, B, L, W, heads, out, q_tiles, stream);
+        // four waves per workgroup (2-3 query tiles each): 50 KB of LDS = three workgroups per CU and no register
+        // spills; eight waves (two workgroups per CU under a 128-VGPR bound, 44 B of scratch per lane, wave 0 taking
+        // tile 8 as well) measured 113 us against 105 at B = 508, L = 129
         return exact ? launch_attention<10, 4, true>(qkv, B, L, W, heads, out, q_tiles, stream)
                      : launch_attention<10, 4, false>(qkv, B, L, W, heads, out, q_tiles, stream);
     }
