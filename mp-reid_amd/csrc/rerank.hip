@@ -1657,15 +1657,16 @@ __global__ __launch_bounds__(JT_) void jaccard_wave_kernel(int64_t N, int64_t nq
     const float mx = rowmax[i];
     const float *row = MT + i * ld;
     const uint16_t H1 = 0x3c00u, H2 = 0x4000u;
-    for (int64_t jb = r0; jb < r1; jb += 8 * JT_) {
-        float dv[8];
+    constexpr int OU = 16;   // independent loads per thread and trip
+    for (int64_t jb = r0; jb < r1; jb += OU * JT_) {
+        float dv[OU];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < OU; ++u) {
             const int64_t j = jb + u * JT_ + tid;
             dv[u] = row[j < r1 ? j : r1 - 1];
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < OU; ++u) {
             const int64_t j = jb + u * JT_ + tid;
             if (j < r1) {
                 const uint16_t tv = t[j - r0];
