@@ -74,7 +74,7 @@ typedef struct {
     int64_t krecip_r_sum; /* sum over rows of |R(i, k1)| (k-reciprocal set sizes before expansion) */
     int64_t fallback_rows;/* sparse algorithm: rows whose candidate list could not be certified (done densely) */
     int64_t cand_total;   /* sparse algorithm: neighbour candidates emitted by the fused GEMM (sum over rows) */
-    int32_t algo;         /* MPREID_RERANK_DENSE or MPREID_RERANK_SPARSE: what the call actually ran */
+    int32_t algo;         /* MPREID_RERANK_DENSE / _SPARSE / _SPARSE_SPLIT3: what the call actually ran */
     /* filled when timing != 0 (hipEvents on the stream).  DENSE: gemm = N x N exact distances, topk = row maxima +
      * neighbour selection.  SPARSE: gemm = fp16 operands + sample pass + thresholds + fused candidate GEMM, topk =
      * exact refinement + fallback rows, dq = exact distance rows of the queries. */
@@ -95,6 +95,11 @@ typedef struct {
 #define MPREID_RERANK_AUTO 0
 #define MPREID_RERANK_DENSE 1
 #define MPREID_RERANK_SPARSE 2
+/* the sparse algorithm with the blend term's distance rows (lambda * d / max, queries x gallery) from the fp16 matrix
+ * cores (3-term split, |error| <= 1e-6 on unit-norm features) instead of the exact fp32 chain: neighbour table, V, V_qe
+ * and the Jaccard term are bit-identical to the other modes, |final - exact final| <= lambda * 1e-6 / max.  Never chosen
+ * by AUTO. */
+#define MPREID_RERANK_SPARSE_SPLIT3 3
 /* Bytes of device workspace re_ranking needs for this problem (DENSE: dominated by the N x N fp32 distance matrix,
  * 4*N*N; SPARSE: by the sample distances N*N/4 bytes and the query rows 4*nq*N). */
 size_t mpreid_rerank_workspace_bytes(int64_t nq, int64_t ng, int d, int k1, int k2, int has_local);      /* AUTO */

@@ -28,6 +28,11 @@
 int mpreid_distance_launch(const float *q, const float *g, int64_t nq, int64_t ng, int d, const float *qn,
                            const float *gn, float *out, int64_t ldo, int epi, hipStream_t stream,
                            const unsigned *m_count = nullptr);
+// gemm_f16.hip: 3-term fp16-split distances (|error| <= 1e-6 on unit-norm rows)
+int mpreid_distance_f16_split3(const float *q, const float *g, int64_t nq, int64_t ng, int d, const float *qn,
+                               const float *gn, float *out, int64_t ldo, int epi, void *ws, size_t ws_bytes,
+                               hipStream_t stream);
+size_t mpreid_distance_split3_ws_bytes(int64_t nq, int64_t ng, int d);
 
 // ---------------------------------------------------------------------------------------------
 // Native binary16 on the device.  include/mpreid_numerics.h spells numpy's float16 arithmetic out in integer code
@@ -2440,10 +2445,10 @@ struct Rerank2Layout {
     int64_t qcap_bound;
     size_t feat, sqn, feat16, samp16, sampn, sampD, tlo, thi, eps, cnt_lo, cnt_hi, list_lo, list_hi, gstat, rowmax, rank, rankd, rbits,
         fb_count, fb_rows, fb_feat, fb_sqn, fb_D, fb_rowmax, fb_rank, vcnt, vidx, vval, ucnt, qcnt, qidx, qval, ccnt, chist,
-        cptr, crow, cval, dq, counters, total;
+        cptr, crow, cval, dq, counters, dq_ws, dq_ws_bytes, total;
 };
 
-static Rerank2Layout make_layout2(int64_t nq, int64_t ng, int d, int k1, int k2) {
+static Rerank2Layout make_layout2(int64_t nq, int64_t ng, int d, int k1, int k2, bool split3_rows = false) {
     Rerank2Layout L{};
     L.N = nq + ng;
     L.Np = (int64_t)align_up((size_t)L.N, 256);
@@ -2503,6 +2508,8 @@ static Rerank2Layout make_layout2(int64_t nq, int64_t ng, int d, int k1, int k2)
     L.cval = take(N * (size_t)L.qcap_bound * 2);
     L.dq = take((size_t)nq * L.ld * 4);
     L.counters = take(64);
+    L.dq_ws_bytes = split3_rows ? mpreid_distance_split3_ws_bytes(nq, ng, d) : 0;
+    L.dq_ws = take(L.dq_ws_bytes);
     L.total = off;
     return L;
 }
@@ -2543,9 +2550,9 @@ static int side_stream(SideStream **out) {
 
 static int rerank_sparse(const float *q, const float *g, int64_t nq, int64_t ng, int d, int k1, int k2, double lambda_value,
                          float *out, int64_t ldo, void *ws, size_t ws_bytes, mpreid_stream_t stream_,
-                         mpreid_rerank_stats *stats, int timing) {
+                         mpreid_rerank_stats *stats, int timing, bool split3_rows) {
     ARG_CHECK(q && g && out && nq > 0 && ng > 0 && d > 0 && k1 >= 0 && k2 >= 1 && ldo >= ng);
-    const Rerank2Layout L = make_layout2(nq, ng, d, k1, k2);
+    const Rerank2Layout L = make_layout2(nq, ng, d, k1, k2, split3_rows);
     const int64_t N = L.N;
     if (N >= (1ll << 28) - 512) {
         mpreid_set_error("N too large for the sparse algorithm");
@@ -2631,6 +2638,12 @@ static int rerank_sparse(const float *q, const float *g, int64_t nq, int64_t ng,
     // nq columns of dq stay unwritten (20 % of the fp32 matrix work at nq = N / 5)
     auto launch_dq = [&](hipStream_t s, int64_t q0, int64_t rows) -> int {
         if (N == nq || rows <= 0) return MPREID_OK;
+        // MPREID_RERANK_SPARSE_SPLIT3: the rows that only feed the blend term lambda * d / max come from the fp16 matrix
+        // cores (3-term split, |error| <= 1e-6: |delta final| <= lambda * 1e-6 / max); everything discrete -- neighbours,
+        // V, V_qe, the Jaccard term -- is computed exactly as in the bit-parity mode
+        if (split3_rows)
+            return mpreid_distance_f16_split3(feat + (size_t)q0 * d, feat + (size_t)nq * d, rows, N - nq, d, sqn + q0, sqn + nq,
+                                              dq + (size_t)q0 * L.ld + nq, L.ld, 0, base + L.dq_ws, L.dq_ws_bytes, s);
         return mpreid_distance_launch(feat + (size_t)q0 * d, feat + (size_t)nq * d, rows, N - nq, d, sqn + q0, sqn + nq,
                                       dq + (size_t)q0 * L.ld + nq, L.ld, 0, s);
     };
@@ -2705,7 +2718,7 @@ static int rerank_sparse(const float *q, const float *g, int64_t nq, int64_t ng,
     ta.cptr = (long long *)(base + L.cptr); ta.crow = (int *)(base + L.crow); ta.cval = (uint16_t *)(base + L.cval);
     ta.chist = (unsigned *)(base + L.chist);
     ta.counters = counters; ta.MT = dq; ta.ld = L.ld; ta.rowmax = rowmax; ta.out = out; ta.ldo = ldo;
-    ta.lambda_value = lambda_value; ta.algo = MPREID_RERANK_SPARSE;
+    ta.lambda_value = lambda_value; ta.algo = split3_rows ? MPREID_RERANK_SPARSE_SPLIT3 : MPREID_RERANK_SPARSE;
     ta.join = ss ? ss->join : nullptr;
     rc = rerank_tail(ta, stream, tm, stats, 3);
     if (rc) return rc;
@@ -2730,9 +2743,10 @@ static int rerank_sparse(const float *q, const float *g, int64_t nq, int64_t ng,
 
 extern "C" size_t mpreid_rerank_workspace_bytes_ex(int64_t nq, int64_t ng, int d, int k1, int k2, int has_local, int algo) {
     if (nq < 0 || ng < 0 || d <= 0 || k1 < 0 || k2 < 1) return 0;
-    const bool sparse = algo == MPREID_RERANK_SPARSE ||
+    const bool sparse = algo == MPREID_RERANK_SPARSE || algo == MPREID_RERANK_SPARSE_SPLIT3 ||
                         (algo == MPREID_RERANK_AUTO && sparse_eligible(nq, ng, k1, k2, has_local ? (const float *)1 : nullptr));
-    return sparse ? make_layout2(nq, ng, d, k1, k2).total : make_layout(nq, ng, d, k1, k2, has_local).total;
+    return sparse ? make_layout2(nq, ng, d, k1, k2, algo == MPREID_RERANK_SPARSE_SPLIT3).total
+                  : make_layout(nq, ng, d, k1, k2, has_local).total;
 }
 extern "C" size_t mpreid_rerank_workspace_bytes(int64_t nq, int64_t ng, int d, int k1, int k2, int has_local) {
     return mpreid_rerank_workspace_bytes_ex(nq, ng, d, k1, k2, has_local, MPREID_RERANK_AUTO);
@@ -2742,14 +2756,17 @@ extern "C" int mpreid_rerank_f32_ex(const float *q, const float *g, int64_t nq, 
                                     double lambda_value, const float *local, int only_local, float *out, int64_t ldo,
                                     void *ws, size_t ws_bytes, mpreid_stream_t stream, mpreid_rerank_stats *stats,
                                     int timing, int algo) {
-    ARG_CHECK(algo == MPREID_RERANK_AUTO || algo == MPREID_RERANK_DENSE || algo == MPREID_RERANK_SPARSE);
+    ARG_CHECK(algo == MPREID_RERANK_AUTO || algo == MPREID_RERANK_DENSE || algo == MPREID_RERANK_SPARSE ||
+              algo == MPREID_RERANK_SPARSE_SPLIT3);
     const bool eligible = sparse_eligible(nq, ng, k1, k2, local);
-    if (algo == MPREID_RERANK_SPARSE && !eligible) {
+    const bool want_sparse = algo == MPREID_RERANK_SPARSE || algo == MPREID_RERANK_SPARSE_SPLIT3;
+    if (want_sparse && !eligible) {
         mpreid_set_error("the sparse re-ranking algorithm needs N >= 2048, max(k1+1, k2) <= 64 and no local_distmat");
         return MPREID_ERR_UNSUPPORTED;
     }
-    if (algo == MPREID_RERANK_SPARSE || (algo == MPREID_RERANK_AUTO && eligible))
-        return rerank_sparse(q, g, nq, ng, d, k1, k2, lambda_value, out, ldo, ws, ws_bytes, stream, stats, timing);
+    if (want_sparse || (algo == MPREID_RERANK_AUTO && eligible))
+        return rerank_sparse(q, g, nq, ng, d, k1, k2, lambda_value, out, ldo, ws, ws_bytes, stream, stats, timing,
+                             algo == MPREID_RERANK_SPARSE_SPLIT3);
     return rerank_dense(q, g, nq, ng, d, k1, k2, lambda_value, local, only_local, out, ldo, ws, ws_bytes, stream, stats,
                         timing);
 }
@@ -2772,10 +2789,10 @@ extern "C" int mpreid_rerank_debug_copy(const void *ws, int64_t nq, int64_t ng, 
 extern "C" int mpreid_rerank_debug_copy_ex(const void *ws, int64_t nq, int64_t ng, int d, int k1, int k2, int has_local,
                                            int32_t *rank_out, int32_t *v_cnt, int32_t *vqe_cnt,
                                            mpreid_stream_t stream_, int algo) {
-    ARG_CHECK(ws && (algo == MPREID_RERANK_DENSE || algo == MPREID_RERANK_SPARSE));
+    ARG_CHECK(ws && (algo == MPREID_RERANK_DENSE || algo == MPREID_RERANK_SPARSE || algo == MPREID_RERANK_SPARSE_SPLIT3));
     // the fields the taps read, from whichever layout the call used
     struct { int64_t N; int K, KR; size_t rank, vcnt, qcnt; } L;
-    if (algo == MPREID_RERANK_SPARSE) {
+    if (algo != MPREID_RERANK_DENSE) {
         const Rerank2Layout s2 = make_layout2(nq, ng, d, k1, k2);
         L.N = s2.N; L.K = s2.K; L.KR = s2.KR; L.rank = s2.rank; L.vcnt = s2.vcnt; L.qcnt = s2.qcnt;
     } else {

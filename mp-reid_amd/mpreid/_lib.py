@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("MPREID_LIB") or os.path.join(_HERE, "libmpreid_hip.so
 GEMM_F32_EXACT = 0
 GEMM_F16_FAST = 1
 GEMM_F16_SPLIT3 = 2
-RERANK_AUTO, RERANK_DENSE, RERANK_SPARSE = 0, 1, 2
+RERANK_AUTO, RERANK_DENSE, RERANK_SPARSE, RERANK_SPARSE_SPLIT3 = 0, 1, 2, 3
 ERR_RETRY_DENSE = -5
 
 #: every symbol include/mpreid.h declares (tests check the library exports all of them)

@@ -12,7 +12,7 @@ import torch
 
 from . import _lib
 from ._lib import GEMM_F16_FAST, GEMM_F16_SPLIT3, GEMM_F32_EXACT  # noqa: F401  (re-exported)
-from ._lib import RERANK_AUTO, RERANK_DENSE, RERANK_SPARSE  # noqa: F401
+from ._lib import RERANK_AUTO, RERANK_DENSE, RERANK_SPARSE, RERANK_SPARSE_SPLIT3  # noqa: F401
 
 _ws_cache: Dict[tuple, torch.Tensor] = {}
 
@@ -109,7 +109,9 @@ def re_ranking(q, g, k1: int, k2: int, lambda_value: float, local_distmat=None, 
     """utils/reranking.py:29-100 on the GPU.  Returns (device tensor [nq, ng] fp32, stats dict)
     and, with debug=True, additionally (initial_rank[:, :k1+1], nnz(V) per row, nnz(V_qe) per row).
     algo: RERANK_AUTO (the candidate pipeline without the N x N matrix when it applies, else the dense one; a sparse
-    call that hits a data-dependent capacity is repeated densely), RERANK_DENSE, RERANK_SPARSE -- same bits."""
+    call that hits a data-dependent capacity is repeated densely), RERANK_DENSE, RERANK_SPARSE -- same bits;
+    RERANK_SPARSE_SPLIT3: the sparse algorithm with the blend term's distance rows from the fp16 matrix cores (3-term
+    split): neighbour table / V / V_qe / Jaccard term bit-identical, |final - exact| <= lambda * 1e-6 / max."""
     dev = _lib.require_gpu()
     L = _lib.load()
     q, g = _dev_f32(q, dev), _dev_f32(g, dev)

@@ -326,3 +326,25 @@ def test_rerank_kernel_forms_against_oracle(tmp_path, env):
         f, _ = synth.clustered_features(n, d, 2.5, seed=77 + n, per_id=10)
         want = orc.re_ranking(f[:nq], f[nq:], k1, k2, 0.3)
         assert np.array_equal(got[f"{n}_{algo}"], want), (env, n, algo)
+
+
+@pytest.mark.parametrize("n,nq,d,k1,k2", [(3000, 600, 256, 50, 15), (2500, 333, 768, 20, 6), (4096, 1000, 1280, 50, 15)])
+def test_rerank_split3_rows_mode(ops, n, nq, d, k1, k2):
+    """RERANK_SPARSE_SPLIT3: only the blend term's distances come from the fp16 matrix cores -- the discrete results
+    (neighbour table, nnz of V / V_qe) equal the oracle's exactly and the output differs by at most lambda * 1e-6 / max"""
+    from mpreid import synth
+    f, pid = synth.clustered_features(n, d, 2.5, seed=500 + n, per_id=10)
+    q, g = torch.from_numpy(f[:nq]), torch.from_numpy(f[nq:])
+    got, st, rank, vc, vq = ops.re_ranking(q, g, k1, k2, 0.3, debug=True, algo=ops.RERANK_SPARSE_SPLIT3)
+    assert st["algo"] == ops.RERANK_SPARSE_SPLIT3
+    want, orank, ovc, ovq = orc.re_ranking(f[:nq], f[nq:], k1, k2, 0.3, debug=True)
+    assert np.array_equal(rank, orank) and np.array_equal(vc, ovc) and np.array_equal(vq, ovq)
+    diff = np.abs(got.cpu().numpy() - want)
+    assert diff.max() <= 1e-6, diff.max()
+    exact, _ = ops.re_ranking(q, g, k1, k2, 0.3, algo=ops.RERANK_SPARSE)
+    assert np.array_equal(exact.cpu().numpy(), want)
+    # ranking metrics are unchanged
+    from utils.metrics import eval_func
+    c1, m1 = eval_func(got.cpu().numpy(), pid[:nq], pid[nq:], None, None)
+    c2, m2 = eval_func(want, pid[:nq], pid[nq:], None, None)
+    assert abs(m1 - m2) <= 1e-6 and np.abs(c1 - c2).max() <= 1e-6
