@@ -123,6 +123,7 @@ class R1_mAP_eval():
         self.feat_norm = feat_norm      # used as a truth value, like upstream ('yes' and 'no' both normalise)
         self.reranking = reranking
         self.distance_mode = _ops.GEMM_F32_EXACT
+        self.rerank_algo = _ops.RERANK_AUTO   # _ops.RERANK_SPARSE_SPLIT3: faster at large N, outputs within 1e-6
         self.last_rerank_stats = None
 
     def reset(self):
@@ -151,7 +152,8 @@ class R1_mAP_eval():
         g_camids = np.asarray(self.camids[self.num_query:])
         if self.reranking:
             print('=> Enter reranking')
-            dist, self.last_rerank_stats = re_ranking_device(qf, gf, k1=50, k2=15, lambda_value=0.3)
+            dist, self.last_rerank_stats = re_ranking_device(qf, gf, k1=50, k2=15, lambda_value=0.3,
+                                                             algo=getattr(self, "rerank_algo", 0))
             # the evaluator is called once per run: do not keep the re-ranking workspace (GBs at MSMT17 scale)
             # pinned beside the encoder's for the rest of the process
             _ops.release_workspaces("rerank")

@@ -16,10 +16,13 @@ import torch
 from mpreid import ops as _ops
 
 
-def re_ranking_device(probFea, galFea, k1, k2, lambda_value, local_distmat=None, only_local=False, timing=False):
-    """Same computation, result left on the GPU; returns (tensor [nq, ng], stats dict)."""
+def re_ranking_device(probFea, galFea, k1, k2, lambda_value, local_distmat=None, only_local=False, timing=False,
+                      algo=_ops.RERANK_AUTO):
+    """Same computation, result left on the GPU; returns (tensor [nq, ng], stats dict).  algo: mpreid.ops.RERANK_AUTO
+    (bit-parity, the default) ... RERANK_SPARSE_SPLIT3 (blend-term distances from the fp16 matrix cores, outputs within
+    1e-6, ranks identical; the large-N option)."""
     return _ops.re_ranking(probFea, galFea, k1, k2, lambda_value, local_distmat=local_distmat,
-                           only_local=only_local, timing=timing)
+                           only_local=only_local, timing=timing, algo=algo)
 
 
 def re_ranking(probFea, galFea, k1, k2, lambda_value, local_distmat=None, only_local=False):
