@@ -355,7 +355,9 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
     // FETCH_SIZE vs 105 MB algorithmic on the FC1 shape.)
     const int ntiles = tiles_m * tiles_n;
     const int nb = (int)gridDim.x;
-    const bool owned = (tiles_m % 8 == 0) && (nb % 8 == 0);
+    // (only when the groups divide evenly among the eight XCDs: with tiles_m = 16 -- the 4000 x 16 000 distance rows of
+    // the re-ranking -- two XCDs owned everything and the other six idled: 1.12 ms instead of 0.4)
+    const bool owned = (tiles_m % 64 == 0) && (nb % 8 == 0);
     // Any other shape on a full grid (the distance GEMMs: 79 x 79 tiles at N = 20 000): "blocked" walk.  In round r
     // XCD x works on block r*8 + x of the tile grid cut into blocks of 8 tile rows x (CUs per XCD / 8) tile columns
     // (8 x 4 on 256 CUs), one tile per CU: 12 operand panels feed 32 tiles.  (The plain grouped walk gave an XCD ONE
