@@ -297,6 +297,14 @@ def extras(ops, dev, with_widened=True):
     sd.update(nq=4000, d=768)
     out["rerank_dense_algorithm_ms"] = round(sd["ms_total"], 3)
     out["rerank_dense_stages_ms"] = {k[3:]: round(v, 3) for k, v in sd.items() if k.startswith("ms_") and k != "ms_total"}
+    # the same call with the blend term's distance rows from the fp16 matrix cores (RERANK_SPARSE_SPLIT3: discrete
+    # results identical, outputs within 1e-6) -- reported beside the bit-parity figure, never instead of it
+    ref_out, _ = ops.re_ranking(ft[:4000], ft[4000:], 50, 15, 0.3)
+    s3_out, s3 = ops.re_ranking(ft[:4000], ft[4000:], 50, 15, 0.3, timing=True, algo=ops.RERANK_SPARSE_SPLIT3)
+    _, s3 = ops.re_ranking(ft[:4000], ft[4000:], 50, 15, 0.3, timing=True, algo=ops.RERANK_SPARSE_SPLIT3)
+    out["rerank_split3_rows_ms"] = round(s3["ms_total"], 3)
+    out["rerank_split3_rows_max_abs_diff_vs_exact"] = float((s3_out - ref_out).abs().max())
+    del ref_out, s3_out
     ms = timed_ms(lambda: ops.re_ranking(ft[:4000], ft[4000:], 50, 15, 0.3), 3)
     out["rerank_N20000_untimed_stages_ms"] = round(ms, 3)
     out["distmat_plus_rerank_20kx20k_ms"] = round(ms, 3)   # the re-rank computes its own all-pairs distance matrix
