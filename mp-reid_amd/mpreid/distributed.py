@@ -87,12 +87,13 @@ def gather_column_blocks_to_host(block: torch.Tensor, dst: int = 0):
 # Row-sharded k-reciprocal re-ranking (SURVEY.md §8e, row "Re-rank")
 #
 #   phase 1  rows [r_lo, r_hi) of D = all-pairs distance, row maxima, first max(k1+1, k2) neighbours
-#            -> ALL-GATHER rank table [N][KR] int32
+#            -> ALL-GATHER rank table [N][KR] int32 (+ one column: the float bits of the row maxima)
 #   phase 2  k-reciprocal expansion -> sparse V rows of the local rows
 #            -> ALL-GATHER V (ELL rows re-strided to the global max count)
 #   phase 3  local query expansion of the local rows (skipped when k2 == 1)
 #            -> ALL-GATHER V_qe
-#   phase 4  queries sharded nq/P: distance rows of the local queries, inverted index of V_qe, Jaccard + blend
+#   phase 4  queries sharded nq/P: distance rows of the local queries over the gallery columns, inverted index of V_qe
+#            (gallery rows), Jaccard + blend
 #            -> each rank owns final_dist[q_lo:q_hi, nq:]; row blocks are concatenated on the host
 #
 # Phases 1-2 have a SPARSE form (default when N >= 2048 and max(k1+1, k2) <= 64): no [N/P][N] distance block per rank --
@@ -113,7 +114,10 @@ class _RerankShard:
 
     def __init__(self, feat_all, norms_all, nq, k1, k2, lam, rank, world, algo=0):
         from . import _lib
-        self.algo = algo          # _lib.RERANK_AUTO / RERANK_DENSE / RERANK_SPARSE for phases 1-2 of this rank
+        # _lib.RERANK_AUTO / RERANK_DENSE / RERANK_SPARSE for phases 1-2 of this rank; RERANK_SPARSE_SPLIT3: sparse phases
+        # and the blend term's distance rows of phase 4 from the fp16 matrix cores (outputs within 1e-6)
+        self.split3_rows = algo == _lib.RERANK_SPARSE_SPLIT3
+        self.algo = _lib.RERANK_SPARSE if self.split3_rows else algo
         self.sparse = False
         self.L = _lib.load()
         self.lib = _lib
@@ -128,6 +132,7 @@ class _RerankShard:
         self.ld = (self.N + 63) // 64 * 64
         self.dev = feat_all.device
         self.vcap = self.L.mpreid_rr_vcap(self.N, k1)
+        self.rowmax_all = None   # [N] fp32 once the extended rank table has been gathered
 
     def phase1(self):
         t, dev = torch, self.dev
@@ -159,6 +164,18 @@ class _RerankShard:
                                                       _rr_ptr(rank_local), self.KR, self.lib.stream_ptr()),
                            "mpreid_rr_dist_rows")
         return rank_local
+
+    def phase1_ext(self):
+        """phase 1 + the row maxima as one more int32 column (their float bits): the all-gather of the rank table then
+        carries them to the ranks that own those rows as QUERIES in phase 4 -- no fourth collective"""
+        rank_local = self.phase1()
+        rm = self.rowmax[:self.rows].contiguous().view(torch.int32).reshape(self.rows, 1)
+        return torch.cat([rank_local, rm], dim=1).contiguous()
+
+    @staticmethod
+    def split_ext(ext, kr):
+        """gathered [N][KR + 1] table -> (rank table [N][KR], row maxima [N] fp32)"""
+        return ext[:, :kr].contiguous(), ext[:, kr].contiguous().view(torch.float32)
 
     def phase2(self, rank_all):
         t, dev = torch, self.dev
@@ -226,10 +243,19 @@ class _RerankShard:
             return out
         self.D = None  # the row block of phase 1 (dense phases) is no longer needed
         dq = t.empty((qrows, self.ld), dtype=t.float32, device=dev)
-        rmq = t.empty(qrows, dtype=t.float32, device=dev)
-        self.lib.check(self.L.mpreid_rr_dist_rows(_rr_ptr(self.feat), _rr_ptr(self.norms), self.N, self.d, self.q_lo, qrows,
-                                                  _rr_ptr(dq), self.ld, _rr_ptr(rmq), None, 0, self.lib.stream_ptr()),
-                       "mpreid_rr_dist_rows")
+        if self.rowmax_all is not None:
+            # the row maxima travelled with the rank table: only the GALLERY columns of the query rows are needed (the
+            # blend of final_dist[:nq, nq:]), exact or -- RERANK_SPARSE_SPLIT3 -- from the fp16 matrix cores
+            from . import ops
+            rmq = self.rowmax_all[self.q_lo:self.q_hi].contiguous()
+            ops.euclidean_distance(self.feat[self.q_lo:self.q_hi], self.feat[self.nq:],
+                                   mode=ops.GEMM_F16_SPLIT3 if self.split3_rows else ops.GEMM_F32_EXACT, out=dq,
+                                   col_offset=self.nq)
+        else:
+            rmq = t.empty(qrows, dtype=t.float32, device=dev)
+            self.lib.check(self.L.mpreid_rr_dist_rows(_rr_ptr(self.feat), _rr_ptr(self.norms), self.N, self.d, self.q_lo,
+                                                      qrows, _rr_ptr(dq), self.ld, _rr_ptr(rmq), None, 0,
+                                                      self.lib.stream_ptr()), "mpreid_rr_dist_rows")
         nnz = int(qcnt_all.sum().item())
         ccnt = t.empty(self.N + 1, dtype=t.int32, device=dev)
         cptr = t.empty(self.N + 1, dtype=t.int64, device=dev)
@@ -273,7 +299,7 @@ def re_ranking_sharded(qf_all, gf_all, k1, k2, lambda_value, algo=0):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return int(tt.item())
 
-    rank_all = all_gather_rows(sh.phase1(), N)
+    rank_all, sh.rowmax_all = sh.split_ext(all_gather_rows(sh.phase1_ext(), N), sh.KR)
     w = max(gmax(sh.phase2(rank_all)), 1)
     vc, vi, vv = sh.pack_v(w)
     vc, vi, vv = all_gather_rows(vc, N), all_gather_rows(vi, N), all_gather_rows(vv, N)
@@ -304,11 +330,14 @@ def re_ranking_virtual(qf_all, gf_all, k1, k2, lambda_value, world, algo=0, timi
     feat, norms = _rr_prepare(qf_all, gf_all)
     nq = qf_all.shape[0]
     shards = [_RerankShard(feat, norms, nq, int(k1), int(k2), float(lambda_value), r, world, algo) for r in range(world)]
-    rank_all = torch.cat([timed("phase1_neighbours", s.phase1) for s in shards], dim=0)
+    rank_all, rowmax_all = _RerankShard.split_ext(torch.cat([timed("phase1_neighbours", s.phase1_ext) for s in shards], dim=0),
+                                                  shards[0].KR)
+    for s in shards:
+        s.rowmax_all = rowmax_all
     w = max(max(timed("phase2_krecip", lambda s=s: s.phase2(rank_all)) for s in shards), 1)
     packs = [s.pack_v(w) for s in shards]
     vc, vi, vv = (torch.cat([p[i] for p in packs], dim=0) for i in range(3))
-    gathers = {"rank_table": rank_all.numel() * 4, "V": vc.numel() * 4 + vi.numel() * 4 + vv.numel() * 2}
+    gathers = {"rank_table": rank_all.numel() * 4 + rowmax_all.numel() * 4, "V": vc.numel() * 4 + vi.numel() * 4 + vv.numel() * 2}
     if k2 != 1:
         qcap = max(max(timed("phase3_qe_count", lambda s=s: s.phase3_count(vc, vi, vv)) for s in shards), 1)
         fills = [timed("phase3_qe_fill", lambda s=s: s.phase3_fill(qcap)) for s in shards]

@@ -348,3 +348,17 @@ def test_rerank_split3_rows_mode(ops, n, nq, d, k1, k2):
     c1, m1 = eval_func(got.cpu().numpy(), pid[:nq], pid[nq:], None, None)
     c2, m2 = eval_func(want, pid[:nq], pid[nq:], None, None)
     assert abs(m1 - m2) <= 1e-6 and np.abs(c1 - c2).max() <= 1e-6
+
+
+def test_sharded_split3_rows_mode(ops):
+    """the row-sharded phases with RERANK_SPARSE_SPLIT3: 3 virtual ranks give the single call's bits (same mode), and
+    both stay within 1e-6 of the exact result"""
+    from mpreid import distributed as D, synth
+    n, nq, d = 3000, 640, 256
+    f, _ = synth.clustered_features(n, d, 2.5, seed=99, per_id=10)
+    ft = torch.from_numpy(f).cuda()
+    single, _ = ops.re_ranking(ft[:nq], ft[nq:], 50, 15, 0.3, algo=ops.RERANK_SPARSE_SPLIT3)
+    virt = D.re_ranking_virtual(ft[:nq], ft[nq:], 50, 15, 0.3, 3, algo=ops.RERANK_SPARSE_SPLIT3)
+    exact, _ = ops.re_ranking(ft[:nq], ft[nq:], 50, 15, 0.3)
+    assert float((virt - exact).abs().max()) <= 1e-6 and float((single - exact).abs().max()) <= 1e-6
+    assert float((virt - single).abs().max()) <= 1e-6
