@@ -239,9 +239,11 @@ def rerank_roofline(st):
             4.0 * N * ((k1 + 1) ** 2 + rbar * (h + h * h)), f"mean |R| = {rbar:.1f}")
     add("rerank.qe", "qe_count/fill_kernel", st["ms_qe"], "hbm", 6.0 * st["v_nnz"] * (1 + k2))
     # the inverted index holds the gallery rows only: ~ng/N of the V_qe entries are read (6 B) and written (6 B)
-    add("rerank.csc", "csc2_*", st["ms_csc"], "hbm", 12.0 * st["vqe_nnz"] * (ng / max(N, 1)),
+    add("rerank.csc", "csc2_*", st["ms_csc"], "hbm", 10.0 * st["vqe_nnz"] * (ng / max(N, 1)),
         "inverted index of the gallery rows (the accumulators of the query rows are never read)")
-    add("rerank.jaccard", "jaccard_kernel", st["ms_jaccard"], "hbm", 6.0 * st["jaccard_pairs"] + 8.0 * nq * ng)
+    # packed index entries: 4 B per gathered (row, value) pair (6 B with the round-1 layout)
+    add("rerank.jaccard", "jaccard_wave_kernel", st["ms_jaccard"], "hbm", 4.0 * st["jaccard_pairs"] + 8.0 * nq * ng,
+        "algorithmic: 4 B per pair of the gallery-row inverted index + the distance row read and the result written")
     return rows
 
 
