@@ -628,7 +628,9 @@ static int launch_rowmax_topk(const float *MT, int64_t ld, int64_t N, int KR, in
 // k-reciprocal sets + 2/3-overlap expansion + exp weights -> V row (ELL).  One wave per row.
 // utils/reranking.py:51-71
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int extract_bits_sorted(const unsigned *mask, int nw, int *list, int lane) {
+// wpre (optional): wpre[w] = number of set bits below word w, written for the words of every non-empty group of 64 (the
+// only ones a set bit can live in): slot(c) = wpre[c >> 5] + popc(mask[c >> 5] & below(c))
+__device__ __forceinline__ int extract_bits_sorted(const unsigned *mask, int nw, int *list, int lane, int *wpre = nullptr) {
     int base = 0;
     for (int w0 = 0; w0 < nw; w0 += 64) {
         const int w = w0 + lane;
@@ -636,6 +638,7 @@ __device__ __forceinline__ int extract_bits_sorted(const unsigned *mask, int nw,
         if (__ballot(word != 0u) == 0ull) continue;
         int tot;
         int pos = base + wave_excl_scan(__popc(word), lane, tot);
+        if (wpre && w < nw) wpre[w] = pos;
         while (word) {
             const int b = __ffs((int)word) - 1;
             word &= word - 1u;
@@ -1051,17 +1054,9 @@ __global__ __launch_bounds__(64) void qe_fill_kernel(int64_t N, const int *__res
     qe_walk<false>(rank, (int64_t)i, KR, k2, vcnt, vidx, nullptr, vcap, lane,
                    [&](int c, uint16_t) { atomicOr(&mask[c >> 5], 1u << (c & 31)); });
     __syncthreads();
-    // word prefix (exclusive popcount) so that slot(c) = wpre[c>>5] + popc(mask[c>>5] & below(c))
-    int base = 0;
-    for (int w0 = 0; w0 < nw; w0 += 64) {
-        const int w = w0 + lane;
-        const int pc = (w < nw) ? __popc(mask[w]) : 0;
-        int tot;
-        const int ex = wave_excl_scan(pc, lane, tot);
-        if (w < nw) wpre[w] = base + ex;
-        base += tot;
-    }
-    const int nU = base;
+    // sorted union (np.unique) and, as a by-product of the same scan, the word prefix: slot(c) = wpre[c>>5] +
+    // popc(mask[c>>5] & below(c))   (one pass over the N-bit mask instead of two)
+    const int nU = extract_bits_sorted(mask, nw, ulist, lane, wpre);
     __syncthreads();
     // fp32 accumulation in rank order; one writer per slot and neighbour (a one-wave workgroup: its LDS operations
     // execute in program order)
@@ -1069,8 +1064,6 @@ __global__ __launch_bounds__(64) void qe_fill_kernel(int64_t N, const int *__res
         const int slot = wpre[c >> 5] + __popc(mask[c >> 5] & ((1u << (c & 31)) - 1u));
         acc[slot] = acc[slot] + h_to_f32(hv);
     });
-    __syncthreads();
-    extract_bits_sorted(mask, nw, ulist, lane);
     __syncthreads();
     const float k2f = (float)k2;
     int out = 0;
