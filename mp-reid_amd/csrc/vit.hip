@@ -229,6 +229,24 @@ __device__ __forceinline__ void store_nt16(_Float16 *p, const uint4 &v) {
         ATT_FOR_EACH_ITER(ATT_LOAD)                                                                  \
     }
 
+// All-reduce over the lanes l, l^16, l^32, l^48 (the four key groups of a query column) with gfx950's
+// v_permlane16_swap / v_permlane32_swap: with both operands = x, the two results hold (own, partner) in one order or the
+// other for every lane, so op(r[0], r[1]) is the xor-16 (then xor-32) exchange -- two VALU operations per step where
+// __shfl_xor compiles to ds_bpermute_b32 (an LDS crossbar round trip, ~120 cycles; four per query tile).  Same bits: the
+// operations are commutative.
+__device__ __forceinline__ float xor16_32_max(float x) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor16_32_sum(float x) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 typedef short att_s4 __attribute__((__vector_size__(4 * sizeof(short))));
 typedef __attribute__((address_space(3))) att_s4 att_lds_s4;
 
@@ -318,8 +336,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && KTP <= 10) ? 4 : 2) void atten
             }
             mx = fmaxf(mx, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = xor16_32_max(mx);
         // p = exp2(s*c - mx*c): one fma + one v_exp per element; masked entries give exp2(-huge) = 0
         const float nmx = -mx * scale_log2e;
         float sum = 0.f;
@@ -331,8 +348,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && KTP <= 10) ? 4 : 2) void atten
                 s[kt][r] = p;
                 sum += p;
             }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = xor16_32_sum(sum);
         // O^T = V^T P^T over 32-key steps; P^T fragment element j <-> key 32*s2 + 16*(j>>2) + 4*fq + (j&3)
         // (V^T columns past L are zero in LDS and their P is 0, so every step runs unconditionally)
         f32x4 o[4];
