@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--rerank", action="store_true",
                     help="also run k-reciprocal re-ranking (k1=50, k2=15, lambda=0.3) in every step "
                          "(rows sharded over the ranks when N > 1)")
+    ap.add_argument("--rerank-algo", choices=("exact", "split3"), default="exact",
+                    help="re-ranking: bit-parity mode (default) or RERANK_SPARSE_SPLIT3 (the blend term's distance rows from "
+                         "the fp16 matrix cores: ranks and sparse vectors identical, outputs within 1e-6)")
     ap.add_argument("--dist-mode", choices=("exact", "f16", "split3"), default="exact",
                     help="arithmetic of the distance GEMM blocks: exact fp32 MFMA (parity mode), one-pass fp16 "
                          "(speed mode, |err| ~1e-4), 3-term fp16 split (|err| <= 1e-6)")
@@ -470,7 +473,8 @@ def run_rank(a):
         ops.euclidean_distance(qf, fg, mode=mode, out=block)
         if a.rerank:
             gf_all = gather_rows(fg, ng_total)          # every rank needs all features for its rows of the N x N problem
-            rr = D.re_ranking_sharded(qf, gf_all, 50, 15, 0.3)   # this rank's final_dist[q_lo:q_hi, nq:]
+            rr = D.re_ranking_sharded(qf, gf_all, 50, 15, 0.3,   # this rank's final_dist[q_lo:q_hi, nq:]
+                                      algo=ops.RERANK_SPARSE_SPLIT3 if a.rerank_algo == "split3" else ops.RERANK_AUTO)
             assert rr.shape[1] == ng_total
             rr_holder["rr"] = rr
 
@@ -563,7 +567,9 @@ def run_rank(a):
                      f"sharded over {world} GPU(s), all-gather query features, euclidean distmat "
                      f"[{nq} x {ng_total}/{world}] per GPU ({a.dist_mode})",
         }[wl] + (", plus k-reciprocal re-ranking (k1=50, k2=15, lambda=0.3) of all queries against the whole gallery, "
-                 "rows sharded over the GPUs" if a.rerank else ", no re-rank")
+                 "rows sharded over the GPUs" + (" [RERANK_SPARSE_SPLIT3: blend-term distances from the fp16 matrix cores, "
+                                                   "outputs within 1e-6 of the bit-parity mode]" if a.rerank_algo == "split3" else "")
+                 if a.rerank else ", no re-rank")
         res = {
             "metric": METRIC,
             "value": round(images_per_step * a.steps / dt, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps,

@@ -11,6 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
 python3 $R/bench.py --workload synth --rerank --steps 2 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_synth_rerank.json 2>> $OUT/bench.err
 python3 $R/bench.py --workload synth --dist-mode split3 --steps 3 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_synth_split3.json 2>> $OUT/bench.err
+python3 $R/bench.py --workload synth --rerank --rerank-algo split3 --dist-mode split3 --steps 2 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_synth_rerank_split3.json 2>> $OUT/bench.err
 python3 $R/bench.py --workload msmt17 --rerank --steps 1 --warmup 1 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_msmt17_rerank.json 2>> $OUT/bench.err
 python3 $R/bench.py --rerank --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_market_rerank.json 2>> $OUT/bench.err
 # 2. kernel trace + stats of the same bench command (single stream so that durations do not overlap)
