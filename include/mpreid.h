@@ -207,7 +207,21 @@ typedef struct {
     int32_t width, layers, heads, out_dim; /* 768, 12, 12, 512 */
     int32_t neck_after;     /* TEST.NECK_FEAT == 'after': apply the eval BatchNorm necks */
     int32_t cls_only_last;  /* 1: last block computes only the CLS row (the only row the output uses) */
+    int32_t precision;      /* MPREID_VIT_F16 or MPREID_VIT_SPLIT (the all-fp32 mode is mpreid_vit_forward_f32) */
 } mpreid_vit_cfg;
+
+/* Arithmetic of the encoder's linear layers and attention products (model/clip/model.py runs them in fp32,
+ * processor/processor.py:187-198 has no autocast):
+ *   F16    fp16 operands, fp32 accumulate: the fast mode; relative feature error ~4e-4 (operand rounding of 24 GEMMs),
+ *          which moves mAP by 1e-4..3e-4 on hard data -- does NOT meet the 1e-4 mAP bound.
+ *   SPLIT  every operand is an fp16 PAIR x = hi + lo (22 significant bits) and every product runs as
+ *          hi.hi' + lo.hi' + hi.lo' with fp32 accumulation on the same fp16 matrix cores: fp32-grade results (relative
+ *          feature error ~1e-6, |dmAP| <= 1e-4) at 3x the matrix work.  The parity mode that is also the measured mode.
+ * In SPLIT mode every *_w pointer of the weight structs is an fp16 pair matrix [out][2*in] = [hi(in) | lo(in)] of
+ * W * 2^e (e per matrix, so that the largest |entry| is in [2^9, 2^10)), and the matching *_s field is 2^-e
+ * (mpreid_split_pack_f32 produces the layout). */
+#define MPREID_VIT_F16 0
+#define MPREID_VIT_SPLIT 1
 
 typedef struct { /* device pointers; *_w are fp16 [out][in] row-major (torch Linear layout) */
     const void *in_proj_w;   /* [3*width][width] fp16 */
@@ -219,6 +233,7 @@ typedef struct { /* device pointers; *_w are fp16 [out][in] row-major (torch Lin
     const float *fc_b;
     const void *proj_w;      /* [width][4*width] fp16 */
     const float *proj_b;
+    float in_proj_s, out_proj_s, fc_s, proj_s;   /* SPLIT mode: 2^-e of the matching weight matrix (ignored in F16 mode) */
 } mpreid_vit_layer;
 
 typedef struct { /* device pointers */
@@ -230,6 +245,7 @@ typedef struct { /* device pointers */
     const float *bn_scale, *bn_shift;           /* [width]   eval BN folded: y = x*scale + shift (or NULL) */
     const float *bn_proj_scale, *bn_proj_shift; /* [out_dim] */
     const mpreid_vit_layer *layers;             /* HOST array of cfg.layers entries */
+    float conv_s;                               /* SPLIT mode: 2^-e of conv_w */
 } mpreid_vit_weights;
 
 size_t mpreid_vit_workspace_bytes(const mpreid_vit_cfg *cfg, int batch);
@@ -347,14 +363,27 @@ int mpreid_gemm_f16_nt(const void *a_dev, const void *b_dev, float *c_dev, int64
  * rounding (the RN50 1x1 convolutions).  Used by the unit tests and tools/gemm_bench.py. */
 int mpreid_gemm_f16_nt_ex(const void *a_dev, const void *b_dev, void *out_dev, const float *bias_dev, int64_t m,
                           int64_t n, int64_t k, int epilogue, mpreid_stream_t stream);
+/* The linear layer of the encoder's SPLIT precision mode, exposed for unit tests and tools/gemm_bench.py:
+ * a2 [M][2*kseg], b2 [N][2*kseg] fp16 pairs [hi | lo]; acc = sum over k of hi.hi' + lo.hi' + hi.lo' (fp32);
+ * epilogue 10: out fp32 [M][N] = acc*oscale + bias; 11: out fp32 [M][N] += acc*oscale + bias;
+ * 12: out fp16 pair [M][2N] = hi | lo of QuickGELU(acc*oscale + bias). */
+int mpreid_gemm_f16_split_nt(const void *a2_dev, const void *b2_dev, void *out_dev, const float *bias_dev, int64_t m,
+                             int64_t n, int64_t kseg, float oscale, int epilogue, mpreid_stream_t stream);
+/* x [rows][cols] fp32 -> y [rows][2*cols] fp16 pair: hi = fp16(x*scale), lo = fp16(x*scale - hi); scale a power of two */
+int mpreid_split_pack_f32(const float *x_dev, int64_t rows, int cols, float scale, void *y_dev, mpreid_stream_t stream);
 /* fp32 -> fp16 (RNE) conversion of a flat array */
 int mpreid_cast_f32_to_f16(const float *x_dev, void *y_dev, int64_t n, mpreid_stream_t stream);
 
 /* ---- measurement hooks (bench.py roofline leg) --------------------------------------------- */
+/* kernel classes of the encoder that are not fp16 GEMMs (mpreid_profile_entry.epilogue); flops_total then holds
+ * ALGORITHMIC BYTES for the HBM-bound ones (layer norm: 4 B read + output bytes per element; attention: q, k, v read +
+ * output written) */
+#define MPREID_PROF_LAYERNORM 100
+#define MPREID_PROF_ATTENTION 101
 typedef struct {
-    int32_t epilogue;        /* GemmEpi id of the fp16 GEMM class */
-    int32_t n, k;            /* GEMM N and K */
-    int64_t m;               /* largest GEMM M launched in the class */
+    int32_t epilogue;        /* GemmEpi id of the fp16 GEMM class, or MPREID_PROF_* */
+    int32_t n, k;            /* GEMM N and K (split epilogues: K = 2 * kseg halfs per operand row; 3 * kseg is executed) */
+    int64_t m;               /* GEMM M (padded rows): classes are keyed by (epilogue, M, N, K) */
     int64_t launches;        /* launches recorded while profiling was enabled */
     double total_ms;         /* sum of per-launch durations (hipEvents on the launch stream) */
     double flops_total;      /* sum over the recorded launches of 2*M*N*K */

@@ -59,6 +59,13 @@ __device__ __forceinline__ float wave_bfly_add(float s) {
 }
 
 
+// Per-launch event timing shared by the kernels bench.py reports a roofline for (gemm_f16.hip owns the registry).
+// prof_begin returns an opaque token (nullptr while profiling is disabled); prof_end records the closing event and files
+// the launch under (cls, m, n, k) with `work` = executed FLOPs (matrix kernels) or algorithmic bytes (HBM-bound kernels).
+// cls: a GemmEpi id for the fp16 GEMM kernels, MPREID_PROF_* for the others.
+void *mpreid_prof_begin(hipStream_t stream);
+void mpreid_prof_end(void *token, hipStream_t stream, int cls, int64_t m, int n, int k, double work);
+
 // Run `f` (returns an mpreid/hip status) once per HIP device for the call site that owns this object: function
 // attributes (dynamic LDS size) and occupancy queries are per device, and one process may drive several GPUs.
 struct PerDeviceOnce {

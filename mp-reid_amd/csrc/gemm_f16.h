@@ -36,15 +36,26 @@ enum GemmEpi {
     GE_COSINE = 6,     // out fp32 = acos(clip(acc / (an[m]*bn[n])))    (bounds checked)
     GE_BIAS_RELU = 7,  // out fp16 = relu(acc + bias[n])                (RN50 1x1 conv + folded BN + ReLU)
     GE_BIAS_ADD_RELU = 8, // out fp16 = relu(acc + bias[n] + identity[m][n]), one rounding (Bottleneck conv3)
-    GE_CAND = 9        // nothing is stored: d = fmaf(-2, acc, an[m] + bn[n]) is compared with per-row thresholds and the
+    GE_CAND = 9,       // nothing is stored: d = fmaf(-2, acc, an[m] + bn[n]) is compared with per-row thresholds and the
                        // few (row, col, d) that pass are appended to per-row candidate lists (re-ranking: the N x N
                        // distance matrix is never materialised; csrc/rerank2.hip)
+    // ---- "split" precision mode of the encoder (MODEL.ENCODER_PRECISION: split): both operands are fp16 PAIRS
+    // x = hi + lo stored as rows [hi(kseg) | lo(kseg)], and the k-loop runs the three products hi.hi' + lo.hi' + hi.lo'
+    // (3 * kseg deep) into the one fp32 accumulator: fp32-grade linear layers on the fp16 matrix cores.  acc is
+    // multiplied by GemmArgs::oscale (the exact power of two that undoes the weight scaling) in the epilogue.
+    GE_S_BIAS_F32 = 10,  // out fp32 = acc * oscale + bias[n]                        (in_proj: q | k | v for the split attention)
+    GE_S_BIAS_RES = 11,  // x fp32 += acc * oscale + bias[n]                         (out-proj, MLP c_proj)
+    GE_S_BIAS_GELU = 12, // out fp16 pair [M][2N]: hi | lo of quickgelu(acc * oscale + bias[n])   (MLP c_fc)
+    GE_S_PATCH = 13      // x fp32[b*L + 1 + p][n] = acc * oscale + pos[1 + p][n]    (patch embed)
 };
+constexpr bool gemm_epi_is_split(int epi) { return epi >= GE_S_BIAS_F32 && epi <= GE_S_PATCH; }
 
 struct GemmArgs {
     const _Float16 *A;   // [M][K]
     const _Float16 *W;   // [N][K]
-    int M, N, K;         // padded sizes (multiples of 128 / 128 / 64)
+    int M, N, K;         // padded sizes (multiples of 128 / 128 / 64); K is also the row stride of A and W in halfs
+    int kseg;            // GE_S_* only: logical K of one operand half (K == 2 * kseg: rows are [hi | lo]); else 0
+    float oscale;        // GE_S_* only: acc is multiplied by this before the epilogue arithmetic
     void *out;           // fp16 or fp32 output, row stride ldo elements
     int64_t ldo;
     const float *bias;   // [N]                       (GE_BIAS_*)

@@ -30,8 +30,12 @@ __device__ __forceinline__ void dma16_sv(uint64_t sbase, unsigned voff, unsigned
                  : "s"(sbase), "v"(voff), "s"(lds_dst)
                  : "memory");
 }
+// (the trailing s_nop 1 is required: a 128-bit store reads its data registers over several cycles and nothing inside an
+// asm string is padded by hipcc's hazard recognizer -- cdna_hip_programming.md 5.7 item 1.  Without it the split-mode
+// instance, whose schedule puts a v_pk_fma_f32 into the same registers right behind the store, wrote garbage into
+// 1 % of the residual stream; the fp16 instance happened to have scalar address arithmetic in that slot.)
 __device__ __forceinline__ void store16_sv(uint64_t sbase, unsigned voff, const f32x4 &v) {
-    asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
 }
 
 // s_waitcnt takes an immediate: callers pass a value that is a constant after unrolling, the switch folds away
@@ -76,6 +80,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int K = g.K;
+    // split precision mode: rows are [hi | lo] (K = 2 * kseg halfs) and the loop walks hi.hi', lo.hi', hi.lo'
+    constexpr bool SPLIT = gemm_epi_is_split(EPI);
+    const int nseg = SPLIT ? g.kseg / GBK : 0;
 
     // ---- staging: wave w moves rows [32w, 32w+32) of both tiles, 8 rows per DMA instruction ----
     const int srow = lane >> 3;
@@ -85,11 +92,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
     auto stage = [&](int s, int kt) {
         unsigned char *abase = smem + s * G_STAGE_BYTES + wave * 4096;
         unsigned char *bbase = abase + G_TILE_BYTES;
-        const int koff = kt * GBK;
+        int koff = kt * GBK, koff_b = koff;
+        if constexpr (SPLIT) {
+            const int seg = (kt >= nseg) + (kt >= 2 * nseg), r = kt - seg * nseg;
+            koff = ((seg == 1 ? nseg : 0) + r) * GBK;     // A: hi, lo, hi
+            koff_b = ((seg == 2 ? nseg : 0) + r) * GBK;   // W: hi, hi, lo
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             dma16(a_src + (int64_t)t * 8 * K + koff, abase + t * 1024);
-            dma16(b_src + (int64_t)t * 8 * K + koff, bbase + t * 1024);
+            dma16(b_src + (int64_t)t * 8 * K + koff_b, bbase + t * 1024);
         }
     };
 
@@ -125,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
         }
     };
 
-    const int nkt = K / GBK;
+    const int nkt = SPLIT ? 3 * nseg : K / GBK;
     stage(0, 0);
     __syncthreads(); // drains the DMA (vmcnt(0)) and publishes tile 0
     int cur = 0;
@@ -162,6 +174,33 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
             const uint4 v = *reinterpret_cast<const uint4 *>(wreg + lr * 72 + ch * 8);
             *reinterpret_cast<uint4 *>(out + (int64_t)(m0 + wm * 64 + lr) * g.ldo + n0 + wn * 64 + ch * 8) = v;
         }
+    } else if constexpr (EPI == GE_S_BIAS_GELU) {
+        // fp16 pair out [M][2N]: the hi parts, then the lo parts, through the same patch
+        _Float16 *wreg = reinterpret_cast<_Float16 *>(smem) + wave * (64 * 72);
+        _Float16 *out = reinterpret_cast<_Float16 *>(g.out);
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float bias = g.bias[n0 + wn * 64 + j * 16 + frow];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float v = quick_gelu(fmaf(acc[i][j][r], g.oscale, bias));
+                        const _Float16 hi = (_Float16)v;
+                        wreg[(i * 16 + fq * 4 + r) * 72 + j * 16 + frow] = part == 0 ? hi : (_Float16)(v - (float)hi);
+                    }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int lr = it * 8 + (lane >> 3), ch = lane & 7;
+                const uint4 v = *reinterpret_cast<const uint4 *>(wreg + lr * 72 + ch * 8);
+                *reinterpret_cast<uint4 *>(out + (int64_t)(m0 + wm * 64 + lr) * g.ldo + part * g.N + n0 + wn * 64 + ch * 8) = v;
+            }
+        }
     } else if constexpr (EPI == GE_BIAS_ADD_RELU) {
         // out fp16 = relu(acc + bias + identity): the sum stays fp32 through the patch and is rounded ONCE (the
         // arithmetic of conv_f16.hip's epilogue, so either kernel may serve a layer); 8-byte pieces per lane
@@ -195,6 +234,31 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
                     o[e] = (_Float16)(v[e] < 0.f ? 0.f : v[e]);
                 }
                 *reinterpret_cast<h4v *>(outh + off) = o;
+            }
+            __syncthreads();
+        }
+    } else if constexpr (EPI == GE_S_BIAS_F32 || EPI == GE_S_BIAS_RES) {
+        // split mode, fp32 outputs (same transposition as below): out = acc * oscale + bias, or x += that
+        __syncthreads();
+        float *wreg = reinterpret_cast<float *>(smem) + wave * (32 * 68);
+        float *outp = reinterpret_cast<float *>(g.out);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        wreg[(ii * 16 + fq * 4 + r) * 68 + j * 16 + frow] = acc[half * 2 + ii][j][r];
+            __syncthreads();
+            const int mbase = m0 + wm * 64 + half * 32, n = n0 + wn * 64 + lane;
+            const float bias = g.bias[n];
+#pragma unroll 4
+            for (int lr = 0; lr < 32; ++lr) {
+                float *dst = outp + (int64_t)(mbase + lr) * g.ldo + n;
+                const float v = fmaf(wreg[lr * 68 + lane], g.oscale, bias);
+                *dst = (EPI == GE_S_BIAS_RES) ? *dst + v : v;
             }
             __syncthreads();
         }
@@ -298,8 +362,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = m0 + wm * 64 + i * 16 + fq * 4 + r;
-                    const float a = acc[i][j][r];
-                    if (EPI == GE_PATCH) {
+                    const float a = (EPI == GE_S_PATCH) ? acc[i][j][r] * g.oscale : acc[i][j][r];
+                    if (EPI == GE_PATCH || EPI == GE_S_PATCH) {
                         if (m < g.m_valid) {
                             const int b = m / g.P, p = m - b * g.P;
                             reinterpret_cast<float *>(g.out)[((int64_t)b * g.L + 1 + p) * g.ldo + n] =
@@ -346,7 +410,20 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int K = g.K;
-    const int nst = K / BBK; // even (K is a multiple of 64)
+    // split precision mode (GE_S_*): rows are [hi | lo], K = 2 * kseg halfs; the stages walk hi.hi', lo.hi', hi.lo'
+    constexpr bool SPLIT = gemm_epi_is_split(EPI);
+    const int nseg = SPLIT ? g.kseg / BBK : 0;
+    const int nst = SPLIT ? 3 * nseg : K / BBK; // even (K, kseg are multiples of 64)
+    auto koff_a = [&](int st) -> int {
+        if constexpr (!SPLIT) return st * BBK;
+        const int seg = (st >= nseg) + (st >= 2 * nseg);
+        return ((seg == 1 ? nseg : 0) + st - seg * nseg) * BBK;
+    };
+    auto koff_b = [&](int st) -> int {
+        if constexpr (!SPLIT) return st * BBK;
+        const int seg = (st >= nseg) + (st >= 2 * nseg);
+        return ((seg == 2 ? nseg : 0) + st - seg * nseg) * BBK;
+    };
 
     // PERSISTENT: gridDim.x workgroups (one per CU) walk the tiles.  L2 is private to an XCD, so each XCD
     // (blockIdx % 8 under round-robin dispatch; locality only, never correctness) OWNS whole groups of 8
@@ -444,11 +521,11 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
     auto dma_stage = [&](int st) {
         unsigned char *abase = smem + (st & (B_NSTAGE - 1)) * B_STAGE_BYTES + wave * 2048;
         unsigned char *bbase = abase + B_PART_BYTES;
-        const int koff = st * BBK;
+        const int koff = koff_a(st), koffb = koff_b(st);
         dma16(a_src + koff, abase);
         dma16(a_src + (int64_t)16 * K + koff, abase + 1024);
-        dma16(b_src + koff, bbase);
-        dma16(b_src + (int64_t)16 * K + koff, bbase + 1024);
+        dma16(b_src + koffb, bbase);
+        dma16(b_src + (int64_t)16 * K + koffb, bbase + 1024);
     };
     auto dma_prologue = [&]() {
         dma_stage(0);
@@ -551,7 +628,7 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
         asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
         unsigned char *dbase = smem + ((t + 3) & (B_NSTAGE - 1)) * B_STAGE_BYTES + wave * 2048;
         const unsigned char *sb = smem + ((t + 1) & (B_NSTAGE - 1)) * B_STAGE_BYTES;
-        const int koff = (t + 3) * BBK;
+        const int koff = koff_a(t + 3), koffb = koff_b(t + 3);
 #define MPREID_FRAG_B(j) nb[j] = *reinterpret_cast<const f16x8 *>(sb + b_off + (j) * 1024)
 #define MPREID_FRAG_A(i) na[i] = *reinterpret_cast<const f16x8 *>(sb + a_off + (i) * 1024)
 #define MPREID_MFMA_ROWS(i0)                                                                             \
@@ -572,12 +649,12 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
         MPREID_MFMA_ROWS(2);
         __builtin_amdgcn_sched_barrier(0);
         // group 2
-        if constexpr (!(DBG & 1)) dma16(b_src + koff, dbase + B_PART_BYTES);
+        if constexpr (!(DBG & 1)) dma16(b_src + koffb, dbase + B_PART_BYTES);
         if constexpr (!(DBG & 4)) { MPREID_FRAG_A(2); MPREID_FRAG_A(3); MPREID_FRAG_A(4); }
         MPREID_MFMA_ROWS(4);
         __builtin_amdgcn_sched_barrier(0);
         // group 3
-        if constexpr (!(DBG & 1)) dma16(b_src + (int64_t)16 * K + koff, dbase + B_PART_BYTES + 1024);
+        if constexpr (!(DBG & 1)) dma16(b_src + (int64_t)16 * K + koffb, dbase + B_PART_BYTES + 1024);
         if constexpr (!(DBG & 4)) { MPREID_FRAG_A(5); MPREID_FRAG_A(6); MPREID_FRAG_A(7); }
         MPREID_MFMA_ROWS(6);
         __builtin_amdgcn_sched_barrier(0);
@@ -758,6 +835,43 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
             }
             __builtin_amdgcn_wave_barrier();
         }
+    } else if constexpr (EPI == GE_S_BIAS_GELU) {
+        // fp16 PAIR out [M][2N] (hi | lo of the fp32 value): two [16][72] patches per pass -- hi in the wave's 4 KB
+        // above the ring, lo in the idle k-loop ring -- so that both leave with one LDS round trip, each as whole
+        // 128-byte row pieces
+        _Float16 *whi = reinterpret_cast<_Float16 *>(patch + wave * 4096);
+        _Float16 *wlo = reinterpret_cast<_Float16 *>(smem + wave * 4096);
+        _Float16 *out = reinterpret_cast<_Float16 *>(g.out);
+        float bias[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bias[j] = g.bias[cur_n0 + wc * 64 + j * 16 + frow];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = quick_gelu(fmaf(acc[i][j][r], g.oscale, bias[j]));
+                    const _Float16 hi = (_Float16)v;
+                    whi[(fq * 4 + r) * 72 + j * 16 + frow] = hi;
+                    wlo[(fq * 4 + r) * 72 + j * 16 + frow] = (_Float16)(v - (float)hi);
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int lr = it * 8 + (lane >> 3), ch = lane & 7;
+                const uint4 vh = *reinterpret_cast<const uint4 *>(whi + lr * 72 + ch * 8);
+                const uint4 vl = *reinterpret_cast<const uint4 *>(wlo + lr * 72 + ch * 8);
+                _Float16 *dsth = out + (int64_t)(cur_m0 + wr * 128 + i * 16 + lr) * g.ldo + cur_n0 + wc * 64 + ch * 8;
+                store_nt(dsth, vh);
+                store_nt(dsth + g.N, vl);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // the lo patches alias stage 0 of the ring, which the next tile's prologue fills: all waves done first
+        asm volatile("s_barrier" ::: "memory");
     } else if constexpr (EPI == GE_BIAS_ADD_RELU) {
         // out fp16 = relu(acc + bias + identity) with ONE rounding: the identity must meet the fp32 accumulators in
         // THEIR layout (one column, four rows per lane), but it should be read from memory as whole rows.  So each
@@ -810,7 +924,7 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
         }
         // the identity patches alias stage 0 of the ring, which the next tile's prologue fills: all waves done first
         asm volatile("s_barrier" ::: "memory");
-    } else if (EPI == GE_BIAS_RES && (g.ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.out) & 15) == 0)) {
+    } else if ((EPI == GE_BIAS_RES || EPI == GE_S_BIAS_RES) && (g.ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.out) & 15) == 0)) {
         // x[m][n] += acc + bias, x fp32 (residual stream).  The x values are the expensive part: fetched pass by pass
         // into VGPRs every pass pays a full HBM round trip (8 per tile, matrix pipe idle), and there are no registers
         // to fetch them ahead.  So they are fetched ahead into LDS instead: the k-loop's ring is idle during the
@@ -871,10 +985,17 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 f32x4_t o;
-                o[0] = x[it][0] + (a[it][0] + bias4.x);
-                o[1] = x[it][1] + (a[it][1] + bias4.y);
-                o[2] = x[it][2] + (a[it][2] + bias4.z);
-                o[3] = x[it][3] + (a[it][3] + bias4.w);
+                if constexpr (EPI == GE_S_BIAS_RES) {
+                    o[0] = x[it][0] + fmaf(a[it][0], g.oscale, bias4.x);
+                    o[1] = x[it][1] + fmaf(a[it][1], g.oscale, bias4.y);
+                    o[2] = x[it][2] + fmaf(a[it][2], g.oscale, bias4.z);
+                    o[3] = x[it][3] + fmaf(a[it][3], g.oscale, bias4.w);
+                } else {
+                    o[0] = x[it][0] + (a[it][0] + bias4.x);
+                    o[1] = x[it][1] + (a[it][1] + bias4.y);
+                    o[2] = x[it][2] + (a[it][2] + bias4.z);
+                    o[3] = x[it][3] + (a[it][3] + bias4.w);
+                }
                 store16_sv(x_base(i * 16 + it * 4), x_loff, o);
             }
             if (i + 4 < 8) x_dma(i + 4);
@@ -897,7 +1018,8 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
             cs1 = g.cscale[nbase + lane];
         }
         if (vec_ok) {
-            if (EPI == GE_BIAS_RES) bias4 = *reinterpret_cast<const float4 *>(g.bias + nbase + c4);
+            if (EPI == GE_BIAS_RES || EPI == GE_S_BIAS_RES || EPI == GE_S_BIAS_F32)
+                bias4 = *reinterpret_cast<const float4 *>(g.bias + nbase + c4);
             if (EPI == GE_EUCLID) {
                 bn4.x = (nbase + c4 + 0 < g.n_valid) ? g.aux2[nbase + c4 + 0] : 0.f;
                 bn4.y = (nbase + c4 + 1 < g.n_valid) ? g.aux2[nbase + c4 + 1] : 0.f;
@@ -905,7 +1027,7 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
                 bn4.w = (nbase + c4 + 3 < g.n_valid) ? g.aux2[nbase + c4 + 3] : 0.f;
             }
         } else {
-            if (EPI == GE_BIAS_RES) bias1 = g.bias[nbase + lane];
+            if (EPI == GE_BIAS_RES || EPI == GE_S_BIAS_RES || EPI == GE_S_BIAS_F32) bias1 = g.bias[nbase + lane];
             if (EPI == GE_EUCLID) bnv1 = (nbase + lane < g.n_valid) ? g.aux2[nbase + lane] : 0.f;
         }
 #pragma unroll
@@ -927,13 +1049,26 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
                     float *dst = outp + (int64_t)m * g.ldo + nbase + c4;
                     if (EPI == GE_F32) {
                         *reinterpret_cast<float4 *>(dst) = a;
-                    } else if (EPI == GE_PATCH) {
+                    } else if (EPI == GE_S_BIAS_F32) {
+                        // q | k | v for the split attention kernel: read once, by a later kernel
+                        store_nt(dst, make_float4(fmaf(a.x, g.oscale, bias4.x), fmaf(a.y, g.oscale, bias4.y),
+                                                  fmaf(a.z, g.oscale, bias4.z), fmaf(a.w, g.oscale, bias4.w)));
+                    } else if (EPI == GE_S_BIAS_RES) {
+                        float4 x = *reinterpret_cast<const float4 *>(dst);
+                        x.x = x.x + fmaf(a.x, g.oscale, bias4.x);
+                        x.y = x.y + fmaf(a.y, g.oscale, bias4.y);
+                        x.z = x.z + fmaf(a.z, g.oscale, bias4.z);
+                        x.w = x.w + fmaf(a.w, g.oscale, bias4.w);
+                        *reinterpret_cast<float4 *>(dst) = x;
+                    } else if (EPI == GE_PATCH || EPI == GE_S_PATCH) {
                         // patch embedding: row m = b*P + p goes to token 1 + p of image b, + positional embedding
                         if (m < g.m_valid) {
                             const int b = m / g.P, pp = m - b * g.P;
+                            const float os = (EPI == GE_S_PATCH) ? g.oscale : 1.0f;   // (a * 1 is exact: same bits as before)
                             const float4 pe = *reinterpret_cast<const float4 *>(g.aux + (int64_t)(1 + pp) * g.N + nbase + c4);
                             *reinterpret_cast<float4 *>(outp + ((int64_t)b * g.L + 1 + pp) * g.ldo + nbase + c4) =
-                                make_float4(a.x + pe.x, a.y + pe.y, a.z + pe.z, a.w + pe.w);
+                                (EPI == GE_S_PATCH) ? make_float4(a.x * os + pe.x, a.y * os + pe.y, a.z * os + pe.z, a.w * os + pe.w)
+                                                    : make_float4(a.x + pe.x, a.y + pe.y, a.z + pe.z, a.w + pe.w);
                         }
                     } else if (EPI == GE_BIAS_RES) {
                         const f32x4_t xv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(dst));
@@ -972,10 +1107,15 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
                     float *dst = outp + (int64_t)m * g.ldo + n;
                     if (EPI == GE_F32) {
                         *dst = a;
-                    } else if (EPI == GE_PATCH) {
+                    } else if (EPI == GE_S_BIAS_F32) {
+                        *dst = fmaf(a, g.oscale, bias1);
+                    } else if (EPI == GE_S_BIAS_RES) {
+                        *dst = *dst + fmaf(a, g.oscale, bias1);
+                    } else if (EPI == GE_PATCH || EPI == GE_S_PATCH) {
                         if (m < g.m_valid) {
                             const int b = m / g.P, pp = m - b * g.P;
-                            outp[((int64_t)b * g.L + 1 + pp) * g.ldo + n] = a + g.aux[(int64_t)(1 + pp) * g.N + n];
+                            outp[((int64_t)b * g.L + 1 + pp) * g.ldo + n] =
+                                ((EPI == GE_S_PATCH) ? a * g.oscale : a) + g.aux[(int64_t)(1 + pp) * g.N + n];
                         }
                     } else if (EPI == GE_BIAS_RES) {
                         *dst = *dst + (a + bias1);
@@ -999,7 +1139,7 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
 
 // ---------------------------------------------------------------------------------------------
 // optional per-launch event timing (bench.py's roofline leg): hipEvents recorded on the launch
-// stream around every GEMM launch while enabled, aggregated per (epilogue, N, K) class.
+// stream around every GEMM launch while enabled, aggregated per (epilogue, M, N, K) class.
 // ---------------------------------------------------------------------------------------------
 #include <map>
 #include <mutex>
@@ -1023,7 +1163,7 @@ int big_mode() {
     return mode;
 }
 std::mutex g_prof_mu;
-std::map<std::tuple<int, int, int>, ProfClass> g_prof;
+std::map<std::tuple<int, int, int, int>, ProfClass> g_prof;   // (epilogue, M, N, K)
 } // namespace
 
 extern "C" int mpreid_profile_enable(int on) {
@@ -1050,8 +1190,8 @@ extern "C" int mpreid_profile_query(mpreid_profile_entry *out, int cap) {
     for (auto &kv : g_prof) {
         mpreid_profile_entry e{};
         e.epilogue = std::get<0>(kv.first);
-        e.n = std::get<1>(kv.first);
-        e.k = std::get<2>(kv.first);
+        e.n = std::get<2>(kv.first);
+        e.k = std::get<3>(kv.first);
         e.m = kv.second.m;
         e.launches = (int64_t)kv.second.ev.size();
         e.flops_total = kv.second.flops_total;
@@ -1071,6 +1211,32 @@ extern "C" int mpreid_profile_query(mpreid_profile_entry *out, int cap) {
     return (int)v.size();
 }
 
+struct ProfToken {
+    hipEvent_t e0;
+};
+void *mpreid_prof_begin(hipStream_t stream) {
+    if (!g_prof_on) return nullptr;
+    ProfToken *t = new ProfToken{};
+    if (hipEventCreate(&t->e0) != hipSuccess || hipEventRecord(t->e0, stream) != hipSuccess) {
+        delete t;
+        return nullptr;
+    }
+    return t;
+}
+void mpreid_prof_end(void *token, hipStream_t stream, int cls, int64_t m, int n, int k, double work) {
+    if (!token) return;
+    ProfToken *t = static_cast<ProfToken *>(token);
+    hipEvent_t e1 = nullptr;
+    if (hipEventCreate(&e1) == hipSuccess && hipEventRecord(e1, stream) == hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        ProfClass &pc = g_prof[std::make_tuple(cls, (int)m, n, k)];
+        pc.ev.emplace_back(t->e0, e1);
+        pc.m = std::max<int64_t>(pc.m, m);
+        pc.flops_total += work;
+    }
+    delete t;
+}
+
 template <int EPI>
 static int launch_one(const GemmArgs &a_in, hipStream_t stream) {
     const GemmArgs &a = a_in;
@@ -1085,7 +1251,14 @@ static int launch_one(const GemmArgs &a_in, hipStream_t stream) {
     }
     constexpr bool HAS_BIG = (EPI == GE_F32 || EPI == GE_BIAS_F16 || EPI == GE_BIAS_RES || EPI == GE_BIAS_GELU ||
                               EPI == GE_EUCLID || EPI == GE_PATCH || EPI == GE_BIAS_RELU || EPI == GE_BIAS_ADD_RELU ||
-                              EPI == GE_CAND);
+                              EPI == GE_CAND || gemm_epi_is_split(EPI));
+    if constexpr (gemm_epi_is_split(EPI)) {
+        if (a.kseg <= 0 || a.kseg % GBK || a.K != 2 * a.kseg) {
+            mpreid_set_error("gemm_f16: split epilogue %d needs K == 2 * kseg, kseg a multiple of %d (K=%d kseg=%d)", EPI, GBK,
+                             a.K, a.kseg);
+            return MPREID_ERR_ARG;
+        }
+    }
     if constexpr (EPI == GE_CAND) {
         if (a.M % BBM || a.N % BBN) {
             mpreid_set_error("gemm_f16: the candidate epilogue needs M, N multiples of %d", BBM);
@@ -1160,10 +1333,11 @@ static int launch_one(const GemmArgs &a_in, hipStream_t stream) {
     if (e0) {
         HIP_TRY(hipEventRecord(e1, stream));
         std::lock_guard<std::mutex> lk(g_prof_mu);
-        ProfClass &pc = g_prof[std::make_tuple(EPI, a.N, a.K)];
+        ProfClass &pc = g_prof[std::make_tuple(EPI, a.M, a.N, a.K)];
         pc.ev.emplace_back(e0, e1);
         pc.m = std::max<int64_t>(pc.m, a.M);
-        pc.flops_total += 2.0 * (double)a.M * (double)a.N * (double)a.K;
+        // split mode: three products per logical multiply-add are EXECUTED on the matrix cores
+        pc.flops_total += 2.0 * (double)a.M * (double)a.N * (gemm_epi_is_split(EPI) ? 3.0 * (double)a.kseg : (double)a.K);
     }
     return MPREID_OK;
 }
@@ -1185,6 +1359,10 @@ int launch_gemm_f16(const GemmArgs &a, int epi, hipStream_t stream) {
     case GE_BIAS_RELU: return launch_one<GE_BIAS_RELU>(a, stream);
     case GE_BIAS_ADD_RELU: return launch_one<GE_BIAS_ADD_RELU>(a, stream);
     case GE_CAND: return launch_one<GE_CAND>(a, stream);
+    case GE_S_BIAS_F32: return launch_one<GE_S_BIAS_F32>(a, stream);
+    case GE_S_BIAS_RES: return launch_one<GE_S_BIAS_RES>(a, stream);
+    case GE_S_BIAS_GELU: return launch_one<GE_S_BIAS_GELU>(a, stream);
+    case GE_S_PATCH: return launch_one<GE_S_PATCH>(a, stream);
     }
     mpreid_set_error("gemm_f16: unknown epilogue %d", epi);
     return MPREID_ERR_ARG;
@@ -1258,6 +1436,48 @@ extern "C" int mpreid_gemm_f16_nt_ex(const void *a, const void *b, void *out, co
     g.ldo = n;
     g.bias = bias;
     return launch_gemm_f16(g, epilogue, (hipStream_t)stream);
+}
+
+// Split-precision GEMM (the linear layers of the encoder's `split` mode), exposed for unit tests and tools/gemm_bench.py:
+// a2 [M][2*kseg], b2 [N][2*kseg] fp16 pairs [hi | lo]; epilogue 10 = out fp32 [M][N] = acc*oscale + bias, 11 = out fp32
+// += acc*oscale + bias, 12 = out fp16 pair [M][2N] = hi | lo of quickgelu(acc*oscale + bias).
+extern "C" int mpreid_gemm_f16_split_nt(const void *a2, const void *b2, void *out, const float *bias, int64_t m, int64_t n,
+                                        int64_t kseg, float oscale, int epilogue, mpreid_stream_t stream) {
+    ARG_CHECK(a2 && b2 && out && bias && epilogue >= GE_S_BIAS_F32 && epilogue <= GE_S_BIAS_GELU);
+    GemmArgs g{};
+    g.A = (const _Float16 *)a2;
+    g.W = (const _Float16 *)b2;
+    g.M = (int)m;
+    g.N = (int)n;
+    g.K = (int)(2 * kseg);
+    g.kseg = (int)kseg;
+    g.oscale = oscale;
+    g.out = out;
+    g.ldo = epilogue == GE_S_BIAS_GELU ? 2 * n : n;
+    g.bias = bias;
+    return launch_gemm_f16(g, epilogue, (hipStream_t)stream);
+}
+
+// x [rows][cols] fp32 -> y [rows][2*cols] fp16 pair: hi = fp16(x * scale), lo = fp16(x * scale - hi)   (scale: a power of two)
+__global__ __launch_bounds__(256) void split_pack_kernel(const float *__restrict__ x, int64_t rows, int cols, float scale,
+                                                         _Float16 *__restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * (int64_t)cols) return;
+    const int64_t r = i / cols;
+    const int c = (int)(i - r * cols);
+    const float v = x[i] * scale;
+    const _Float16 hi = (_Float16)v;
+    y[r * 2 * cols + c] = hi;
+    y[r * 2 * cols + cols + c] = (_Float16)(v - (float)hi);
+}
+
+extern "C" int mpreid_split_pack_f32(const float *x, int64_t rows, int cols, float scale, void *y, mpreid_stream_t stream) {
+    ARG_CHECK(x && y && rows >= 0 && cols > 0);
+    if (rows == 0) return MPREID_OK;
+    hipLaunchKernelGGL(split_pack_kernel, dim3((unsigned)((rows * cols + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, rows,
+                       cols, scale, (_Float16 *)y);
+    LAUNCH_CHECK();
+    return MPREID_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -28,7 +28,25 @@
 //   0 original   1 torch.flip(img, [3]) (mirror in W)   2 pseudo-IR: img.mean(dim=1) in all 3 channels
 //   3 pseudo-RGB: channel 0 in all 3 channels
 // ---------------------------------------------------------------------------------------------
-template <int VIEW>
+// SPLIT (the `split` precision mode): rows are fp16 pairs [hi(Kp) | lo(Kp)] with hi + lo = the fp32 value to ~2^-22
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+template <bool SPLIT>
+__device__ __forceinline__ void store_patch_row(_Float16 *__restrict__ out, int64_t m, int Kp, int ch, const float (&v)[8]) {
+    h8_t hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        hi[j] = (_Float16)v[j];
+        lo[j] = (_Float16)(v[j] - (float)hi[j]);
+    }
+    if constexpr (SPLIT) {
+        *reinterpret_cast<h8_t *>(out + m * 2 * Kp + ch * 8) = hi;
+        *reinterpret_cast<h8_t *>(out + m * 2 * Kp + Kp + ch * 8) = lo;
+    } else {
+        *reinterpret_cast<h8_t *>(out + m * Kp + ch * 8) = hi;
+    }
+}
+
+template <int VIEW, bool SPLIT>
 __global__ __launch_bounds__(256) void im2col_kernel(const float *__restrict__ img, int B, int H, int Wd, int p,
                                                      int stride, int h_res, int w_res, _Float16 *__restrict__ out,
                                                      int mp_pad) {
@@ -38,8 +56,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float *__restrict__ i
     if (gid >= (int64_t)mp_pad * chunks) return;
     const int m = (int)(gid / chunks), ch = (int)(gid % chunks);
     const int P = h_res * w_res;
-    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-    h8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (m < B * P) {
         const int b = m / P, pi = m % P;
         const int ph = pi / w_res, pw = pi % w_res;
@@ -55,17 +72,17 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float *__restrict__ i
             float v = row[x];
             // torch mean over the channel dim: ((c0 + c1) + c2) / 3
             if (VIEW == 2) v = __fdiv_rn((v + row[plane + x]) + row[2 * plane + x], 3.0f);
-            o[j] = (_Float16)v;
+            o[j] = v;
         }
     }
-    *reinterpret_cast<h8 *>(out + (int64_t)m * Kp + ch * 8) = o;
+    store_patch_row<SPLIT>(out, m, Kp, ch, o);
 }
 
 // uint8 variant: img [B][H][W][3] (HWC, what PIL / cv2 hand over after Resize).  ToTensor (x / 255) and
 // Normalize ((x - mean) / std) of the reference's val_transforms (datasets/make_dataloader.py:57-61) are applied
 // while gathering, in fp32, before the fp16 rounding -- the same values the fp32 entry point receives.  The views
 // act on the normalised values, as in the reference.
-template <int VIEW>
+template <int VIEW, bool SPLIT>
 __global__ __launch_bounds__(256) void im2col_u8_kernel(const unsigned char *__restrict__ img, int B, int H, int Wd, int p,
                                                         int stride, int h_res, int w_res, float m0, float m1, float m2,
                                                         float s0, float s1, float s2, _Float16 *__restrict__ out,
@@ -76,8 +93,7 @@ __global__ __launch_bounds__(256) void im2col_u8_kernel(const unsigned char *__r
     if (gid >= (int64_t)mp_pad * chunks) return;
     const int m = (int)(gid / chunks), ch = (int)(gid % chunks);
     const int P = h_res * w_res;
-    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-    h8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (m < B * P) {
         const int b = m / P, pi = m % P;
         const int ph = pi / w_res, pw = pi % w_res;
@@ -96,10 +112,10 @@ __global__ __launch_bounds__(256) void im2col_u8_kernel(const unsigned char *__r
                 const float v2 = __fdiv_rn(__fdiv_rn((float)row[x * 3 + 2], 255.0f) - m2, s2);
                 v = __fdiv_rn((v + v1) + v2, 3.0f);
             }
-            o[j] = (_Float16)v;
+            o[j] = v;
         }
     }
-    *reinterpret_cast<h8 *>(out + (int64_t)m * Kp + ch * 8) = o;
+    store_patch_row<SPLIT>(out, m, Kp, ch, o);
 }
 
 // x[b*L + 0][:] = class_embedding + pos[0] (+ cv_emb[b])      model/clip/model.py:419-422
@@ -116,9 +132,10 @@ __global__ __launch_bounds__(256) void cls_token_kernel(const float *__restrict_
 
 // ---------------------------------------------------------------------------------------------
 // LayerNorm over the last dim (biased variance, eps 1e-5, fp32 stats); one wave per row.
-// OUT_F16: write fp16 (GEMM operand) else fp32 (may alias the input: ln_pre is in place).
+// MODE 0: write fp32 (may alias the input: ln_pre is in place); 1: fp16 (GEMM operand); 2: fp16 pair [hi(W) | lo(W)]
+// per row (GEMM operand of the `split` precision mode).
 // ---------------------------------------------------------------------------------------------
-template <bool OUT_F16>
+template <int MODE>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, int64_t rows, int W,
                                                         const float *__restrict__ gamma,
                                                         const float *__restrict__ beta, void *__restrict__ out,
@@ -166,10 +183,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
         y.y = (v[i].y - mean) * rstd * gm.y + bt.y;
         y.z = (v[i].z - mean) * rstd * gm.z + bt.z;
         y.w = (v[i].w - mean) * rstd * gm.w + bt.w;
-        if (OUT_F16) {
+        if (MODE == 1) {
             typedef _Float16 h4 __attribute__((ext_vector_type(4)));
             h4 o = {(_Float16)y.x, (_Float16)y.y, (_Float16)y.z, (_Float16)y.w};
             *reinterpret_cast<h4 *>(reinterpret_cast<_Float16 *>(out) + row * (int64_t)W + k) = o;
+        } else if (MODE == 2) {
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            const h4 hi = {(_Float16)y.x, (_Float16)y.y, (_Float16)y.z, (_Float16)y.w};
+            const h4 lo = {(_Float16)(y.x - (float)hi[0]), (_Float16)(y.y - (float)hi[1]), (_Float16)(y.z - (float)hi[2]),
+                           (_Float16)(y.w - (float)hi[3])};
+            _Float16 *orow = reinterpret_cast<_Float16 *>(out) + row * 2 * (int64_t)W;
+            *reinterpret_cast<h4 *>(orow + k) = hi;
+            *reinterpret_cast<h4 *>(orow + W + k) = lo;
         } else {
             *reinterpret_cast<float4 *>(reinterpret_cast<float *>(out) + row * (int64_t)W + k) = y;
         }
@@ -412,6 +437,216 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && KTP <= 10) ? 4 : 2) void atten
 }
 
 // ---------------------------------------------------------------------------------------------
+// attention of the `split` precision mode: the same "key on the lane" scheme, fp32-grade on the fp16 matrix cores.
+// q | k | v arrive as fp32 [M][3W] (GE_S_BIAS_F32); K and V are split into fp16 pairs (hi, lo) while they are staged into
+// LDS (Kh, Kl, Vh, Vl: four arrays in the layouts of the fp16 kernel), Q in registers, and every product runs as
+// hi.hi' + lo.hi' + hi.lo' into the one fp32 accumulator:
+//   S^T = Kh Qh^T + Kl Qh^T + Kh Ql^T          O^T = Vh^T Ph^T + Vl^T Ph^T + Vh^T Pl^T
+// The softmax is fp32 in registers as before; P carries a factor 2^10 (added to the exponent, cancelled by the
+// division by the row sum, which carries it too) so that the lo parts of small probabilities stay far away from the
+// bottom of the fp16 range.  O leaves as the fp16 pair [hi(W) | lo(W)] per row: the A operand of the out-proj GEMM.
+// One workgroup per CU (80-128 KB of LDS); persistent over (image, head) pairs with the next pair's K / V prefetched
+// into registers, like the fp16 kernel.
+// ---------------------------------------------------------------------------------------------
+typedef float att_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 load_nt_f4(const float *p) {
+    const att_f4 v = __builtin_nontemporal_load(reinterpret_cast<const att_f4 *>(p));
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void split4(const float4 &v, h4_t &hi, h4_t &lo) {
+    hi = h4_t{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+    lo = h4_t{(_Float16)(v.x - (float)hi[0]), (_Float16)(v.y - (float)hi[1]), (_Float16)(v.z - (float)hi[2]),
+              (_Float16)(v.w - (float)hi[3])};
+}
+#define ATS_FOR_EACH_ITER(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define ATS_DECL(i) float4 k##i = make_float4(0.f, 0.f, 0.f, 0.f), v##i = k##i;
+// thread -> (row, 16-byte chunk of 4 floats), 16 lanes per 256-byte row; rows past L clamped (see the fp16 kernel)
+#define ATS_LOAD(i)                                                                                  \
+    if constexpr (K_ITERS > i) {                                                                     \
+        const int idx_ = tid + i * NT;                                                               \
+        const int row_ = idx_ >> 4, c_ = idx_ & 15;                                                  \
+        const int rc_ = row_ < L ? row_ : L - 1;                                                     \
+        k##i = load_nt_f4(pbase_ + (int64_t)rc_ * ld + W + c_ * 4);                                  \
+        v##i = load_nt_f4(pbase_ + (int64_t)rc_ * ld + 2 * W + c_ * 4);                              \
+    }
+#define ATS_STORE(i)                                                                                 \
+    if constexpr (K_ITERS > i) {                                                                     \
+        const int idx_ = tid + i * NT;                                                               \
+        const int row_ = idx_ >> 4, c_ = idx_ & 15;                                                  \
+        if (idx_ < KEYS * 16) {                                                                      \
+            h4_t hi_, lo_;                                                                           \
+            const int ko_ = row_ * 128 + (((c_ >> 1) ^ (row_ & 7)) << 4) + (c_ & 1) * 8;             \
+            split4(k##i, hi_, lo_);                                                                  \
+            *reinterpret_cast<h4_t *>(Kh + ko_) = hi_;                                               \
+            *reinterpret_cast<h4_t *>(Kl + ko_) = lo_;                                               \
+            const int vo_ = row_ * 128 + (((c_ >> 1) ^ (((row_ >> 1) & 3) << 1)) << 4) + (c_ & 1) * 8; \
+            split4(v##i, hi_, lo_);                                                                  \
+            *reinterpret_cast<h4_t *>(Vh + vo_) = hi_;                                               \
+            *reinterpret_cast<h4_t *>(Vl + vo_) = lo_;                                               \
+        }                                                                                            \
+    }
+#define ATS_PREFETCH(pr)                                                                             \
+    {                                                                                                \
+        const int pb_ = (pr) / heads, ph_ = (pr) - pb_ * heads;                                      \
+        const float *pbase_ = qkv + (int64_t)pb_ * L * ld + ph_ * 64;                                \
+        ATS_FOR_EACH_ITER(ATS_LOAD)                                                                  \
+    }
+
+template <int KTP, int NW>
+__global__ __launch_bounds__(64 * NW, NW >= 8 ? 2 : 1) void attention_split_kernel(const float *__restrict__ qkv, int L, int W,
+                                                                                   int heads, _Float16 *__restrict__ out,
+                                                                                   int q_tiles, int total_pairs) {
+    constexpr int KEYS = KTP * 16;
+    constexpr int NT = 64 * NW;
+    constexpr int K_ITERS = (KEYS * 16 + NT - 1) / NT;
+    static_assert(K_ITERS <= 8, "extend ATS_FOR_EACH_ITER");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *Kh = smem, *Kl = smem + KEYS * 128, *Vh = smem + 2 * KEYS * 128, *Vl = smem + 3 * KEYS * 128;
+    constexpr int OS = 72;
+    _Float16 *Ot = reinterpret_cast<_Float16 *>(smem + 4 * KEYS * 128);   // [NW][16][OS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int64_t ld = 3 * (int64_t)W;
+    const int nqt = (q_tiles > 0) ? q_tiles : (L + 15) / 16;
+    const float scale_log2e = 0.125f * 1.44269504088896340736f;
+
+    ATS_FOR_EACH_ITER(ATS_DECL)
+
+    int pair = blockIdx.x;
+    if (pair >= total_pairs) return;
+    ATS_PREFETCH(pair)
+    for (; pair < total_pairs; pair += gridDim.x) {
+        const int b = pair / heads, h = pair - b * heads;
+        const float *base = qkv + (int64_t)b * L * ld + h * 64;
+        __syncthreads(); // every wave is done reading the previous pair from LDS
+        ATS_FOR_EACH_ITER(ATS_STORE)
+        __syncthreads();
+        {
+            const int nxt = pair + (int)gridDim.x < total_pairs ? pair + (int)gridDim.x : pair;
+            ATS_PREFETCH(nxt)
+        }
+        for (int qt = wave; qt < nqt; qt += NW) {
+            // Q fragment (B operand: B[k = d][col = query]): 8 consecutive d per lane and 32-wide k step, as a pair
+            f16x8 qh[2], ql[2];
+            {
+                const int q = qt * 16 + fr;
+                const int qc = q < L ? q : L - 1;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const float *qp = base + (int64_t)qc * ld + ks * 32 + fq * 8;
+                    const float4 a0 = *reinterpret_cast<const float4 *>(qp), a1 = *reinterpret_cast<const float4 *>(qp + 4);
+                    const float qv[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        qh[ks][e] = (_Float16)qv[e];
+                        ql[ks][e] = (_Float16)(qv[e] - (float)qh[ks][e]);
+                    }
+                }
+            }
+            f32x4 s[KTP];
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int kt = 0; kt < KTP; ++kt) {
+                s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int ko = (kt * 16 + fr) * 128 + (((ks * 4 + fq) ^ (lane & 7)) << 4);
+                    const f16x8 kh = *reinterpret_cast<const f16x8 *>(Kh + ko);
+                    const f16x8 kl = *reinterpret_cast<const f16x8 *>(Kl + ko);
+                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[ks], s[kt], 0, 0, 0);
+                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[ks], s[kt], 0, 0, 0);
+                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[ks], s[kt], 0, 0, 0);
+                }
+                if (kt & 1) __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int kt = 0; kt < KTP; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kt * 16 + fq * 4 + r >= L) s[kt][r] = -3.0e38f;
+                mx = fmaxf(mx, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
+            }
+            mx = xor16_32_max(mx);
+            // p * 2^10 = exp2(s*c - mx*c + 10); masked entries give exp2(-huge) = 0
+            const float nmx = fmaf(-mx, scale_log2e, 10.0f);
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < KTP; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], scale_log2e, nmx));
+                    s[kt][r] = p;
+                    sum += p;
+                }
+            sum = xor16_32_sum(sum);
+            f32x4 o[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < KTP / 2; ++s2) {
+                f16x8 ph, pl;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ph[j] = (_Float16)s[2 * s2][j];
+                    pl[j] = (_Float16)(s[2 * s2][j] - (float)ph[j]);
+                    ph[4 + j] = (_Float16)s[2 * s2 + 1][j];
+                    pl[4 + j] = (_Float16)(s[2 * s2 + 1][j] - (float)ph[4 + j]);
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const int trq = fr >> 2, trp = fr & 3;
+                    const int row0 = s2 * 32 + fq * 4 + trq, row1 = row0 + 16;
+                    const int chunk = dt * 2 + (trp >> 1);
+                    const int o0 = row0 * 128 + ((chunk ^ (((row0 >> 1) & 3) << 1)) << 4) + (trp & 1) * 8;
+                    const int o1 = row1 * 128 + ((chunk ^ (((row1 >> 1) & 3) << 1)) << 4) + (trp & 1) * 8;
+                    typedef short s8_t __attribute__((ext_vector_type(8)));
+                    const att_s4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((att_lds_s4 *)(Vh + o0));
+                    const att_s4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((att_lds_s4 *)(Vh + o1));
+                    const att_s4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((att_lds_s4 *)(Vl + o0));
+                    const att_s4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((att_lds_s4 *)(Vl + o1));
+                    const s8_t vh8 = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                    const s8_t vl8 = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                    const f16x8 vh = __builtin_bit_cast(f16x8, vh8), vl = __builtin_bit_cast(f16x8, vl8);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph, o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph, o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl, o[dt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            {   // O^T -> fp16 pair, through the wave's LDS patch as whole 128-byte rows: hi part, then lo part
+                const float inv = 1.0f / sum;
+                _Float16 *ot = Ot + wave * (16 * OS);
+#pragma unroll
+                for (int part = 0; part < 2; ++part) {
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        h4_t ov;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float v = o[dt][r] * inv;
+                            const _Float16 hi = (_Float16)v;
+                            ov[r] = part == 0 ? hi : (_Float16)(v - (float)hi);
+                        }
+                        *reinterpret_cast<h4_t *>(ot + fr * OS + dt * 16 + fq * 4) = ov;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        const int row = it * 8 + (lane >> 3), ch = lane & 7;
+                        const uint4 v = *reinterpret_cast<const uint4 *>(ot + row * OS + ch * 8);
+                        const int qrow = qt * 16 + row;
+                        if (qrow < L) store_nt16(out + ((int64_t)b * L + qrow) * 2 * W + part * W + h * 64 + ch * 8, v);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        } // query tiles
+    }     // (image, head) pairs
+}
+
+// ---------------------------------------------------------------------------------------------
 // head: ln_post on the CLS row, CLS @ proj, optional eval-BN necks, concat -> [B][W + out_dim]
 // model/clip/model.py:471-474, model/make_model.py:98-115
 // ---------------------------------------------------------------------------------------------
@@ -481,14 +716,13 @@ __global__ __launch_bounds__(256) void cls_proj_kernel(const float *__restrict__
 }
 
 // CLS rows of the residual stream / attention output -> compact [Bpad][W] buffers (last block only)
+// (aw = row length of a in halfs: W, or 2W for the fp16 pairs of the split mode)
 __global__ __launch_bounds__(256) void gather_cls_kernel(const float *__restrict__ x, const _Float16 *__restrict__ a,
-                                                         int B, int L, int W, float *__restrict__ x_cls,
+                                                         int B, int L, int W, int aw, float *__restrict__ x_cls,
                                                          _Float16 *__restrict__ a_cls) {
     const int b = blockIdx.x;
-    for (int k = threadIdx.x; k < W; k += 256) {
-        x_cls[(int64_t)b * W + k] = x[(int64_t)b * L * W + k];
-        a_cls[(int64_t)b * W + k] = a[(int64_t)b * L * W + k];
-    }
+    for (int k = threadIdx.x; k < W; k += 256) x_cls[(int64_t)b * W + k] = x[(int64_t)b * L * W + k];
+    for (int k = threadIdx.x; k < aw; k += 256) a_cls[(int64_t)b * aw + k] = a[(int64_t)b * L * aw + k];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -514,15 +748,17 @@ static VitLayout vit_layout(const mpreid_vit_cfg *c, int B) {
         return o;
     };
     const size_t W = (size_t)c->width;
-    v.patches = take((size_t)v.MPpad * v.Kp * 2);
+    // split precision mode: every GEMM operand is an fp16 pair (2x the halfs per row), q | k | v are fp32
+    const size_t pr = c->precision == MPREID_VIT_SPLIT ? 2 : 1;
+    v.patches = take((size_t)v.MPpad * v.Kp * 2 * pr);
     v.x = take((size_t)v.Mpad * W * 4);
-    v.a = take((size_t)v.Mpad * W * 2);
-    v.qkv = take((size_t)v.Mpad * 3 * W * 2);
-    v.hbuf = take((size_t)v.Mpad * 4 * W * 2);
+    v.a = take((size_t)v.Mpad * W * 2 * pr);
+    v.qkv = take((size_t)v.Mpad * 3 * W * 2 * pr);
+    v.hbuf = take((size_t)v.Mpad * 4 * W * 2 * pr);
     v.Bpad = (int)align_up((size_t)B, GBM);
     v.x_cls = take((size_t)v.Bpad * W * 4);
-    v.a_cls = take((size_t)v.Bpad * W * 2);
-    v.h_cls = take((size_t)v.Bpad * 4 * W * 2);
+    v.a_cls = take((size_t)v.Bpad * W * 2 * pr);
+    v.h_cls = take((size_t)v.Bpad * 4 * W * 2 * pr);
     v.y_cls = take((size_t)v.Bpad * W * 4);
     v.total = off;
     return v;
@@ -531,6 +767,7 @@ static VitLayout vit_layout(const mpreid_vit_cfg *c, int B) {
 static int vit_check_cfg(const mpreid_vit_cfg *c) {
     ARG_CHECK(c != nullptr);
     ARG_CHECK(c->width > 0 && c->heads > 0 && c->layers >= 0 && c->out_dim > 0);
+    ARG_CHECK(c->precision == MPREID_VIT_F16 || c->precision == MPREID_VIT_SPLIT);
     if (c->width != c->heads * 64) {
         mpreid_set_error("head dim must be 64 (width %d, heads %d)", c->width, c->heads);
         return MPREID_ERR_UNSUPPORTED;
@@ -596,12 +833,48 @@ static int launch_attention(const _Float16 *qkv, int B, int L, int W, int heads,
     return MPREID_OK;
 }
 
+template <int KTP, int NW>
+static int launch_attention_split(const float *qkv, int B, int L, int W, int heads, _Float16 *out, int q_tiles,
+                                  hipStream_t stream) {
+    constexpr int KEYS = KTP * 16;
+    const size_t lds = (size_t)4 * KEYS * 128 + (size_t)NW * 16 * 72 * 2;
+    static PerDeviceOnce attr_once;
+    const int rc = attr_once.run([&]() -> int {
+        if (lds > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_split_kernel<KTP, NW>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        return MPREID_OK;
+    });
+    if (rc) return rc;
+    int dev = 0, cus = 256;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int total = B * heads;
+    // persistent: as many workgroups as the LDS lets a CU hold (one for L = 129; the small test shapes fit several)
+    int per_cu = (int)((160 * 1024) / lds);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    int grid = cus * per_cu;
+    if (grid > total) grid = total;
+    hipLaunchKernelGGL((attention_split_kernel<KTP, NW>), dim3((unsigned)grid), dim3(64 * NW), lds, stream, qkv, L, W, heads,
+                       out, q_tiles, total);
+    LAUNCH_CHECK();
+    return MPREID_OK;
+}
+
+static int attention_split_dispatch(const float *qkv, int B, int L, int W, int heads, _Float16 *out, int q_tiles,
+                                    hipStream_t stream) {
+    const int kt = (L + 15) / 16;
+    if (kt <= 2) return launch_attention_split<2, 2>(qkv, B, L, W, heads, out, q_tiles, stream);
+    if (kt <= 10) return launch_attention_split<10, 8>(qkv, B, L, W, heads, out, q_tiles, stream);
+    if (kt <= 14) return launch_attention_split<14, 8>(qkv, B, L, W, heads, out, q_tiles, stream);
+    return launch_attention_split<16, 8>(qkv, B, L, W, heads, out, q_tiles, stream);
+}
+
 // waves per workgroup: one per 16-query tile when the block can hold them; at least 4 so that the
 // K/V staging of a CLS-only call (one query tile) is still spread over 256 threads
 static int attention_dispatch(const _Float16 *qkv, int B, int L, int W, int heads, _Float16 *out, int q_tiles,
                               hipStream_t stream) {
     const int kt = (L + 15) / 16;
-    const int nqt = (q_tiles > 0) ? q_tiles : kt;
     if (kt <= 2) return launch_attention<2, 2, true>(qkv, B, L, W, heads, out, q_tiles, stream);
     if (kt <= 10) {
         const bool exact = kt >= 9;
@@ -645,43 +918,56 @@ static int vit_forward_impl(const mpreid_vit_cfg *cfg, const mpreid_vit_weights 
     _Float16 *h_cls = (_Float16 *)(base + v.h_cls);
     float *y_cls = (float *)(base + v.y_cls);
     const bool cls_last = cfg->cls_only_last != 0 && cfg->layers > 0;
+    // split precision mode: every linear layer runs hi.hi' + lo.hi' + hi.lo' over fp16 pairs (gemm_f16.h GE_S_*)
+    const bool split = cfg->precision == MPREID_VIT_SPLIT;
+    const int pr = split ? 2 : 1;   // halfs per logical element of a GEMM operand row
+    auto linear = [&](GemmArgs &g, int kdim, float wscale, int epi_f16, int epi_split) -> int {
+        g.K = pr * kdim;
+        if (split) {
+            g.kseg = kdim;
+            g.oscale = wscale;
+        }
+        return launch_gemm_f16(g, split ? epi_split : epi_f16, stream);
+    };
 
     // patch embedding (conv1, no bias) + positional embedding; CLS row; ln_pre
     {
         const int64_t threads = (int64_t)v.MPpad * (v.Kp / 8);
         const dim3 grid((unsigned)((threads + 255) / 256));
-#define MPREID_IM2COL(V)                                                                                               \
-    case V:                                                                                                            \
+#define MPREID_IM2COL_S(V, S)                                                                                          \
         if (img_u8)                                                                                                    \
-            hipLaunchKernelGGL(im2col_u8_kernel<V>, grid, dim3(256), 0, stream, img_u8, B, cfg->img_h, cfg->img_w,     \
+            hipLaunchKernelGGL((im2col_u8_kernel<V, S>), grid, dim3(256), 0, stream, img_u8, B, cfg->img_h, cfg->img_w, \
                                cfg->patch, cfg->stride, cfg->h_res, cfg->w_res, mean3[0], mean3[1], mean3[2], std3[0], \
                                std3[1], std3[2], patches, v.MPpad);                                                    \
         else                                                                                                           \
-            hipLaunchKernelGGL(im2col_kernel<V>, grid, dim3(256), 0, stream, img, B, cfg->img_h, cfg->img_w,           \
-                               cfg->patch, cfg->stride, cfg->h_res, cfg->w_res, patches, v.MPpad);                     \
+            hipLaunchKernelGGL((im2col_kernel<V, S>), grid, dim3(256), 0, stream, img, B, cfg->img_h, cfg->img_w,      \
+                               cfg->patch, cfg->stride, cfg->h_res, cfg->w_res, patches, v.MPpad);
+#define MPREID_IM2COL(V)                                                                                               \
+    case V:                                                                                                            \
+        if (split) { MPREID_IM2COL_S(V, true) } else { MPREID_IM2COL_S(V, false) }                                     \
         break;
         switch (view) {
             MPREID_IM2COL(0) MPREID_IM2COL(1) MPREID_IM2COL(2) MPREID_IM2COL(3)
         }
 #undef MPREID_IM2COL
+#undef MPREID_IM2COL_S
         LAUNCH_CHECK();
         GemmArgs g{};
         g.A = patches;
         g.W = (const _Float16 *)w->conv_w;
         g.M = v.MPpad;
         g.N = W;
-        g.K = v.Kp;
         g.out = x;
         g.ldo = W;
         g.aux = w->pos_emb;
         g.m_valid = B * v.P;
         g.P = v.P;
         g.L = L;
-        rc = launch_gemm_f16(g, GE_PATCH, stream);
+        rc = linear(g, v.Kp, w->conv_s, GE_PATCH, GE_S_PATCH);
         if (rc) return rc;
         hipLaunchKernelGGL(cls_token_kernel, dim3((unsigned)B), dim3(256), 0, stream, w->class_emb, w->pos_emb, cv_emb,
                            B, L, W, x);
-        hipLaunchKernelGGL(layernorm_kernel<false>, dim3((unsigned)((v.M + 3) / 4)), dim3(256), 0, stream, x,
+        hipLaunchKernelGGL(layernorm_kernel<0>, dim3((unsigned)((v.M + 3) / 4)), dim3(256), 0, stream, x,
                            (int64_t)v.M, W, w->ln_pre_g, w->ln_pre_b, (void *)x, (int64_t)W);
         LAUNCH_CHECK();
     }
@@ -690,40 +976,58 @@ static int vit_forward_impl(const mpreid_vit_cfg *cfg, const mpreid_vit_weights 
         const bool tail = cls_last && (l == cfg->layers - 1);
         GemmArgs g{};
         // x = x + out_proj(attn(ln_1(x)))
-        hipLaunchKernelGGL(layernorm_kernel<true>, dim3((unsigned)((v.M + 3) / 4)), dim3(256), 0, stream, x,
-                           (int64_t)v.M, W, ly.ln1_g, ly.ln1_b, (void *)a, (int64_t)W);
+        void *ptok = mpreid_prof_begin(stream);
+        if (split)
+            hipLaunchKernelGGL(layernorm_kernel<2>, dim3((unsigned)((v.M + 3) / 4)), dim3(256), 0, stream, x,
+                               (int64_t)v.M, W, ly.ln1_g, ly.ln1_b, (void *)a, (int64_t)W);
+        else
+            hipLaunchKernelGGL(layernorm_kernel<1>, dim3((unsigned)((v.M + 3) / 4)), dim3(256), 0, stream, x,
+                               (int64_t)v.M, W, ly.ln1_g, ly.ln1_b, (void *)a, (int64_t)W);
+        mpreid_prof_end(ptok, stream, MPREID_PROF_LAYERNORM, v.M, W, pr, (double)v.M * W * (4.0 + 2.0 * pr));
         LAUNCH_CHECK();
         g = GemmArgs{};
-        g.A = a; g.W = (const _Float16 *)ly.in_proj_w; g.M = v.Mpad; g.N = 3 * W; g.K = W;
+        g.A = a; g.W = (const _Float16 *)ly.in_proj_w; g.M = v.Mpad; g.N = 3 * W;
         g.out = qkv; g.ldo = 3 * W; g.bias = ly.in_proj_b;
-        if ((rc = launch_gemm_f16(g, GE_BIAS_F16, stream))) return rc;
+        if ((rc = linear(g, W, ly.in_proj_s, GE_BIAS_F16, GE_S_BIAS_F32))) return rc;
         // in the last block only the CLS row reaches the output (model/make_model.py:98-100): the
         // attention runs the first query tile only and everything after it runs on the B CLS rows.
-        if ((rc = attention_dispatch(qkv, B, L, W, cfg->heads, a, tail ? 1 : 0, stream))) return rc;
+        ptok = mpreid_prof_begin(stream);
+        if (split)
+            rc = attention_split_dispatch(reinterpret_cast<const float *>(qkv), B, L, W, cfg->heads, a, tail ? 1 : 0, stream);
+        else
+            rc = attention_dispatch(qkv, B, L, W, cfg->heads, a, tail ? 1 : 0, stream);
+        // algorithmic bytes: k, v of every token + q and the output of the query rows (all of them, or the CLS tile's 16)
+        mpreid_prof_end(ptok, stream, MPREID_PROF_ATTENTION, v.M, tail ? 1 : 0, pr,
+                        ((double)v.M * 2.0 * W + (tail ? (double)B * 16 : (double)v.M) * 2.0 * W) * 2.0 * pr);
+        if (rc) return rc;
         float *xr = x;
         _Float16 *ar = a, *hr = hbuf;
         int rows = v.M, rows_pad = v.Mpad;
         if (tail) {
-            hipLaunchKernelGGL(gather_cls_kernel, dim3((unsigned)B), dim3(256), 0, stream, x, a, B, L, W, x_cls, a_cls);
+            hipLaunchKernelGGL(gather_cls_kernel, dim3((unsigned)B), dim3(256), 0, stream, x, a, B, L, W, pr * W, x_cls, a_cls);
             LAUNCH_CHECK();
             xr = x_cls; ar = a_cls; hr = h_cls; rows = B; rows_pad = v.Bpad;
         }
         g = GemmArgs{};
-        g.A = ar; g.W = (const _Float16 *)ly.out_proj_w; g.M = rows_pad; g.N = W; g.K = W;
+        g.A = ar; g.W = (const _Float16 *)ly.out_proj_w; g.M = rows_pad; g.N = W;
         g.out = xr; g.ldo = W; g.bias = ly.out_proj_b;
-        if ((rc = launch_gemm_f16(g, GE_BIAS_RES, stream))) return rc;
+        if ((rc = linear(g, W, ly.out_proj_s, GE_BIAS_RES, GE_S_BIAS_RES))) return rc;
         // x = x + c_proj(quickgelu(c_fc(ln_2(x))))
-        hipLaunchKernelGGL(layernorm_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, xr,
-                           (int64_t)rows, W, ly.ln2_g, ly.ln2_b, (void *)ar, (int64_t)W);
+        if (split)
+            hipLaunchKernelGGL(layernorm_kernel<2>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, xr,
+                               (int64_t)rows, W, ly.ln2_g, ly.ln2_b, (void *)ar, (int64_t)W);
+        else
+            hipLaunchKernelGGL(layernorm_kernel<1>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, xr,
+                               (int64_t)rows, W, ly.ln2_g, ly.ln2_b, (void *)ar, (int64_t)W);
         LAUNCH_CHECK();
         g = GemmArgs{};
-        g.A = ar; g.W = (const _Float16 *)ly.fc_w; g.M = rows_pad; g.N = 4 * W; g.K = W;
-        g.out = hr; g.ldo = 4 * W; g.bias = ly.fc_b;
-        if ((rc = launch_gemm_f16(g, GE_BIAS_GELU, stream))) return rc;
+        g.A = ar; g.W = (const _Float16 *)ly.fc_w; g.M = rows_pad; g.N = 4 * W;
+        g.out = hr; g.ldo = pr * 4 * W; g.bias = ly.fc_b;
+        if ((rc = linear(g, W, ly.fc_s, GE_BIAS_GELU, GE_S_BIAS_GELU))) return rc;
         g = GemmArgs{};
-        g.A = hr; g.W = (const _Float16 *)ly.proj_w; g.M = rows_pad; g.N = W; g.K = 4 * W;
+        g.A = hr; g.W = (const _Float16 *)ly.proj_w; g.M = rows_pad; g.N = W;
         g.out = xr; g.ldo = W; g.bias = ly.proj_b;
-        if ((rc = launch_gemm_f16(g, GE_BIAS_RES, stream))) return rc;
+        if ((rc = linear(g, 4 * W, ly.proj_s, GE_BIAS_RES, GE_S_BIAS_RES))) return rc;
     }
     const bool neck = cfg->neck_after != 0 && w->bn_scale && w->bn_proj_scale;
     hipLaunchKernelGGL(cls_ln_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, cls_last ? x_cls : x,
@@ -874,7 +1178,7 @@ extern "C" int mpreid_vit_forward_f32(const mpreid_vit_cfg *cfg, const mpreid_vi
                            v.P, L, W, x);
         hipLaunchKernelGGL(cls_token_kernel, dim3((unsigned)B), dim3(256), 0, stream, w->class_emb, w->pos_emb, cv_emb, B, L, W,
                            x);
-        hipLaunchKernelGGL(layernorm_kernel<false>, dim3((unsigned)((v.M + 3) / 4)), dim3(256), 0, stream, x, (int64_t)v.M, W,
+        hipLaunchKernelGGL(layernorm_kernel<0>, dim3((unsigned)((v.M + 3) / 4)), dim3(256), 0, stream, x, (int64_t)v.M, W,
                            w->ln_pre_g, w->ln_pre_b, (void *)x, (int64_t)W);
         LAUNCH_CHECK();
     }
@@ -884,7 +1188,7 @@ extern "C" int mpreid_vit_forward_f32(const mpreid_vit_cfg *cfg, const mpreid_vi
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)att_lds));
     for (int l = 0; l < cfg->layers; ++l) {
         const mpreid_vit_layer &ly = w->layers[l];
-        hipLaunchKernelGGL(layernorm_kernel<false>, dim3((unsigned)((v.M + 3) / 4)), dim3(256), 0, stream, x, (int64_t)v.M, W,
+        hipLaunchKernelGGL(layernorm_kernel<0>, dim3((unsigned)((v.M + 3) / 4)), dim3(256), 0, stream, x, (int64_t)v.M, W,
                            ly.ln1_g, ly.ln1_b, (void *)a, (int64_t)W);
         LAUNCH_CHECK();
         if ((rc = mpreid_gemm_f32_linear(a, (const float *)ly.in_proj_w, v.M, 3 * W, W, ly.in_proj_b, qkv, 3 * W, F32_LIN, stream)))
@@ -894,7 +1198,7 @@ extern "C" int mpreid_vit_forward_f32(const mpreid_vit_cfg *cfg, const mpreid_vi
         LAUNCH_CHECK();
         if ((rc = mpreid_gemm_f32_linear(a, (const float *)ly.out_proj_w, v.M, W, W, ly.out_proj_b, x, W, F32_LIN_RES, stream)))
             return rc;
-        hipLaunchKernelGGL(layernorm_kernel<false>, dim3((unsigned)((v.M + 3) / 4)), dim3(256), 0, stream, x, (int64_t)v.M, W,
+        hipLaunchKernelGGL(layernorm_kernel<0>, dim3((unsigned)((v.M + 3) / 4)), dim3(256), 0, stream, x, (int64_t)v.M, W,
                            ly.ln2_g, ly.ln2_b, (void *)a, (int64_t)W);
         LAUNCH_CHECK();
         if ((rc = mpreid_gemm_f32_linear(a, (const float *)ly.fc_w, v.M, 4 * W, W, ly.fc_b, hbuf, 4 * W, F32_LIN_GELU, stream)))

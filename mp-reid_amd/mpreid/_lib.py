@@ -32,7 +32,7 @@ SYMBOLS = [
     "mpreid_vit_workspace_bytes_f32", "mpreid_vit_forward_f32",
     "mpreid_tta_mean_f32", "mpreid_resize_workspace_bytes", "mpreid_resize_bilinear_u8", "mpreid_conv_f16_nhwc",
     "mpreid_rn50_workspace_bytes", "mpreid_rn50_forward",
-    "mpreid_gemm_f16_nt", "mpreid_gemm_f16_nt_ex",
+    "mpreid_gemm_f16_nt", "mpreid_gemm_f16_nt_ex", "mpreid_gemm_f16_split_nt", "mpreid_split_pack_f32",
     "mpreid_cast_f32_to_f16", "mpreid_profile_enable", "mpreid_profile_reset", "mpreid_profile_query",
 ]
 
@@ -51,18 +51,19 @@ class RerankStats(C.Structure):
 
 class VitCfg(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("img_h", "img_w", "patch", "stride", "h_res", "w_res", "width", "layers",
-                                         "heads", "out_dim", "neck_after", "cls_only_last")]
+                                         "heads", "out_dim", "neck_after", "cls_only_last", "precision")]
 
 
 class VitLayer(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "ln1_g", "ln1_b",
-                                          "ln2_g", "ln2_b", "fc_w", "fc_b", "proj_w", "proj_b")]
+                                          "ln2_g", "ln2_b", "fc_w", "fc_b", "proj_w", "proj_b")] + \
+               [(k, C.c_float) for k in ("in_proj_s", "out_proj_s", "fc_s", "proj_s")]
 
 
 class VitWeights(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("conv_w", "class_emb", "pos_emb", "ln_pre_g", "ln_pre_b", "ln_post_g",
                                           "ln_post_b", "proj", "bn_scale", "bn_shift", "bn_proj_scale",
-                                          "bn_proj_shift")] + [("layers", C.POINTER(VitLayer))]
+                                          "bn_proj_shift")] + [("layers", C.POINTER(VitLayer)), ("conv_s", C.c_float)]
 
 
 class Rn50Conv(C.Structure):
@@ -91,7 +92,10 @@ class ProfileEntry(C.Structure):
 
 
 GEMM_EPILOGUE_NAMES = {0: "f32", 1: "qkv_bias_f16", 2: "bias_residual", 3: "fc_bias_quickgelu", 4: "patch_embed",
-                       5: "euclid", 6: "cosine", 7: "conv1x1_bias_relu", 8: "conv1x1_bias_residual_relu"}
+                       5: "euclid", 6: "cosine", 7: "conv1x1_bias_relu", 8: "conv1x1_bias_residual_relu", 9: "candidates",
+                       10: "split_qkv_bias_f32", 11: "split_bias_residual", 12: "split_fc_bias_quickgelu",
+                       13: "split_patch_embed"}
+VIT_F16, VIT_SPLIT = 0, 1
 
 _lib = None
 
@@ -196,6 +200,10 @@ def load():
     L.mpreid_gemm_f16_nt.argtypes = [vp, vp, vp, i64, i64, i64, vp]
     L.mpreid_gemm_f16_nt_ex.restype = i32
     L.mpreid_gemm_f16_nt_ex.argtypes = [vp, vp, vp, vp, i64, i64, i64, i32, vp]
+    L.mpreid_gemm_f16_split_nt.restype = i32
+    L.mpreid_gemm_f16_split_nt.argtypes = [vp, vp, vp, vp, i64, i64, i64, f32, i32, vp]
+    L.mpreid_split_pack_f32.restype = i32
+    L.mpreid_split_pack_f32.argtypes = [vp, i64, i32, f32, vp, vp]
     L.mpreid_cast_f32_to_f16.restype = i32
     L.mpreid_cast_f32_to_f16.argtypes = [vp, vp, i64, vp]
     L.mpreid_profile_enable.restype = i32

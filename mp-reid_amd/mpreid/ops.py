@@ -240,10 +240,12 @@ class VitEncoder:
 
     def __init__(self, cfg: dict, state_dict: dict, img_hw, neck_after: bool = False, bn: Optional[dict] = None,
                  device=None, cls_only_last: bool = True, ws_tag: str = "vit", precision: str = "fp16"):
-        """precision: 'fp16' = fp16 MFMA operands, fp32 accumulate / residual stream (the throughput path, relative
-        feature error ~4e-4); 'fp32' = every weight and activation fp32, exact fp32 matrix instruction (parity mode,
-        ~1e-6, ~1/8 of the throughput; mpreid_vit_forward_f32)."""
-        assert precision in ("fp16", "fp32"), precision
+        """precision: 'split' = every GEMM operand an fp16 pair hi + lo, products hi.hi' + lo.hi' + hi.lo' on the fp16
+        matrix cores with fp32 accumulation -- fp32-grade features (~1e-6) at 3x the matrix work: the mode that meets
+        the 1e-4 mAP bound AND is the measured one; 'fp16' = fp16 operands, fp32 accumulate / residual stream (fastest,
+        relative feature error ~4e-4: misses the bound on hard data); 'fp32' = every weight and activation fp32, exact
+        fp32 matrix instruction (~1e-6, ~1/8 of the fp16 throughput; mpreid_vit_forward_f32)."""
+        assert precision in ("fp16", "fp32", "split"), precision
         self.precision = precision
         self.device = device or _lib.require_gpu()
         self.ws_tag = ws_tag   # encoders that run concurrently on different streams need distinct workspaces
@@ -261,10 +263,23 @@ class VitEncoder:
         def f32(name):
             return get(name).to(device=dev, dtype=torch.float32).contiguous()
 
+        scales = {}
+
         def f16(name, shape=None):   # a GEMM weight: fp16 for the MFMA path, fp32 in the all-fp32 mode
             t = get(name).to(device=dev, dtype=torch.float32)
             if shape is not None:
                 t = t.reshape(shape)
+            if precision == "split":
+                # fp16 pair [out][hi(in) | lo(in)] of W * 2^e with the largest |entry| in [2^9, 2^10): hi + lo carries
+                # 22 significant bits of every entry that matters; 2^-e is undone in the GEMM epilogue (exact)
+                t = t.contiguous()
+                amax = float(t.abs().max())
+                e = 9 - int(np.floor(np.log2(amax))) if amax > 0 and np.isfinite(amax) else 0
+                pair = torch.empty((t.shape[0], 2 * t.shape[1]), dtype=torch.float16, device=dev)
+                _lib.check(_lib.load().mpreid_split_pack_f32(_ptr(t), t.shape[0], t.shape[1], float(2.0 ** e), _ptr(pair),
+                                                             _lib.stream_ptr()), "mpreid_split_pack_f32")
+                scales[name] = float(2.0 ** -e)
+                return pair
             return t.contiguous() if precision == "fp32" else t.to(torch.float16).contiguous()
 
         w = cfg["width"]
@@ -272,7 +287,7 @@ class VitEncoder:
         keep = self._keep.append
         self.c_cfg = _lib.VitCfg(self.img_hw[0], self.img_hw[1], cfg["patch"], cfg["stride"], cfg["h_res"],
                                  cfg["w_res"], w, cfg["layers"], cfg["heads"], cfg["out_dim"], int(bool(neck_after)),
-                                 int(bool(cls_only_last)))
+                                 int(bool(cls_only_last)), _lib.VIT_SPLIT if precision == "split" else _lib.VIT_F16)
         layers = (_lib.VitLayer * max(cfg["layers"], 1))()
         for i in range(cfg["layers"]):
             b = f"transformer.resblocks.{i}"
@@ -285,6 +300,11 @@ class VitEncoder:
             for k, v in t.items():
                 keep(v)
                 setattr(layers[i], k, v.data_ptr())
+            if precision == "split":
+                layers[i].in_proj_s = scales[b + ".attn.in_proj_weight"]
+                layers[i].out_proj_s = scales[b + ".attn.out_proj.weight"]
+                layers[i].fc_s = scales[b + ".mlp.c_fc.weight"]
+                layers[i].proj_s = scales[b + ".mlp.c_proj.weight"]
         self._layers = layers
         top = dict(conv_w=f16("conv1.weight", (w, -1)), class_emb=f32("class_embedding"),
                    pos_emb=f32("positional_embedding"), ln_pre_g=f32("ln_pre.weight"), ln_pre_b=f32("ln_pre.bias"),
@@ -295,6 +315,9 @@ class VitEncoder:
         for k, v in top.items():
             keep(v)
             setattr(self.c_w, k, v.data_ptr())
+        if precision == "split":
+            self.c_w.conv_s = scales["conv1.weight"]
+            torch.cuda.current_stream().synchronize()   # the pack kernels read temporaries of this constructor
         if bn is not None:
             for name, (sk, bk) in (("bottleneck", ("bn_scale", "bn_shift")),
                                    ("bottleneck_proj", ("bn_proj_scale", "bn_proj_shift"))):

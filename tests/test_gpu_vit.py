@@ -143,3 +143,134 @@ def test_gemm_kernels_agree_bitwise(name, n, k, epi):
     elif epi == 8:
         ref = torch.relu(init[:ms].float() + (ref + bias))
     assert torch.allclose(osm.float(), ref, rtol=2e-3, atol=2e-3)
+
+
+# ---- `split` precision mode (MODEL.ENCODER_PRECISION: split): fp16 operand PAIRS hi + lo, three products per
+# multiply-add on the fp16 matrix cores, fp32 accumulation -- fp32-grade results.  Reference: the encoder runs in fp32
+# (processor/processor.py:187-198 has no autocast, model/clip/model.py:654-675 casts the weights to float).
+def _pair(x, scale=1.0):
+    """fp32 [r, c] -> fp16 pair [r, 2c] = hi | lo of x * scale, through the C ABI"""
+    import ctypes as C
+    from mpreid import _lib
+    x = x.contiguous()
+    y = torch.empty((x.shape[0], 2 * x.shape[1]), dtype=torch.float16, device=x.device)
+    _lib.check(_lib.load().mpreid_split_pack_f32(C.c_void_p(x.data_ptr()), x.shape[0], x.shape[1], float(scale),
+                                                 C.c_void_p(y.data_ptr()), _lib.stream_ptr()), "split_pack")
+    return y
+
+
+def test_split_pack_is_exact_pair():
+    from mpreid import _lib
+    dev = _lib.require_gpu()
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    x = (torch.randn((37, 200), generator=gen) * torch.logspace(-6, 2, 200)).to(dev)
+    y = _pair(x, 4.0)
+    hi, lo = y[:, :200].double(), y[:, 200:].double()
+    assert torch.equal(y[:, :200], (x * 4).half())
+    # hi + lo reproduces x * scale to 2^-22 relative (or the bottom of the fp16 subnormal range)
+    err = (hi + lo - x.double() * 4).abs()
+    assert bool((err <= (x.double() * 4).abs() * 2.0 ** -22 + 2.0 ** -25).all())
+
+
+@pytest.mark.parametrize("name,n,k,epi", [("qkv", 2304, 768, 10), ("out", 768, 768, 11), ("fc1", 3072, 768, 12),
+                                            ("fc2", 768, 3072, 11)])
+def test_split_gemm_kernels_agree_bitwise_and_are_fp32_grade(name, n, k, epi):
+    """128x128 and persistent 256x256 kernel give the same bits in split mode too, and the result is at the fp32
+    rounding level of an fp64 reference (the fp16 one-pass GEMM is ~1e-3 away on the same data)"""
+    import ctypes as C
+    from mpreid import _lib
+    L = _lib.load()
+    dev = _lib.require_gpu()
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    mb, ms = 16384, 256
+    a = (torch.rand((mb, k), generator=gen) * 2 - 1).to(dev)
+    w = ((torch.rand((n, k), generator=gen) * 2 - 1) * 0.05).to(dev)
+    e = 9 - int(np.floor(np.log2(float(w.abs().max()))))
+    a2, w2 = _pair(a), _pair(w, 2.0 ** e)
+    bias = torch.randn(n, generator=gen).to(dev)
+    init = torch.randn((mb, n), generator=gen).to(dev)
+    if epi == 12:
+        ob = torch.empty((mb, 2 * n), dtype=torch.float16, device=dev)
+        osm = torch.empty((ms, 2 * n), dtype=torch.float16, device=dev)
+    else:
+        ob, osm = init.clone(), init[:ms].clone()
+    for x, o in ((a2, ob), (a2[:ms].contiguous(), osm)):
+        _lib.check(L.mpreid_gemm_f16_split_nt(C.c_void_p(x.data_ptr()), C.c_void_p(w2.data_ptr()), C.c_void_p(o.data_ptr()),
+                                              C.c_void_p(bias.data_ptr()), x.shape[0], n, k, float(2.0 ** -e), epi,
+                                              _lib.stream_ptr()), name)
+    torch.cuda.synchronize()
+    assert torch.equal(ob[:ms], osm)
+    ref = a[:ms].double() @ w.double().T + bias.double()
+    if epi == 11:
+        ref = init[:ms].double() + ref
+        got = osm.double()
+    elif epi == 12:
+        ref = ref * torch.sigmoid(1.702 * ref)
+        got = osm[:, :n].double() + osm[:, n:].double()
+    else:
+        got = osm.double()
+    rel = float((got - ref).norm() / ref.norm())
+    print(f"split gemm {name}: rel-L2 vs fp64 {rel:.2e}, max abs {float((got - ref).abs().max()):.2e}")
+    # (fp32 accumulation over 3 * k / 32 matrix instructions: ~1.7e-7 at k = 768, ~4.4e-7 at k = 3072; one-pass fp16: ~3e-4)
+    assert rel <= 6e-7 and float((got - ref).abs().max()) <= 4e-6 * max(1.0, float(ref.abs().max()))
+
+
+def test_split_vit_vs_reference_goldens(golden):
+    """the split mode against the reference's own fp32 outputs (tests/golden/vit.npz) at fp32 accuracy: reduced
+    config (128x128-tile GEMM kernels, 2-tile attention), ViT-B/16, camera embedding, stride 12 (L = 211)"""
+    from mpreid import synth
+    g = golden("vit.npz")
+    enc = _encoder(SMALL, synth.vit_state_dict(SMALL, seed=7, std=0.05, ln_jitter=0.1), (64, 32), precision="split")
+    f = enc(torch.from_numpy(synth.synthetic_images(3, 64, 32, seed=3))).cpu().numpy()
+    assert np.abs(f - g["small_feat"]).max() <= 2e-5
+    big = synth.VIT_B16
+    sd = synth.vit_state_dict(big, seed=7, std=0.02, ln_jitter=0.05)
+    imgs = torch.from_numpy(synth.synthetic_images(4, 256, 128, seed=1234))
+    enc = _encoder(big, sd, (256, 128), precision="split")
+    f = enc(imgs).cpu().numpy()
+    print("split b16 max |d| vs reference:", np.abs(f - g["b16_feat"]).max(),
+          "rel-L2", np.linalg.norm(f - g["b16_feat"]) / np.linalg.norm(g["b16_feat"]))
+    assert np.abs(f - g["b16_feat"]).max() <= 5e-5
+    assert np.abs(enc(imgs, cv_emb=torch.from_numpy(g["b16_cv"])).cpu().numpy() - g["b16_feat_cv"]).max() <= 5e-5
+    # batch independence (the same image through the 128x128 or the 256x256 kernels, any position): same bits
+    more = synth.synthetic_images(70, 256, 128, seed=99)
+    more[10:14] = imgs.numpy()
+    assert np.array_equal(enc(torch.from_numpy(more)).cpu().numpy()[10:14], f)
+    # the last block restricted to the CLS row: same bits
+    full = _encoder(big, sd, (256, 128), precision="split", cls_only_last=False)(imgs).cpu().numpy()
+    assert np.array_equal(full, f)
+    s12 = dict(big, h_res=21, w_res=10, stride=12)
+    enc = _encoder(s12, synth.vit_state_dict(s12, seed=8, std=0.02, ln_jitter=0.05), (256, 128), precision="split")
+    assert np.abs(enc(imgs[:2]).cpu().numpy() - g["b16_s12_feat"]).max() <= 5e-5
+
+
+def test_split_vit_uint8_and_views_match_float_path():
+    """split mode: uint8 input == transformed fp32 input bit for bit; fused view gather == materialised view tensor"""
+    from mpreid import ops, synth
+    rng = np.random.default_rng(0)
+    sd = synth.vit_state_dict(SMALL, seed=7, std=0.05, ln_jitter=0.1)
+    enc = _encoder(SMALL, sd, (64, 32), precision="split")
+    u8 = rng.integers(0, 256, size=(5, 64, 32, 3), dtype=np.uint8)
+    mean, std = (0.5, 0.4, 0.45), (0.5, 0.25, 0.3)
+    x = torch.from_numpy(u8).permute(0, 3, 1, 2).float().div(255.0)
+    x = (x - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+    want = enc(x).cpu().numpy()
+    assert np.array_equal(enc.forward_u8(torch.from_numpy(u8), mean, std).cpu().numpy(), want)
+    assert np.array_equal(enc.forward_view(x, ops.VIEW_FLIP).cpu().numpy(), enc(torch.flip(x, [3]).contiguous()).cpu().numpy())
+    assert np.array_equal(enc.forward_view(x, ops.VIEW_PSEUDO_RGB).cpu().numpy(),
+                          enc(x[:, 0:1].repeat(1, 3, 1, 1).contiguous()).cpu().numpy())
+
+
+def test_split_vit_bn_neck_vs_oracle():
+    from mpreid import synth
+    rng = np.random.default_rng(0)
+    sd = synth.vit_state_dict(SMALL, seed=11, std=0.05, ln_jitter=0.1)
+    bn = dict(bottleneck=(1 + 0.1 * rng.standard_normal(128), 0.1 * rng.standard_normal(128),
+                          0.2 * rng.standard_normal(128), 0.5 + rng.random(128)),
+              bottleneck_proj=(1 + 0.1 * rng.standard_normal(64), 0.1 * rng.standard_normal(64),
+                               0.2 * rng.standard_normal(64), 0.5 + rng.random(64)))
+    bn = {k: tuple(np.asarray(a, np.float32) for a in v) for k, v in bn.items()}
+    imgs = synth.synthetic_images(5, 64, 32, seed=4)
+    enc = _encoder(SMALL, sd, (64, 32), neck_after=True, bn=bn, precision="split")
+    want = orc.vit_features(sd, SMALL, imgs, bn=bn, neck_feat="after")
+    assert np.abs(enc(torch.from_numpy(imgs)).cpu().numpy() - want).max() <= 3e-5
