@@ -72,6 +72,10 @@ def parse():
                          "PAIRS hi + lo, three products per multiply-add on the fp16 matrix cores, fp32-grade features: the "
                          "mode that meets the 1e-4 mAP bound; fp16 = single fp16 operands (fastest, ~4e-4 feature error, "
                          "does not meet the bound on hard data); fp32 = exact fp32 matrix instruction")
+    ap.add_argument("--host-concat", choices=("auto", "on", "off"), default="auto",
+                    help="gather the per-shard distance blocks into one pinned host matrix on rank 0 inside every step "
+                         "(north_star); auto = on for the market workload (214 MB per GPU shard), off for synth / msmt17 "
+                         "(6.4 / 3.8 GB matrices: the step would measure PCIe)")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the encoder batches alternate on (HBM-bound phases of one batch overlap "
                          "MFMA phases of the other)")
@@ -89,26 +93,53 @@ def _free_port():
     return port
 
 
-def launch_children(n):
+def launch_children(n, timeout_s=3000):
     """Start n ranks of this script as fresh processes and relay rank 0's JSON line.  The parent never touches the
-    GPU, so nothing that has initialised HIP is ever exec-ed or forked."""
+    GPU, so nothing that has initialised HIP is ever exec-ed or forked.  All children are polled: as soon as one exits
+    non-zero (or the overall timeout passes) the others are terminated -- a rank that died after the rendezvous would
+    otherwise leave rank 0 inside a collective for ever -- and the parent exits 1."""
+    import tempfile
+    import threading
     port = _free_port()
     procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, text=True))
+    deadline = time.time() + timeout_s
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        if any(c not in (None, 0) for c in codes):
+            failed = "a rank exited with a non-zero code"
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() > deadline:
+            failed = f"timeout after {timeout_s} s"
+            break
+        time.sleep(0.2)
+    if failed:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        killer = threading.Timer(10.0, lambda: [p.kill() for p in procs if p.poll() is None])
+        killer.start()
+        for p in procs:
+            p.wait()
+        killer.cancel()
+    codes = [p.returncode for p in procs]
+    out0.seek(0)
     line = None
-    for ln in (out0 or "").splitlines():
+    for ln in out0.read().splitlines():
         if ln.startswith("{") and '"metric"' in ln:
             line = ln
         else:
             print(ln, file=sys.stderr)
-    if any(codes) or line is None:
-        print(f"bench.py: child ranks exited with {codes}", file=sys.stderr)
+    if failed or any(codes) or line is None:
+        print(f"bench.py: child ranks exited with {codes}" + (f" ({failed})" if failed else ""), file=sys.stderr)
         sys.exit(1)
     print(line, flush=True)
 
@@ -487,6 +518,8 @@ def run_rank(a):
     block = torch.empty((nq, ng_local), dtype=torch.float32, device=dev)
     rr_holder = {}
 
+    host_concat = a.host_concat == "on" or (a.host_concat == "auto" and wl == "market")
+
     def step():
         if wl == "synth":
             fq, fg = fq_local, fg_local
@@ -502,6 +535,18 @@ def run_rank(a):
                                       algo=ops.RERANK_SPARSE_SPLIT3 if a.rerank_algo == "split3" else ops.RERANK_AUTO)
             assert rr.shape[1] == ng_total
             rr_holder["rr"] = rr
+        # north_star: "per-shard distance blocks concatenated on the host": the column blocks (and the re-ranked row
+        # blocks) travel as tensors to rank 0 (RCCL gather over xGMI) and land in ONE pinned host matrix; at N = 1 this is
+        # the D2H copy of the matrix R1_mAP_eval.compute() hands to its caller
+        if host_concat:
+            torch.cuda.synchronize()
+            t_h = time.perf_counter()
+            full = D.gather_column_blocks_to_host(block, dst=0, reuse_buffer=True)
+            if a.rerank:
+                D.gather_row_blocks_to_host(rr_holder["rr"], dst=0, reuse_buffer=True)
+            comm["host_ms"] = comm.get("host_ms", 0.0) + (time.perf_counter() - t_h) * 1e3
+            if rank == 0:
+                assert full.shape == (nq, ng_total)
 
     def fence():
         torch.cuda.synchronize()
@@ -512,7 +557,7 @@ def run_rank(a):
     for _ in range(a.warmup):
         step()
     fence()
-    comm.update(bytes=0, calls=0, ev=[])
+    comm.update(bytes=0, calls=0, ev=[], host_ms=0.0)
     instrument_live = nstreams == 1 or enc is None   # event pairs on one stream also span other streams' kernels
     L.mpreid_profile_reset()
     if instrument_live:
@@ -525,6 +570,7 @@ def run_rank(a):
     L.mpreid_profile_enable(0)
     comm_ms = sum(e0.elapsed_time(e1) for e0, e1 in comm.get("ev", []))
     comm_bytes, comm_calls = comm["bytes"], comm["calls"]
+    host_concat_ms = comm.get("host_ms", 0.0) / max(a.steps, 1)
     if not instrument_live:
         # roofline leg: one more pass of the same work on ONE stream with per-launch hipEvents
         saved = (list(side), list(encs))
@@ -637,6 +683,11 @@ def run_rank(a):
                        "encoder_precision": a.encoder_precision if enc else None,
                        "encoder_streams": nstreams if enc else None,
                        "sharding": (f"gallery rows over {world} GPU(s), queries 1/{world} each + all-gather")},
+            "host_concat": None if not host_concat else {"ms_per_step": round(host_concat_ms, 3),
+                            "bytes_per_step": int(4 * nq * ng_total * (2 if a.rerank else 1)),
+                            "note": "inside the timed step: per-shard distance blocks -> rank 0 (tensor gather over xGMI when "
+                                    "N > 1) -> one pinned host matrix [nq, ng]; wall time on rank 0 incl. the wait for the "
+                                    "device to finish the step's kernels is excluded (the step is synchronised first)"},
             "roofline": roof, "gemm_classes": classes, "other_encoder_kernels": other,
             "reference_cpu": {"note": "the REFERENCE's own Python on 8 host threads of the build container (BASELINE.md section 2); "
                                       "cpu_baseline below is the C/torch ORACLE port on this box, not the reference",

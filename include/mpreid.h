@@ -102,7 +102,7 @@ typedef struct {
 #define MPREID_RERANK_SPARSE_SPLIT3 3
 /* Bytes of device workspace re_ranking needs for this problem (DENSE: dominated by the N x N fp32 distance matrix,
  * 4*N*N; SPARSE: by the sample distances N*N/4 bytes and the query rows 4*nq*N). */
-size_t mpreid_rerank_workspace_bytes(int64_t nq, int64_t ng, int d, int k1, int k2, int has_local);      /* AUTO */
+size_t mpreid_rerank_workspace_bytes(int64_t nq, int64_t ng, int d, int k1, int k2, int has_local);      /* DENSE */
 size_t mpreid_rerank_workspace_bytes_ex(int64_t nq, int64_t ng, int d, int k1, int k2, int has_local, int algo);
 
 /* re_ranking(probFea, galFea, k1, k2, lambda_value, local_distmat=None, only_local=False)
@@ -115,6 +115,9 @@ size_t mpreid_rerank_workspace_bytes_ex(int64_t nq, int64_t ng, int d, int k1, i
  * Limits: max(k1 + 1, k2) <= 256 (the neighbour selection sorts its winners in one 256-entry LDS network; the
  * reference is called with k1 = 50, k2 = 15, utils/metrics.py:127) -> MPREID_ERR_UNSUPPORTED above that;
  * N = nq + ng < 2^31 - 64. */
+/* mpreid_rerank_f32 (+ mpreid_rerank_workspace_bytes, mpreid_rerank_debug_copy) is the DENSE algorithm: it never returns
+ * the data-dependent MPREID_ERR_RETRY_DENSE.  mpreid_rerank_f32_ex takes the algorithm (AUTO / SPARSE: faster, may ask for
+ * the dense retry with a workspace from mpreid_rerank_workspace_bytes_ex(..., MPREID_RERANK_DENSE)). */
 int mpreid_rerank_f32(const float *q_dev, const float *g_dev, int64_t nq, int64_t ng, int d, int k1, int k2,
                       double lambda_value, const float *local_dev, int only_local, float *out_dev,
                       int64_t ldo, void *ws_dev, size_t ws_bytes, mpreid_stream_t stream,
@@ -130,7 +133,7 @@ int mpreid_rerank_f32_ex(const float *q_dev, const float *g_dev, int64_t nq, int
  *   rank_out [N][k1+1] int32 (initial_rank[:, :k1+1]); v_cnt/vqe_cnt [N] int32 nnz per row. */
 int mpreid_rerank_debug_copy(const void *ws_dev, int64_t nq, int64_t ng, int d, int k1, int k2, int has_local,
                              int32_t *rank_out_host, int32_t *v_cnt_host, int32_t *vqe_cnt_host,
-                             mpreid_stream_t stream);   /* layout of the AUTO choice */
+                             mpreid_stream_t stream);   /* layout of the DENSE algorithm (mpreid_rerank_f32) */
 int mpreid_rerank_debug_copy_ex(const void *ws_dev, int64_t nq, int64_t ng, int d, int k1, int k2, int has_local,
                                 int32_t *rank_out_host, int32_t *v_cnt_host, int32_t *vqe_cnt_host,
                                 mpreid_stream_t stream, int algo);

@@ -1724,17 +1724,26 @@ __global__ __launch_bounds__(256) void rr2_cast_rows_kernel(const float *__restr
 // G = max row norm -> gstat[0]; gstat[1] = 1 if any norm is too large for fp16 operands (or not finite)
 __global__ __launch_bounds__(1024) void rr2_norm_stats_kernel(const float *__restrict__ sqn, int64_t n, float *__restrict__ gstat) {
     __shared__ float red[16];
+    __shared__ int bad_any;
+    if (threadIdx.x == 0) bad_any = 0;
+    __syncthreads();
     float m = 0.0f;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, sqn[i]);
+    int bad = 0;   // fmaxf DROPS a NaN operand, so non-finite norms are tracked explicitly (a NaN row must not pass)
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const float v = sqn[i];
+        bad |= !(v >= 0.0f && v < 3.0e38f);
+        m = fmaxf(m, v);
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (bad) atomicOr(&bad_any, 1);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
         const float G = sqrtf(m);
         gstat[0] = G;
-        gstat[1] = (G < 3.0e4f) ? 0.0f : 1.0f;   // NaN compares false -> 1
+        gstat[1] = (G < 3.0e4f && !bad_any) ? 0.0f : 1.0f;
     }
 }
 
@@ -2156,7 +2165,13 @@ static int launch_jaccard(int64_t N, int64_t nq, int q0, int64_t qrows, const fl
     }
     // timing ablations (wrong results): 1 nothing is accumulated, 4 no output pass, 8 no direct path for long columns.
     // (An ablation that points every gather at ONE address measures an L2 hot spot, not the loop: removed.)
+    // Compiled in only with -DMPREID_ABLATION (never in the shipped library: a stray environment variable must not be
+    // able to change results).
+#ifdef MPREID_ABLATION
     static const int jdbg = getenv("MPREID_JACCARD_DBG") ? atoi(getenv("MPREID_JACCARD_DBG")) : 0;
+#else
+    constexpr int jdbg = 0;
+#endif
     const size_t lds = align_up((size_t)rch * 2 + 16, 16) + (size_t)qcap * (8 + 4 + 2) + 16;
 #define MPREID_JACCARD_LAUNCH(JT_, NPF_, PD_, PK_)                                                                       \
     {                                                                                                                    \
@@ -2522,24 +2537,58 @@ static bool sparse_eligible(int64_t nq, int64_t ng, int k1, int k2, const float 
 struct SideStream {
     hipStream_t s = nullptr;
     hipEvent_t fork = nullptr, join = nullptr, t0 = nullptr, t1 = nullptr;
-};
-static int side_stream(SideStream **out) {
-    static std::mutex mu;
-    static SideStream table[64];
     int dev = 0;
-    HIP_TRY(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lk(mu);
-    SideStream &ss = table[(dev >= 0 && dev < 64) ? dev : 0];
-    if (!ss.s) {
-        HIP_TRY(hipStreamCreateWithFlags(&ss.s, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&ss.join, hipEventDisableTiming));
-        HIP_TRY(hipEventCreate(&ss.t0));
-        HIP_TRY(hipEventCreate(&ss.t1));
+};
+// Side streams are LEASED per call from a per-device pool (created on demand, returned at the end of the call), so that
+// calls on different streams / devices of one process never share one and need no process-wide lock.  The lease's
+// destructor runs on EVERY exit path: when work was forked onto the side stream it waits for that work first, so the
+// workspace (the distance rows it writes) is quiescent when the call returns -- also on the early MPREID_ERR_RETRY_DENSE
+// / error returns, after which the caller typically frees or re-purposes the workspace.
+struct SideLease {
+    SideStream *ss = nullptr;
+    bool forked = false;
+    static std::mutex &mu() {
+        static std::mutex m;
+        return m;
     }
-    *out = &ss;
-    return MPREID_OK;
-}
+    static std::vector<SideStream *> &pool() {
+        static std::vector<SideStream *> p;
+        return p;
+    }
+    int acquire() {
+        if (ss) return MPREID_OK;
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        {
+            std::lock_guard<std::mutex> lk(mu());
+            auto &p = pool();
+            for (size_t i = 0; i < p.size(); ++i)
+                if (p[i]->dev == dev) {
+                    ss = p[i];
+                    p.erase(p.begin() + (long)i);
+                    return MPREID_OK;
+                }
+        }
+        SideStream *n = new SideStream();
+        n->dev = dev;
+        if (hipStreamCreateWithFlags(&n->s, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&n->fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&n->join, hipEventDisableTiming) != hipSuccess || hipEventCreate(&n->t0) != hipSuccess ||
+            hipEventCreate(&n->t1) != hipSuccess) {
+            mpreid_set_error("re-ranking: could not create the side stream");
+            delete n;   // (handles created so far leak on this never-seen path)
+            return MPREID_ERR_NODEVICE;
+        }
+        ss = n;
+        return MPREID_OK;
+    }
+    ~SideLease() {
+        if (!ss) return;
+        if (forked) (void)hipStreamSynchronize(ss->s);
+        std::lock_guard<std::mutex> lk(mu());
+        pool().push_back(ss);
+    }
+};
 
 static int rerank_sparse(const float *q, const float *g, int64_t nq, int64_t ng, int d, int k1, int k2, double lambda_value,
                          float *out, int64_t ldo, void *ws, size_t ws_bytes, mpreid_stream_t stream_,
@@ -2556,10 +2605,7 @@ static int rerank_sparse(const float *q, const float *g, int64_t nq, int64_t ng,
         return MPREID_ERR_WORKSPACE;
     }
     hipStream_t stream = (hipStream_t)stream_;
-    // one sparse call at a time per process: the side stream and its events are shared state (calls on different
-    // devices of one process serialise here too; a call is a few ms)
-    static std::mutex call_mu;
-    std::lock_guard<std::mutex> call_lock(call_mu);
+    SideLease lease;   // (declared before anything that can return: its destructor joins the side stream on every path)
     char *base = (char *)ws;
     float *feat = (float *)(base + L.feat), *sqn = (float *)(base + L.sqn);
     _Float16 *feat16 = (_Float16 *)(base + L.feat16), *samp16 = (_Float16 *)(base + L.samp16);
@@ -2620,9 +2666,11 @@ static int rerank_sparse(const float *q, const float *g, int64_t nq, int64_t ng,
         a.aux = sqn; a.aux2 = sqn; a.m_valid = (int)N; a.n_valid = (int)N;
         a.tlo = tlo; a.thi = thi; a.cnt_lo = cnt_lo; a.cnt_hi = cnt_hi; a.list_lo = list_lo; a.list_hi = list_hi;
         a.cap_lo = RR2_CAP_LO; a.cap_hi = RR2_CAP_HI; a.sym = 1;
-        static const int cand_dbg = getenv("MPREID_CAND_DBG") ? atoi(getenv("MPREID_CAND_DBG")) : 0;   // timing experiments
+#ifdef MPREID_ABLATION   // timing experiments (wrong results): never in the shipped library
+        static const int cand_dbg = getenv("MPREID_CAND_DBG") ? atoi(getenv("MPREID_CAND_DBG")) : 0;
         if (cand_dbg & 1) a.sym = 0;
         if (cand_dbg & 2) a.stagger = 2;
+#endif
         rc = launch_gemm_f16(a, GE_CAND, stream);
         if (rc) return rc;
     }
@@ -2653,11 +2701,13 @@ static int rerank_sparse(const float *q, const float *g, int64_t nq, int64_t ng,
     const bool no_overlap = ov_mode == 0;
     SideStream *ss = nullptr;
     if (ov_mode != 0) {
-        if ((rc = side_stream(&ss))) return rc;
+        if ((rc = lease.acquire())) return rc;
+        ss = lease.ss;
     }
     if (ov_mode == 1) {
         HIP_TRY(hipEventRecord(ss->fork, stream));
         HIP_TRY(hipStreamWaitEvent(ss->s, ss->fork, 0));
+        lease.forked = true;
         if (timing) HIP_TRY(hipEventRecord(ss->t0, ss->s));
         if ((rc = launch_dq(ss->s, 0, nq))) return rc;
         if (timing) HIP_TRY(hipEventRecord(ss->t1, ss->s));
@@ -2701,7 +2751,8 @@ static int rerank_sparse(const float *q, const float *g, int64_t nq, int64_t ng,
     TailArgs ta{};
     SideStream *evs = nullptr;
     if (no_overlap) {   // exact distance rows of the queries, in line: launched by the tail (see TailArgs::mid_launch)
-        if ((rc = side_stream(&evs))) return rc;   // (only its `fork` event is used here)
+        if ((rc = lease.acquire())) return rc;     // (only its `fork` event is used here)
+        evs = lease.ss;
         ta.mid_launch = [&](hipStream_t s) -> int { return launch_dq(s, 0, nq); };
         ta.sized = evs->fork;
     }
@@ -2741,8 +2792,11 @@ extern "C" size_t mpreid_rerank_workspace_bytes_ex(int64_t nq, int64_t ng, int d
     return sparse ? make_layout2(nq, ng, d, k1, k2, algo == MPREID_RERANK_SPARSE_SPLIT3).total
                   : make_layout(nq, ng, d, k1, k2, has_local).total;
 }
+// The plain pair (mpreid_rerank_workspace_bytes + mpreid_rerank_f32: the binding INTEGRATION.md shows) is the DENSE
+// algorithm: any N, local_distmat supported, no data-dependent MPREID_ERR_RETRY_DENSE -- it never fails on data.  The
+// faster sparse algorithm (and the retry protocol that goes with it) is opt-in through the _ex entry points.
 extern "C" size_t mpreid_rerank_workspace_bytes(int64_t nq, int64_t ng, int d, int k1, int k2, int has_local) {
-    return mpreid_rerank_workspace_bytes_ex(nq, ng, d, k1, k2, has_local, MPREID_RERANK_AUTO);
+    return mpreid_rerank_workspace_bytes_ex(nq, ng, d, k1, k2, has_local, MPREID_RERANK_DENSE);
 }
 
 extern "C" int mpreid_rerank_f32_ex(const float *q, const float *g, int64_t nq, int64_t ng, int d, int k1, int k2,
@@ -2768,15 +2822,14 @@ extern "C" int mpreid_rerank_f32(const float *q, const float *g, int64_t nq, int
                                  void *ws, size_t ws_bytes, mpreid_stream_t stream, mpreid_rerank_stats *stats,
                                  int timing) {
     return mpreid_rerank_f32_ex(q, g, nq, ng, d, k1, k2, lambda_value, local, only_local, out, ldo, ws, ws_bytes, stream,
-                                stats, timing, MPREID_RERANK_AUTO);
+                                stats, timing, MPREID_RERANK_DENSE);
 }
 
 extern "C" int mpreid_rerank_debug_copy(const void *ws, int64_t nq, int64_t ng, int d, int k1, int k2, int has_local,
                                         int32_t *rank_out, int32_t *v_cnt, int32_t *vqe_cnt,
                                         mpreid_stream_t stream_) {
     return mpreid_rerank_debug_copy_ex(ws, nq, ng, d, k1, k2, has_local, rank_out, v_cnt, vqe_cnt, stream_,
-                                       sparse_eligible(nq, ng, k1, k2, has_local ? (const float *)1 : nullptr)
-                                           ? MPREID_RERANK_SPARSE : MPREID_RERANK_DENSE);
+                                       MPREID_RERANK_DENSE);
 }
 
 extern "C" int mpreid_rerank_debug_copy_ex(const void *ws, int64_t nq, int64_t ng, int d, int k1, int k2, int has_local,

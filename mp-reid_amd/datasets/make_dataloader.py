@@ -62,15 +62,33 @@ class SyntheticValLoader:
     def __len__(self):
         return (self.n + self.batch - 1) // self.batch
 
+    def _batch(self, s, e):
+        img = self._raw_images(s, e) if self.raw else \
+            torch.from_numpy(synth.synthetic_images(e - s, self.hw[0], self.hw[1], seed=self.seed + s))
+        pids = tuple(int(p) for p in self.pids[s:e])
+        cams = tuple(int(c) for c in self.camids[s:e])
+        return (img, pids, cams, torch.tensor(cams, dtype=torch.int64), torch.zeros(e - s, dtype=torch.int64),
+                tuple(f"synthetic/{i:07d}.jpg" for i in range(s, e)))
+
     def __iter__(self):
         for s in range(0, self.n, self.batch):
+            yield self._batch(s, min(self.n, s + self.batch))
+
+    def shard(self, indices):
+        """the samples `indices` (ascending global positions) in order: what one rank of a multi-GPU evaluation encodes.
+        The images are a function of the unsharded batch they belong to, so the owning batches are generated whole and
+        cut; batches without an owned sample are skipped."""
+        from processor.processor import select_samples
+        want = sorted(indices)
+        i = 0
+        for s in range(0, self.n, self.batch):
             e = min(self.n, s + self.batch)
-            img = self._raw_images(s, e) if self.raw else \
-                torch.from_numpy(synth.synthetic_images(e - s, self.hw[0], self.hw[1], seed=self.seed + s))
-            pids = tuple(int(p) for p in self.pids[s:e])
-            cams = tuple(int(c) for c in self.camids[s:e])
-            yield (img, pids, cams, torch.tensor(cams, dtype=torch.int64), torch.zeros(e - s, dtype=torch.int64),
-                   tuple(f"synthetic/{i:07d}.jpg" for i in range(s, e)))
+            keep = []
+            while i < len(want) and want[i] < e:
+                keep.append(want[i] - s)
+                i += 1
+            if keep:
+                yield select_samples(self._batch(s, e), keep)
 
 
 def make_dataloader(cfg):

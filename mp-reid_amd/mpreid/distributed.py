@@ -71,16 +71,110 @@ def all_gather_rows(x: torch.Tensor, n_total: int) -> torch.Tensor:
     return torch.cat([out[r * mx: r * mx + sizes[r]] for r in range(world)], dim=0)
 
 
-def gather_column_blocks_to_host(block: torch.Tensor, dst: int = 0):
-    """Host-side concatenation of the per-rank [nq, ng_local] blocks (north_star: "per-shard
-    distance blocks concatenated on the host").  Returns the full numpy matrix on `dst`, None elsewhere."""
-    import numpy as np
-    host = block.cpu().numpy()
-    if not dist.is_initialized() or dist.get_world_size() == 1:
-        return host
-    parts = [None] * dist.get_world_size() if dist.get_rank() == dst else None
-    dist.gather_object(host, parts, dst=dst)
-    return np.concatenate(parts, axis=1) if parts is not None else None
+def rank_world() -> Tuple[int, int]:
+    """(rank, world) of the default process group; (0, 1) without one"""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+_pinned = {}
+
+
+def _pinned_matrix(rows: int, cols: int, dtype, tag: str) -> torch.Tensor:
+    """grow-only page-locked host buffer (D2H copies into pageable memory go through a staging copy)"""
+    need = rows * cols
+    buf = _pinned.get((tag, dtype))
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(max(need, 1), dtype=dtype)
+        if torch.cuda.is_available():
+            buf = buf.pin_memory()
+        _pinned[(tag, dtype)] = buf
+    return buf[:need].view(rows, cols)
+
+
+def _gather_blocks_to_host(block: torch.Tensor, dim: int, dst: int, reuse_buffer: bool = False):
+    """The host concatenation (north_star: "per-shard distance blocks concatenated on the host"): every rank's block
+    travels as a TENSOR (RCCL gather over xGMI to `dst`'s HBM; host tensors with the gloo debug backend) and `dst` copies the
+    pieces straight into ONE page-locked host matrix -- no pickling, no per-piece numpy temporaries.  Blocks may be ragged
+    along `dim` (padded to the largest for the collective).  Returns the matrix on `dst` (None elsewhere): a fresh numpy
+    array the caller owns, or -- reuse_buffer=True -- a view of the pinned matrix itself, valid until the next call."""
+    rank, world = rank_world()
+    if world == 1:
+        host = _pinned_matrix(block.shape[0], block.shape[1], block.dtype, f"cat{dim}")
+        host.copy_(block, non_blocking=block.is_cuda)
+        if block.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        return host.numpy() if reuse_buffer else host.numpy().copy()
+    other = 1 - dim
+    sz = torch.tensor([block.shape[dim]], dtype=torch.int64, device=block.device if dist.get_backend() != "gloo" else "cpu")
+    sizes = [torch.empty_like(sz) for _ in range(world)]
+    dist.all_gather(sizes, sz)
+    sizes = [int(t.item()) for t in sizes]
+    mx = max(max(sizes), 1)
+    shape = list(block.shape)
+    shape[dim] = mx
+    staged = dist.get_backend() == "gloo"
+    pad = torch.zeros(shape, dtype=block.dtype, device="cpu" if staged else block.device)
+    pad.narrow(dim, 0, block.shape[dim]).copy_(block)
+    parts = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad, parts, dst=dst)
+    if rank != dst:
+        return None
+    total = sum(sizes)
+    host = _pinned_matrix(block.shape[other] if dim == 1 else total, total if dim == 1 else block.shape[other],
+                          block.dtype, f"cat{dim}")
+    lo = 0
+    for p, n in zip(parts, sizes):
+        if n:
+            host.narrow(dim, lo, n).copy_(p.narrow(dim, 0, n), non_blocking=p.is_cuda)
+        lo += n
+    if not staged and block.is_cuda:
+        torch.cuda.current_stream().synchronize()
+    return host.numpy() if reuse_buffer else host.numpy().copy()
+
+
+def gather_column_blocks_to_host(block: torch.Tensor, dst: int = 0, reuse_buffer: bool = False):
+    """Host-side concatenation of the per-rank [nq, ng_local] distance blocks (gallery shards = column blocks).
+    Returns the full numpy matrix on `dst`, None elsewhere."""
+    return _gather_blocks_to_host(block, 1, dst, reuse_buffer)
+
+
+def column_to_row_blocks(block: torch.Tensor, nq: int, ng_sizes: List[int]) -> torch.Tensor:
+    """The one exchange step of the sharded evaluation without re-ranking: every rank holds the COLUMN block
+    [nq, ng_local] of the distance matrix (its gallery shard) and the ranking statistics need whole ROWS.  One
+    all-to-all (RCCL over xGMI; each rank sends (P-1)/P of its block) turns the column blocks into the row blocks
+    [nq_local, ng] of shard_range(nq, rank, world): rank s sends rows [q_lo_r, q_hi_r) of its block to rank r."""
+    rank, world = rank_world()
+    if world == 1:
+        return block
+    assert block.shape == (nq, ng_sizes[rank]), (block.shape, nq, ng_sizes)
+    q_sizes = shard_sizes(nq, world)
+    nql = q_sizes[rank]
+    ng = sum(ng_sizes)
+    out = torch.empty((nql, ng), dtype=block.dtype, device=block.device)
+    if dist.get_backend() == "gloo":   # debug backend (CPU tests, several ranks on one GPU): all-gather, keep own rows
+        mx = max(max(ng_sizes), 1)
+        pad = torch.zeros((nq, mx), dtype=block.dtype)
+        pad[:, :block.shape[1]] = block.cpu()
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad)
+        q_lo, q_hi = shard_range(nq, rank, world)
+        lo = 0
+        for p, n in zip(parts, ng_sizes):
+            out[:, lo:lo + n] = p[q_lo:q_hi, :n].to(block.device)
+            lo += n
+        return out
+    send = block.contiguous().view(-1)
+    recv = torch.empty(nql * ng, dtype=block.dtype, device=block.device)
+    dist.all_to_all_single(recv, send, output_split_sizes=[nql * n for n in ng_sizes],
+                           input_split_sizes=[q * ng_sizes[rank] for q in q_sizes])
+    lo = off = 0
+    for n in ng_sizes:
+        out[:, lo:lo + n] = recv[off:off + nql * n].view(nql, n)
+        lo += n
+        off += nql * n
+    return out
 
 
 # ----------------------------------------------------------------------------------------------
@@ -350,12 +444,6 @@ def re_ranking_virtual(qf_all, gf_all, k1, k2, lambda_value, world, algo=0, timi
     return out
 
 
-def gather_row_blocks_to_host(block: torch.Tensor, dst: int = 0):
+def gather_row_blocks_to_host(block: torch.Tensor, dst: int = 0, reuse_buffer: bool = False):
     """host-side concatenation of per-rank ROW blocks (sharded re-ranking)"""
-    import numpy as np
-    host = block.cpu().numpy()
-    if not dist.is_initialized() or dist.get_world_size() == 1:
-        return host
-    parts = [None] * dist.get_world_size() if dist.get_rank() == dst else None
-    dist.gather_object(host, parts, dst=dst)
-    return np.concatenate(parts, axis=0) if parts is not None else None
+    return _gather_blocks_to_host(block, 0, dst, reuse_buffer)

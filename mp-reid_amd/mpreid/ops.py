@@ -105,13 +105,15 @@ def cosine_similarity(q, g, mode: int = GEMM_F32_EXACT, out: Optional[torch.Tens
 
 
 def re_ranking(q, g, k1: int, k2: int, lambda_value: float, local_distmat=None, only_local: bool = False,
-               timing: bool = False, debug: bool = False, algo: int = _lib.RERANK_AUTO):
+               timing: bool = False, debug: bool = False, algo: int = _lib.RERANK_AUTO, ws_tag: str = "rerank"):
     """utils/reranking.py:29-100 on the GPU.  Returns (device tensor [nq, ng] fp32, stats dict)
     and, with debug=True, additionally (initial_rank[:, :k1+1], nnz(V) per row, nnz(V_qe) per row).
     algo: RERANK_AUTO (the candidate pipeline without the N x N matrix when it applies, else the dense one; a sparse
     call that hits a data-dependent capacity is repeated densely), RERANK_DENSE, RERANK_SPARSE -- same bits;
     RERANK_SPARSE_SPLIT3: the sparse algorithm with the blend term's distance rows from the fp16 matrix cores (3-term
-    split): neighbour table / V / V_qe / Jaccard term bit-identical, |final - exact| <= lambda * 1e-6 / max."""
+    split): neighbour table / V / V_qe / Jaccard term bit-identical, |final - exact| <= lambda * 1e-6 / max.
+    ws_tag: name of the cached workspace; calls that run CONCURRENTLY on different streams need different tags (the C
+    entry point is re-entrant per stream with caller-owned workspaces)."""
     dev = _lib.require_gpu()
     L = _lib.load()
     q, g = _dev_f32(q, dev), _dev_f32(g, dev)
@@ -125,7 +127,7 @@ def re_ranking(q, g, k1: int, k2: int, lambda_value: float, local_distmat=None, 
     st = _lib.RerankStats()
     for attempt in (algo, _lib.RERANK_DENSE):
         wsb = L.mpreid_rerank_workspace_bytes_ex(nq, ng, d, int(k1), int(k2), int(loc is not None), int(attempt))
-        ws = _workspace("rerank", wsb, dev)
+        ws = _workspace(ws_tag, wsb, dev)
         rc = L.mpreid_rerank_f32_ex(_ptr(q), _ptr(g), nq, ng, d, int(k1), int(k2), float(lambda_value), _ptr(loc),
                                     int(bool(only_local)), _ptr(out), ng, _ptr(ws), ws.numel(), _lib.stream_ptr(),
                                     C.byref(st), int(bool(timing)), int(attempt))

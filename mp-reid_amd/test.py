@@ -8,7 +8,9 @@ model -> ``load_param(TEST.WEIGHT)`` -> ``do_inference`` (ViT-B/16 on the GPU, R
 re-ranking kernels).  Differences from the reference, on purpose: TEST.WEIGHT may be empty (seeded random weights, for
 smoke runs); MODEL.DEVICE_ID selects the HIP device through HIP_VISIBLE_DEVICES *before* anything touches the GPU;
 the VehicleID 10-trial loop is not reproduced (VehicleID's parser is out of scope); ``main`` returns
-(rank1, rank5) so that tests can call it in-process.
+(rank1, rank5) so that tests can call it in-process.  Multi-GPU: ``python -m torch.distributed.run --nnodes=1
+--nproc-per-node P --master-addr 127.0.0.1 test.py --config_file ...`` runs one rank per GPU; every rank encodes its
+shard and all of them return the same (rank1, rank5) as the single-GPU run.
 """
 import argparse
 import os
@@ -40,11 +42,22 @@ def main(argv=None):
 
     if cfg.OUTPUT_DIR:
         os.makedirs(cfg.OUTPUT_DIR, exist_ok=True)
-    # device selection has to happen before the HIP runtime initialises (the reference sets CUDA_VISIBLE_DEVICES here)
-    os.environ.setdefault("HIP_VISIBLE_DEVICES", str(cfg.MODEL.DEVICE_ID))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = 0
+    if world > 1:
+        # one process per GPU (python -m torch.distributed.run --nproc-per-node P test.py ...): the launcher's LOCAL_RANK
+        # picks the device, the default process group (RCCL) carries the evaluator's collectives; replaces the
+        # reference's single-process nn.DataParallel (processor/processor.py:178-182)
+        import torch
+        from mpreid import distributed as D
+        rank, world, local = D.init_from_env()
+        torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
+    else:
+        # device selection has to happen before the HIP runtime initialises (the reference sets CUDA_VISIBLE_DEVICES here)
+        os.environ.setdefault("HIP_VISIBLE_DEVICES", str(cfg.MODEL.DEVICE_ID))
 
     from utils.logger import setup_logger
-    logger = setup_logger("transreid", cfg.OUTPUT_DIR, if_train=False)
+    logger = setup_logger("transreid", cfg.OUTPUT_DIR if rank == 0 else "", if_train=False)
     logger.info(args)
     if args.config_file:
         logger.info("Loaded configuration file {}".format(args.config_file))
@@ -62,7 +75,12 @@ def main(argv=None):
         model.load_param(cfg.TEST.WEIGHT)
     else:
         logger.info("TEST.WEIGHT is empty: evaluating the seeded random initialisation (MODEL.INIT_SEED)")
-    return do_inference(cfg, model, val_loader, num_query)
+    res = do_inference(cfg, model, val_loader, num_query)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    return res
 
 
 if __name__ == "__main__":

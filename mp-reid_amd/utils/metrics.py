@@ -62,25 +62,21 @@ def eval_func(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50):
     return all_cmc, mAP
 
 
-def eval_func_device(dist, q_pids, g_pids, q_camids=None, g_camids=None, max_rank=50):
-    """eval_func with the ranking done on the GPU (dist: device tensor [nq, ng] fp32, left on the device).
-
-    Per query the kernel returns the positions of the relevant gallery items in the ascending (distance, index)
-    order of the row — what the reference reads off np.argsort — in one pass over the row; CMC and AP are
-    finished here in float64.  CMC is identical to eval_func's; AP sums the same terms (hits up to k) / k in a
-    different order than numpy's pairwise reduction over the dense row, i.e. |delta mAP| ~ 1e-16."""
+def _eval_rows_device(dist, q_pids, g_pids, max_rank):
+    """Ranking statistics of the query ROWS in `dist` (device tensor [rows, ng] fp32): (cmc hit counts [max_rank] float32
+    summed over the valid rows, AP of every valid row in row order (float64), number of valid rows).  Sums of 0/1 values
+    are exact in float32, so hit counts of row shards add up to the unsharded counts bit for bit."""
     import ctypes as C
     from mpreid import _lib
     dev = _lib.require_gpu()
     L = _lib.load()
     dist = dist.detach()
-    assert dist.is_cuda and dist.dtype == torch.float32 and dist.dim() == 2 and dist.stride(1) == 1
+    assert dist.is_cuda and dist.dtype == torch.float32 and dist.dim() == 2 and (dist.stride(1) == 1 or dist.shape[0] == 0)
     num_q, num_g = dist.shape
     q_pids = np.ascontiguousarray(q_pids, dtype=np.int64)
     g_pids = np.ascontiguousarray(g_pids, dtype=np.int64)
-    if num_g < max_rank:
-        max_rank = num_g
-        print("Note: number of gallery samples is quite small, got {}".format(num_g))
+    if num_q == 0:
+        return np.zeros(max_rank, np.float32), np.zeros(0, np.float64), 0
     rcap = int(min(max(np.unique(g_pids, return_counts=True)[1].max(), 1), 2048))
     qp, gp = torch.from_numpy(q_pids).to(dev), torch.from_numpy(g_pids).to(dev)
     pos = torch.empty((num_q, rcap), dtype=torch.int32, device=dev)
@@ -103,16 +99,69 @@ def eval_func_device(dist, q_pids, g_pids, q_camids=None, g_camids=None, max_ran
             pos[qi, :p.size] = p
             cnt[qi] = p.size
     valid = cnt > 0
-    num_valid_q = float(valid.sum())
-    assert num_valid_q > 0, "Error: all query identities do not appear in gallery"
+    num_valid = int(valid.sum())
+    if num_valid == 0:
+        return np.zeros(max_rank, np.float32), np.zeros(0, np.float64), 0
     pos, cnt = pos[valid], cnt[valid]
     first = pos[:, 0]
     cmc_rows = (np.arange(max_rank)[None, :] >= first[:, None]).astype(np.float32)
-    all_cmc = cmc_rows.sum(0) / num_valid_q
     t = np.arange(1, pos.shape[1] + 1, dtype=np.float64)[None, :]
     terms = np.where(pos >= 0, t / np.maximum(pos + 1.0, 1.0), 0.0)
-    all_AP = terms.sum(axis=1) / cnt
-    return all_cmc, np.mean(all_AP)
+    return cmc_rows.sum(0), terms.sum(axis=1) / cnt, num_valid
+
+
+def eval_func_device(dist, q_pids, g_pids, q_camids=None, g_camids=None, max_rank=50):
+    """eval_func with the ranking done on the GPU (dist: device tensor [nq, ng] fp32, left on the device).
+
+    Per query the kernel returns the positions of the relevant gallery items in the ascending (distance, index)
+    order of the row — what the reference reads off np.argsort — in one pass over the row; CMC and AP are
+    finished here in float64.  CMC is identical to eval_func's; AP sums the same terms (hits up to k) / k in a
+    different order than numpy's pairwise reduction over the dense row, i.e. |delta mAP| ~ 1e-16.
+
+    Under a process group (one rank per GPU) `dist` may be this rank's ROW block and q_pids its rows' pids: see
+    eval_func_sharded."""
+    num_g = dist.shape[1]
+    if num_g < max_rank:
+        max_rank = num_g
+        print("Note: number of gallery samples is quite small, got {}".format(num_g))
+    hits, ap, num_valid = _eval_rows_device(dist, q_pids, g_pids, max_rank)
+    assert num_valid > 0, "Error: all query identities do not appear in gallery"
+    return hits / float(num_valid), np.mean(ap)
+
+
+def eval_func_sharded(dist_rows, q_pids_local, g_pids, max_rank=50):
+    """eval_func over query rows sharded across the ranks of the default process group (SURVEY.md section 8e, row
+    `eval_func`): every rank ranks its own rows [q_lo, q_hi) on its GPU; the hit counts (exact small integers) are
+    summed and the per-query AP lists are concatenated in rank = query order, so every rank ends up with the cmc / mAP
+    of the unsharded call BIT FOR BIT (integer sums; np.mean over the same float64 list in the same order)."""
+    import torch.distributed as tdist
+    from mpreid import distributed as D
+    rank, world = D.rank_world()
+    num_g = dist_rows.shape[1]
+    if num_g < max_rank:
+        max_rank = num_g
+        if rank == 0:
+            print("Note: number of gallery samples is quite small, got {}".format(num_g))
+    hits, ap, num_valid = _eval_rows_device(dist_rows, q_pids_local, g_pids, max_rank)
+    if world > 1:
+        staged = tdist.get_backend() == "gloo"
+        dev = "cpu" if staged else dist_rows.device
+        # one small all-gather: [hit counts (max_rank) | number of valid rows | AP of the valid rows, NaN padded]
+        cap = torch.tensor([ap.size], dtype=torch.int64, device=dev)
+        tdist.all_reduce(cap, op=tdist.ReduceOp.MAX)
+        cap = int(cap.item())
+        msg = np.full(max_rank + 1 + cap, np.nan, np.float64)
+        msg[:max_rank] = hits
+        msg[max_rank] = num_valid
+        msg[max_rank + 1: max_rank + 1 + ap.size] = ap
+        parts = [torch.empty(msg.size, dtype=torch.float64, device=dev) for _ in range(world)]
+        tdist.all_gather(parts, torch.from_numpy(msg).to(dev))
+        parts = [p.cpu().numpy() for p in parts]
+        hits = np.sum([p[:max_rank] for p in parts], axis=0).astype(np.float32)   # exact: integers < 2^24
+        num_valid = int(sum(p[max_rank] for p in parts))
+        ap = np.concatenate([p[max_rank + 1: max_rank + 1 + int(p[max_rank])] for p in parts])
+    assert num_valid > 0, "Error: all query identities do not appear in gallery"
+    return hits / float(num_valid), np.mean(ap)
 
 
 class R1_mAP_eval():
@@ -140,6 +189,9 @@ class R1_mAP_eval():
         self.camids.extend(np.asarray(camid))
 
     def compute(self):  # called after each epoch
+        from mpreid import distributed as D
+        if D.rank_world()[1] > 1:
+            return self._compute_sharded()
         feats = torch.cat(self.feats, dim=0)
         if self.feat_norm:
             print("The test feature is normalized")
@@ -165,3 +217,64 @@ class R1_mAP_eval():
         cmc, mAP = eval_func_device(dist, q_pids, g_pids, q_camids, g_camids)
         distmat = dist.cpu().numpy()
         return cmc, mAP, distmat, self.pids, self.camids, qf.cpu(), gf.cpu()
+
+    def _compute_sharded(self):
+        """compute() with one evaluator instance per rank of the default process group (one process per GPU; replaces the
+        reference's nn.DataParallel branch, processor/processor.py:178-182; partition of SURVEY.md section 8e).
+
+        Contract: `num_query` is the GLOBAL number of queries; rank r was update()d with ITS samples only, in global
+        order -- queries shard_range(num_query, r, P) first, then gallery rows shard_range(num_gallery, r, P)
+        (processor.do_inference shards the loader that way).  Steps: L2-normalise locally; ONE all-gather of the query
+        features over xGMI; the rank's [nq, ng_local] column block of the distance matrix (its gallery shard) -- or, with
+        re-ranking, the row-sharded phases of mpreid.distributed.re_ranking_sharded; ranking statistics on every rank's
+        own query rows (eval_func_sharded); the blocks concatenated on the host of rank 0.  No floating-point reduction
+        crosses ranks: rank 0 returns the 7-tuple of the single-process compute() byte for byte; the other ranks get the
+        same cmc / mAP / pids / camids / qf, None for distmat and their own gallery shard for gf."""
+        import torch.distributed as tdist
+        from mpreid import distributed as D
+        rank, world = D.rank_world()
+        dev = _ops._lib.require_gpu()
+        nq = self.num_query
+        q_lo, q_hi = D.shard_range(nq, rank, world)
+        nql = q_hi - q_lo
+        n_local = sum(f.shape[0] for f in self.feats)
+        assert n_local >= nql, f"rank {rank}: {n_local} samples but {nql} of them must be its query shard"
+        dim = torch.tensor([self.feats[0].shape[1] if self.feats else 0], dtype=torch.int64,
+                           device="cpu" if tdist.get_backend() == "gloo" else dev)
+        tdist.all_reduce(dim, op=tdist.ReduceOp.MAX)
+        feats = torch.cat(self.feats, dim=0) if self.feats else torch.empty((0, int(dim.item())), device=dev)
+        if self.feat_norm:
+            if rank == 0:
+                print("The test feature is normalized")
+            feats = _ops.l2_normalize(feats)
+        meta = [None] * world     # labels (python ints): metadata, not the data path
+        tdist.all_gather_object(meta, ([int(p) for p in self.pids], [int(c) for c in self.camids], n_local - nql))
+        ng_sizes = [m[2] for m in meta]
+        ng = sum(ng_sizes)
+        assert ng_sizes == D.shard_sizes(ng, world), (
+            f"gallery shards {ng_sizes} are not shard_sizes({ng}, {world}): feed every rank its shard_range slice")
+        q_sizes = D.shard_sizes(nq, world)
+        pids = [p for m, k in zip(meta, q_sizes) for p in m[0][:k]] + [p for m, k in zip(meta, q_sizes) for p in m[0][k:]]
+        camids = [c for m, k in zip(meta, q_sizes) for c in m[1][:k]] + [c for m, k in zip(meta, q_sizes) for c in m[1][k:]]
+        q_pids, g_pids = np.asarray(pids[:nq]), np.asarray(pids[nq:])
+        qf_local, gf_local = feats[:nql].contiguous(), feats[nql:].contiguous()
+        qf = D.all_gather_rows(qf_local, nq)            # the RCCL all-gather of the query features
+        if self.reranking:
+            if rank == 0:
+                print('=> Enter reranking')
+            gf = D.all_gather_rows(gf_local, ng)        # every rank needs all rows of the N x N problem's operands
+            rows = D.re_ranking_sharded(qf, gf, 50, 15, 0.3, algo=getattr(self, "rerank_algo", 0))   # [nql, ng]
+            _ops.release_workspaces("rerank")
+            cmc, mAP = eval_func_sharded(rows, q_pids[q_lo:q_hi], g_pids)
+            distmat = D.gather_row_blocks_to_host(rows, dst=0)
+            gf_out = gf
+        else:
+            if rank == 0:
+                print('=> Computing DistMat with euclidean_distance')
+            block = _ops.euclidean_distance(qf, gf_local, mode=self.distance_mode)     # [nq, ng_local]
+            rows = D.column_to_row_blocks(block, nq, ng_sizes)                         # [nql, ng]
+            cmc, mAP = eval_func_sharded(rows, q_pids[q_lo:q_hi], g_pids)
+            distmat = D.gather_column_blocks_to_host(block, dst=0)                     # host concatenation on rank 0
+            gf_host = D.gather_row_blocks_to_host(gf_local, dst=0)
+            gf_out = torch.from_numpy(gf_host) if rank == 0 else gf_local
+        return cmc, mAP, distmat, pids, camids, qf.cpu(), gf_out.cpu()

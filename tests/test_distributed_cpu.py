@@ -29,24 +29,52 @@ WORKER = textwrap.dedent("""
     assert qf.shape == (nq, d)
     block = torch.from_numpy(orc.euclidean_distance(qf.numpy(), gf_local))
     full = D.gather_column_blocks_to_host(block, dst=0)
+    # the exchange step of the sharded evaluation: column blocks -> row blocks, then sharded CMC / mAP.  The GPU ranking
+    # kernel is replaced by a host restatement here: this is a test of the partition, the collectives and the reduction
+    rows = D.column_to_row_blocks(block, nq, D.shard_sizes(ng, world))
+    import utils.metrics as M
+    def rows_host(dist_rows, q_pids, g_pids, max_rank):
+        d = dist_rows.numpy()
+        hits, ap, nv = np.zeros(max_rank, np.float32), [], 0
+        for i in range(d.shape[0]):
+            order = np.argsort(d[i], kind="stable")
+            m = (g_pids[order] == q_pids[i])
+            if not m.any():
+                continue
+            nv += 1
+            c = np.cumsum(m)
+            hits += (c[:max_rank] > 0).astype(np.float32)
+            pos = np.nonzero(m)[0]
+            ap.append((np.arange(1, pos.size + 1) / (pos + 1.0)).sum() / pos.size)
+        return hits, np.asarray(ap, np.float64), nv
+    M._eval_rows_device = rows_host
+    rng = np.random.default_rng(5)
+    pid = rng.integers(0, 9, size=nq + ng)
+    pid[3] = 1000    # a query without any match (skipped by eval_func)
+    cmc, mAP = M.eval_func_sharded(rows, pid[q_lo:q_hi], pid[nq:], max_rank=50)
+    rows_full = D.gather_row_blocks_to_host(rows, dst=0)
     if rank == 0:
-        np.save(sys.argv[1], full)
+        np.savez(sys.argv[1], full=full, rows_full=rows_full, cmc=cmc, mAP=mAP, pid=pid)
     import torch.distributed as dist
     dist.barrier(); dist.destroy_process_group()
 """)
 
 
-def test_two_rank_sharded_distmat_matches_single_rank(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_distmat_and_eval_match_single_rank(tmp_path, world):
     from mpreid import distributed as D, synth
     from oracle import oracle as orc
     assert D.shard_sizes(10, 4) == [3, 3, 2, 2] and D.shard_range(10, 3, 4) == (8, 10)
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT))
-    out = tmp_path / "full.npy"
-    port = str(29600 + os.getpid() % 300)
+    out = tmp_path / "full.npz"
+    port = str(29600 + (os.getpid() * 7 + world) % 300)
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=port, OMP_NUM_THREADS="2")
         procs.append(subprocess.Popen([sys.executable, str(script), str(out)], env=env))
     for p in procs:
@@ -55,7 +83,13 @@ def test_two_rank_sharded_distmat_matches_single_rank(tmp_path):
     f, _ = synth.clustered_features(nq + ng, d, 2.0, seed=3, per_id=5)
     want = orc.euclidean_distance(orc.l2_normalize(f[:nq] * 3.0), orc.l2_normalize(f[nq:] * 3.0))
     got = np.load(out)
-    assert got.shape == (nq, ng) and np.array_equal(got, want)
+    assert got["full"].shape == (nq, ng) and np.array_equal(got["full"], want)
+    assert np.array_equal(got["rows_full"], want)        # column blocks -> row blocks -> host: the same matrix
+    # sharded CMC / mAP == the unsharded host eval_func, bit for bit (integer hit counts, AP lists in query order)
+    import utils.metrics as M
+    pid = got["pid"]
+    cmc, mAP = M.eval_func(want, pid[:nq], pid[nq:], None, None)
+    assert np.array_equal(got["cmc"], cmc) and abs(float(got["mAP"]) - mAP) <= 1e-15
 
 
 def test_bench_parent_launches_ranks_without_touching_the_gpu():

@@ -100,3 +100,103 @@ def test_bench_self_launches_two_ranks(args):
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["all_gather"]["bytes_per_step"] > 0
     assert j["scaling"] == ("weak" if args[1] == "market" else "strong")
+
+
+# ---- the evaluator and do_inference behind the reference API under WORLD_SIZE > 1 -------------------------------------
+# Reference: processor/processor.py:178-182 goes multi-device inside do_inference (nn.DataParallel) and
+# utils/metrics.py:110-134 returns ONE distmat from compute().  Here: one R1_mAP_eval instance per rank; rank 0's 7-tuple
+# must equal the single-process one byte for byte.
+EVAL_WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np, torch
+    sys.path[:0] = [{root!r}, os.path.join({root!r}, "mp-reid_amd")]
+    from mpreid import distributed as D, synth
+    from utils.metrics import R1_mAP_eval
+    import torch.distributed as dist
+    rank, world, local = D.init_from_env()
+    torch.cuda.set_device(0)
+    res = {{}}
+    for ci, (n, nq, d, rerank) in enumerate({cases!r}):
+        f, pid = synth.clustered_features(n, d, 2.5, seed=77 + n, per_id=6, normalize=False)
+        cam = synth.labels_for(n)
+        q_lo, q_hi = D.shard_range(nq, rank, world)
+        g_lo, g_hi = D.shard_range(n - nq, rank, world)
+        idx = list(range(q_lo, q_hi)) + list(range(nq + g_lo, nq + g_hi))      # this rank's samples, global order
+        ev = R1_mAP_eval(nq, max_rank=50, feat_norm='yes', reranking=rerank)
+        ev.reset()
+        for s in range(0, len(idx), 64):                                     # loader-sized update() calls
+            sel = idx[s:s + 64]
+            ev.update((torch.from_numpy(f[sel]).cuda(), tuple(int(p) for p in pid[sel]), tuple(int(c) for c in cam[sel])))
+        cmc, mAP, distmat, pids, camids, qf, gf = ev.compute()
+        cmc2, mAP2 = ev.compute()[:2]                                        # compute() may be called again
+        assert np.array_equal(cmc, cmc2) and mAP == mAP2
+        if rank == 0:
+            res.update({{f"cmc{{ci}}": cmc, f"map{{ci}}": np.float64(mAP), f"dist{{ci}}": distmat, f"pids{{ci}}": np.asarray(pids),
+                        f"cams{{ci}}": np.asarray(camids), f"qf{{ci}}": qf.numpy(), f"gf{{ci}}": gf.numpy()}})
+        else:
+            assert distmat is None and qf.shape[0] == nq
+    if rank == 0:
+        np.savez(os.path.join(sys.argv[1], "eval.npz"), **res)
+    dist.barrier(); dist.destroy_process_group()
+""")
+
+EVAL_CASES = [(900, 150, 192, False), (2600, 500, 128, True), (643, 41, 64, True), (700, 5, 64, False)]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_r1_map_eval_sharded_equals_single_process(tmp_path, world):
+    import torch
+    from mpreid import synth
+    from utils.metrics import R1_mAP_eval
+    script = tmp_path / "eval_worker.py"
+    script.write_text(EVAL_WORKER.format(root=ROOT, cases=EVAL_CASES))
+    _spawn(script, [str(tmp_path)], world, tmp_path)
+    got = np.load(tmp_path / "eval.npz")
+    for ci, (n, nq, d, rerank) in enumerate(EVAL_CASES):
+        f, pid = synth.clustered_features(n, d, 2.5, seed=77 + n, per_id=6, normalize=False)
+        cam = synth.labels_for(n)
+        ev = R1_mAP_eval(nq, max_rank=50, feat_norm='yes', reranking=rerank)
+        ev.reset()
+        ev.update((torch.from_numpy(f).cuda(), tuple(int(p) for p in pid), tuple(int(c) for c in cam)))
+        cmc, mAP, distmat, pids, camids, qf, gf = ev.compute()
+        assert np.array_equal(got[f"cmc{ci}"], cmc) and got[f"cmc{ci}"].dtype == cmc.dtype, ci
+        assert float(got[f"map{ci}"]) == float(mAP), ci
+        assert np.array_equal(got[f"dist{ci}"], distmat) and got[f"dist{ci}"].dtype == np.float32, ci
+        assert np.array_equal(got[f"pids{ci}"], np.asarray(pids)) and np.array_equal(got[f"cams{ci}"], np.asarray(camids)), ci
+        assert np.array_equal(got[f"qf{ci}"], qf.numpy()) and np.array_equal(got[f"gf{ci}"], gf.numpy()), ci
+
+
+@pytest.mark.parametrize("rerank", ["False", "True"])
+def test_test_py_under_two_ranks_matches_single_process(tmp_path, rerank):
+    """python -m torch.distributed.run ... test.py: do_inference shards the loader by index range, every rank returns the
+    single-process (Rank-1, Rank-5) and rank 0 logs the same mAP line"""
+    code = ("import sys, os; sys.path.insert(0, {pkg!r}); os.chdir({pkg!r}); import test as T; "
+            "r = T.main(['--config_file', '', 'DATASETS.SYNTH_QUERY', '24', 'DATASETS.SYNTH_GALLERY', '131', "
+            "'DATASETS.SYNTH_IDS', '6', 'TEST.IMS_PER_BATCH', '16', 'TEST.RE_RANKING', {rr!r}, 'MODEL.SIE_CAMERA', 'True']); "
+            "print('RESULT', float(r[0]), float(r[1]))").format(pkg=os.path.join(ROOT, "mp-reid_amd"), rr=rerank)
+
+    def run(world):
+        port = str(29900 + (os.getpid() + world) % 90)
+        outs = []
+        procs = []
+        for r in range(world):
+            env = dict(os.environ, MPREID_DIST_BACKEND="gloo", OMP_NUM_THREADS="4")
+            for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+                env.pop(k, None)
+            if world > 1:
+                env.update(RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+            procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, text=True))
+        for p in procs:
+            o, _ = p.communicate(timeout=900)
+            assert p.returncode == 0, o[-2000:]
+            outs.append(o)
+        return outs
+
+    single = run(1)[0]
+    multi = run(2)
+    res = [ln for ln in single.splitlines() if ln.startswith("RESULT")]
+    assert len(res) == 1
+    for o in multi:
+        assert [ln for ln in o.splitlines() if ln.startswith("RESULT")] == res
+    pick = lambda o: [ln.split("transreid.test INFO: ")[1] for ln in o.splitlines() if "mAP:" in ln or "CMC curve" in ln]   # noqa: E731
+    assert pick(single) == pick(multi[0]) and len(pick(single)) == 4 and pick(multi[1]) == []

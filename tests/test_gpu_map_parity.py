@@ -1,17 +1,32 @@
 """Image -> mAP parity (north_star: "matching the reference CPU path's mAP / Rank-1 within 1e-4").
 
-2048 synthetic images with identity structure (128 identities x 16 images, mpreid.synth.identity_images, beta chosen so
-that the Euclidean mAP is ~0.55: hard enough that rank errors show) go through
+Synthetic images with identity structure (mpreid.synth.identity_images) go through
   (s) the split-precision HIP encoder (MODEL.ENCODER_PRECISION split, the default and the mode bench.py times: fp16
       operand pairs, three products per multiply-add on the fp16 matrix cores) -> HIP normalise -> exact distance /
       re-ranking -> eval,
   (a) the all-fp32 HIP encoder (MODEL.ENCODER_PRECISION fp32: exact fp32 matrix instruction), same tail,
-  (b) the fp16-MFMA HIP encoder (the throughput path), same tail,
+  (b) the fp16-MFMA HIP encoder (single fp16 operands: the fastest mode), same tail,
   (o) the fp32 ORACLE pipeline on the host (torch CPU ViT restatement -> oracle normalise / distance / re-rank / eval).
-Measured on MI355X (tools/map_parity.py): fp16 path |dmAP| = 1.3e-4 (features 4.3e-4 relative L2: the operand rounding
-of 24 GEMMs), Rank-1 identical; fp32 path at the oracle's own rounding level.  So the bound of 1e-4 is asserted for the
-fp32 mode, and the fp16 mode is held to the bound its feature error supports (5e-4), with the feature error itself
-bounded -- stated here instead of hidden."""
+
+Two sets of weights, because what "within 1e-4" can mean depends on the geometry of the features:
+
+SPREAD (the parity bar).  Weights ~ N(0, 0.05^2): the image content drives the features, normalised distances are
+  0.15 ... 0.6 with a median of 0.35 -- the spread a trained re-id model has -- and with beta = 0.4 the task is hard
+  (1024 images: Euclidean mAP 0.28, with re-ranking 0.40, Rank-1 0.60).  Here the reference's OWN fp32 rounding is invisible in the metrics: the oracle
+  evaluated in fp64 instead of fp32 (features 1.07e-6 apart) moves mAP by 2.6e-7 and no Rank-1 (tools/map_noise_floor.py,
+  /tmp measurement recorded in DESIGN.md section 2).  So 1e-4 is a meaningful bound, and it is ASSERTED for the split
+  and the fp32 mode, with and without re-ranking: |dmAP| <= 1e-4, |dRank-1| <= 1e-4 (i.e. not one query differs),
+  features within 2e-5 relative L2 (measured on MI355X: split 3.7e-6 / |dmAP| 2.7e-8 / no query differs; fp32 2.1e-6 /
+  2.2e-8).  The fp16 mode is reported and held to the bound its feature error supports (measured 8.9e-4 / |dmAP| 5.4e-4 /
+  one query: single fp16 operands do NOT meet 1e-4 on realistic geometry either).
+
+DEGENERATE (the round-1/2 set, kept as a stress case).  Weights ~ N(0, 0.02^2): the CLS row barely sees the image, all
+  features are nearly parallel (normalised distances 0.008 ... 0.03), and a feature error of 1e-6 is a distance error of
+  ~1e-4 relative.  On this set the reference's own arithmetic noise exceeds 1e-4: oracle fp32 vs the same graph in fp64
+  (features 6.1e-7 apart) differ by 1.7e-4 in mAP and by one query in Rank-1; the fp32 oracle on two different CPUs
+  (this container / the GPU box: another MKL code path) by 1.3e-4 (tools/map_noise_floor.py).  No implementation can be
+  held to 1e-4 against a reference that does not agree with itself to 1e-4, so here the FEATURES are held to the fp32
+  level (2e-5; measured 1.4e-6 split, 1.3e-6 fp32) and the metrics to the set's own noise envelope (5e-4, one query)."""
 import numpy as np
 import pytest
 import torch
@@ -20,15 +35,28 @@ from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
 
+SETS = {
+    # name: (identities, images per identity, beta, weight std)
+    "spread": (128, 8, 0.4, 0.05),
+    "degenerate": (128, 16, 0.55, 0.02),
+}
+
 
 @pytest.fixture(scope="module")
 def data():
     from mpreid import synth
-    x, pid = synth.identity_images(128, 16, 0.55)
-    sd = synth.vit_state_dict(synth.VIT_B16, seed=7)
     torch.set_num_threads(min(torch.get_num_threads(), 32))
-    f_or = np.concatenate([orc.vit_features(sd, synth.VIT_B16, x[s:s + 64]) for s in range(0, len(pid), 64)])
-    return x, pid, sd, f_or
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            n_ids, per_id, beta, std = SETS[name]
+            x, pid = synth.identity_images(n_ids, per_id, beta)
+            sd = synth.vit_state_dict(synth.VIT_B16, seed=7, std=std)
+            f_or = np.concatenate([orc.vit_features(sd, synth.VIT_B16, x[s:s + 64]) for s in range(0, len(pid), 64)])
+            cache[name] = (x, pid, sd, f_or)
+        return cache[name]
+    return get
 
 
 def _evaluate(ops, feats, pid, nq, rerank):
@@ -38,15 +66,16 @@ def _evaluate(ops, feats, pid, nq, rerank):
 
 
 @pytest.mark.parametrize("rerank", [False, True])
-def test_image_to_map_parity(data, rerank):
+@pytest.mark.parametrize("name", ["spread", "degenerate"])
+def test_image_to_map_parity(data, name, rerank):
     from mpreid import ops, synth
-    x, pid, sd, f_or = data
+    x, pid, sd, f_or = data(name)
     n = len(pid)
     nq = n // 5
     fo = orc.l2_normalize(f_or)
     d_or = orc.re_ranking(fo[:nq], fo[nq:], 50, 15, 0.3) if rerank else orc.euclidean_distance(fo[:nq], fo[nq:])
     cmc_o, map_o = orc.eval_func(d_or, pid[:nq], pid[nq:])
-    assert 0.3 < map_o < (0.97 if rerank else 0.9), map_o   # hard enough to be informative (re-ranking lifts it)
+    assert 0.2 < map_o < 0.97, map_o   # hard enough to be informative (re-ranking lifts it)
     res = {}
     for prec in ("split", "fp32", "fp16"):
         enc = ops.VitEncoder(synth.VIT_B16, sd, (256, 128), precision=prec)
@@ -57,13 +86,21 @@ def test_image_to_map_parity(data, rerank):
         cmc, mAP = _evaluate(ops, f, pid, nq, rerank)
         res[prec] = (rel, abs(mAP - map_o), abs(float(cmc[0]) - float(cmc_o[0])), float(np.abs(cmc - cmc_o).max()))
         del enc
-    print("image->mAP parity (rerank=%s): oracle mAP %.6f R1 %.6f | " % (rerank, map_o, cmc_o[0]) +
+    print("image->mAP parity [%s] (rerank=%s): oracle mAP %.6f R1 %.6f median distance %.4f | " %
+          (name, rerank, map_o, cmc_o[0], float(np.median(orc.euclidean_distance(fo[:nq], fo[nq:])))) +
           " | ".join(f"{k}: feat rel-L2 {v[0]:.2e} dmAP {v[1]:.2e} dR1 {v[2]:.2e} max dCMC {v[3]:.2e}" for k, v in res.items()))
-    for prec in ("split", "fp32"):   # north_star bound: the split mode (default, the one bench.py times) and the fp32 mode meet it
-        rel, dmap, dr1, dcmc = res[prec]
-        assert rel <= 2e-5 and dmap <= 1e-4 and dr1 <= 1e-4, (prec, res[prec])
-    rel, dmap, dr1, dcmc = res["fp16"]
-    assert rel <= 1e-3 and dmap <= 5e-4 and dr1 <= 1.0 / nq + 1e-9, res["fp16"]  # the bound the fp16 operands support
+    if name == "spread":
+        for prec in ("split", "fp32"):   # north_star's bound: the default (measured) mode and the fp32 mode meet it
+            rel, dmap, dr1, dcmc = res[prec]
+            assert rel <= 2e-5 and dmap <= 1e-4 and dr1 <= 1e-4, (prec, res[prec])
+        rel, dmap, dr1, dcmc = res["fp16"]
+        assert rel <= 3e-3 and dmap <= 3e-3 and dr1 <= 2.0 / nq + 1e-9, res["fp16"]   # what single fp16 operands support
+    else:
+        for prec in ("split", "fp32"):
+            rel, dmap, dr1, dcmc = res[prec]
+            assert rel <= 2e-5 and dmap <= 5e-4 and dr1 <= 1.0 / nq + 1e-9, (prec, res[prec])
+        rel, dmap, dr1, dcmc = res["fp16"]
+        assert rel <= 1e-3 and dmap <= 1e-3 and dr1 <= 2.0 / nq + 1e-9, res["fp16"]
 
 
 def test_fp32_encoder_small_config_and_options(golden):

@@ -3,7 +3,7 @@
 Bar: BIT-EXACT against the oracle (outputs, neighbour table, nnz of V / V_qe); BIT-EXACT against the reference
 itself when both are fed the same distance matrix (tests/golden/rerank_seeds.npz, 10 unselected seeds); against the
 reference as called (its MKL distance GEMM rounds differently from the k-ascending fmaf chain) within the bounds set
-from the measured distribution: frac(|d| > 1e-5) <= 3e-4, max <= 1e-3."""
+from the measured distribution: frac(|d| > 1e-5) <= 1e-4, max <= 5e-4 = one fp16 quantum."""
 import numpy as np
 import pytest
 import torch
@@ -11,7 +11,7 @@ import torch
 from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
-RR_FRAC, RR_MAX = 3e-4, 1e-3
+RR_FRAC, RR_MAX = 1e-4, 5e-4   # one fp16 quantum (4.88e-4), at most 1 entry in 10 000
 
 
 @pytest.fixture(scope="module")
@@ -200,7 +200,10 @@ def test_r1_map_eval_vs_reference(golden):
             scale = max(1.0, float(np.abs(want).max()))
             dd = np.abs(distmat - want) / scale
             if rr:
-                assert (dd > 1e-5).mean() <= RR_FRAC and dd.max() <= RR_MAX, (tag, (dd > 1e-5).mean(), dd.max())
+                # (the un-normalised fixture rr1_fn0 is the one case measured above one quantum: 3 of 36 864 entries,
+                # max 7.32e-4 = 1.5 quanta -- bounded on its own, not by loosening RR_MAX for everything)
+                mx_bound = 7.5e-4 if tag == "rr1_fn0" else RR_MAX
+                assert (dd > 1e-5).mean() <= RR_FRAC and dd.max() <= mx_bound, (tag, (dd > 1e-5).mean(), dd.max())
             else:
                 assert dd.max() < 1e-5, (tag, dd.max())
 
@@ -362,3 +365,75 @@ def test_sharded_split3_rows_mode(ops):
     exact, _ = ops.re_ranking(ft[:nq], ft[nq:], 50, 15, 0.3)
     assert float((virt - exact).abs().max()) <= 1e-6 and float((single - exact).abs().max()) <= 1e-6
     assert float((virt - single).abs().max()) <= 1e-6
+
+
+_CONCURRENT_WORKER = """
+import os, sys, threading
+import numpy as np, torch
+sys.path[:0] = [{root!r}, os.path.join({root!r}, "mp-reid_amd")]
+from mpreid import ops, synth
+cases = {cases!r}
+feats = []
+for n, nq, d, k1, k2 in cases:
+    f, _ = synth.clustered_features(n, d, 2.5, seed=177 + n, per_id=10)
+    feats.append(torch.from_numpy(f).cuda())
+want = [ops.re_ranking(ft[:c[1]], ft[c[1]:], c[3], c[4], 0.3, algo=ops.RERANK_SPARSE)[0].clone() for ft, c in zip(feats, cases)]
+torch.cuda.synchronize()
+errors = []
+def run(i):
+    try:
+        st = torch.cuda.Stream()
+        n, nq, d, k1, k2 = cases[i]
+        with torch.cuda.stream(st):
+            for rep in range(6):
+                out, _ = ops.re_ranking(feats[i][:nq], feats[i][nq:], k1, k2, 0.3, algo=ops.RERANK_SPARSE, ws_tag=f"rr{{i}}")
+                st.synchronize()
+                if not torch.equal(out, want[i]):
+                    errors.append((i, rep))
+    except Exception as e:   # noqa: BLE001
+        errors.append((i, repr(e)))
+ths = [threading.Thread(target=run, args=(i,)) for i in range(len(cases))]
+[t.start() for t in ths]; [t.join() for t in ths]
+assert not errors, errors
+print("CONCURRENT OK")
+"""
+
+
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_sparse_rerank_concurrent_streams(tmp_path, overlap):
+    """Two host threads call the sparse algorithm at the same time on two HIP streams with their own workspaces (the header's
+    contract: stream-ordered, caller-owned workspace, re-entrant per stream -- there is no process-wide lock and every call
+    leases its own side stream): every result equals the one of the same call made alone, bit for bit.  overlap = 1 forces
+    the forked side stream (the default only from N = 50 000) so that both calls really have one in flight."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = [(4100, 700, 128, 50, 15), (3300, 500, 256, 20, 6)]
+    script = tmp_path / "cw.py"
+    script.write_text(_CONCURRENT_WORKER.format(root=root, cases=cases))
+    r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, MPREID_RERANK_OVERLAP=overlap), capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0 and "CONCURRENT OK" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
+
+
+def test_rerank_market_shape_d1280(ops):
+    """BASELINE configs[2] stand-in at the feature width the model really produces (SURVEY.md section 8d shape A:
+    nq = 3368, ng = 15913, D = 1280 = 768 + 512): sparse == dense bit for bit, lambda = 1 collapses to the normalised
+    distance rows, and the oracle agrees on a 1/8 sub-sample."""
+    from mpreid import synth
+    N, nq, d = 19281, 3368, 1280
+    f, pid = synth.clustered_features(N, d, 3.5, seed=4321)
+    ft = torch.from_numpy(f).cuda()
+    q, g = ft[:nq], ft[nq:]
+    rs, st = ops.re_ranking(q, g, 50, 15, 0.3, algo=ops.RERANK_SPARSE)
+    rd, _ = ops.re_ranking(q, g, 50, 15, 0.3, algo=ops.RERANK_DENSE)
+    assert st["algo"] == ops.RERANK_SPARSE and torch.equal(rs, rd)
+    r1, _ = ops.re_ranking(q, g, 50, 15, 1.0)
+    colmax = ops.euclidean_distance(ft, ft[:nq]).max(dim=0).values
+    assert torch.equal(r1, (ops.euclidean_distance(q, ft) / colmax[:, None])[:, nq:])
+    sub = np.arange(0, N, 8)
+    fs = f[sub]
+    nqs = int((sub < nq).sum())
+    got, _ = ops.re_ranking(ft[sub[:nqs]], ft[sub[nqs:]], 50, 15, 0.3)
+    assert np.array_equal(got.cpu().numpy(), orc.re_ranking(fs[:nqs], fs[nqs:], 50, 15, 0.3))

@@ -7,7 +7,8 @@ Tolerances (DESIGN.md section 2 holds the measured distribution they are set fro
   * re-ranking as called (the reference's distance GEMM is MKL's, ours is the k-ascending fmaf chain): a 1-ulp
     difference in D can move a V entry by one fp16 quantum; measured over 10 unselected seeds (N 1000-4000,
     D 256-1280): frac(|d| > 1e-5) <= 4.7e-5, max |d| = 4.88e-4 (one quantum), |dmAP| <= 7e-7.  Bounds asserted:
-    frac <= 3e-4 on the 16384 sampled entries (<= 4 entries), max <= 1e-3 (two quanta), |dmAP| <= 1e-5.
+    frac <= 1e-4 (<= 1 of the 16384 sampled entries), max <= 5e-4 (one quantum), |dmAP| <= 1e-5; the one fixture above
+    that (un-normalised features, r1_map_eval rr1_fn0: max 7.32e-4 on 3 of 36 864 entries) is bounded on its own.
   * mAP / CMC: 1e-4
 """
 import numpy as np
@@ -94,7 +95,7 @@ def test_eval_func_vs_reference(golden):
 
 
 # as-called re-rank deviation from the reference (MKL GEMM order only, see the module docstring)
-RR_FRAC, RR_MAX = 3e-4, 1e-3
+RR_FRAC, RR_MAX = 1e-4, 5e-4   # one fp16 quantum (4.88e-4), at most 1 entry in 10 000
 
 
 def _rr_check(got, want, lam):
@@ -147,7 +148,10 @@ def test_r1_map_eval_pipeline_vs_reference(golden):
             scale = max(1.0, float(np.abs(want).max()))
             dd = np.abs(d - want) / scale
             if rr:
-                assert (dd > 1e-5).mean() <= RR_FRAC and dd.max() <= RR_MAX, (tag, (dd > 1e-5).mean(), dd.max())
+                # (the un-normalised fixture rr1_fn0 is the one case measured above one quantum: 3 of 36 864 entries,
+                # max 7.32e-4 = 1.5 quanta -- bounded on its own, not by loosening RR_MAX for everything)
+                mx_bound = 7.5e-4 if tag == "rr1_fn0" else RR_MAX
+                assert (dd > 1e-5).mean() <= RR_FRAC and dd.max() <= mx_bound, (tag, (dd > 1e-5).mean(), dd.max())
             else:
                 assert dd.max() < 1e-5, (tag, dd.max())
 
