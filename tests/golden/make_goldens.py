@@ -293,6 +293,58 @@ def gen_vit():
     save("vit.npz", **out)
 
 
+def gen_head():
+    """build_transformer.forward, eval branch (model/make_model.py:89-115), on the reference's own VisionTransformer class.
+    model/make_model.py itself cannot be imported here (torchvision / timm / the CLIP download), so its
+    head is composed from the pieces it is made of: the SIE index rules :89-96 (three one-line expressions, restated
+    below), torch.nn.BatchNorm1d in eval mode (:58-63, :102-103: torch's published operator, here with NON-trivial running
+    statistics and affine parameters) and the two torch.cat of :110-115."""
+    big = synth.VIT_B16
+    sd = synth.vit_state_dict(big, seed=21, std=0.02, ln_jitter=0.05)
+    imgs = synth.synthetic_images(6, 256, 128, seed=77)
+    m = ref_clip.VisionTransformer(big["h_res"], big["w_res"], big["patch"], big["stride"], big["width"], big["layers"],
+                                   big["heads"], big["out_dim"])
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m.eval()
+    camera_num, view_num, sie_coe = 6, 3, 3.0
+    rng = np.random.default_rng(5)
+    cam = rng.integers(0, camera_num, 6).astype(np.int64)
+    view = rng.integers(0, view_num, 6).astype(np.int64)
+    out = {"cam": cam, "view": view, "camera_num": camera_num, "view_num": view_num, "sie_coe": sie_coe}
+    bns = {}
+    for name, n in (("bottleneck", 768), ("bottleneck_proj", 512)):
+        bn = torch.nn.BatchNorm1d(n)
+        with torch.no_grad():
+            bn.weight.copy_(torch.from_numpy((1 + 0.2 * rng.standard_normal(n)).astype(np.float32)))
+            bn.bias.copy_(torch.from_numpy((0.1 * rng.standard_normal(n)).astype(np.float32)))
+            bn.running_mean.copy_(torch.from_numpy((0.3 * rng.standard_normal(n)).astype(np.float32)))
+            bn.running_var.copy_(torch.from_numpy((0.4 + rng.random(n)).astype(np.float32)))
+        bn.eval()
+        bns[name] = bn
+        for k in ("weight", "bias", "running_mean", "running_var"):
+            out[f"{name}.{k}"] = getattr(bn, k).detach().numpy().copy()
+    rows = {"cam_view": camera_num * view_num, "cam": camera_num, "view": view_num}
+    with torch.no_grad():
+        for mode in ("cam_view", "cam", "view", "none"):
+            cv = None
+            if mode != "none":
+                table = torch.from_numpy((0.02 * rng.standard_normal((rows[mode], 768))).astype(np.float32))
+                out[f"cv_embed_{mode}"] = table.numpy()
+                cam_label, view_label = torch.from_numpy(cam), torch.from_numpy(view)
+                if mode == "cam_view":      # model/make_model.py:89-90
+                    cv = sie_coe * table[cam_label * view_num + view_label]
+                elif mode == "cam":         # :91-92
+                    cv = sie_coe * table[cam_label]
+                else:                       # :93-94
+                    cv = sie_coe * table[view_label]
+            _, x12, xproj = m(torch.from_numpy(imgs), cv)
+            img_feature, img_feature_proj = x12[:, 0], xproj[:, 0]                     # :98-100
+            feat, feat_proj = bns["bottleneck"](img_feature), bns["bottleneck_proj"](img_feature_proj)   # :102-103
+            out[f"{mode}_after"] = torch.cat([feat, feat_proj], dim=1).numpy()          # :110-112
+            out[f"{mode}_before"] = torch.cat([img_feature, img_feature_proj], dim=1).numpy()   # :113-115
+    save("head.npz", **out)
+
+
 def gen_resize():
     """T.Resize of val_transforms (datasets/make_dataloader.py:57-58): torchvision hands the PIL image to
     Image.resize(size[::-1], BILINEAR).  torchvision is not installed here; the Pillow call it makes is.  Ragged
@@ -395,6 +447,8 @@ if __name__ == "__main__":
         gen_np_exp()
     if "vit" in which:
         gen_vit()
+    if "head" in which:
+        gen_head()
     if "resize" in which:
         gen_resize()
     if "tta" in which:

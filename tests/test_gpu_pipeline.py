@@ -415,3 +415,40 @@ DATASETS:
     model.load_param(str(ckpt))
     r1d, r5d = do_inference(cfg, model, loader, nq)
     assert float(r1) == float(r1d) and float(r5) == float(r5d)
+
+
+@pytest.mark.parametrize("mode", ["cam_view", "cam", "view", "none"])
+@pytest.mark.parametrize("neck", ["before", "after"])
+def test_head_vs_reference_golden(golden, mode, neck):
+    """build_transformer.forward (eval) against tests/golden/head.npz: the reference's own VisionTransformer class + the
+    SIE index rules of model/make_model.py:89-96 + torch.nn.BatchNorm1d(eval) with non-trivial running statistics + the
+    concatenations of :110-115 (make_goldens.py:gen_head) -- the pin for the head that round 2 only checked against the
+    oracle's own restatement.  Default (split) encoder precision: fp32-grade agreement."""
+    from config import cfg_base
+    from mpreid import synth
+    from model.make_model import make_model
+    g = golden("head.npz")
+    cfg = cfg_base.clone()
+    cfg.defrost()
+    cfg.merge_from_list(["MODEL.SIE_CAMERA", mode in ("cam_view", "cam"), "MODEL.SIE_VIEW", mode in ("cam_view", "view"),
+                         "MODEL.SIE_COE", float(g["sie_coe"]), "TEST.NECK_FEAT", neck])
+    cfg.freeze()
+    m = make_model(cfg, num_class=5, camera_num=int(g["camera_num"]), view_num=int(g["view_num"]))
+    sd = synth.vit_state_dict(synth.VIT_B16, seed=21, std=0.02, ln_jitter=0.05)
+    state = {"image_encoder." + k: torch.from_numpy(v) for k, v in sd.items()}
+    for n in ("bottleneck", "bottleneck_proj"):
+        for k in ("weight", "bias", "running_mean", "running_var"):
+            state[f"{n}.{k}"] = torch.from_numpy(g[f"{n}.{k}"])
+    if mode != "none":
+        state["cv_embed"] = torch.from_numpy(g[f"cv_embed_{mode}"])
+    own = m.state_dict()
+    for k, v in state.items():           # what load_param does (model/make_model.py:118-122)
+        own[k].copy_(v)
+    m._invalidate()
+    imgs = torch.from_numpy(synth.synthetic_images(6, 256, 128, seed=77)).cuda()
+    cam = torch.from_numpy(g["cam"]).cuda() if mode in ("cam_view", "cam") else None
+    view = torch.from_numpy(g["view"]).cuda() if mode in ("cam_view", "view") else None
+    got = m(imgs, cam_label=cam, view_label=view).cpu().numpy()
+    want = g[f"{mode}_{neck}"]
+    assert got.shape == want.shape == (6, 1280)
+    assert np.abs(got - want).max() <= 5e-5, np.abs(got - want).max()

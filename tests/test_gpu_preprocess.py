@@ -12,7 +12,18 @@ SMALL = dict(h_res=4, w_res=2, patch=16, stride=16, width=128, layers=2, heads=2
 
 
 def test_resize_bit_exact_vs_pillow_goldens(golden):
-    """integer/byte work: every output byte equals PIL.Image.resize(BILINEAR)'s"""
+    """integer/byte work: every output byte equals PIL.Image.resize(BILINEAR)'s.
+
+    VERSION CAVEAT (stated, not hidden): tests/golden/resize.npz was produced by the Pillow in this image, 12.2.0; the
+    reference pins pillow 10.4.0 (requirements.txt:122), which cannot be installed here (no index access, no wheel in the
+    offline wheelhouse), so the two `Resample.c` versions could not be diffed or run side by side.  What the fixture pins
+    is the 8-bit two-pass resample as Pillow publishes it: `precompute_coeffs` in IEEE double with the triangle filter
+    widened by the down-scale factor, coefficients rounded to 22-bit fixed point (PRECISION_BITS = 32 - 8 - 2), int32
+    accumulation from 1 << 21, `clip8` after an arithmetic shift, horizontal pass into an 8-bit intermediate, then the
+    vertical pass.  That code path has carried the same constants since the fixed-point resampler was introduced
+    (Pillow 3.x) -- to the best of our knowledge 10.4.0 and 12.2.0 agree byte for byte on plain `Image.resize(size,
+    BILINEAR)` (no `box`, no `reducing_gap`), but this build has no way to PROVE it: a maintainer with both wheels runs
+    tests/golden/make_goldens.py resize under 10.4.0 and compares the npz."""
     from mpreid import ops
     g = golden("resize.npz")
     n = int(g["n"])
