@@ -1030,6 +1030,25 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
             if (EPI == GE_BIAS_RES || EPI == GE_S_BIAS_RES || EPI == GE_S_BIAS_F32) bias1 = g.bias[nbase + lane];
             if (EPI == GE_EUCLID) bnv1 = (nbase + lane < g.n_valid) ? g.aux2[nbase + lane] : 0.f;
         }
+        // (round-3 ablation of the stored 20k x 20k x 768 distance GEMM, one device: 0.848 ms = k-loop + operand casts 0.618,
+        // epilogue instructions 0.138, stores 0.092.  Tried and NOT kept: the matrix instruction with swapped operands, so
+        // that a lane owns four consecutive output columns and stores 16 bytes straight from the accumulators with no LDS
+        // pass -- bit-identical, but 0.909 ms: a store instruction then covers 16 rows x 64 bytes, i.e. half lines, and the
+        // memory system takes those slower than whole 256-byte row pieces.  A start stagger of 3-30 us: no change.)
+        // GE_EUCLID: the wave's 128 row norms (and row scales) are fetched ONCE per tile into a wave-private table in the
+        // idle k-loop ring.  Fetched per pass -- as this epilogue did until round 3 -- every load sat behind the stores of
+        // the pass before it (vmcnt retires in order and a load is the youngest operation, so its wait is a vmcnt(0)):
+        // 32 dependent store round trips per tile, ~10 us of an ~31 us tile with the matrix pipe idle.
+        float *rt = reinterpret_cast<float *>(smem + wave * 16384);   // [128] |q|^2, then [128] row scales
+        if constexpr (EPI == GE_EUCLID) {
+            const int r0 = cur_m0 + wr * 128;
+            rt[lane] = (r0 + lane < g.m_valid) ? g.aux[r0 + lane] : 0.f;
+            rt[64 + lane] = (r0 + 64 + lane < g.m_valid) ? g.aux[r0 + 64 + lane] : 0.f;
+            if (g.rscale) {
+                rt[128 + lane] = g.rscale[r0 + lane];           // (padded to the tile size)
+                rt[192 + lane] = g.rscale[r0 + 64 + lane];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
 #pragma unroll
@@ -1079,10 +1098,10 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
                         x.w = x.w + (a.w + bias4.w);
                         *reinterpret_cast<float4 *>(dst) = x;   // (streaming stores measured neutral here)
                     } else if (m < g.m_valid) { // GE_EUCLID
-                        const float am = g.aux[m];
+                        const float am = rt[i * 16 + lr];
                         float4 o, s4 = make_float4(1.f, 1.f, 1.f, 1.f);
                         if (g.rscale) {
-                            const float rs = g.rscale[m];
+                            const float rs = rt[128 + i * 16 + lr];
                             s4 = make_float4(rs * cs4.x, rs * cs4.y, rs * cs4.z, rs * cs4.w);
                         }
                         o.x = fmaf(-2.0f, a.x * s4.x, am + bn4.x);
@@ -1120,13 +1139,15 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
                     } else if (EPI == GE_BIAS_RES) {
                         *dst = *dst + (a + bias1);
                     } else if (m < g.m_valid && n < g.n_valid) {
-                        const float sc = g.rscale ? g.rscale[m] * cs1 : 1.0f;
-                        *dst = fmaf(-2.0f, a * sc, g.aux[m] + bnv1);
+                        const float sc = g.rscale ? rt[128 + i * 16 + lr] * cs1 : 1.0f;
+                        *dst = fmaf(-2.0f, a * sc, rt[i * 16 + lr] + bnv1);
                     }
                 }
             }
             __builtin_amdgcn_wave_barrier();
         }
+        // the row tables alias stage 0 of the ring, which the next tile's prologue fills: all waves done first
+        if constexpr (EPI == GE_EUCLID) asm volatile("s_barrier" ::: "memory");
     }
     // next tile: its first three DMA stages go out right behind this tile's stores (the ring was released by
     // the barrier above), so their cold latency overlaps the store drain

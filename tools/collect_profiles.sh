@@ -1,14 +1,15 @@
 #!/bin/bash
 # Collect the round's evidence on the GPU box (run through gpurun from the repo root):
-#   bash tools/collect_profiles.sh r02
+#   bash tools/collect_profiles.sh r03
 # Writes everything under gpurun_out/profiles_<tag>/; the summaries are then copied into profiles/ (tracked).
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # 1. the default bench line (N = 1), and the other workloads
 python3 $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
+python3 $R/bench.py --encoder-precision fp16 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_fp16_encoder.json 2>> $OUT/bench.err
 python3 $R/bench.py --workload synth --rerank --steps 2 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_synth_rerank.json 2>> $OUT/bench.err
 python3 $R/bench.py --workload synth --dist-mode split3 --steps 3 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_synth_split3.json 2>> $OUT/bench.err
 python3 $R/bench.py --workload synth --rerank --rerank-algo split3 --dist-mode split3 --steps 2 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_synth_rerank_split3.json 2>> $OUT/bench.err
@@ -28,9 +29,9 @@ cp $OUT/kt_euclid/e_kernel_stats.csv $OUT/${TAG}_featgemm_kernel_stats.csv
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_e_sq -o e -- python3 $R/tools/distgemm_bench.py 20000 20000 768 f16 > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_e_fetch -o e -- python3 $R/tools/distgemm_bench.py 20000 20000 768 f16 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_e_write -o e -- python3 $R/tools/distgemm_bench.py 20000 20000 768 f16 > /dev/null 2>&1
-# 5. encoder GEMM classes: FETCH / WRITE passes over the micro-benchmark (tools/pmc_traffic.py reduces them)
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_g_fetch -o g -- python3 $R/tools/gemm_bench.py --reps 3 --rounds 2 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_g_write -o g -- python3 $R/tools/gemm_bench.py --reps 3 --rounds 2 > /dev/null 2>&1
+# 5. encoder GEMM classes (fp16 and split-precision): FETCH / WRITE passes over the micro-benchmark (tools/pmc_traffic.py reduces them)
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_g_fetch -o g -- python3 $R/tools/gemm_bench.py --reps 3 --rounds 2 --only qkv,out,fc1,fc2,sqkv,sout,sfc1,sfc2 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_g_write -o g -- python3 $R/tools/gemm_bench.py --reps 3 --rounds 2 --only qkv,out,fc1,fc2,sqkv,sout,sfc1,sfc2 > /dev/null 2>&1
 python3 $R/tools/pmc_traffic.py $OUT/pmc_g_fetch $OUT/pmc_g_write $OUT/${TAG}_gemm_pmc_traffic.json > /dev/null 2>&1
 python3 $R/tools/pmc_summary.py $OUT $TAG > $OUT/${TAG}_pmc_summary.json 2> $OUT/pmc_summary.err
 ls -la $OUT | head -40

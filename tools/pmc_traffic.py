@@ -9,7 +9,8 @@ import json
 import sys
 from collections import defaultdict
 
-NAMES = {"1": ("qkv_bias_f16", 2304, 768), "3": ("fc_bias_quickgelu", 3072, 768)}
+NAMES = {"1": ("qkv_bias_f16", 2304, 768), "3": ("fc_bias_quickgelu", 3072, 768),
+         "10": ("split_qkv_bias_f32", 2304, 768), "12": ("split_fc_bias_quickgelu", 3072, 768)}
 
 
 def collect(d, counter):
@@ -39,16 +40,17 @@ def main():
         epi = kname.split("<")[1].split(",")[0].strip()
         fv = [v for _, v in sorted(fetch[kname])]
         wv = [v for _, v in sorted(write.get(kname, []))]
-        if epi == "2":   # two shapes share the residual epilogue: out-proj (K=768) and FC2 (K=3072) alternate
+        if epi in ("2", "11"):   # two shapes share the residual epilogue: out-proj (K=768) and FC2 (K=3072) alternate
             # gemm_bench launches `reps` of one shape back to back; split by value clusters (FC2 fetches ~4x more)
             cut = (min(fv) + max(fv)) / 2
-            groups = {"bias_residual:768:768": ([v for v in fv if v < cut], None),
-                      "bias_residual:768:3072": ([v for v in fv if v >= cut], None)}
+            nm2 = "bias_residual" if epi == "2" else "split_bias_residual"
+            groups = {f"{nm2}:768:768": ([v for v in fv if v < cut], None),
+                      f"{nm2}:768:3072": ([v for v in fv if v >= cut], None)}
             wmed = med(wv) if wv else None
             for key, (vals, _) in groups.items():
                 if vals:
                     f_kb = med(vals)
-                    out["classes"][key] = {"kernel": "gemm_f16_big_kernel<2,0>", "FETCH_SIZE_KB": f_kb, "WRITE_SIZE_KB": wmed,
+                    out["classes"][key] = {"kernel": f"gemm_f16_big_kernel<{epi},0>", "FETCH_SIZE_KB": f_kb, "WRITE_SIZE_KB": wmed,
                                            "hbm_bytes_per_launch": None if wmed is None else int((2 * f_kb + wmed) * 1024)}
         elif epi in NAMES:
             nm, n, k = NAMES[epi]
