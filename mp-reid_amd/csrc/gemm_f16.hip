@@ -1,6 +1,7 @@
 // gemm_f16.hip — see gemm_f16.h for the design.  Roofline: MFMA fp16 (2.5 PFLOP/s dense peak).
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "gemm_f16.h"
 
@@ -92,16 +93,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
     auto stage = [&](int s, int kt) {
         unsigned char *abase = smem + s * G_STAGE_BYTES + wave * 4096;
         unsigned char *bbase = abase + G_TILE_BYTES;
-        int koff = kt * GBK, koff_b = koff;
-        if constexpr (SPLIT) {
-            const int seg = (kt >= nseg) + (kt >= 2 * nseg), r = kt - seg * nseg;
-            koff = ((seg == 1 ? nseg : 0) + r) * GBK;     // A: hi, lo, hi
-            koff_b = ((seg == 2 ? nseg : 0) + r) * GBK;   // W: hi, hi, lo
-        }
+        const int koff = kt * GBK;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             dma16(a_src + (int64_t)t * 8 * K + koff, abase + t * 1024);
-            dma16(b_src + (int64_t)t * 8 * K + koff_b, bbase + t * 1024);
+            dma16(b_src + (int64_t)t * 8 * K + koff, bbase + t * 1024);
         }
     };
 
@@ -137,7 +133,54 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
         }
     };
 
-    const int nkt = SPLIT ? 3 * nseg : K / GBK;
+    if constexpr (SPLIT) {
+        // Split precision: per 32-wide k block the three products hi.hi', lo.hi', hi.lo' in THIS order -- the accumulation
+        // order of the persistent 256 x 256 kernel, so that a row gives the same bits whichever kernel its batch selects.
+        // Plain synchronous form (this kernel only sees the small shapes of the split mode: the CLS-only tail, reduced test
+        // models): the hi and lo parts of a 64-wide k block of both operands are staged into two stage buffers
+        // (buffer 0: hi | hi', buffer 1: lo | lo'), then consumed.
+        for (int kb = 0; kb < nseg; ++kb) {
+            if (kb) __syncthreads();   // every wave is done reading the buffers
+            {
+                unsigned char *abase = smem + wave * 4096;
+#pragma unroll
+                for (int part = 0; part < 2; ++part) {       // 0: hi, 1: lo
+                    const int koff = part * g.kseg + kb * GBK;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        dma16(a_src + (int64_t)t * 8 * K + koff, abase + part * G_STAGE_BYTES + t * 1024);
+                        dma16(b_src + (int64_t)t * 8 * K + koff, abase + part * G_STAGE_BYTES + G_TILE_BYTES + t * 1024);
+                    }
+                }
+            }
+            __syncthreads();   // drains the DMA and publishes the four parts
+            const unsigned char *ah = smem, *bh = smem + G_TILE_BYTES, *al = smem + G_STAGE_BYTES,
+                                *bl = smem + G_STAGE_BYTES + G_TILE_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f16x8 afh[4], afl[4], bfh[4], bfl[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    afh[i] = *reinterpret_cast<const f16x8 *>(ah + a_row_off + i * 2048 + ksw[ks]);
+                    afl[i] = *reinterpret_cast<const f16x8 *>(al + a_row_off + i * 2048 + ksw[ks]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bfh[j] = *reinterpret_cast<const f16x8 *>(bh + b_row_off + j * 2048 + ksw[ks]);
+                    bfl[j] = *reinterpret_cast<const f16x8 *>(bl + b_row_off + j * 2048 + ksw[ks]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afh[i], bfh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afl[i], bfh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(afh[i], bfl[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+    } else {
+    const int nkt = K / GBK;
     stage(0, 0);
     __syncthreads(); // drains the DMA (vmcnt(0)) and publishes tile 0
     int cur = 0;
@@ -148,6 +191,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
         cur ^= 1;
     }
     compute(cur);
+    }
 
     // ---- epilogue.  C/D map of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg ----
     if constexpr (EPI == GE_BIAS_F16 || EPI == GE_BIAS_GELU || EPI == GE_BIAS_RELU) {
@@ -414,15 +458,21 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
     constexpr bool SPLIT = gemm_epi_is_split(EPI);
     const int nseg = SPLIT ? g.kseg / BBK : 0;
     const int nst = SPLIT ? 3 * nseg : K / BBK; // even (K, kseg are multiples of 64)
+    // SPLIT stage order is k-block major: stage 3r + s works on the 32-wide k block r with
+    //   s = 0: hi . hi'      s = 1: lo . hi'      s = 2: hi . lo'
+    // so consecutive stages SHARE an operand: stage 3r+1 keeps the W fragments (hi') of stage 3r in registers and stage
+    // 3r+2 the A fragments (hi) -- their LDS parts are neither staged nor read a second time: 4 operand parts of 16 KB per
+    // k block instead of 6 (one third less L2 -> LDS traffic and one third fewer fragment reads per matrix instruction).
+    // k offset of a stage's A / W part inside a row [hi(kseg) | lo(kseg)], -1 = the stage has no such part:
     auto koff_a = [&](int st) -> int {
         if constexpr (!SPLIT) return st * BBK;
-        const int seg = (st >= nseg) + (st >= 2 * nseg);
-        return ((seg == 1 ? nseg : 0) + st - seg * nseg) * BBK;
+        const int r = st / 3, sidx = st - 3 * r;
+        return sidx == 0 ? r * BBK : (sidx == 1 ? g.kseg + r * BBK : -1);
     };
     auto koff_b = [&](int st) -> int {
         if constexpr (!SPLIT) return st * BBK;
-        const int seg = (st >= nseg) + (st >= 2 * nseg);
-        return ((seg == 2 ? nseg : 0) + st - seg * nseg) * BBK;
+        const int r = st / 3, sidx = st - 3 * r;
+        return sidx == 0 ? r * BBK : (sidx == 2 ? g.kseg + r * BBK : -1);
     };
 
     // PERSISTENT: gridDim.x workgroups (one per CU) walk the tiles.  L2 is private to an XCD, so each XCD
@@ -522,10 +572,14 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
         unsigned char *abase = smem + (st & (B_NSTAGE - 1)) * B_STAGE_BYTES + wave * 2048;
         unsigned char *bbase = abase + B_PART_BYTES;
         const int koff = koff_a(st), koffb = koff_b(st);
-        dma16(a_src + koff, abase);
-        dma16(a_src + (int64_t)16 * K + koff, abase + 1024);
-        dma16(b_src + koffb, bbase);
-        dma16(b_src + (int64_t)16 * K + koffb, bbase + 1024);
+        if (!SPLIT || koff >= 0) {
+            dma16(a_src + koff, abase);
+            dma16(a_src + (int64_t)16 * K + koff, abase + 1024);
+        }
+        if (!SPLIT || koffb >= 0) {
+            dma16(b_src + koffb, bbase);
+            dma16(b_src + (int64_t)16 * K + koffb, bbase + 1024);
+        }
     };
     auto dma_prologue = [&]() {
         dma_stage(0);
@@ -606,7 +660,8 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
 
     // stage 0 of this tile has landed everywhere (its DMA was issued before the previous tile's last
     // stores drained, or at kernel start); in-order vmcnt also retires every older store
-    if (nst > 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    if constexpr (SPLIT) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");   // stages 1 (2 pieces) + 2 (2) may be in flight
+    else if (nst > 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
 
     f16x8 fa0[8], fb0[4], fa1[8], fb1[4];
@@ -676,6 +731,86 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
     // t+1; LDS traffic unchanged, same bits.  Both formulations that hipcc accepts -- two copies of the loop selected
     // by the wave number, or one copy with a wave-uniform branch per MFMA group -- make the register allocator spill
     // 300-1000 VGPRs around the accumulators; it needs an assembly k-loop.)
+    if constexpr (SPLIT) {
+        // Six steps = two k blocks form the period of the register roles (S = t mod 6):
+        //   S   stage     uses        meanwhile fetches (fragments of stage t+1)
+        //   0   hi.hi'    fa0, fb0    fa1 <- lo
+        //   1   lo.hi'    fa1, fb0    fb1 <- lo'
+        //   2   hi.lo'    fa0, fb1    fa1 <- hi, fb0 <- hi'   (next k block)
+        //   3   hi.hi'    fa1, fb0    fa0 <- lo
+        //   4   lo.hi'    fa0, fb0    fb1 <- lo'
+        //   5   hi.lo'    fa1, fb1    fa0 <- hi, fb0 <- hi'
+        // DMA of stage t+3 (the parts it has) goes out in step t; the wait at the start of step t lets the pieces of stage
+        // t+2 stay in flight (4 when that stage has both parts, else 2).
+        auto sstep = [&](auto S_, auto TAIL_, int t) {
+            constexpr int S = decltype(S_)::value;
+            constexpr bool TAIL = decltype(TAIL_)::value;
+            constexpr int s0 = S % 3;                     // this stage: 0 hi.hi', 1 lo.hi', 2 hi.lo'
+            constexpr bool ldA = s0 != 1, ldB = s0 != 0;  // stage t+1 has an A part unless it is hi.lo' (s0+1 == 2); a W part unless lo.hi'
+            constexpr bool dmA = s0 != 2, dmB = s0 != 1;  // stage t+3 has the same kind as stage t
+            f16x8 (&fa)[8] = (S & 1) ? fa1 : fa0;
+            f16x8 (&fb)[4] = (s0 == 2) ? fb1 : fb0;
+            f16x8 (&na)[8] = (S < 3) ? fa1 : fa0;
+            f16x8 (&nb)[4] = (s0 == 1) ? fb1 : fb0;
+            // the tail group is the last six stages (nst is a multiple of six: kseg % 64 == 0), so what is left to fetch is
+            // known at compile time: stage t+1 exists for S < 5, stage t+2 for S < 4, stage t+3 for S < 3
+            constexpr bool more1 = !TAIL || S < 5, more3 = !TAIL || S < 3;
+            if constexpr (more1) {
+                if constexpr (TAIL && S >= 4) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                else if constexpr (s0 == 1) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");   // stage t+2 is hi.hi': 4 pieces
+                else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
+            }
+            unsigned char *dbase = smem + ((t + 3) & (B_NSTAGE - 1)) * B_STAGE_BYTES + wave * 2048;
+            const unsigned char *sb = smem + ((t + 1) & (B_NSTAGE - 1)) * B_STAGE_BYTES;
+            const int r3 = (t + 3) / 3;
+            const int koff = (s0 == 1 ? g.kseg : 0) + r3 * BBK, koffb = (s0 == 2 ? g.kseg : 0) + r3 * BBK;
+            auto piece = [&](int q) {   // q-th DMA piece of stage t+3 (A pieces first)
+                if (!more3) return;
+                if (dmA && q < 2) dma16(a_src + (int64_t)(q * 16) * K + koff, dbase + q * 1024);
+                else if (dmB && q - (dmA ? 2 : 0) >= 0 && q - (dmA ? 2 : 0) < 2)
+                    dma16(b_src + (int64_t)((q - (dmA ? 2 : 0)) * 16) * K + koffb, dbase + B_PART_BYTES + (q - (dmA ? 2 : 0)) * 1024);
+            };
+            auto rd_a = [&](int i) { if (more1) na[i] = *reinterpret_cast<const f16x8 *>(sb + a_off + i * 1024); };
+            auto rd_b = [&](int j) { if (more1) nb[j] = *reinterpret_cast<const f16x8 *>(sb + b_off + j * 1024); };
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                piece(gq);
+                if constexpr (ldA && ldB) {          // 12 reads: B0 B1 B2 | B3 A0 A1 | A2 A3 A4 | A5 A6 A7
+                    if (gq == 0) { rd_b(0); rd_b(1); rd_b(2); }
+                    if (gq == 1) { rd_b(3); rd_a(0); rd_a(1); }
+                    if (gq == 2) { rd_a(2); rd_a(3); rd_a(4); }
+                    if (gq == 3) { rd_a(5); rd_a(6); rd_a(7); }
+                } else if constexpr (ldA) {          // 8 reads, two per group
+                    rd_a(2 * gq);
+                    rd_a(2 * gq + 1);
+                } else {                             // 4 reads, one per group
+                    rd_b(gq);
+                }
+#pragma unroll
+                for (int ii = 2 * gq; ii < 2 * gq + 2; ++ii)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[ii], fb[j], acc[ii][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        using std::integral_constant;
+        int t = 0;
+        for (; t + 6 < nst; t += 6) {
+            sstep(integral_constant<int, 0>{}, integral_constant<bool, false>{}, t);
+            sstep(integral_constant<int, 1>{}, integral_constant<bool, false>{}, t + 1);
+            sstep(integral_constant<int, 2>{}, integral_constant<bool, false>{}, t + 2);
+            sstep(integral_constant<int, 3>{}, integral_constant<bool, false>{}, t + 3);
+            sstep(integral_constant<int, 4>{}, integral_constant<bool, false>{}, t + 4);
+            sstep(integral_constant<int, 5>{}, integral_constant<bool, false>{}, t + 5);
+        }
+        sstep(integral_constant<int, 0>{}, integral_constant<bool, true>{}, t);
+        sstep(integral_constant<int, 1>{}, integral_constant<bool, true>{}, t + 1);
+        sstep(integral_constant<int, 2>{}, integral_constant<bool, true>{}, t + 2);
+        sstep(integral_constant<int, 3>{}, integral_constant<bool, true>{}, t + 3);
+        sstep(integral_constant<int, 4>{}, integral_constant<bool, true>{}, t + 4);
+        sstep(integral_constant<int, 5>{}, integral_constant<bool, true>{}, t + 5);
+    } else {
     int t = 0;
     for (; t + 4 < nst; t += 2) {
         step_steady(t, fa0, fb0, fa1, fb1);
@@ -684,6 +819,7 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
     for (; t < nst; t += 2) {
         step_tail(t, fa0, fb0, fa1, fb1);
         step_tail(t + 1, fa1, fb1, fa0, fb0);
+    }
     }
 
     // ---- epilogue.  The accumulators leave through wave-private patches in the 32 KB of LDS above the

@@ -18,20 +18,38 @@ from mpreid import _lib  # noqa: E402
 
 
 def run(L, A, W, bias, out, epi, stream):
+    if epi >= 10:   # split precision: A, W are fp16 pairs [hi | lo]; kseg = half the row length
+        _lib.check(L.mpreid_gemm_f16_split_nt(C.c_void_p(A.data_ptr()), C.c_void_p(W.data_ptr()), C.c_void_p(out.data_ptr()),
+                                              C.c_void_p(bias.data_ptr()), A.shape[0], W.shape[0], A.shape[1] // 2, 2.0 ** -13,
+                                              epi, stream), "gemm")
+        return
     _lib.check(L.mpreid_gemm_f16_nt_ex(C.c_void_p(A.data_ptr()), C.c_void_p(W.data_ptr()), C.c_void_p(out.data_ptr()),
                                        C.c_void_p(bias.data_ptr()), A.shape[0], W.shape[0], A.shape[1], epi, stream), "gemm")
 
 
 SHAPES = [("qkv", 2304, 768, 1), ("out", 768, 768, 2), ("fc1", 3072, 768, 3), ("fc2", 768, 3072, 2),
-          ("conv_relu", 512, 2048, 7), ("conv_add_relu", 2048, 512, 8), ("conv_add_relu_n256", 256, 64, 8)]
+          ("conv_relu", 512, 2048, 7), ("conv_add_relu", 2048, 512, 8), ("conv_add_relu_n256", 256, 64, 8),
+          # split precision (round 3): k-block-major stage order with operand reuse, counted waits of 2 / 4 pieces
+          ("s_qkv", 2304, 768, 10), ("s_out", 768, 768, 11), ("s_fc1", 3072, 768, 12), ("s_fc2", 768, 3072, 11),
+          ("s_k64", 768, 64, 11), ("s_k128", 512, 128, 10)]
 MS = (16384, 32768 + 256)   # whole sweeps and a ragged tile count (non-owned walk)
 
 
 def inputs(name, N, K, epi, Mb, dev):
     g = torch.Generator(device="cpu").manual_seed(zlib.crc32(f"{name}:{Mb}".encode()))   # same in parent and child
-    A = (torch.rand((Mb, K), generator=g) * 2 - 1).half().to(dev)
-    W = ((torch.rand((N, K), generator=g) * 2 - 1) * 0.05).half().to(dev)
+    A = (torch.rand((Mb, K), generator=g) * 2 - 1)
+    W = ((torch.rand((N, K), generator=g) * 2 - 1) * 0.05)
     bias = torch.randn(N, generator=g).to(dev)
+    if epi >= 10:
+        def pair(x, scale):
+            x = x.to(dev).contiguous()
+            y = torch.empty((x.shape[0], 2 * x.shape[1]), dtype=torch.float16, device=dev)
+            _lib.check(_lib.load().mpreid_split_pack_f32(C.c_void_p(x.data_ptr()), x.shape[0], x.shape[1], scale,
+                                                         C.c_void_p(y.data_ptr()), _lib.stream_ptr()), "pack")
+            return y
+        init = (torch.randn((Mb, 2 * N), generator=g).half() if epi == 12 else torch.randn((Mb, N), generator=g)).to(dev)
+        return pair(A, 1.0), pair(W, 2.0 ** 13), bias, init
+    A, W = A.half().to(dev), W.half().to(dev)
     dt = torch.float16 if epi in (1, 3, 7, 8) else torch.float32
     init = torch.randn((Mb, N), generator=g).to(dt).to(dev)
     return A, W, bias, init
@@ -75,7 +93,7 @@ def main():
                 torch.cuda.synchronize()
                 if not torch.equal(out, ref):
                     fails += 1
-            print(f"{name:20s} M={Mb:6d} N={N:5d} K={K:5d}: {a.iters - fails}/{a.iters} identical to the 128x128 kernel")
+            print(f"{name:20s} M={Mb:6d} N={N:5d} K={K:5d}: {a.iters - fails}/{a.iters} identical to the 128x128 kernel", flush=True)
             bad += fails
     sys.exit(1 if bad else 0)
 
