@@ -182,6 +182,14 @@ int mpreid_rr_krecip_sparse(const float *feat_all_dev, const float *norms_all_de
 int mpreid_rr_pack_rows(const int32_t *cnt_dev, const int32_t *idx_dev, const uint16_t *val_dev, int64_t rows,
                         int src_stride, int dst_stride, int32_t *idx_out_dev, uint16_t *val_out_dev,
                         mpreid_stream_t stream);
+/* CSR transport of sparse rows (what the all-gathers of V and V_qe move: nnz entries of 6 bytes instead of rows x the
+ * global maximum row length): rowptr [rows + 1] = exclusive prefix sums of cnt; ell_to_csr packs the first cnt[r] entries of
+ * every ELL row back to back; csr_to_ell is the inverse (entries past cnt[r] of the ELL rows are left untouched). */
+int mpreid_rr_rowptr(const int32_t *cnt_dev, int64_t rows, long long *rowptr_dev, mpreid_stream_t stream);
+int mpreid_rr_ell_to_csr(const long long *rowptr_dev, const int32_t *idx_dev, const uint16_t *val_dev, int64_t rows, int stride,
+                         int32_t *idx_out_dev, uint16_t *val_out_dev, mpreid_stream_t stream);
+int mpreid_rr_csr_to_ell(const long long *rowptr_dev, const int32_t *idx_dev, const uint16_t *val_dev, int64_t rows, int stride,
+                         int32_t *idx_out_dev, uint16_t *val_out_dev, mpreid_stream_t stream);
 /* phase 3: local query expansion of the local rows from the global V (row stride vstride) */
 int mpreid_rr_qe_count(int64_t n, const int32_t *rank_all_dev, int kr, int k2, int64_t r_lo, int64_t rows,
                        const int32_t *vcnt_all_dev, const int32_t *vidx_all_dev, int vstride,

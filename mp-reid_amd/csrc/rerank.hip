@@ -3128,6 +3128,82 @@ extern "C" int mpreid_rr_pack_rows(const int32_t *cnt, const int32_t *idx, const
     return MPREID_OK;
 }
 
+// ---- CSR transport of the sparse rows (the all-gathers of V and V_qe move nnz entries instead of rows x global max) ----
+// rowptr[0 .. rows] = exclusive prefix sums of cnt (one workgroup walks the rows in 1024-row chunks with a running carry)
+__global__ __launch_bounds__(1024) void rowptr_scan_kernel(const int *__restrict__ cnt, int64_t rows, long long *__restrict__ rowptr) {
+    __shared__ long long wsum[16];
+    __shared__ long long carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < rows; base += 1024) {
+        const int64_t i = base + tid;
+        const long long v = i < rows ? (long long)cnt[i] : 0;
+        long long x = v;   // inclusive scan inside the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const long long y = __shfl_up(x, off, 64);
+            if (lane >= off) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        long long pre = carry_s;
+        for (int w = 0; w < wave; ++w) pre += wsum[w];
+        if (i < rows) rowptr[i] = pre + x - v;
+        __syncthreads();
+        if (tid == 1023) carry_s = pre + x;
+        __syncthreads();
+    }
+    if (tid == 0) rowptr[rows] = carry_s;
+}
+
+// TO_CSR: packed[rowptr[r] + e] = ell[r][e] for e < cnt[r]; else the inverse (ELL padding is left untouched)
+template <bool TO_CSR>
+__global__ __launch_bounds__(256) void csr_ell_kernel(const long long *__restrict__ rowptr, int64_t rows, int stride,
+                                                      int *__restrict__ ell_idx, uint16_t *__restrict__ ell_val,
+                                                      int *__restrict__ csr_idx, uint16_t *__restrict__ csr_val) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const long long p0 = rowptr[r];
+    const int n = (int)(rowptr[r + 1] - p0);
+    for (int e = threadIdx.x & 63; e < n; e += 64) {
+        if (TO_CSR) {
+            csr_idx[p0 + e] = ell_idx[r * stride + e];
+            csr_val[p0 + e] = ell_val[r * stride + e];
+        } else {
+            ell_idx[r * stride + e] = csr_idx[p0 + e];
+            ell_val[r * stride + e] = csr_val[p0 + e];
+        }
+    }
+}
+
+extern "C" int mpreid_rr_rowptr(const int32_t *cnt, int64_t rows, long long *rowptr, mpreid_stream_t stream_) {
+    ARG_CHECK(cnt && rowptr && rows >= 0);
+    hipLaunchKernelGGL(rowptr_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream_, cnt, rows, rowptr);
+    LAUNCH_CHECK();
+    return MPREID_OK;
+}
+
+extern "C" int mpreid_rr_ell_to_csr(const long long *rowptr, const int32_t *idx, const uint16_t *val, int64_t rows, int stride,
+                                    int32_t *idx_out, uint16_t *val_out, mpreid_stream_t stream_) {
+    ARG_CHECK(rowptr && idx && val && idx_out && val_out && rows >= 0 && stride > 0);
+    if (rows == 0) return MPREID_OK;
+    hipLaunchKernelGGL(csr_ell_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, rowptr, rows,
+                       stride, const_cast<int *>(idx), const_cast<uint16_t *>(val), idx_out, val_out);
+    LAUNCH_CHECK();
+    return MPREID_OK;
+}
+
+extern "C" int mpreid_rr_csr_to_ell(const long long *rowptr, const int32_t *idx, const uint16_t *val, int64_t rows, int stride,
+                                    int32_t *idx_out, uint16_t *val_out, mpreid_stream_t stream_) {
+    ARG_CHECK(rowptr && idx && val && idx_out && val_out && rows >= 0 && stride > 0);
+    if (rows == 0) return MPREID_OK;
+    hipLaunchKernelGGL(csr_ell_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, rowptr, rows,
+                       stride, idx_out, val_out, const_cast<int *>(idx), const_cast<uint16_t *>(val));
+    LAUNCH_CHECK();
+    return MPREID_OK;
+}
+
 // phase 3: query expansion of the local rows from the GLOBAL V (row stride vstride).  Two steps: union sizes
 // (ucnt_local), then the fill with row stride qcap >= max union size.
 extern "C" int mpreid_rr_qe_count(int64_t n, const int32_t *rank_all, int kr, int k2, int64_t r_lo, int64_t rows,

@@ -26,7 +26,7 @@ SYMBOLS = [
     "mpreid_rerank_workspace_bytes", "mpreid_rerank_f32", "mpreid_rerank_debug_copy",
     "mpreid_rerank_workspace_bytes_ex", "mpreid_rerank_f32_ex", "mpreid_rerank_debug_copy_ex",
     "mpreid_eval_rank_positions", "mpreid_rr_dist_rows", "mpreid_rr_vcap", "mpreid_rr_krecip", "mpreid_rr_krecip_scratch_bytes",
-    "mpreid_rr_sparse_workspace_bytes", "mpreid_rr_neighbours_sparse", "mpreid_rr_krecip_sparse", "mpreid_rr_pack_rows", "mpreid_rr_qe_count",
+    "mpreid_rr_sparse_workspace_bytes", "mpreid_rr_neighbours_sparse", "mpreid_rr_krecip_sparse", "mpreid_rr_pack_rows", "mpreid_rr_rowptr", "mpreid_rr_ell_to_csr", "mpreid_rr_csr_to_ell", "mpreid_rr_qe_count",
     "mpreid_rr_qe_fill", "mpreid_rr_jaccard", "mpreid_rr_jaccard_hist_bytes",
     "mpreid_vit_workspace_bytes", "mpreid_vit_forward", "mpreid_vit_forward_u8", "mpreid_vit_forward_view",
     "mpreid_vit_workspace_bytes_f32", "mpreid_vit_forward_f32",
@@ -161,6 +161,11 @@ def load():
     L.mpreid_rr_krecip_sparse.argtypes = [vp, vp, i64, i32, vp, vp, vp, i32, i32, i64, i64, vp, vp, vp, vp, vp]
     L.mpreid_rr_pack_rows.restype = i32
     L.mpreid_rr_pack_rows.argtypes = [vp, vp, vp, i64, i32, i32, vp, vp, vp]
+    L.mpreid_rr_rowptr.restype = i32
+    L.mpreid_rr_rowptr.argtypes = [vp, i64, vp, vp]
+    for f in (L.mpreid_rr_ell_to_csr, L.mpreid_rr_csr_to_ell):
+        f.restype = i32
+        f.argtypes = [vp, vp, vp, i64, i32, vp, vp, vp]
     L.mpreid_rr_qe_count.restype = i32
     L.mpreid_rr_qe_count.argtypes = [i64, vp, i32, i32, i64, i64, vp, vp, i32, vp, vp]
     L.mpreid_rr_qe_fill.restype = i32

@@ -183,7 +183,7 @@ def column_to_row_blocks(block: torch.Tensor, nq: int, ng_sizes: List[int]) -> t
 #   phase 1  rows [r_lo, r_hi) of D = all-pairs distance, row maxima, first max(k1+1, k2) neighbours
 #            -> ALL-GATHER rank table [N][KR] int32 (+ one column: the float bits of the row maxima)
 #   phase 2  k-reciprocal expansion -> sparse V rows of the local rows
-#            -> ALL-GATHER V (ELL rows re-strided to the global max count)
+#            -> ALL-GATHER V (CSR transport: row counts + the nnz entries of 6 bytes, all_gather_sparse_rows)
 #   phase 3  local query expansion of the local rows (skipped when k2 == 1)
 #            -> ALL-GATHER V_qe
 #   phase 4  queries sharded nq/P: distance rows of the local queries over the gallery columns, inverted index of V_qe
@@ -364,6 +364,85 @@ class _RerankShard:
         return out
 
 
+# ---- CSR transport of the sparse rows (V, V_qe) ------------------------------------------------------------------------
+# The phases produce ELL rows (fixed stride); what crosses xGMI is the CSR payload: the row counts (4 B per row) and the
+# nnz entries (4 B index + 2 B value) of every rank back to back, padded only to the LARGEST RANK PAYLOAD -- not every row
+# to the globally longest row (round 2: 434 MB for V_qe at N = 100 000 against 6 B x nnz = 210 MB).  Every rank unpacks the
+# payloads into ELL rows of the global maximum length for the next phase's kernels.
+def _csr_pack(lib, L, cnt, idx, val):
+    """ELL rows of one shard -> (nnz, idx_csr [nnz], val_csr [nnz])"""
+    t = torch
+    rows = cnt.shape[0]
+    dev = cnt.device
+    rowptr = t.empty(rows + 1, dtype=t.int64, device=dev)
+    lib.check(L.mpreid_rr_rowptr(_rr_ptr(cnt), rows, _rr_ptr(rowptr), lib.stream_ptr()), "mpreid_rr_rowptr")
+    nnz = int(rowptr[rows].item())
+    ci = t.empty(max(nnz, 1), dtype=t.int32, device=dev)
+    cv = t.empty(max(nnz, 1), dtype=t.int16, device=dev)
+    if rows:
+        lib.check(L.mpreid_rr_ell_to_csr(_rr_ptr(rowptr), _rr_ptr(idx), _rr_ptr(val), rows, idx.shape[1], _rr_ptr(ci), _rr_ptr(cv),
+                                         lib.stream_ptr()), "mpreid_rr_ell_to_csr")
+    return nnz, ci, cv
+
+
+def _csr_unpack(lib, L, cnt_all, payloads, row_ranges):
+    """cnt_all [N] + per-rank payloads [(idx_csr, val_csr)] in rank order -> ELL (idx_all [N][W], val_all [N][W]), W = global max"""
+    import ctypes as C
+    t = torch
+    N = cnt_all.shape[0]
+    dev = cnt_all.device
+    W = max(int(cnt_all.max().item()) if N else 0, 1)
+    rowptr = t.empty(N + 1, dtype=t.int64, device=dev)
+    lib.check(L.mpreid_rr_rowptr(_rr_ptr(cnt_all), N, _rr_ptr(rowptr), lib.stream_ptr()), "mpreid_rr_rowptr")
+    starts = rowptr[t.tensor([lo for lo, _ in row_ranges], dtype=t.int64, device=dev)].cpu().tolist()
+    idx_all = t.zeros((N, W), dtype=t.int32, device=dev)
+    val_all = t.zeros((N, W), dtype=t.int16, device=dev)
+    for (lo, hi), off, (ci, cv) in zip(row_ranges, starts, payloads):
+        if hi <= lo:
+            continue
+        # rowptr holds GLOBAL offsets; the rank's payload starts at global offset `off`: shift the payload base instead of
+        # rewriting the offsets (the kernel only ever touches [off, off + nnz_rank))
+        lib.check(L.mpreid_rr_csr_to_ell(C.c_void_p(rowptr.data_ptr() + 8 * lo), C.c_void_p(ci.data_ptr() - 4 * off),
+                                         C.c_void_p(cv.data_ptr() - 2 * off), hi - lo, W,
+                                         C.c_void_p(idx_all.data_ptr() + 4 * lo * W), C.c_void_p(val_all.data_ptr() + 2 * lo * W),
+                                         lib.stream_ptr()), "mpreid_rr_csr_to_ell")
+    return idx_all, val_all
+
+
+def all_gather_sparse_rows(cnt, idx, val, n_total):
+    """All-gather of sparse row shards (shard sizes shard_sizes(n_total, world)) with CSR transport.  Returns
+    (cnt_all [N], idx_all [N][W], val_all [N][W], bytes moved per rank)."""
+    from . import _lib as lib
+    L = lib.load()
+    rank, world = rank_world()
+    cnt_all = all_gather_rows(cnt, n_total)
+    nnz, ci, cv = _csr_pack(lib, L, cnt, idx, val)
+    ranges = [shard_range(n_total, r, world) for r in range(world)]
+    if world == 1:
+        return (cnt_all,) + _csr_unpack(lib, L, cnt_all, [(ci, cv)], ranges) + (0,)
+    staged = dist.get_backend() == "gloo"
+    sz = torch.tensor([nnz], dtype=torch.int64, device="cpu" if staged else cnt.device)
+    sizes = [torch.empty_like(sz) for _ in range(world)]
+    dist.all_gather(sizes, sz)
+    mx = max(max(int(x.item()) for x in sizes), 1)
+    payloads = []
+    for buf in (ci, cv.view(torch.uint8)):        # (int16 has no collective type: bytes)
+        per = buf.numel() // max(ci.numel(), 1)    # elements of `buf` per entry (1 for idx, 2 bytes for val)
+        pad = torch.zeros(mx * per, dtype=buf.dtype, device=buf.device)
+        pad[: nnz * per] = buf[: nnz * per]
+        if staged and pad.is_cuda:
+            host = [torch.empty(pad.shape, dtype=pad.dtype) for _ in range(world)]
+            dist.all_gather(host, pad.cpu())
+            out = torch.cat(host).to(buf.device)
+        else:
+            out = torch.empty(world * mx * per, dtype=buf.dtype, device=buf.device)
+            dist.all_gather_into_tensor(out, pad)
+        payloads.append([out[r * mx * per: (r + 1) * mx * per] for r in range(world)])
+    pl = [(payloads[0][r], payloads[1][r].view(torch.int16)) for r in range(world)]
+    idx_all, val_all = _csr_unpack(lib, L, cnt_all, pl, ranges)
+    return cnt_all, idx_all, val_all, 4 * n_total + 6 * world * mx
+
+
 def _rr_prepare(qf, gf):
     from . import ops
     dev = ops._lib.require_gpu()
@@ -394,13 +473,12 @@ def re_ranking_sharded(qf_all, gf_all, k1, k2, lambda_value, algo=0):
         return int(tt.item())
 
     rank_all, sh.rowmax_all = sh.split_ext(all_gather_rows(sh.phase1_ext(), N), sh.KR)
-    w = max(gmax(sh.phase2(rank_all)), 1)
-    vc, vi, vv = sh.pack_v(w)
-    vc, vi, vv = all_gather_rows(vc, N), all_gather_rows(vi, N), all_gather_rows(vv, N)
+    sh.phase2(rank_all)
+    vc, vi, vv, _ = all_gather_sparse_rows(sh.vcnt, sh.vidx, sh.vval, N)          # CSR transport: counts + nnz entries
     if k2 != 1:
         qcap = max(gmax(sh.phase3_count(vc, vi, vv)), 1)
         qc, qi, qv = sh.phase3_fill(qcap)
-        vc, vi, vv = all_gather_rows(qc, N), all_gather_rows(qi, N), all_gather_rows(qv, N)
+        vc, vi, vv, _ = all_gather_sparse_rows(qc, qi, qv, N)
     return sh.phase4(vc, vi, vv)
 
 
@@ -428,15 +506,29 @@ def re_ranking_virtual(qf_all, gf_all, k1, k2, lambda_value, world, algo=0, timi
                                                   shards[0].KR)
     for s in shards:
         s.rowmax_all = rowmax_all
-    w = max(max(timed("phase2_krecip", lambda s=s: s.phase2(rank_all)) for s in shards), 1)
-    packs = [s.pack_v(w) for s in shards]
-    vc, vi, vv = (torch.cat([p[i] for p in packs], dim=0) for i in range(3))
-    gathers = {"rank_table": rank_all.numel() * 4 + rowmax_all.numel() * 4, "V": vc.numel() * 4 + vi.numel() * 4 + vv.numel() * 2}
+    from . import _lib as lib
+    Lc = lib.load()
+    N = feat.shape[0]
+    ranges = [shard_range(N, r, world) for r in range(world)]
+
+    def virtual_gather(parts):
+        """the CSR all-gather of all_gather_sparse_rows with concatenation in place of the collective; bytes as on the wire"""
+        cnt_all = torch.cat([p[0] for p in parts], dim=0)
+        packed = [_csr_pack(lib, Lc, *p) for p in parts]
+        idx_all, val_all = _csr_unpack(lib, Lc, cnt_all, [(ci, cv) for _, ci, cv in packed], ranges)
+        return cnt_all, idx_all, val_all, 4 * N + 6 * world * max(max(n for n, _, _ in packed), 1)
+
+    for s in shards:
+        timed("phase2_krecip", lambda s=s: s.phase2(rank_all))
+    vc, vi, vv, bv = virtual_gather([(s.vcnt, s.vidx, s.vval) for s in shards])
+    gathers = {"rank_table": rank_all.numel() * 4 + rowmax_all.numel() * 4, "V": bv,
+               "V_ell_round2": vc.numel() * 4 + vi.numel() * 6}
     if k2 != 1:
         qcap = max(max(timed("phase3_qe_count", lambda s=s: s.phase3_count(vc, vi, vv)) for s in shards), 1)
         fills = [timed("phase3_qe_fill", lambda s=s: s.phase3_fill(qcap)) for s in shards]
-        vc, vi, vv = (torch.cat([f[i] for f in fills], dim=0) for i in range(3))
-        gathers["V_qe"] = vc.numel() * 4 + vi.numel() * 4 + vv.numel() * 2
+        vc, vi, vv, bq = virtual_gather(fills)
+        gathers["V_qe"] = bq
+        gathers["V_qe_ell_round2"] = vc.numel() * 4 + vi.numel() * 6
     out = torch.cat([timed("phase4_jaccard", lambda s=s: s.phase4(vc, vi, vv)) for s in shards], dim=0)
     if timings is not None:
         timings["all_gather_bytes"] = gathers

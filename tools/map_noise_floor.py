@@ -1,5 +1,6 @@
-"""How much do mAP / Rank-1 of the image->mAP parity set move under fp32 rounding noise of the REFERENCE itself?
-oracle fp32 features vs the same graph in fp64 (CPU only).  Writes tests/golden/map_parity_f64.npz (fp64 features)."""
+"""How much do mAP / Rank-1 of the image->mAP parity sets (tests/test_gpu_map_parity.py: SETS) move under the fp32
+rounding noise of the REFERENCE itself?  oracle fp32 features vs the same graph evaluated in fp64 (CPU only).
+Usage: python tools/map_noise_floor.py [spread|degenerate]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "mp-reid_amd")]
@@ -8,8 +9,12 @@ import torch
 from mpreid import synth
 from oracle import oracle as orc
 
-x, pid = synth.identity_images(128, 16, 0.55)
-sd = synth.vit_state_dict(synth.VIT_B16, seed=7)
+SETS = {"spread": (128, 8, 0.4, 0.05), "degenerate": (128, 16, 0.55, 0.02)}   # tests/test_gpu_map_parity.py
+name = sys.argv[1] if len(sys.argv) > 1 else "spread"
+n_ids, per_id, beta, std = SETS[name]
+x, pid = synth.identity_images(n_ids, per_id, beta)
+sd = synth.vit_state_dict(synth.VIT_B16, seed=7, std=std)
+print("set", name, SETS[name], flush=True)
 n = len(pid); nq = n // 5
 t0 = time.time()
 f32 = np.concatenate([orc.vit_features(sd, synth.VIT_B16, x[s:s + 64]) for s in range(0, n, 64)])
@@ -17,7 +22,6 @@ print("fp32 features", time.time() - t0, flush=True)
 t0 = time.time()
 f64 = np.concatenate([orc.vit_features(sd, synth.VIT_B16, x[s:s + 64], dtype="float64") for s in range(0, n, 64)])
 print("fp64 features", time.time() - t0, flush=True)
-np.savez_compressed(os.path.join(ROOT, "gpurun_out", "map_parity_feats.npz"), f32=f32, f64=f64, pid=pid)
 print("rel-L2 fp32 vs fp64", np.linalg.norm(f32 - f64) / np.linalg.norm(f64))
 
 def ev64(f):
