@@ -495,7 +495,7 @@ __device__ __forceinline__ void split4(const float4 &v, h4_t &hi, h4_t &lo) {
 template <int KTP, int NW>
 __global__ __launch_bounds__(64 * NW, NW >= 8 ? 2 : 1) void attention_split_kernel(const float *__restrict__ qkv, int L, int W,
                                                                                    int heads, _Float16 *__restrict__ out,
-                                                                                   int q_tiles, int total_pairs) {
+                                                                                   int q_tiles, int total_pairs, int dbg) {
     constexpr int KEYS = KTP * 16;
     constexpr int NT = 64 * NW;
     constexpr int K_ITERS = (KEYS * 16 + NT - 1) / NT;
@@ -512,9 +512,10 @@ __global__ __launch_bounds__(64 * NW, NW >= 8 ? 2 : 1) void attention_split_kern
 
     ATS_FOR_EACH_ITER(ATS_DECL)
 
+    // dbg (MPREID_ATT_DBG, timing ablations only, wrong results): 1 no K / V loads, 2 no compute, 4 no output stores
     int pair = blockIdx.x;
     if (pair >= total_pairs) return;
-    ATS_PREFETCH(pair)
+    if (!(dbg & 1)) ATS_PREFETCH(pair)
     for (; pair < total_pairs; pair += gridDim.x) {
         const int b = pair / heads, h = pair - b * heads;
         const float *base = qkv + (int64_t)b * L * ld + h * 64;
@@ -539,9 +540,9 @@ __global__ __launch_bounds__(64 * NW, NW >= 8 ? 2 : 1) void attention_split_kern
         __syncthreads();
         {
             const int nxt = pair + (int)gridDim.x < total_pairs ? pair + (int)gridDim.x : pair;
-            ATS_PREFETCH(nxt)
+            if (!(dbg & 1)) ATS_PREFETCH(nxt)
         }
-        for (int qt = wave; qt < nqt; qt += NW) {
+        for (int qt = wave; qt < ((dbg & 2) ? 0 : nqt); qt += NW) {
             f16x8 qh[2], ql[2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -648,7 +649,7 @@ __global__ __launch_bounds__(64 * NW, NW >= 8 ? 2 : 1) void attention_split_kern
                         const int row = it * 8 + (lane >> 3), ch = lane & 7;
                         const uint4 v = *reinterpret_cast<const uint4 *>(ot + row * OS + ch * 8);
                         const int qrow = qt * 16 + row;
-                        if (qrow < L) store_nt16(out + ((int64_t)b * L + qrow) * 2 * W + part * W + h * 64 + ch * 8, v);
+                        if (qrow < L && !(dbg & 4)) store_nt16(out + ((int64_t)b * L + qrow) * 2 * W + part * W + h * 64 + ch * 8, v);
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -866,8 +867,9 @@ static int launch_attention_split(const float *qkv, int B, int L, int W, int hea
     per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
     int grid = cus * per_cu;
     if (grid > total) grid = total;
+    static const int att_dbg = getenv("MPREID_ATT_DBG") ? atoi(getenv("MPREID_ATT_DBG")) : 0;
     hipLaunchKernelGGL((attention_split_kernel<KTP, NW>), dim3((unsigned)grid), dim3(64 * NW), lds, stream, qkv, L, W, heads,
-                       out, q_tiles, total);
+                       out, q_tiles, total, att_dbg);
     LAUNCH_CHECK();
     return MPREID_OK;
 }

@@ -108,3 +108,52 @@ def test_bench_parent_launches_ranks_without_touching_the_gpu():
     assert r.returncode == 1
     assert "child ranks exited with" in r.stderr and "AssertionError: --gpus" not in r.stderr
     assert r.stdout.strip() == ""
+
+
+def test_sharded_loader_paths_cover_every_sample_once():
+    """processor.shard_val_loader: a rank's shard = its query range then its gallery range, in order, for the three loader
+    kinds (a loader that shards itself, a torch DataLoader -> Subset, any other iterable -> filtered); the union over the
+    ranks is every sample exactly once (host logic only: no GPU, no process group -- rank / world are passed explicitly)."""
+    import torch
+    from datasets.make_dataloader import SyntheticValLoader
+    from mpreid import distributed as D
+    from processor.processor import _ShardedLoader
+
+    nq, ng, batch, world = 10, 37, 8, 3
+    syn = SyntheticValLoader(nq, ng, 5, (32, 16), batch, 3)
+    full = list(syn)
+    img_all = torch.cat([b[0] for b in full])
+    pid_all = [p for b in full for p in b[1]]
+    path_all = [p for b in full for p in b[5]]
+
+    class Plain:                       # an iterable without .shard / .dataset: the filter path
+        def __iter__(self):
+            return iter(full)
+
+    class DS(torch.utils.data.Dataset):   # a map-style dataset behind a real DataLoader: the Subset path
+        def __len__(self):
+            return nq + ng
+
+        def __getitem__(self, i):
+            return img_all[i], int(pid_all[i]), 0, 0, path_all[i]
+
+    def collate(batch_):
+        imgs, pids, cams, views, paths = zip(*batch_)
+        return (torch.stack(imgs), pids, cams, torch.tensor(cams), torch.tensor(views), paths)
+
+    dl = torch.utils.data.DataLoader(DS(), batch_size=batch, shuffle=False, collate_fn=collate)
+    seen = {"synthetic": [], "plain": [], "dataloader": []}
+    for rank in range(world):
+        q_lo, q_hi = D.shard_range(nq, rank, world)
+        g_lo, g_hi = D.shard_range(ng, rank, world)
+        idx = list(range(q_lo, q_hi)) + list(range(nq + g_lo, nq + g_hi))
+        for name, ld in (("synthetic", syn), ("plain", Plain()), ("dataloader", dl)):
+            got = list(_ShardedLoader(ld, idx))
+            gi = torch.cat([b[0] for b in got])
+            assert torch.equal(gi, img_all[idx]), (name, rank)
+            assert [p for b in got for p in b[1]] == [pid_all[i] for i in idx], (name, rank)
+            assert [p for b in got for p in b[5]] == [path_all[i] for i in idx], (name, rank)
+            assert all(len(b[1]) == b[3].shape[0] == b[4].shape[0] for b in got)
+            seen[name] += idx
+    for name, ids in seen.items():
+        assert sorted(ids) == list(range(nq + ng)), name
