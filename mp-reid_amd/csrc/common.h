@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 
 #include "../../include/mpreid.h"
@@ -30,6 +31,20 @@ void mpreid_set_error(const char *fmt, ...);
     } while (0)
 
 __host__ __device__ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Timing-ablation switches (MPREID_GEMM_DBG, MPREID_ATT_DBG, MPREID_CAND_DBG, MPREID_JACCARD_DBG: kernels that skip loads,
+// matrix instructions or stores -- WRONG RESULTS by design) are honoured only by a library built with -DMPREID_ABLATION
+// (MPREID_ABLATION=1 python mp-reid_amd/mpreid/build.py); the shipped library ignores them, so a stray environment
+// variable cannot change results.
+static inline int mpreid_ablation_env(const char *name) {
+#ifdef MPREID_ABLATION
+    const char *e = getenv(name);
+    return e ? atoi(e) : 0;
+#else
+    (void)name;
+    return 0;
+#endif
+}
 
 // Bijective XCD-aware remap of a 1-D block id: blocks b and b+8 share an XCD (round-robin
 // dispatch), so give each XCD a contiguous chunk of the logical tile order (L2 locality only;

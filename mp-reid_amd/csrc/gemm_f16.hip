@@ -1443,7 +1443,7 @@ static int launch_one(const GemmArgs &a_in, hipStream_t stream) {
     }
     if (use_big) {
         if constexpr (HAS_BIG) {
-            static const int dbg = getenv("MPREID_GEMM_DBG") ? atoi(getenv("MPREID_GEMM_DBG")) : 0;
+            static const int dbg = mpreid_ablation_env("MPREID_GEMM_DBG");
             // persistent: one workgroup per CU (the kernel owns the CU's whole LDS), each walking tiles
             int big_cus = 0;
             {

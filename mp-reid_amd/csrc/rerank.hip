@@ -2167,11 +2167,7 @@ static int launch_jaccard(int64_t N, int64_t nq, int q0, int64_t qrows, const fl
     // (An ablation that points every gather at ONE address measures an L2 hot spot, not the loop: removed.)
     // Compiled in only with -DMPREID_ABLATION (never in the shipped library: a stray environment variable must not be
     // able to change results).
-#ifdef MPREID_ABLATION
-    static const int jdbg = getenv("MPREID_JACCARD_DBG") ? atoi(getenv("MPREID_JACCARD_DBG")) : 0;
-#else
-    constexpr int jdbg = 0;
-#endif
+    static const int jdbg = mpreid_ablation_env("MPREID_JACCARD_DBG");
     const size_t lds = align_up((size_t)rch * 2 + 16, 16) + (size_t)qcap * (8 + 4 + 2) + 16;
 #define MPREID_JACCARD_LAUNCH(JT_, NPF_, PD_, PK_)                                                                       \
     {                                                                                                                    \
@@ -2666,11 +2662,9 @@ static int rerank_sparse(const float *q, const float *g, int64_t nq, int64_t ng,
         a.aux = sqn; a.aux2 = sqn; a.m_valid = (int)N; a.n_valid = (int)N;
         a.tlo = tlo; a.thi = thi; a.cnt_lo = cnt_lo; a.cnt_hi = cnt_hi; a.list_lo = list_lo; a.list_hi = list_hi;
         a.cap_lo = RR2_CAP_LO; a.cap_hi = RR2_CAP_HI; a.sym = 1;
-#ifdef MPREID_ABLATION   // timing experiments (wrong results): never in the shipped library
-        static const int cand_dbg = getenv("MPREID_CAND_DBG") ? atoi(getenv("MPREID_CAND_DBG")) : 0;
+        static const int cand_dbg = mpreid_ablation_env("MPREID_CAND_DBG");   // timing experiments (wrong results)
         if (cand_dbg & 1) a.sym = 0;
         if (cand_dbg & 2) a.stagger = 2;
-#endif
         rc = launch_gemm_f16(a, GE_CAND, stream);
         if (rc) return rc;
     }

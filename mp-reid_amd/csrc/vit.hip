@@ -512,7 +512,11 @@ __global__ __launch_bounds__(64 * NW, NW >= 8 ? 2 : 1) void attention_split_kern
 
     ATS_FOR_EACH_ITER(ATS_DECL)
 
-    // dbg (MPREID_ATT_DBG, timing ablations only, wrong results): 1 no K / V loads, 2 no compute, 4 no output stores
+    // dbg (MPREID_ATT_DBG in an MPREID_ABLATION build; timing ablations only, wrong results): 1 no K / V loads, 2 no compute,
+    // 4 no output stores, 8 no PV, 16 no O write-out, 32 no QK products.  Round-3 ablation at B = 508, L = 129 (us per
+    // layer-batch): full 263; loads + staging only 100; compute on stale LDS 220 = QK 40 + PV 60 + O write-out 26 + the
+    // rest 102 (softmax and the P pairs ~60: ~400 VALU instructions per tile, K / V staging, two barriers per pair, the
+    // 9 tiles over 8 waves).
     int pair = blockIdx.x;
     if (pair >= total_pairs) return;
     if (!(dbg & 1)) ATS_PREFETCH(pair)
@@ -557,17 +561,20 @@ __global__ __launch_bounds__(64 * NW, NW >= 8 ? 2 : 1) void attention_split_kern
             if (qt + NW < nqt) q_request(qt + NW);
             f32x4 s[KTP];
             float mx = -3.0e38f;
+            const int nkt = (L + 15) >> 4;   // key tiles that hold a valid key (9 of the 10 at L = 129: the tenth only pads the PV step)
 #pragma unroll
             for (int kt = 0; kt < KTP; ++kt) {
                 s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (kt < nkt && !(dbg & 32)) {
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const int ko = (kt * 16 + fr) * 128 + (((ks * 4 + fq) ^ (lane & 7)) << 4);
-                    const f16x8 kh = *reinterpret_cast<const f16x8 *>(Kh + ko);
-                    const f16x8 kl = *reinterpret_cast<const f16x8 *>(Kl + ko);
-                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[ks], s[kt], 0, 0, 0);
-                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[ks], s[kt], 0, 0, 0);
-                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[ks], s[kt], 0, 0, 0);
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const int ko = (kt * 16 + fr) * 128 + (((ks * 4 + fq) ^ (lane & 7)) << 4);
+                        const f16x8 kh = *reinterpret_cast<const f16x8 *>(Kh + ko);
+                        const f16x8 kl = *reinterpret_cast<const f16x8 *>(Kl + ko);
+                        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[ks], s[kt], 0, 0, 0);
+                        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[ks], s[kt], 0, 0, 0);
+                        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[ks], s[kt], 0, 0, 0);
+                    }
                 }
                 if (kt & 1) __builtin_amdgcn_sched_barrier(0);
             }
@@ -595,7 +602,7 @@ __global__ __launch_bounds__(64 * NW, NW >= 8 ? 2 : 1) void attention_split_kern
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int s2 = 0; s2 < KTP / 2; ++s2) {
+            for (int s2 = 0; s2 < ((dbg & 8) ? 0 : KTP / 2); ++s2) {
                 f16x8 ph, pl;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -625,7 +632,7 @@ __global__ __launch_bounds__(64 * NW, NW >= 8 ? 2 : 1) void attention_split_kern
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            {   // O^T -> fp16 pair, through the wave's LDS patch as whole 128-byte rows: hi part, then lo part
+            if (!(dbg & 16)) {   // O^T -> fp16 pair, through the wave's LDS patch as whole 128-byte rows: hi part, then lo part
                 const float inv = 1.0f / sum;
                 _Float16 *ot = Ot + wave * (16 * OS);
 #pragma unroll
@@ -840,7 +847,7 @@ static int launch_attention(const _Float16 *qkv, int B, int L, int W, int heads,
     int grid = cus * blocks_per_cu;
     if (grid > total) grid = total;
     hipLaunchKernelGGL((attention_kernel<KTP, NW, EXACT>), dim3((unsigned)grid), dim3(64 * NW), lds, stream, qkv, L, W,
-                       heads, out, q_tiles, total, getenv("MPREID_ATT_DBG") ? atoi(getenv("MPREID_ATT_DBG")) : 0);
+                       heads, out, q_tiles, total, mpreid_ablation_env("MPREID_ATT_DBG"));
     LAUNCH_CHECK();
     return MPREID_OK;
 }
@@ -867,7 +874,7 @@ static int launch_attention_split(const float *qkv, int B, int L, int W, int hea
     per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
     int grid = cus * per_cu;
     if (grid > total) grid = total;
-    static const int att_dbg = getenv("MPREID_ATT_DBG") ? atoi(getenv("MPREID_ATT_DBG")) : 0;
+    static const int att_dbg = mpreid_ablation_env("MPREID_ATT_DBG");
     hipLaunchKernelGGL((attention_split_kernel<KTP, NW>), dim3((unsigned)grid), dim3(64 * NW), lds, stream, qkv, L, W, heads,
                        out, q_tiles, total, att_dbg);
     LAUNCH_CHECK();

@@ -19,6 +19,9 @@ SOURCES = ["api.cpp", "distance.hip", "rerank.hip", "gemm_f16.hip", "vit.hip", "
 # (include/mpreid_numerics.h); fused multiply-adds are written as explicit fmaf().
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function", "-x", "hip"]
+# MPREID_ABLATION=1: a library that honours the timing-ablation switches (wrong results by design; csrc/common.h)
+if os.environ.get("MPREID_ABLATION"):
+    FLAGS = FLAGS[:-2] + ["-DMPREID_ABLATION"] + FLAGS[-2:]
 
 
 # The encoder is a floating-point kernel with a stated tolerance: assuming finite values there removes the
