@@ -492,8 +492,14 @@ __device__ __forceinline__ void split4(const float4 &v, h4_t &hi, h4_t &lo) {
         ATS_FOR_EACH_ITER(ATS_LOAD)                                                                  \
     }
 
-template <int KTP, int NW>
-__global__ __launch_bounds__(64 * NW, NW >= 8 ? 2 : 1) void attention_split_kernel(const float *__restrict__ qkv, int L, int W,
+// XKEY (L == 16 * KTP + 1, i.e. ViT-B/16 at 256 x 128: L = 129 = 8 key tiles + ONE token): the tiles cover keys 0 .. L-2
+// exactly and the last token is handled as an extra key OUTSIDE the matrix instructions -- its K / V rows sit in LDS as
+// fp32; its score is 16 fp32 FMAs per lane on the raw Q values + one cross-group sum, its P x V contribution 16 FMAs on the
+// O accumulators.  Without it the one odd key costs two of ten key tiles (the PV step is 32 keys wide): 20 % of the QK
+// products, a fifth PV step, 20 % of the softmax and 16 KB of LDS -- and with 64 + 1 KB of K / V pairs instead of 80 a
+// 256-thread workgroup fits a CU TWICE, so one workgroup's loads / staging / barriers overlap the other's compute.
+template <int KTP, int NW, bool XKEY>
+__global__ __launch_bounds__(64 * NW, (NW >= 8 || XKEY) ? 2 : 1) void attention_split_kernel(const float *__restrict__ qkv, int L, int W,
                                                                                    int heads, _Float16 *__restrict__ out,
                                                                                    int q_tiles, int total_pairs, int dbg) {
     constexpr int KEYS = KTP * 16;
@@ -504,6 +510,7 @@ __global__ __launch_bounds__(64 * NW, NW >= 8 ? 2 : 1) void attention_split_kern
     unsigned char *Kh = smem, *Kl = smem + KEYS * 128, *Vh = smem + 2 * KEYS * 128, *Vl = smem + 3 * KEYS * 128;
     constexpr int OS = 72;
     _Float16 *Ot = reinterpret_cast<_Float16 *>(smem + 4 * KEYS * 128);   // [NW][16][OS]
+    float *Xk = reinterpret_cast<float *>(smem + 4 * KEYS * 128 + NW * 16 * OS * 2);   // XKEY: [64] K row, [64] V row of token L-1 (fp32)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int64_t ld = 3 * (int64_t)W;
@@ -512,6 +519,15 @@ __global__ __launch_bounds__(64 * NW, NW >= 8 ? 2 : 1) void attention_split_kern
 
     ATS_FOR_EACH_ITER(ATS_DECL)
 
+    float4 xrow = make_float4(0.f, 0.f, 0.f, 0.f);   // XKEY: lanes 0-15 of wave 0 hold the K row of token L-1, lanes 16-31 its V row
+    auto x_request = [&](int pr) {
+        if constexpr (XKEY) {
+            if (tid < 32) {
+                const int pb = pr / heads, ph = pr - pb * heads;
+                xrow = load_nt_f4(qkv + ((int64_t)pb * L + (L - 1)) * ld + ph * 64 + (tid < 16 ? W : 2 * W) + (tid & 15) * 4);
+            }
+        }
+    };
     // dbg (MPREID_ATT_DBG in an MPREID_ABLATION build; timing ablations only, wrong results): 1 no K / V loads, 2 no compute,
     // 4 no output stores, 8 no PV, 16 no O write-out, 32 no QK products.  Round-3 ablation at B = 508, L = 129 (us per
     // layer-batch): full 263; loads + staging only 100; compute on stale LDS 220 = QK 40 + PV 60 + O write-out 26 + the
@@ -519,12 +535,18 @@ __global__ __launch_bounds__(64 * NW, NW >= 8 ? 2 : 1) void attention_split_kern
     // 9 tiles over 8 waves).
     int pair = blockIdx.x;
     if (pair >= total_pairs) return;
-    if (!(dbg & 1)) ATS_PREFETCH(pair)
+    if (!(dbg & 1)) {
+        ATS_PREFETCH(pair)
+        x_request(pair);
+    }
     for (; pair < total_pairs; pair += gridDim.x) {
         const int b = pair / heads, h = pair - b * heads;
         const float *base = qkv + (int64_t)b * L * ld + h * 64;
         __syncthreads(); // every wave is done reading the previous pair from LDS
         ATS_FOR_EACH_ITER(ATS_STORE)
+        if constexpr (XKEY) {
+            if (tid < 32) *reinterpret_cast<float4 *>(Xk + tid * 4) = xrow;
+        }
         // Q of this wave's first query tile (B operand: B[k = d][col = query]; 8 consecutive d per lane and 32-wide k step),
         // requested BEFORE the barrier so that its round trip is hidden behind it; the next tile's Q (a wave has a second
         // tile only when there are more tiles than waves) is requested while the current tile is computed.  Fetched at the
@@ -544,7 +566,10 @@ __global__ __launch_bounds__(64 * NW, NW >= 8 ? 2 : 1) void attention_split_kern
         __syncthreads();
         {
             const int nxt = pair + (int)gridDim.x < total_pairs ? pair + (int)gridDim.x : pair;
-            if (!(dbg & 1)) ATS_PREFETCH(nxt)
+            if (!(dbg & 1)) {
+                ATS_PREFETCH(nxt)
+                x_request(nxt);
+            }
         }
         for (int qt = wave; qt < ((dbg & 2) ? 0 : nqt); qt += NW) {
             f16x8 qh[2], ql[2];
@@ -558,10 +583,22 @@ __global__ __launch_bounds__(64 * NW, NW >= 8 ? 2 : 1) void attention_split_kern
                     ql[ks][e] = (_Float16)(qv[e] - (float)qh[ks][e]);
                 }
             }
+            float sx = 0.f;   // XKEY: q . k of the extra key (token L-1), fp32, for this lane's query column
+            if constexpr (XKEY) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {   // this lane's 16 d values: ks * 32 + fq * 8 + (c & 1) * 4 .. + 3
+                    const float4 kx = *reinterpret_cast<const float4 *>(Xk + (c >> 1) * 32 + fq * 8 + (c & 1) * 4);
+                    sx = fmaf(qraw[c].x, kx.x, sx);
+                    sx = fmaf(qraw[c].y, kx.y, sx);
+                    sx = fmaf(qraw[c].z, kx.z, sx);
+                    sx = fmaf(qraw[c].w, kx.w, sx);
+                }
+                sx = xor16_32_sum(sx);
+            }
             if (qt + NW < nqt) q_request(qt + NW);
             f32x4 s[KTP];
             float mx = -3.0e38f;
-            const int nkt = (L + 15) >> 4;   // key tiles that hold a valid key (9 of the 10 at L = 129: the tenth only pads the PV step)
+            const int nkt = XKEY ? KTP : (L + 15) >> 4;   // key tiles that hold a valid key
 #pragma unroll
             for (int kt = 0; kt < KTP; ++kt) {
                 s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -580,12 +617,15 @@ __global__ __launch_bounds__(64 * NW, NW >= 8 ? 2 : 1) void attention_split_kern
             }
 #pragma unroll
             for (int kt = 0; kt < KTP; ++kt) {
+                if constexpr (!XKEY) {   // (XKEY: every key of the tiles is valid)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (kt * 16 + fq * 4 + r >= L) s[kt][r] = -3.0e38f;
+                    for (int r = 0; r < 4; ++r)
+                        if (kt * 16 + fq * 4 + r >= L) s[kt][r] = -3.0e38f;
+                }
                 mx = fmaxf(mx, fmaxf(fmaxf(s[kt][0], s[kt][1]), fmaxf(s[kt][2], s[kt][3])));
             }
             mx = xor16_32_max(mx);
+            if constexpr (XKEY) mx = fmaxf(mx, sx);
             // p * 2^10 = exp2(s*c - mx*c + 10); masked entries give exp2(-huge) = 0
             const float nmx = fmaf(-mx, scale_log2e, 10.0f);
             float sum = 0.f;
@@ -598,6 +638,11 @@ __global__ __launch_bounds__(64 * NW, NW >= 8 ? 2 : 1) void attention_split_kern
                     sum += p;
                 }
             sum = xor16_32_sum(sum);
+            float px = 0.f;
+            if constexpr (XKEY) {
+                px = __builtin_amdgcn_exp2f(fmaf(sx, scale_log2e, nmx));
+                sum += px;
+            }
             f32x4 o[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -631,6 +676,16 @@ __global__ __launch_bounds__(64 * NW, NW >= 8 ? 2 : 1) void attention_split_kern
                     o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl, o[dt], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (XKEY) {   // + p_x * v_x: lane (query fr) owns d = dt * 16 + fq * 4 .. + 3
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const float4 vx = *reinterpret_cast<const float4 *>(Xk + 64 + dt * 16 + fq * 4);
+                    o[dt][0] = fmaf(px, vx.x, o[dt][0]);
+                    o[dt][1] = fmaf(px, vx.y, o[dt][1]);
+                    o[dt][2] = fmaf(px, vx.z, o[dt][2]);
+                    o[dt][3] = fmaf(px, vx.w, o[dt][3]);
+                }
             }
             if (!(dbg & 16)) {   // O^T -> fp16 pair, through the wave's LDS patch as whole 128-byte rows: hi part, then lo part
                 const float inv = 1.0f / sum;
@@ -852,15 +907,15 @@ static int launch_attention(const _Float16 *qkv, int B, int L, int W, int heads,
     return MPREID_OK;
 }
 
-template <int KTP, int NW>
+template <int KTP, int NW, bool XKEY = false>
 static int launch_attention_split(const float *qkv, int B, int L, int W, int heads, _Float16 *out, int q_tiles,
                                   hipStream_t stream) {
     constexpr int KEYS = KTP * 16;
-    const size_t lds = (size_t)4 * KEYS * 128 + (size_t)NW * 16 * 72 * 2;
+    const size_t lds = (size_t)4 * KEYS * 128 + (size_t)NW * 16 * 72 * 2 + (XKEY ? 512 : 0);
     static PerDeviceOnce attr_once;
     const int rc = attr_once.run([&]() -> int {
         if (lds > 48 * 1024)
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_split_kernel<KTP, NW>),
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(attention_split_kernel<KTP, NW, XKEY>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         return MPREID_OK;
     });
@@ -875,7 +930,7 @@ static int launch_attention_split(const float *qkv, int B, int L, int W, int hea
     int grid = cus * per_cu;
     if (grid > total) grid = total;
     static const int att_dbg = mpreid_ablation_env("MPREID_ATT_DBG");
-    hipLaunchKernelGGL((attention_split_kernel<KTP, NW>), dim3((unsigned)grid), dim3(64 * NW), lds, stream, qkv, L, W, heads,
+    hipLaunchKernelGGL((attention_split_kernel<KTP, NW, XKEY>), dim3((unsigned)grid), dim3(64 * NW), lds, stream, qkv, L, W, heads,
                        out, q_tiles, total, att_dbg);
     LAUNCH_CHECK();
     return MPREID_OK;
@@ -885,6 +940,7 @@ static int attention_split_dispatch(const float *qkv, int B, int L, int W, int h
                                     hipStream_t stream) {
     const int kt = (L + 15) / 16;
     if (kt <= 2) return launch_attention_split<2, 2>(qkv, B, L, W, heads, out, q_tiles, stream);
+    if (L == 129) return launch_attention_split<8, 4, true>(qkv, B, L, W, heads, out, q_tiles, stream);   // ViT-B/16 at 256 x 128
     if (kt <= 10) return launch_attention_split<10, 8>(qkv, B, L, W, heads, out, q_tiles, stream);
     if (kt <= 14) return launch_attention_split<14, 8>(qkv, B, L, W, heads, out, q_tiles, stream);
     return launch_attention_split<16, 8>(qkv, B, L, W, heads, out, q_tiles, stream);
