@@ -48,7 +48,7 @@ def shard_sizes(n: int, world: int) -> List[int]:
 def all_gather_rows(x: torch.Tensor, n_total: int) -> torch.Tensor:
     """Concatenate the row shards of every rank (shard sizes from shard_sizes(n_total, world)).
     Ragged shards are padded to the largest one for the collective and trimmed afterwards."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single():
         return x
     if x.dtype == torch.int16:   # fp16 bit patterns: neither NCCL/RCCL nor gloo has a 16-bit integer type
         x2 = x.contiguous().view(torch.uint8)
@@ -78,6 +78,20 @@ def rank_world() -> Tuple[int, int]:
     return 0, 1
 
 
+def _single() -> bool:
+    """True when the single-process shortcuts apply.  MPREID_DIST_FORCE_COLLECTIVES=1 (tests) sends a ONE-rank process group
+    through every collective instead, so that the RCCL branches (device tensors, all_to_all_single, gather, byte views) run
+    on one GPU -- RCCL refuses two ranks per device, so this is the only way to execute them without a second GPU."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    return dist.get_world_size() == 1 and os.environ.get("MPREID_DIST_FORCE_COLLECTIVES") != "1"
+
+
+def sharded_active() -> bool:
+    """the evaluator / loader take their multi-rank path"""
+    return not _single()
+
+
 _pinned = {}
 
 
@@ -100,7 +114,7 @@ def _gather_blocks_to_host(block: torch.Tensor, dim: int, dst: int, reuse_buffer
     along `dim` (padded to the largest for the collective).  Returns the matrix on `dst` (None elsewhere): a fresh numpy
     array the caller owns, or -- reuse_buffer=True -- a view of the pinned matrix itself, valid until the next call."""
     rank, world = rank_world()
-    if world == 1:
+    if _single():
         host = _pinned_matrix(block.shape[0], block.shape[1], block.dtype, f"cat{dim}")
         host.copy_(block, non_blocking=block.is_cuda)
         if block.is_cuda:
@@ -146,7 +160,7 @@ def column_to_row_blocks(block: torch.Tensor, nq: int, ng_sizes: List[int]) -> t
     all-to-all (RCCL over xGMI; each rank sends (P-1)/P of its block) turns the column blocks into the row blocks
     [nq_local, ng] of shard_range(nq, rank, world): rank s sends rows [q_lo_r, q_hi_r) of its block to rank r."""
     rank, world = rank_world()
-    if world == 1:
+    if _single():
         return block
     assert block.shape == (nq, ng_sizes[rank]), (block.shape, nq, ng_sizes)
     q_sizes = shard_sizes(nq, world)
@@ -418,7 +432,7 @@ def all_gather_sparse_rows(cnt, idx, val, n_total):
     cnt_all = all_gather_rows(cnt, n_total)
     nnz, ci, cv = _csr_pack(lib, L, cnt, idx, val)
     ranges = [shard_range(n_total, r, world) for r in range(world)]
-    if world == 1:
+    if _single():
         return (cnt_all,) + _csr_unpack(lib, L, cnt_all, [(ci, cv)], ranges) + (0,)
     staged = dist.get_backend() == "gloo"
     sz = torch.tensor([nnz], dtype=torch.int64, device="cpu" if staged else cnt.device)
@@ -456,7 +470,7 @@ def re_ranking_sharded(qf_all, gf_all, k1, k2, lambda_value, algo=0):
     final_dist[q_lo:q_hi, nq:] block on the GPU; use gather_row_blocks_to_host() for the full matrix."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
-    if world == 1:
+    if _single():
         # one GPU: the single call (symmetric distance GEMM: half the tiles) gives the same bits as the phases below
         # (tests/test_gpu_rerank.py::test_sharded_rerank_is_rank_count_independent)
         from . import ops
@@ -466,7 +480,7 @@ def re_ranking_sharded(qf_all, gf_all, k1, k2, lambda_value, algo=0):
     sh = _RerankShard(feat, norms, nq, int(k1), int(k2), float(lambda_value), rank, world, algo)
 
     def gmax(v):
-        if world == 1:
+        if _single():
             return v
         tt = torch.tensor([v], dtype=torch.int64, device=feat.device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -143,7 +143,7 @@ def eval_func_sharded(dist_rows, q_pids_local, g_pids, max_rank=50):
         if rank == 0:
             print("Note: number of gallery samples is quite small, got {}".format(num_g))
     hits, ap, num_valid = _eval_rows_device(dist_rows, q_pids_local, g_pids, max_rank)
-    if world > 1:
+    if D.sharded_active():
         staged = tdist.get_backend() == "gloo"
         dev = "cpu" if staged else dist_rows.device
         # one small all-gather: [hit counts (max_rank) | number of valid rows | AP of the valid rows, NaN padded]
@@ -190,7 +190,7 @@ class R1_mAP_eval():
 
     def compute(self):  # called after each epoch
         from mpreid import distributed as D
-        if D.rank_world()[1] > 1:
+        if D.sharded_active():
             return self._compute_sharded()
         feats = torch.cat(self.feats, dim=0)
         if self.feat_norm:

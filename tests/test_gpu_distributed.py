@@ -200,3 +200,58 @@ def test_test_py_under_two_ranks_matches_single_process(tmp_path, rerank):
         assert [ln for ln in o.splitlines() if ln.startswith("RESULT")] == res
     pick = lambda o: [ln.split("transreid.test INFO: ")[1] for ln in o.splitlines() if "mAP:" in ln or "CMC curve" in ln]   # noqa: E731
     assert pick(single) == pick(multi[0]) and len(pick(single)) == 4 and pick(multi[1]) == []
+
+
+RCCL_WORKER = textwrap.dedent("""
+    import os, sys
+    import numpy as np, torch
+    sys.path[:0] = [{root!r}, os.path.join({root!r}, "mp-reid_amd")]
+    import torch.distributed as dist
+    from mpreid import distributed as D, ops, synth
+    from utils.metrics import R1_mAP_eval
+    rank, world, local = D.init_from_env("nccl") if int(os.environ["WORLD_SIZE"]) > 1 else (0, 1, 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)      # ONE rank on the real RCCL backend
+    assert dist.get_backend() == "nccl" and D.sharded_active()
+    res = {{}}
+    for ci, (n, nq, d, rerank) in enumerate({cases!r}):
+        f, pid = synth.clustered_features(n, d, 2.5, seed=77 + n, per_id=6, normalize=False)
+        cam = synth.labels_for(n)
+        ev = R1_mAP_eval(nq, max_rank=50, feat_norm='yes', reranking=rerank)
+        ev.reset()
+        ev.update((torch.from_numpy(f).cuda(), tuple(int(p) for p in pid), tuple(int(c) for c in cam)))
+        cmc, mAP, distmat, pids, camids, qf, gf = ev.compute()
+        res.update({{f"cmc{{ci}}": cmc, f"map{{ci}}": np.float64(mAP), f"dist{{ci}}": distmat, f"qf{{ci}}": qf.numpy(), f"gf{{ci}}": gf.numpy()}})
+    np.savez(os.path.join(sys.argv[1], "rccl.npz"), **res)
+    dist.barrier(); dist.destroy_process_group()
+""")
+
+
+def test_sharded_evaluator_on_the_rccl_backend_one_rank(tmp_path):
+    """RCCL refuses two ranks per device, so the multi-rank tests above stage their collectives through gloo.  This one runs
+    the SAME sharded code path -- all_gather_into_tensor, the all_to_all_single of column_to_row_blocks, the tensor gather
+    into the pinned host matrix, the CSR all-gather of the sparse rows, the evaluator's metadata exchange -- on the real
+    `nccl` (= RCCL) backend with a one-rank group (MPREID_DIST_FORCE_COLLECTIVES=1 disables the single-process shortcuts):
+    device tensors, dtypes and split sizes as an 8-GPU run issues them.  Bar: the single-process result byte for byte."""
+    import torch
+    from mpreid import synth
+    from utils.metrics import R1_mAP_eval
+    cases = [(900, 150, 192, False), (2600, 500, 128, True)]
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER.format(root=ROOT, cases=cases))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(29950 + os.getpid() % 40), MPREID_DIST_FORCE_COLLECTIVES="1")
+    env.pop("MPREID_DIST_BACKEND", None)
+    r = subprocess.run([sys.executable, str(script), str(tmp_path)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = np.load(tmp_path / "rccl.npz")
+    for ci, (n, nq, d, rerank) in enumerate(cases):
+        f, pid = synth.clustered_features(n, d, 2.5, seed=77 + n, per_id=6, normalize=False)
+        cam = synth.labels_for(n)
+        ev = R1_mAP_eval(nq, max_rank=50, feat_norm='yes', reranking=rerank)
+        ev.reset()
+        ev.update((torch.from_numpy(f).cuda(), tuple(int(p) for p in pid), tuple(int(c) for c in cam)))
+        cmc, mAP, distmat, pids, camids, qf, gf = ev.compute()
+        assert np.array_equal(got[f"cmc{ci}"], cmc) and float(got[f"map{ci}"]) == float(mAP), ci
+        assert np.array_equal(got[f"dist{ci}"], distmat), ci
+        assert np.array_equal(got[f"qf{ci}"], qf.numpy()) and np.array_equal(got[f"gf{ci}"], gf.numpy()), ci
