@@ -355,6 +355,26 @@ int mpreid_rn50_forward(const mpreid_rn50_cfg *cfg, const mpreid_rn50_weights *w
                         const uint8_t *img_hwc_u8_dev, const float *pixel_mean3, const float *pixel_std3, int batch,
                         float *out_dev, void *ws_dev, size_t ws_bytes, mpreid_stream_t stream);
 
+/* All-fp32 mode of the RN50 tower (MODEL.NAME 'RN50' + MODEL.ENCODER_PRECISION 'fp32'; the reference runs the tower in
+ * fp32): fp32 NHWC activations, every convolution a GEMM on the exact fp32 matrix instruction (3x3: im2col, k order
+ * (kh, kw, c)), BatchNorm folded on the host, fp32 attention pool -- relative feature error ~1e-6 against the fp32 CPU path
+ * instead of the fp16 tower's 2.6e-3, at ~1/10 of its throughput.  Weight matrices are fp32 [cout][taps*cin] with the REAL
+ * channel counts (no padding); input fp32 NCHW only. */
+typedef struct { const float *w; const float *bias; int32_t cin, cout, taps; } mpreid_rn50_conv_f32;
+typedef struct { mpreid_rn50_conv_f32 conv1, conv2, conv3, down; int32_t stride; } mpreid_rn50_block_f32;  /* down.w NULL: none */
+typedef struct {
+    const float *stem1_w, *stem1_b;              /* conv1+bn1 folded, [width/2][3][3][3], [width/2] */
+    mpreid_rn50_conv_f32 stem2, stem3;
+    const mpreid_rn50_block_f32 *blocks;         /* HOST array of n_blocks entries */
+    const float *pos_emb;                        /* [S+1][E] */
+    const float *q_w, *q_b, *k_w, *k_b, *v_w, *v_b;   /* [E][E], [E] */
+    const float *c_w, *c_b;                      /* [out_dim][E], [out_dim] */
+    const float *bn_scale, *bn_shift;            /* eval BN necks folded, [E + out_dim], or NULL */
+} mpreid_rn50_weights_f32;
+size_t mpreid_rn50_workspace_bytes_f32(const mpreid_rn50_cfg *cfg, int batch);
+int mpreid_rn50_forward_f32(const mpreid_rn50_cfg *cfg, const mpreid_rn50_weights_f32 *w, const float *img_f32_dev, int batch,
+                            float *out_dev, void *ws_dev, size_t ws_bytes, mpreid_stream_t stream);
+
 /* One convolution layer of the RN50 tower as the encoder runs it (unit tests, micro-benchmarks):
  * NHWC fp16 in [batch][h][w][cin] (cin % 64 == 0), stride 1, taps = 1 (1x1) or 9 (3x3, pad 1); weights fp16
  * [cout_pad][taps*cin] (k order: tap = kh*3+kw, then channel; cout_pad % 128 == 0, rows >= cout zero) with the

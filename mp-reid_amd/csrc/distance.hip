@@ -57,7 +57,9 @@ enum { EPI_EUCLID = 0, EPI_COSINE = 1,
        // linear layers of the all-fp32 encoder mode (vit.hip): bn = bias[n] (or NULL), C = out
        EPI_LIN = 2,        // C = acc + bias
        EPI_LIN_GELU = 3,   // C = quickgelu(acc + bias)
-       EPI_LIN_RES = 4 };  // C += acc + bias
+       EPI_LIN_RES = 4,    // C += acc + bias
+       EPI_LIN_RELU = 5,   // C = relu(acc + bias)                      (RN50 fp32 mode: conv + folded BN + ReLU)
+       EPI_LIN_RES_RELU = 6 };  // C = relu(C + (acc + bias))           (Bottleneck: relu(bn3(conv3) + identity), identity in C)
 
 constexpr int XBM = 128, XBN = 128, XBK = 16, XLD = 132;
 constexpr int XKC = XBK / 4;            // float4 chunks per row of a k tile
@@ -236,6 +238,12 @@ __global__ __launch_bounds__(256) void gemm_f32_exact_kernel(const float *__rest
                     v = __fdiv_rn(t, 1.0f + expf(-1.702f * t));
                 } else if (EPI == EPI_LIN_RES) {
                     v = C[row * ldc + col] + (dot + bnv);
+                } else if (EPI == EPI_LIN_RELU) {
+                    v = dot + bnv;
+                    v = v < 0.0f ? 0.0f : v;
+                } else if (EPI == EPI_LIN_RES_RELU) {
+                    v = C[row * ldc + col] + (dot + bnv);
+                    v = v < 0.0f ? 0.0f : v;
                 } else {
                     float c = dot * __fdiv_rn(1.0f, an[row] * bnv);
                     const float lo = (float)(-1.0 + 0.00001), hi = (float)(1.0 - 0.00001);
@@ -359,6 +367,14 @@ int mpreid_gemm_f32_linear(const float *A, const float *Wt, int64_t M, int64_t N
     case EPI_LIN_RES:
         hipLaunchKernelGGL((gemm_f32_exact_kernel<EPI_LIN_RES, false>), grid, dim3(256), 0, stream, A, Wt, M, N, K, none, bias,
                            C, ldc, tiles_m, tiles_n, vec_ok, nocount);
+        break;
+    case EPI_LIN_RELU:
+        hipLaunchKernelGGL((gemm_f32_exact_kernel<EPI_LIN_RELU, false>), grid, dim3(256), 0, stream, A, Wt, M, N, K, none, bias,
+                           C, ldc, tiles_m, tiles_n, vec_ok, nocount);
+        break;
+    case EPI_LIN_RES_RELU:
+        hipLaunchKernelGGL((gemm_f32_exact_kernel<EPI_LIN_RES_RELU, false>), grid, dim3(256), 0, stream, A, Wt, M, N, K, none,
+                           bias, C, ldc, tiles_m, tiles_n, vec_ok, nocount);
         break;
     default:
         mpreid_set_error("gemm_f32_linear: unknown epilogue %d", epi);

@@ -105,7 +105,9 @@ class build_transformer(nn.Module):
                       self._modules[n].running_var) for n in ("bottleneck", "bottleneck_proj")}
         kw = {} if ws_tag is None else {"ws_tag": ws_tag}
         if self.model_name == 'RN50':
-            return _ops.Rn50Encoder(self.rn_cfg, sd, self.img_hw, neck_after=neck_after, bn=bn, **kw)
+            # RN50 has two modes: 'fp32' (parity) and the fp16 tower ('fp16'; also what 'split' -- a ViT mode -- selects)
+            return _ops.Rn50Encoder(self.rn_cfg, sd, self.img_hw, neck_after=neck_after, bn=bn,
+                                    precision="fp32" if self.precision == "fp32" else "fp16", **kw)
         return _ops.VitEncoder(self.vit_cfg, sd, self.img_hw, neck_after=neck_after, bn=bn, precision=self.precision, **kw)
 
     def _get_encoder(self):

@@ -31,7 +31,7 @@ SYMBOLS = [
     "mpreid_vit_workspace_bytes", "mpreid_vit_forward", "mpreid_vit_forward_u8", "mpreid_vit_forward_view",
     "mpreid_vit_workspace_bytes_f32", "mpreid_vit_forward_f32",
     "mpreid_tta_mean_f32", "mpreid_resize_workspace_bytes", "mpreid_resize_bilinear_u8", "mpreid_conv_f16_nhwc",
-    "mpreid_rn50_workspace_bytes", "mpreid_rn50_forward",
+    "mpreid_rn50_workspace_bytes", "mpreid_rn50_forward", "mpreid_rn50_workspace_bytes_f32", "mpreid_rn50_forward_f32",
     "mpreid_gemm_f16_nt", "mpreid_gemm_f16_nt_ex", "mpreid_gemm_f16_split_nt", "mpreid_split_pack_f32",
     "mpreid_cast_f32_to_f16", "mpreid_profile_enable", "mpreid_profile_reset", "mpreid_profile_query",
 ]
@@ -84,6 +84,22 @@ class Rn50Weights(C.Structure):
                 ("blocks", C.POINTER(Rn50Block)), ("pos_emb", C.c_void_p), ("kt_w", C.c_void_p), ("v_w", C.c_void_p), ("v_b", C.c_void_p),
                 ("q_w", C.c_void_p), ("q_b", C.c_void_p), ("c_w", C.c_void_p), ("c_b", C.c_void_p),
                 ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p)]
+
+
+class Rn50ConvF32(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("bias", C.c_void_p), ("cin", C.c_int32), ("cout", C.c_int32), ("taps", C.c_int32)]
+
+
+class Rn50BlockF32(C.Structure):
+    _fields_ = [("conv1", Rn50ConvF32), ("conv2", Rn50ConvF32), ("conv3", Rn50ConvF32), ("down", Rn50ConvF32),
+                ("stride", C.c_int32)]
+
+
+class Rn50WeightsF32(C.Structure):
+    _fields_ = [("stem1_w", C.c_void_p), ("stem1_b", C.c_void_p), ("stem2", Rn50ConvF32), ("stem3", Rn50ConvF32),
+                ("blocks", C.POINTER(Rn50BlockF32)), ("pos_emb", C.c_void_p), ("q_w", C.c_void_p), ("q_b", C.c_void_p),
+                ("k_w", C.c_void_p), ("k_b", C.c_void_p), ("v_w", C.c_void_p), ("v_b", C.c_void_p), ("c_w", C.c_void_p),
+                ("c_b", C.c_void_p), ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p)]
 
 
 class ProfileEntry(C.Structure):
@@ -199,6 +215,10 @@ def load():
     L.mpreid_rn50_forward.restype = i32
     L.mpreid_rn50_forward.argtypes = [C.POINTER(Rn50Cfg), C.POINTER(Rn50Weights), vp, vp, C.POINTER(C.c_float),
                                       C.POINTER(C.c_float), i32, vp, vp, sz, vp]
+    L.mpreid_rn50_workspace_bytes_f32.restype = sz
+    L.mpreid_rn50_workspace_bytes_f32.argtypes = [C.POINTER(Rn50Cfg), i32]
+    L.mpreid_rn50_forward_f32.restype = i32
+    L.mpreid_rn50_forward_f32.argtypes = [C.POINTER(Rn50Cfg), C.POINTER(Rn50WeightsF32), vp, i32, vp, vp, sz, vp]
     L.mpreid_conv_f16_nhwc.restype = i32
     L.mpreid_conv_f16_nhwc.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, vp, i32, vp, vp, vp]
     L.mpreid_gemm_f16_nt.restype = i32

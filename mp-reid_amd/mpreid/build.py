@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libmpreid_hip.so")
-SOURCES = ["api.cpp", "distance.hip", "rerank.hip", "gemm_f16.hip", "vit.hip", "evalrank.hip", "preprocess.hip", "conv_f16.hip", "rn50.hip"]
+SOURCES = ["api.cpp", "distance.hip", "rerank.hip", "gemm_f16.hip", "vit.hip", "evalrank.hip", "preprocess.hip", "conv_f16.hip", "rn50.hip", "rn50_f32.hip"]
 # -ffp-contract=off: the rounding sequence of the re-ranking path is part of the contract
 # (include/mpreid_numerics.h); fused multiply-adds are written as explicit fmaf().
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",

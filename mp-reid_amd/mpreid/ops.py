@@ -516,11 +516,19 @@ class Rn50Encoder:
     multiples of 64 are stored zero-padded to 64 (the 32-channel stem; reduced test configurations)."""
 
     def __init__(self, cfg: dict, state_dict: dict, img_hw, neck_after: bool = False, bn: Optional[dict] = None,
-                 device=None, ws_tag: str = "rn50"):
+                 device=None, ws_tag: str = "rn50", precision: str = "fp16"):
+        """precision: 'fp16' = fp16 NHWC activations, implicit-GEMM convolutions on the fp16 matrix cores (the throughput
+        path, relative feature error 2.6e-3); 'fp32' = everything fp32 on the exact fp32 matrix instruction
+        (mpreid_rn50_forward_f32: ~1e-6, the parity mode)."""
+        assert precision in ("fp16", "fp32"), precision
+        self.precision = precision
         self.device = dev = device or _lib.require_gpu()
         self.ws_tag, self.cfg, self.img_hw = ws_tag, dict(cfg), tuple(img_hw)
         width, layers = cfg["width"], tuple(cfg["layers"])
         assert self.img_hw[0] // 16 == cfg["h_res"] and self.img_hw[1] // 16 == cfg["w_res"], (img_hw, cfg)
+        if precision == "fp32":
+            self._init_f32(cfg, state_dict, neck_after, bn)
+            return
 
         def get(name):
             for k in (name, "image_encoder." + name):
@@ -611,12 +619,98 @@ class Rn50Encoder:
         self.c_w.c_w, self.c_w.c_b = _ptr(cw), _ptr(cb)
         self.c_w.bn_scale, self.c_w.bn_shift = _ptr(scale), _ptr(shift)
 
+    def _init_f32(self, cfg, state_dict, neck_after, bn):
+        """fp32 mode: BatchNorm folded in fp64 and rounded once to fp32; real channel counts; [cout][kh][kw][cin] rows"""
+        dev = self.device
+        width, layers = cfg["width"], tuple(cfg["layers"])
+
+        def get(name):
+            for k in (name, "image_encoder." + name):
+                if k in state_dict:
+                    v = state_dict[k]
+                    return v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            raise KeyError(name)
+
+        self._keep = []
+
+        def dev32(a):
+            t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+            self._keep.append(t)
+            return t
+
+        def fold(cname, bname):
+            w = get(cname + ".weight").astype(np.float64)
+            g, b, m, v = (get(f"{bname}.{a}").astype(np.float64) for a in ("weight", "bias", "running_mean", "running_var"))
+            sc = g / np.sqrt(v + 1e-5)
+            return w * sc[:, None, None, None], b - m * sc
+
+        def conv(cname, bname):
+            w, b = fold(cname, bname)
+            cout, cin, kh, kw = w.shape
+            wk = dev32(w.transpose(0, 2, 3, 1).reshape(cout, kh * kw * cin))   # k order (kh, kw, c)
+            return _lib.Rn50ConvF32(_ptr(wk), _ptr(dev32(b)), cin, cout, kh * kw)
+
+        s1w, s1b = fold("conv1", "bn1")
+        blocks = []
+        inplanes = width
+        for li, (planes, nb, stride) in enumerate(zip((width, width * 2, width * 4, width * 8), layers, (1, 2, 2, 1)), 1):
+            for b in range(nb):
+                pre = f"layer{li}.{b}"
+                blk = _lib.Rn50BlockF32()
+                blk.conv1, blk.conv2, blk.conv3 = conv(pre + ".conv1", pre + ".bn1"), conv(pre + ".conv2", pre + ".bn2"), \
+                    conv(pre + ".conv3", pre + ".bn3")
+                blk.stride = stride if b == 0 else 1
+                if blk.stride > 1 or inplanes != planes * 4:
+                    blk.down = conv(pre + ".downsample.0", pre + ".downsample.1")
+                blocks.append(blk)
+                inplanes = planes * 4
+        self.c_blocks = (_lib.Rn50BlockF32 * len(blocks))(*blocks)
+        E, od = width * 32, cfg["out_dim"]
+        self.feat_dim = E + od
+        self.c_cfg = _lib.Rn50Cfg(self.img_hw[0], self.img_hw[1], width, len(blocks), cfg["heads"], od)
+        cw = self.c_w = _lib.Rn50WeightsF32()
+        cw.stem1_w, cw.stem1_b = _ptr(dev32(s1w)), _ptr(dev32(s1b))
+        cw.stem2, cw.stem3 = conv("conv2", "bn2"), conv("conv3", "bn3")
+        cw.blocks = C.cast(self.c_blocks, C.POINTER(_lib.Rn50BlockF32))
+        cw.pos_emb = _ptr(dev32(get("attnpool.positional_embedding")))
+        for n in ("q", "k", "v", "c"):
+            setattr(cw, n + "_w", _ptr(dev32(get(f"attnpool.{n}_proj.weight"))))
+            setattr(cw, n + "_b", _ptr(dev32(get(f"attnpool.{n}_proj.bias"))))
+        if neck_after:
+            assert bn is not None
+            parts = []
+            for name in ("bottleneck", "bottleneck_proj"):
+                w_, b_, m_, v_ = (_np64(a) for a in bn[name])
+                s_ = w_ / np.sqrt(v_ + 1e-5)
+                parts.append((s_, b_ - m_ * s_))
+            cw.bn_scale = _ptr(dev32(np.concatenate([p[0] for p in parts])))
+            cw.bn_shift = _ptr(dev32(np.concatenate([p[1] for p in parts])))
+
     @torch.no_grad()
     def forward(self, img: torch.Tensor, cv_emb=None, pixel_mean=(0.5, 0.5, 0.5), pixel_std=(0.5, 0.5, 0.5),
                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """img: fp32 [B,3,H,W] (val_transforms applied) or uint8 [B,H,W,3] (after Resize).  cv_emb is ignored: the
         reference's RN50 branch has no SIE embedding (model/make_model.py:82-86)."""
         L = _lib.load()
+        if self.precision == "fp32":
+            if img.dtype == torch.uint8:   # ToTensor + Normalize of val_transforms with tensor ops, then the fp32 tower
+                t = img.detach().to(self.device).permute(0, 3, 1, 2).to(torch.float32).div(255)
+                mean = torch.tensor(pixel_mean, dtype=torch.float32, device=self.device)[None, :, None, None]
+                std = torch.tensor(pixel_std, dtype=torch.float32, device=self.device)[None, :, None, None]
+                img = ((t - mean) / std).contiguous()
+            img = _dev_f32(img, self.device)
+            assert tuple(img.shape[1:]) == (3,) + self.img_hw, img.shape
+            B = img.shape[0]
+            if out is None:
+                out = torch.empty((B, self.feat_dim), dtype=torch.float32, device=self.device)
+            step = 64    # fp32 activations and the im2col matrix: 4x-36x the bytes per image
+            for s0 in range(0, B, step):
+                e0 = min(B, s0 + step)
+                ws = _workspace(self.ws_tag + "_f32", L.mpreid_rn50_workspace_bytes_f32(C.byref(self.c_cfg), e0 - s0), self.device)
+                _lib.check(L.mpreid_rn50_forward_f32(C.byref(self.c_cfg), C.byref(self.c_w), _ptr(img[s0:e0]), e0 - s0,
+                                                     _ptr(out[s0:e0]), _ptr(ws), ws.numel(), _lib.stream_ptr()),
+                           "mpreid_rn50_forward_f32")
+            return out
         u8 = img.dtype == torch.uint8
         if u8:
             img = img.detach().to(device=self.device).contiguous()

