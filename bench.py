@@ -446,7 +446,13 @@ def extras(ops, dev, with_widened=True):
                   "note": "whole tower (about 60 launches); algorithmic = 11.49 GFLOP per image as the reference computes it "
                           "(the attention pool here skips the K / V projections: 9.5 GFLOP executed); the 1x1 layers of "
                           "layer1-2 are HBM-bound (K = 64..256)"})
+    del enc, fo
+    enc = ops.Rn50Encoder(synth.RN50, synth.rn50_state_dict(synth.RN50, seed=11), (256, 128), precision="fp32")
+    fo = torch.empty((64, enc.feat_dim), device=dev)
+    ms = timed_ms(lambda: enc(img[:64], out=fo), 2)
+    out["rn50_fp32_mode_images_per_s_batch64"] = round(64 / ms * 1e3, 1)   # the parity mode (4.7e-6 vs 2.6e-3)
     del enc, img, fo
+    ops.release_workspaces()
     rng = np.random.default_rng(5)
     raws = [rng.integers(0, 256, (128, 64, 3), dtype=np.uint8) for _ in range(512)]   # Market-1501 native size
     ops.resize_bilinear_u8(raws, (256, 128))
