@@ -38,6 +38,18 @@ __device__ __forceinline__ void dma16_sv(uint64_t sbase, unsigned voff, unsigned
 __device__ __forceinline__ void store16_sv(uint64_t sbase, unsigned voff, const f32x4 &v) {
     asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
 }
+__device__ __forceinline__ void store16_nt_sv(uint64_t sbase, unsigned voff, const f32x4 &v) {   // streaming variant
+    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+template <int F>   // (ablation builds) cache-policy flavours of the same store
+__device__ __forceinline__ void store16_flav_sv(uint64_t sbase, unsigned voff, const f32x4 &v) {
+    if constexpr (F == 1) asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+    else if constexpr (F == 2) asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+    else if constexpr (F == 3) asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+    else if constexpr (F == 4) asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1 nt\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+    else if constexpr (F == 5) asm volatile("global_store_dwordx4 %0, %1, %2 sc0\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+    else store16_nt_sv(sbase, voff, v);
+}
 
 // s_waitcnt takes an immediate: callers pass a value that is a constant after unrolling, the switch folds away
 __device__ __forceinline__ void wait_vmcnt(int n) {
@@ -581,10 +593,36 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
             dma16(b_src + (int64_t)16 * K + koffb, bbase + 1024);
         }
     };
+    // PAIRED DMA (non-split instances; DBG bit 16 = the unpaired schedule of rounds 1-2, for A/B timing).  A stage is a
+    // 64-byte k slab of every row = HALF a 128-byte line; fetched one stage at a time, every line crosses the L1 -> L2
+    // path twice, ~0.5 us apart -- by then the first fill has left the 32 KB L1.  Measured on the DMA path alone
+    // (20k x 20k x 768, matrix instructions and epilogue compiled out): 12 TB/s with half-line requests, 18 TB/s with
+    // whole lines.  The stages 2D and 2D+1 (the two halves of the same lines) are therefore requested back to back,
+    // piece by piece, so that the second request meets the first one's fill: odd steps issue two stages, even steps none
+    // (see step_steady); the prologue fills all four slots.
+    constexpr bool PAIR = !SPLIT && !(DBG & 16);
+    auto dma_pair = [&](int st) {   // stages st (even) and st + 1, pieces interleaved
+        unsigned char *a0 = smem + (st & (B_NSTAGE - 1)) * B_STAGE_BYTES + wave * 2048;
+        unsigned char *a1 = smem + ((st + 1) & (B_NSTAGE - 1)) * B_STAGE_BYTES + wave * 2048;
+        const int k0 = st * BBK, k1 = k0 + BBK;
+        dma16(a_src + k0, a0);
+        dma16(a_src + k1, a1);
+        dma16(a_src + (int64_t)16 * K + k0, a0 + 1024);
+        dma16(a_src + (int64_t)16 * K + k1, a1 + 1024);
+        dma16(b_src + k0, a0 + B_PART_BYTES);
+        dma16(b_src + k1, a1 + B_PART_BYTES);
+        dma16(b_src + (int64_t)16 * K + k0, a0 + B_PART_BYTES + 1024);
+        dma16(b_src + (int64_t)16 * K + k1, a1 + B_PART_BYTES + 1024);
+    };
     auto dma_prologue = [&]() {
-        dma_stage(0);
-        if (1 < nst) dma_stage(1);
-        if (2 < nst) dma_stage(2);
+        if constexpr (PAIR) {
+            dma_pair(0);               // nst is even and >= 2
+            if (2 < nst) dma_pair(2);
+        } else {
+            dma_stage(0);
+            if (1 < nst) dma_stage(1);
+            if (2 < nst) dma_stage(2);
+        }
     };
 
     // ---- fragment addresses ----
@@ -651,6 +689,7 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
     }
     set_tile(tile);
     dma_prologue();
+    [[maybe_unused]] int stamp_tile = 0;
     for (;;) {
     f32x4 acc[8][4];
 #pragma unroll
@@ -661,9 +700,19 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
     // stage 0 of this tile has landed everywhere (its DMA was issued before the previous tile's last
     // stores drained, or at kernel start); in-order vmcnt also retires every older store
     if constexpr (SPLIT) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");   // stages 1 (2 pieces) + 2 (2) may be in flight
-    else if (nst > 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    else if constexpr (PAIR) {   // the pair (0, 1) has landed, the pair (2, 3) may be in flight
+        if (nst > 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    } else if (nst > 2) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
 
+    auto stamp = [&](int which) {
+        if constexpr ((DBG & 32) != 0) {
+            if (g.stamps && tid == 0 && stamp_tile < 32)
+                g.stamps[((size_t)blockIdx.x * 32 + stamp_tile) * 8 + which] = __builtin_amdgcn_s_memrealtime();
+        }
+    };
+    stamp(0);
     f16x8 fa0[8], fb0[4], fa1[8], fb1[4];
     load_frags(0, fa0, fb0);
 
@@ -679,9 +728,19 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
     // steady state (no conditions, one basic block): the 4 DMA pieces and the 12 fragment reads are
     // spread between the MFMAs (1 DMA + 3 ds_read per 8 MFMA) so that the CU's load path works
     // beside the matrix pipe instead of in a burst after the barrier
-    auto step_steady = [&](int t, f16x8 (&fa)[8], f16x8 (&fb)[4], f16x8 (&na)[8], f16x8 (&nb)[4]) {
-        asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    // PAIR: even steps (ODD_ = 0) wait for the pair that ends with stage t+1 (the next pair, 8 pieces, stays in flight) and
+    // issue nothing; odd steps wait for stage t+1 = the first of its pair (pieces are interleaved: only the last piece
+    // of stage t+2 may still fly), then issue stages t+3 | t+4 into the slots of stages t-1 and t.  Stage t's fragments were
+    // read in step t-1: lgkmcnt(0) before the barrier makes every wave's reads of that slot complete before any wave's
+    // DMA can land in it.
+    auto step_steady = [&](auto ODD_, int t, f16x8 (&fa)[8], f16x8 (&fb)[4], f16x8 (&na)[8], f16x8 (&nb)[4]) {
+        constexpr bool ODD = decltype(ODD_)::value != 0;
+        constexpr bool ISSUE = !PAIR || ODD;   // this step issues DMA
+        if constexpr (!PAIR) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+        else if constexpr (ODD) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
         unsigned char *dbase = smem + ((t + 3) & (B_NSTAGE - 1)) * B_STAGE_BYTES + wave * 2048;
+        unsigned char *dbase2 = smem + ((t + 4) & (B_NSTAGE - 1)) * B_STAGE_BYTES + wave * 2048;   // PAIR only
         const unsigned char *sb = smem + ((t + 1) & (B_NSTAGE - 1)) * B_STAGE_BYTES;
         const int koff = koff_a(t + 3), koffb = koff_b(t + 3);
 #define MPREID_FRAG_B(j) nb[j] = *reinterpret_cast<const f16x8 *>(sb + b_off + (j) * 1024)
@@ -694,22 +753,34 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
             asm volatile("" ::"v"(fa[ii]), "v"(fb[j]));                                                  \
     }
         // group 0
-        if constexpr (!(DBG & 1)) dma16(a_src + koff, dbase);
+        if constexpr (!(DBG & 1) && ISSUE) {
+            dma16(a_src + koff, dbase);
+            if constexpr (PAIR) dma16(a_src + koff + BBK, dbase2);
+        }
         if constexpr (!(DBG & 4)) { MPREID_FRAG_B(0); MPREID_FRAG_B(1); MPREID_FRAG_B(2); }
         MPREID_MFMA_ROWS(0);
         __builtin_amdgcn_sched_barrier(0);
         // group 1
-        if constexpr (!(DBG & 1)) dma16(a_src + (int64_t)16 * K + koff, dbase + 1024);
+        if constexpr (!(DBG & 1) && ISSUE) {
+            dma16(a_src + (int64_t)16 * K + koff, dbase + 1024);
+            if constexpr (PAIR) dma16(a_src + (int64_t)16 * K + koff + BBK, dbase2 + 1024);
+        }
         if constexpr (!(DBG & 4)) { MPREID_FRAG_B(3); MPREID_FRAG_A(0); MPREID_FRAG_A(1); }
         MPREID_MFMA_ROWS(2);
         __builtin_amdgcn_sched_barrier(0);
         // group 2
-        if constexpr (!(DBG & 1)) dma16(b_src + koffb, dbase + B_PART_BYTES);
+        if constexpr (!(DBG & 1) && ISSUE) {
+            dma16(b_src + koffb, dbase + B_PART_BYTES);
+            if constexpr (PAIR) dma16(b_src + koffb + BBK, dbase2 + B_PART_BYTES);
+        }
         if constexpr (!(DBG & 4)) { MPREID_FRAG_A(2); MPREID_FRAG_A(3); MPREID_FRAG_A(4); }
         MPREID_MFMA_ROWS(4);
         __builtin_amdgcn_sched_barrier(0);
         // group 3
-        if constexpr (!(DBG & 1)) dma16(b_src + (int64_t)16 * K + koffb, dbase + B_PART_BYTES + 1024);
+        if constexpr (!(DBG & 1) && ISSUE) {
+            dma16(b_src + (int64_t)16 * K + koffb, dbase + B_PART_BYTES + 1024);
+            if constexpr (PAIR) dma16(b_src + (int64_t)16 * K + koffb + BBK, dbase2 + B_PART_BYTES + 1024);
+        }
         if constexpr (!(DBG & 4)) { MPREID_FRAG_A(5); MPREID_FRAG_A(6); MPREID_FRAG_A(7); }
         MPREID_MFMA_ROWS(6);
         __builtin_amdgcn_sched_barrier(0);
@@ -719,9 +790,16 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
     };
     auto step_tail = [&](int t, f16x8 (&fa)[8], f16x8 (&fb)[4], f16x8 (&na)[8], f16x8 (&nb)[4]) {
         if (t + 1 < nst) {
-            if (t + 2 < nst) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            if (t + 3 < nst) dma_stage(t + 3);
+            if constexpr (PAIR) {
+                // every stage has been issued (by the prologue or the steady loop's last odd step): an even step with a
+                // whole pair behind stage t+1 lets that pair fly, everything else drains
+                if (!(t & 1) && t + 3 < nst) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            } else {
+                if (t + 2 < nst) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                if (t + 3 < nst) dma_stage(t + 3);
+            }
             load_frags(t + 1, na, nb);
         }
         mfma32(fa, fb);
@@ -813,8 +891,8 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
     } else {
     int t = 0;
     for (; t + 4 < nst; t += 2) {
-        step_steady(t, fa0, fb0, fa1, fb1);
-        step_steady(t + 1, fa1, fb1, fa0, fb0);
+        step_steady(std::integral_constant<int, 0>{}, t, fa0, fb0, fa1, fb1);
+        step_steady(std::integral_constant<int, 1>{}, t + 1, fa1, fb1, fa0, fb0);
     }
     for (; t < nst; t += 2) {
         step_tail(t, fa0, fb0, fa1, fb1);
@@ -826,6 +904,7 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
     // ring, so the ring itself is free for the next tile's first stages as soon as every wave has passed
     // this barrier ----
     __syncthreads();
+    stamp(1);
     const int cur_m0 = m0, cur_n0 = n0;
     pos += pos_step;
     const int next_tile = tile_at(pos);
@@ -1175,16 +1254,106 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
         // idle k-loop ring.  Fetched per pass -- as this epilogue did until round 3 -- every load sat behind the stores of
         // the pass before it (vmcnt retires in order and a load is the youngest operation, so its wait is a vmcnt(0)):
         // 32 dependent store round trips per tile, ~10 us of an ~31 us tile with the matrix pipe idle.
-        float *rt = reinterpret_cast<float *>(smem + wave * 16384);   // [128] |q|^2, then [128] row scales
+        // fast path (below): the ring -- idle until the next prologue -- holds four patches per wave and the tables sit in
+        // the wave's 4 KB above the ring; general path: one patch above the ring, the tables in the ring
+        bool fast_path = false;
+        if constexpr (EPI == GE_EUCLID || EPI == GE_S_BIAS_F32)
+            fast_path = vec_ok && g.ldo < (1 << 24) &&
+                        (EPI == GE_S_BIAS_F32 || (cur_m0 + BBM <= g.m_valid && cur_n0 + BBN <= g.n_valid));
+        float *rt = fast_path ? reinterpret_cast<float *>(patch + wave * 4096)
+                              : reinterpret_cast<float *>(smem + wave * 16384);   // [128] |q|^2, then [128] row scales
         if constexpr (EPI == GE_EUCLID) {
             const int r0 = cur_m0 + wr * 128;
-            rt[lane] = (r0 + lane < g.m_valid) ? g.aux[r0 + lane] : 0.f;
-            rt[64 + lane] = (r0 + 64 + lane < g.m_valid) ? g.aux[r0 + 64 + lane] : 0.f;
+            const float t0 = (r0 + lane < g.m_valid) ? g.aux[r0 + lane] : 0.f;
+            const float t1 = (r0 + 64 + lane < g.m_valid) ? g.aux[r0 + 64 + lane] : 0.f;
+            float t2 = 1.f, t3 = 1.f;
             if (g.rscale) {
-                rt[128 + lane] = g.rscale[r0 + lane];           // (padded to the tile size)
-                rt[192 + lane] = g.rscale[r0 + 64 + lane];
+                t2 = g.rscale[r0 + lane];           // (padded to the tile size)
+                t3 = g.rscale[r0 + 64 + lane];
+            }
+            rt[lane] = t0;
+            rt[64 + lane] = t1;
+            rt[128 + lane] = t2;
+            rt[192 + lane] = t3;
+        }
+        // Fast path: GE_EUCLID on an interior tile (every tile but the last tile row / column) and GE_S_BIAS_F32 (the
+        // split mode's q | k | v output, never ragged).  The general loop below makes eight dependent round trips per
+        // tile -- 16 x 64 block into the wave's one patch, wait, four (LDS read -> wait -> arithmetic -> store), wait --
+        // and was LATENCY-bound: 0.8 us per pass, 8.5 us per 256 x 256 tile (tools/gemm_tile_stamps.py), although one CU
+        // retires a tile's 256 KB of stores in 2.0 us when nothing else holds it up and the whole chip sustains 5.6 TB/s
+        // (tools/probes/store_probe.hip); halving its instruction count (64-bit address arithmetic, bounds, exec
+        // masking) changed nothing.  Here the idle ring gives every wave FOUR patches: half a tile (4 blocks) is laid
+        // down, then its 16 row reads are all issued before the first store needs one -- two round trips per tile
+        // instead of eight.  Addresses: wave-uniform 64-bit base (SGPR pair) + four per-lane 32-bit offsets computed once
+        // per tile; no bounds; the scale test hoisted.  Same arithmetic in the same order: same bits.
+        bool fast_done = false;
+        if constexpr (EPI == GE_EUCLID || EPI == GE_S_BIAS_F32) {
+            if (fast_path) {
+                fast_done = true;
+                float *tp4 = reinterpret_cast<float *>(smem + wave * 16384);   // four [16][64] patches
+                const uint64_t obase = reinterpret_cast<uint64_t>(outp + (int64_t)(cur_m0 + wr * 128) * g.ldo + nbase);
+                const unsigned ldo_b = (unsigned)g.ldo * 4u;
+                unsigned voff[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) voff[it] = (unsigned)(it * 4 + (lane >> 4)) * ldo_b + (unsigned)c4 * 4u;
+                const bool scaled = g.rscale != nullptr;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                tp4[ii * 1024 + (fq * 4 + r) * 64 + j * 16 + frow] = acc[h * 4 + ii][j][r];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (h == 0) stamp(3);
+                    float4 av[16];
+                    float amv[16], rsv[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int ii = e >> 2, lr = (e & 3) * 4 + (lane >> 4);
+                        av[e] = *reinterpret_cast<const float4 *>(tp4 + ii * 1024 + lr * 64 + c4);
+                        if constexpr (EPI == GE_EUCLID) {
+                            amv[e] = rt[(h * 4 + ii) * 16 + lr];
+                            rsv[e] = scaled ? rt[128 + (h * 4 + ii) * 16 + lr] : 1.0f;
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int ii = e >> 2, it = e & 3;
+                        const uint64_t pbase = obase + (uint64_t)(h * 4 + ii) * 16u * ldo_b;
+                        const float4 a = av[e];
+                        f32x4 o;
+                        if constexpr (EPI == GE_S_BIAS_F32) {
+                            o[0] = fmaf(a.x, g.oscale, bias4.x);
+                            o[1] = fmaf(a.y, g.oscale, bias4.y);
+                            o[2] = fmaf(a.z, g.oscale, bias4.z);
+                            o[3] = fmaf(a.w, g.oscale, bias4.w);
+                        } else if (scaled) {
+                            const float rs = rsv[e], am = amv[e];
+                            o[0] = fmaf(-2.0f, a.x * (rs * cs4.x), am + bn4.x);
+                            o[1] = fmaf(-2.0f, a.y * (rs * cs4.y), am + bn4.y);
+                            o[2] = fmaf(-2.0f, a.z * (rs * cs4.z), am + bn4.z);
+                            o[3] = fmaf(-2.0f, a.w * (rs * cs4.w), am + bn4.w);
+                        } else {
+                            const float am = amv[e];
+                            o[0] = fmaf(-2.0f, a.x, am + bn4.x);
+                            o[1] = fmaf(-2.0f, a.y, am + bn4.y);
+                            o[2] = fmaf(-2.0f, a.z, am + bn4.z);
+                            o[3] = fmaf(-2.0f, a.w, am + bn4.w);
+                        }
+                        store16_flav_sv<(DBG >> 7) & 7>(pbase, voff[it], o);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (h == 0) stamp(6);
+                    if (h == 1) stamp(5);
+                }
             }
         }
+        if (!fast_done) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
 #pragma unroll
@@ -1282,11 +1451,14 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
             }
             __builtin_amdgcn_wave_barrier();
         }
-        // the row tables alias stage 0 of the ring, which the next tile's prologue fills: all waves done first
-        if constexpr (EPI == GE_EUCLID) asm volatile("s_barrier" ::: "memory");
+        }
+        // the fast path's patches alias the ring, which the next tile's prologue fills: all waves done first
+        if constexpr (EPI == GE_EUCLID || EPI == GE_S_BIAS_F32) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     // next tile: its first three DMA stages go out right behind this tile's stores (the ring was released by
     // the barrier above), so their cold latency overlaps the store drain
+    stamp(2);
+    if constexpr ((DBG & 32) != 0) ++stamp_tile;
     tile = next_tile;
     if (tile < 0) break;
     set_tile(tile);
@@ -1473,11 +1645,36 @@ static int launch_one(const GemmArgs &a_in, hipStream_t stream) {
     }
                 switch (dbg) {
                     MPREID_DBG_CASE(1) MPREID_DBG_CASE(2) MPREID_DBG_CASE(3) MPREID_DBG_CASE(4) MPREID_DBG_CASE(5)
-                    MPREID_DBG_CASE(7) MPREID_DBG_CASE(8) MPREID_DBG_CASE(9) MPREID_DBG_CASE(15)
+                    MPREID_DBG_CASE(7) MPREID_DBG_CASE(8) MPREID_DBG_CASE(9) MPREID_DBG_CASE(15) MPREID_DBG_CASE(16)
+                    MPREID_DBG_CASE(24)
                 default:
                     hipLaunchKernelGGL(gemm_f16_big_kernel<EPI>, grid, dim3(512), B_LDS_TOTAL, stream, a, tiles_m, tiles_n);
                 }
 #undef MPREID_DBG_CASE
+            } else if constexpr (EPI == GE_EUCLID || EPI == GE_BIAS_GELU) {
+                if (dbg == 32) {   // (ablation builds) per-tile phase stamps; MPREID_GEMM_STAMPS = device pointer (hex)
+                    GemmArgs as = a;
+                    const char *sp = getenv("MPREID_GEMM_STAMPS");
+                    as.stamps = sp ? reinterpret_cast<unsigned long long *>(strtoull(sp, nullptr, 16)) : nullptr;
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_big_kernel<EPI, 32>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_TOTAL));
+                    hipLaunchKernelGGL((gemm_f16_big_kernel<EPI, 32>), grid, dim3(512), B_LDS_TOTAL, stream, as, tiles_m, tiles_n);
+                } else if (dbg >= 128 && dbg <= 5 * 128 && dbg % 128 == 0) {   // (ablation builds) store cache policies
+#define MPREID_FLAV_CASE(F)                                                                                         \
+    case F * 128:                                                                                                    \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_big_kernel<EPI, F * 128>),               \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_TOTAL));                       \
+        hipLaunchKernelGGL((gemm_f16_big_kernel<EPI, F * 128>), grid, dim3(512), B_LDS_TOTAL, stream, a, tiles_m, tiles_n); \
+        break;
+                    switch (dbg) { MPREID_FLAV_CASE(1) MPREID_FLAV_CASE(2) MPREID_FLAV_CASE(3) MPREID_FLAV_CASE(4) MPREID_FLAV_CASE(5) }
+#undef MPREID_FLAV_CASE
+                } else if (dbg == 16) {   // (ablation builds) the unpaired DMA schedule
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_big_kernel<EPI, 16>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_TOTAL));
+                    hipLaunchKernelGGL((gemm_f16_big_kernel<EPI, 16>), grid, dim3(512), B_LDS_TOTAL, stream, a, tiles_m, tiles_n);
+                } else {
+                    hipLaunchKernelGGL(gemm_f16_big_kernel<EPI>, grid, dim3(512), B_LDS_TOTAL, stream, a, tiles_m, tiles_n);
+                }
             } else {
                 hipLaunchKernelGGL(gemm_f16_big_kernel<EPI>, grid, dim3(512), B_LDS_TOTAL, stream, a, tiles_m, tiles_n);
             }

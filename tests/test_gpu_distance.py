@@ -240,3 +240,40 @@ def test_split3_gives_the_oracles_neighbour_tables_on_the_goldens(ops, golden, c
     o = (d / d.max(dim=0).values[None, :]).t().contiguous()            # utils/reranking.py:46
     rank = torch.argsort(o, dim=1, stable=True)[:, :k1 + 1].cpu().numpy()
     assert np.array_equal(rank, orank)
+
+
+def test_stored_distance_kernels_bit_identical():
+    """the persistent 256 x 256 kernel's stored-distance path (paired DMA, early prologue with store-tolerant waits,
+    interior-tile fast epilogue + the general one on ragged edges) against the 128 x 128 kernel (MPREID_GEMM_BIG=0, latched
+    per process: child processes): same k order inside every accumulator => the outputs must agree bit for bit.  Shapes:
+    Market-1501 (ragged rows and columns), K = 128 and K = 64 (pipelines shorter than the early-prologue threshold), the
+    3-term split (row / column scales, K = 3 d), a single tile row, and a 20k-class square"""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent(f"""
+        import sys, hashlib, numpy as np, torch
+        sys.path[:0] = [{root!r}, {root!r} + "/mp-reid_amd"]
+        from mpreid import ops, synth
+        res = []
+        for nq, ng, d, mode in ((3368, 15913, 768, "fast"), (3368, 15913, 768, "split3"), (2900, 11111, 100, "fast"),
+                                (4096, 8192, 64, "fast"), (3000, 11000, 1280, "split3"), (200, 9000, 768, "fast"),
+                                (12000, 12000, 768, "fast")):
+            q = torch.from_numpy(synth.clustered_features(nq, d, 3.0, seed=5, per_id=10)[0]).cuda()
+            g = torch.from_numpy(synth.clustered_features(ng, d, 3.0, seed=6, per_id=10)[0]).cuda()
+            m = ops.GEMM_F16_FAST if mode == "fast" else ops.GEMM_F16_SPLIT3
+            hs = set()
+            for _ in range(3):
+                o = ops.euclidean_distance(q, g, mode=m)
+                torch.cuda.synchronize()
+                hs.add(hashlib.sha256(o.cpu().numpy().tobytes()).hexdigest())
+            assert len(hs) == 1, (nq, ng, d, mode, "not reproducible")
+            res.append(hs.pop())
+        print("HASHES " + " ".join(res))
+    """)
+    outs = []
+    for big in ("0", "2"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MPREID_GEMM_BIG=big), capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("HASHES ")][0].split()[1:])
+    assert outs[0] == outs[1], list(zip(outs[0], outs[1]))

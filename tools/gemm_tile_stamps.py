@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Per-tile phase timeline of the persistent 256 x 256 GEMM on the stored distance matrix (ablation build only:
+MPREID_ABLATION=1 python mp-reid_amd/mpreid/build.py --force).  Every workgroup stamps the 100 MHz real-time counter
+after a tile's first barrier (operands of stage 0 landed), after the k-loop and after the epilogue.
+Usage: python tools/gemm_tile_stamps.py [n d]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "mp-reid_amd")]
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+d = int(sys.argv[2]) if len(sys.argv) > 2 else 768
+os.environ["MPREID_GEMM_TWIN"] = "0"
+os.environ["MPREID_GEMM_DBG"] = "32"
+from mpreid import ops, synth  # noqa: E402
+
+f, _ = synth.clustered_features(n, d, 3.0, seed=1234)
+ft = torch.from_numpy(f).cuda()
+out = torch.empty((n, n), device="cuda")
+stamps = torch.zeros((256, 32, 8), dtype=torch.int64, device="cuda")
+os.environ["MPREID_GEMM_STAMPS"] = "%x" % stamps.data_ptr()
+for _ in range(3):
+    stamps.zero_()
+    ops.euclidean_distance(ft, ft, mode=ops.GEMM_F16_FAST, out=out)
+torch.cuda.synchronize()
+s = stamps.cpu().numpy().astype(np.int64)
+ok = s[:, :, 0] > 0
+t0 = s[:, :, 0][ok].min()
+tiles = ok.sum(1)
+print("tiles per workgroup: min %d max %d" % (tiles.min(), tiles.max()))
+kl = (s[:, :, 1] - s[:, :, 0])[ok] / 100.0          # us
+ep = (s[:, :, 2] - s[:, :, 1])[ok] / 100.0
+nxt = (s[:, 1:, 0] - s[:, :-1, 2])[ok[:, 1:]] / 100.0
+print("k-loop   us: mean %.2f  p10 %.2f  p50 %.2f  p90 %.2f" % (kl.mean(), *np.percentile(kl, [10, 50, 90])))
+print("epilogue us: mean %.2f  p10 %.2f  p50 %.2f  p90 %.2f" % (ep.mean(), *np.percentile(ep, [10, 50, 90])))
+print("restart  us: mean %.2f  p10 %.2f  p50 %.2f  p90 %.2f  (end of epilogue -> stage 0 of the next tile landed)"
+      % (nxt.mean(), *np.percentile(nxt, [10, 50, 90])))
+for name, a, b in (("tables ready (k-loop end -> first pass written to LDS)", 1, 3), ("pass 0 (reads, math, 4 stores issued)", 3, 4),
+                   ("passes 1-3", 4, 6), ("passes 4-7", 6, 5), ("trailing barrier", 5, 2)):
+    x = (s[:, :, b] - s[:, :, a])[ok & (s[:, :, 3] > 0)] / 100.0
+    if x.size:
+        print("  epilogue part %-58s us: mean %.2f  p50 %.2f  p90 %.2f" % (name, x.mean(), *np.percentile(x, [50, 90])))
+end = s[:, :, 2].max()
+print("kernel span %.1f us; first tile start spread %.2f us; last tile end spread %.2f us"
+      % ((end - t0) / 100.0, (s[:, 0, 0].max() - s[:, 0, 0].min()) / 100.0,
+         (np.array([s[w, tiles[w] - 1, 2] for w in range(256)]).max() - np.array([s[w, tiles[w] - 1, 2] for w in range(256)]).min()) / 100.0))
+for w in (0, 1, 8, 100):
+    row = " ".join("%.1f/%.1f" % ((s[w, t, 1] - s[w, t, 0]) / 100.0, (s[w, t, 2] - s[w, t, 1]) / 100.0) for t in range(min(8, tiles[w])))
+    print("wg %3d start %.1f us: k-loop/epilogue us per tile: %s" % (w, (s[w, 0, 0] - t0) / 100.0, row))
+# how synchronised are the epilogues chip-wide?  fraction of workgroups inside an epilogue, sampled over time
+ts = np.linspace(t0, end, 2000)
+inside = np.zeros_like(ts)
+for w in range(256):
+    for t in range(tiles[w]):
+        inside += (ts >= s[w, t, 1]) & (ts < s[w, t, 2])
+print("workgroups inside an epilogue at a time: mean %.1f  max %d (of 256)" % (inside.mean(), inside.max()))
