@@ -1635,6 +1635,16 @@ static int launch_one(const GemmArgs &a_in, hipStream_t stream) {
             }
             const unsigned total_tiles = (unsigned)tiles_m * (unsigned)tiles_n;
             const dim3 grid(total_tiles < (unsigned)big_cus ? total_tiles : (unsigned)big_cus);
+#ifdef MPREID_ABLATION
+            if (dbg == 32 && EPI != GE_EUCLID && EPI != GE_BIAS_GELU) {   // per-tile phase stamps for any epilogue (tools/gemm_tile_stamps.py)
+                GemmArgs as = a;
+                const char *sp = getenv("MPREID_GEMM_STAMPS");
+                as.stamps = sp ? reinterpret_cast<unsigned long long *>(strtoull(sp, nullptr, 16)) : nullptr;
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_big_kernel<EPI, 32>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_TOTAL));
+                hipLaunchKernelGGL((gemm_f16_big_kernel<EPI, 32>), grid, dim3(512), B_LDS_TOTAL, stream, as, tiles_m, tiles_n);
+            } else
+#endif
             if constexpr (EPI == GE_BIAS_F16) {
 #define MPREID_DBG_CASE(D)                                                                                  \
     case D: {                                                                                               \

@@ -11,6 +11,55 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "mp-reid_amd")]
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
+if len(sys.argv) > 1 and sys.argv[1] == "enc":
+    # the encoder's GEMM classes instead (M = 65536): python tools/gemm_tile_stamps.py enc sqkv|sout|sfc1|sfc2|qkv|out|fc1|fc2
+    import ctypes as C
+    os.environ["MPREID_GEMM_DBG"] = "32"
+    os.environ["MPREID_GEMM_BIG"] = "2"
+    from mpreid import _lib
+    L = _lib.load()
+    dev = _lib.require_gpu()
+    SH = {"qkv": (2304, 768, 1), "out": (768, 768, 2), "fc1": (3072, 768, 3), "fc2": (768, 3072, 2),
+          "sqkv": (2304, 768, 10), "sout": (768, 768, 11), "sfc1": (3072, 768, 12), "sfc2": (768, 3072, 11)}
+    M = 65536
+    for name in sys.argv[2:]:
+        N, K, epi = SH[name]
+        A = torch.rand((M, K), device=dev) * 2 - 1
+        W = (torch.rand((N, K), device=dev) * 2 - 1) * 0.05
+        bias = torch.randn(N, device=dev)
+        if epi >= 10:
+            def pair(x, scale):
+                y = torch.empty((x.shape[0], 2 * x.shape[1]), dtype=torch.float16, device=dev)
+                _lib.check(L.mpreid_split_pack_f32(C.c_void_p(x.data_ptr()), x.shape[0], x.shape[1], scale, C.c_void_p(y.data_ptr()),
+                                                   _lib.stream_ptr()), "pack")
+                return y
+            A, W = pair(A.contiguous(), 1.0), pair(W.contiguous(), 2.0 ** 13)
+            out = torch.zeros((M, 2 * N), device=dev, dtype=torch.float16) if epi == 12 else torch.zeros((M, N), device=dev)
+        else:
+            A, W = A.half(), W.half()
+            out = torch.zeros((M, N), device=dev, dtype=torch.float16 if epi in (1, 3) else torch.float32)
+        stamps = torch.zeros((256, 32, 8), dtype=torch.int64, device=dev)
+        os.environ["MPREID_GEMM_STAMPS"] = "%x" % stamps.data_ptr()
+        for _ in range(3):
+            stamps.zero_()
+            if epi >= 10:
+                _lib.check(L.mpreid_gemm_f16_split_nt(C.c_void_p(A.data_ptr()), C.c_void_p(W.data_ptr()), C.c_void_p(out.data_ptr()),
+                                                      C.c_void_p(bias.data_ptr()), M, N, K, 2.0 ** -13, epi, _lib.stream_ptr()), "gemm")
+            else:
+                _lib.check(L.mpreid_gemm_f16_nt_ex(C.c_void_p(A.data_ptr()), C.c_void_p(W.data_ptr()), C.c_void_p(out.data_ptr()),
+                                                   C.c_void_p(bias.data_ptr()), M, N, K, epi, _lib.stream_ptr()), "gemm")
+        torch.cuda.synchronize()
+        s = stamps.cpu().numpy().astype(np.int64)
+        ok = s[:, :, 0] > 0
+        kl = (s[:, :, 1] - s[:, :, 0])[ok] / 100.0
+        ep = (s[:, :, 2] - s[:, :, 1])[ok] / 100.0
+        nx = (s[:, 1:, 0] - s[:, :-1, 2])[ok[:, 1:]] / 100.0
+        span = (s[:, :, 2].max() - s[:, :, 0][ok].min()) / 100.0
+        mult = 3 if epi >= 10 else 1
+        print("%-5s tiles/wg %d-%d | k-loop %.1f us (%.2f PF executed) | epilogue %.1f us | restart %.1f us | span %.0f us | idle share %.1f %%"
+              % (name, ok.sum(1).min(), ok.sum(1).max(), kl.mean(), 256 * 256 * K * 2.0 * mult / kl.mean() / 1e6 * 256 / 1e3, ep.mean(),
+                 nx.mean(), span, 100.0 * (ep.mean() + nx.mean()) / (kl.mean() + ep.mean() + nx.mean())), flush=True)
+    sys.exit(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 768
 os.environ["MPREID_GEMM_TWIN"] = "0"
