@@ -348,7 +348,7 @@ def extras(ops, dev, with_widened=True):
     buf = torch.empty((20000, 20000), dtype=torch.float32, device=dev)
     flop = 2.0 * 20000 * 20000 * 768
     byts = 2.0 * 2 * 20000 * 768 + 4.0 * 20000 * 20000
-    ms = timed_ms(lambda: ops.euclidean_distance(ft, ft, mode=ops.GEMM_F16_FAST, out=buf), 5)
+    ms = timed_ms(lambda: ops.euclidean_distance(ft, ft, mode=ops.GEMM_F16_FAST, out=buf), 10, warm=3)   # mean of 10 whole calls
     out["feat_gemm_20kx20k_d768_fp16_ms"] = round(ms, 4)
     out["feat_gemm_20kx20k_d768_fp16_tflops"] = round(flop / ms / 1e9, 1)
     out["feat_gemm_20kx20k_d768_fp16_frac_of_peak"] = round(flop / ms / 1e9 / PEAK_F16_TFLOPS, 4)
@@ -370,7 +370,7 @@ def extras(ops, dev, with_widened=True):
                   "hbm": {"achieved": round(byts / ms / 1e6, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                           "frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 4), "algorithmic_bytes": int(byts)}})
     if hasattr(ops, "GEMM_F16_SPLIT3"):
-        ms = timed_ms(lambda: ops.euclidean_distance(ft, ft, mode=ops.GEMM_F16_SPLIT3, out=buf), 5)
+        ms = timed_ms(lambda: ops.euclidean_distance(ft, ft, mode=ops.GEMM_F16_SPLIT3, out=buf), 10, warm=3)
         out["feat_gemm_20kx20k_d768_split3_ms"] = round(ms, 4)
         out["feat_gemm_20kx20k_d768_split3_executed_tflops"] = round(3 * flop / ms / 1e9, 1)
         roofs.append({"stage": "feat_gemm_20kx20k_d768 (3-term fp16 split, |err| <= 1e-6)", "kernel": "gemm_f16_big_kernel<euclid_split3>",

@@ -1297,6 +1297,11 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
 #pragma unroll
                 for (int it = 0; it < 4; ++it) voff[it] = (unsigned)(it * 4 + (lane >> 4)) * ldo_b + (unsigned)c4 * 4u;
                 const bool scaled = g.rscale != nullptr;
+                if constexpr (((DBG >> 7) & 7) == 6) {   // (timing experiment, wrong data) the 32 stores straight from the accumulators
+#pragma unroll
+                    for (int e = 0; e < 32; ++e)
+                        store16_nt_sv(obase + (uint64_t)(e >> 2) * 16u * ldo_b, voff[e & 3], acc[e >> 2][e & 3]);
+                } else
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -1634,6 +1639,9 @@ static int launch_one(const GemmArgs &a_in, hipStream_t stream) {
                 a.stagger_mode = 1;
             }
             const unsigned total_tiles = (unsigned)tiles_m * (unsigned)tiles_n;
+#ifdef MPREID_ABLATION
+            if (const char *gg = getenv("MPREID_GEMM_GRID")) big_cus = atoi(gg);   // (ablation) fewer workgroups than CUs
+#endif
             const dim3 grid(total_tiles < (unsigned)big_cus ? total_tiles : (unsigned)big_cus);
 #ifdef MPREID_ABLATION
             if (dbg == 32 && EPI != GE_EUCLID && EPI != GE_BIAS_GELU) {   // per-tile phase stamps for any epilogue (tools/gemm_tile_stamps.py)
@@ -1662,21 +1670,28 @@ static int launch_one(const GemmArgs &a_in, hipStream_t stream) {
                 }
 #undef MPREID_DBG_CASE
             } else if constexpr (EPI == GE_EUCLID || EPI == GE_BIAS_GELU) {
-                if (dbg == 32) {   // (ablation builds) per-tile phase stamps; MPREID_GEMM_STAMPS = device pointer (hex)
+                if (dbg == 800) {   // stamps + raw stores
+                    GemmArgs as = a;
+                    const char *sp = getenv("MPREID_GEMM_STAMPS");
+                    as.stamps = sp ? reinterpret_cast<unsigned long long *>(strtoull(sp, nullptr, 16)) : nullptr;
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_big_kernel<EPI, 800>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_TOTAL));
+                    hipLaunchKernelGGL((gemm_f16_big_kernel<EPI, 800>), grid, dim3(512), B_LDS_TOTAL, stream, as, tiles_m, tiles_n);
+                } else if (dbg == 32) {   // (ablation builds) per-tile phase stamps; MPREID_GEMM_STAMPS = device pointer (hex)
                     GemmArgs as = a;
                     const char *sp = getenv("MPREID_GEMM_STAMPS");
                     as.stamps = sp ? reinterpret_cast<unsigned long long *>(strtoull(sp, nullptr, 16)) : nullptr;
                     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_big_kernel<EPI, 32>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_TOTAL));
                     hipLaunchKernelGGL((gemm_f16_big_kernel<EPI, 32>), grid, dim3(512), B_LDS_TOTAL, stream, as, tiles_m, tiles_n);
-                } else if (dbg >= 128 && dbg <= 5 * 128 && dbg % 128 == 0) {   // (ablation builds) store cache policies
+                } else if (dbg >= 128 && dbg <= 6 * 128 && dbg % 128 == 0) {   // (ablation builds) store cache policies
 #define MPREID_FLAV_CASE(F)                                                                                         \
     case F * 128:                                                                                                    \
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_big_kernel<EPI, F * 128>),               \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_TOTAL));                       \
         hipLaunchKernelGGL((gemm_f16_big_kernel<EPI, F * 128>), grid, dim3(512), B_LDS_TOTAL, stream, a, tiles_m, tiles_n); \
         break;
-                    switch (dbg) { MPREID_FLAV_CASE(1) MPREID_FLAV_CASE(2) MPREID_FLAV_CASE(3) MPREID_FLAV_CASE(4) MPREID_FLAV_CASE(5) }
+                    switch (dbg) { MPREID_FLAV_CASE(1) MPREID_FLAV_CASE(2) MPREID_FLAV_CASE(3) MPREID_FLAV_CASE(4) MPREID_FLAV_CASE(5) MPREID_FLAV_CASE(6) }
 #undef MPREID_FLAV_CASE
                 } else if (dbg == 16) {   // (ablation builds) the unpaired DMA schedule
                     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_big_kernel<EPI, 16>),

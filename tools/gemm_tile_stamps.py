@@ -62,8 +62,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "enc":
     sys.exit(0)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 768
-os.environ["MPREID_GEMM_TWIN"] = "0"
-os.environ["MPREID_GEMM_DBG"] = "32"
+os.environ.setdefault("MPREID_GEMM_DBG", "32")
 from mpreid import ops, synth  # noqa: E402
 
 f, _ = synth.clustered_features(n, d, 3.0, seed=1234)
@@ -79,6 +78,7 @@ s = stamps.cpu().numpy().astype(np.int64)
 ok = s[:, :, 0] > 0
 t0 = s[:, :, 0][ok].min()
 tiles = ok.sum(1)
+nwg = int((tiles > 0).sum())
 print("tiles per workgroup: min %d max %d" % (tiles.min(), tiles.max()))
 kl = (s[:, :, 1] - s[:, :, 0])[ok] / 100.0          # us
 ep = (s[:, :, 2] - s[:, :, 1])[ok] / 100.0
@@ -94,15 +94,15 @@ for name, a, b in (("tables ready (k-loop end -> first pass written to LDS)", 1,
         print("  epilogue part %-58s us: mean %.2f  p50 %.2f  p90 %.2f" % (name, x.mean(), *np.percentile(x, [50, 90])))
 end = s[:, :, 2].max()
 print("kernel span %.1f us; first tile start spread %.2f us; last tile end spread %.2f us"
-      % ((end - t0) / 100.0, (s[:, 0, 0].max() - s[:, 0, 0].min()) / 100.0,
-         (np.array([s[w, tiles[w] - 1, 2] for w in range(256)]).max() - np.array([s[w, tiles[w] - 1, 2] for w in range(256)]).min()) / 100.0))
-for w in (0, 1, 8, 100):
+      % ((end - t0) / 100.0, (s[:nwg, 0, 0].max() - s[:nwg, 0, 0].min()) / 100.0,
+         (np.array([s[w, tiles[w] - 1, 2] for w in range(nwg)]).max() - np.array([s[w, tiles[w] - 1, 2] for w in range(nwg)]).min()) / 100.0))
+for w in [w for w in (0, 1, 8, 100) if w < nwg]:
     row = " ".join("%.1f/%.1f" % ((s[w, t, 1] - s[w, t, 0]) / 100.0, (s[w, t, 2] - s[w, t, 1]) / 100.0) for t in range(min(8, tiles[w])))
     print("wg %3d start %.1f us: k-loop/epilogue us per tile: %s" % (w, (s[w, 0, 0] - t0) / 100.0, row))
 # how synchronised are the epilogues chip-wide?  fraction of workgroups inside an epilogue, sampled over time
 ts = np.linspace(t0, end, 2000)
 inside = np.zeros_like(ts)
-for w in range(256):
+for w in range(nwg):
     for t in range(tiles[w]):
         inside += (ts >= s[w, t, 1]) & (ts < s[w, t, 2])
 print("workgroups inside an epilogue at a time: mean %.1f  max %d (of 256)" % (inside.mean(), inside.max()))
