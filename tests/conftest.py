@@ -22,3 +22,61 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name))
     return load
+
+
+def free_port():
+    """a port the kernel just handed out (bound to port 0, then released)"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def run_ranks(cmd, world, timeout, extra_env=None, local_rank=lambda r: r, capture_dir=None):
+    """Start `world` ranks of `cmd` (fresh child processes, rendezvous on 127.0.0.1), poll ALL of them, and as soon as one
+    exits non-zero -- or the deadline passes -- terminate the others (a rank stuck in a collective with a dead peer
+    would otherwise hang the test until the backend's own timeout, or forever with gloo).  Asserts that every rank
+    returned 0.  capture_dir: every rank's stdout goes to a file there and the texts are returned (rank order)."""
+    import subprocess
+    import time
+    port = str(free_port())
+    procs, files = [], []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(local_rank(r)), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=port, **(extra_env or {}))
+        fh = open(os.path.join(str(capture_dir), "rank%d_of_%d.out" % (r, world)), "w+") if capture_dir else None
+        files.append(fh)
+        procs.append(subprocess.Popen(cmd, env=env, stdout=fh))
+
+    def texts():
+        out = []
+        for fh in files:
+            fh.seek(0)
+            out.append(fh.read())
+            fh.close()
+        return out
+    deadline = time.time() + timeout
+    failed = None
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                failed = "rank %d exited with code %d" % bad[0]
+                break
+            if all(c == 0 for c in codes):
+                return texts() if capture_dir else None
+            if time.time() > deadline:
+                failed = "timeout after %d s (exit codes so far: %s)" % (timeout, codes)
+                break
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except Exception:
+                p.kill()
+    raise AssertionError(failed)

@@ -71,14 +71,8 @@ def test_sharded_distmat_and_eval_match_single_rank(tmp_path, world):
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT))
     out = tmp_path / "full.npz"
-    port = str(29600 + (os.getpid() * 7 + world) % 300)
-    procs = []
-    for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=port, OMP_NUM_THREADS="2")
-        procs.append(subprocess.Popen([sys.executable, str(script), str(out)], env=env))
-    for p in procs:
-        assert p.wait(timeout=300) == 0
+    from conftest import run_ranks
+    run_ranks([sys.executable, str(script), str(out)], world, 300, dict(OMP_NUM_THREADS="2"))
     nq, ng, d = 37, 101, 48
     f, _ = synth.clustered_features(nq + ng, d, 2.0, seed=3, per_id=5)
     want = orc.euclidean_distance(orc.l2_normalize(f[:nq] * 3.0), orc.l2_normalize(f[nq:] * 3.0))
@@ -157,3 +151,20 @@ def test_sharded_loader_paths_cover_every_sample_once():
             seen[name] += idx
     for name, ids in seen.items():
         assert sorted(ids) == list(range(nq + ng)), name
+
+
+def test_rank_launcher_terminates_survivors_when_a_rank_dies(tmp_path):
+    """the tests' rank launcher (conftest.run_ranks; bench.py's launch_children follows the same rule): a rank that dies
+    must not leave the others waiting in a collective -- they are terminated and the failure is reported at once"""
+    import time
+    from conftest import run_ranks
+    script = tmp_path / "w.py"
+    script.write_text("import os, sys, time\nif os.environ['RANK'] == '1':\n    sys.exit(3)\ntime.sleep(120)\n")
+    t0 = time.time()
+    with pytest.raises(AssertionError, match="rank 1 exited with code 3"):
+        run_ranks([sys.executable, str(script)], 3, 100)
+    assert time.time() - t0 < 30
+    ok = tmp_path / "ok.py"
+    ok.write_text("import os\nprint('rank', os.environ['RANK'], os.environ['MASTER_ADDR'])\n")
+    outs = run_ranks([sys.executable, str(ok)], 2, 60, capture_dir=tmp_path)
+    assert [o.strip() for o in outs] == ["rank 0 127.0.0.1", "rank 1 127.0.0.1"]

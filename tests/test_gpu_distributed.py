@@ -56,14 +56,9 @@ CASES = [(1500, 300, 256, 50, 15, 0.3), (901, 7, 64, 20, 6, 0.3), (700, 101, 128
 
 
 def _spawn(script, args, world, tmp_path, extra_env=None):
-    port = str(29700 + os.getpid() % 200)
-    procs = []
-    for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=port, MPREID_DIST_BACKEND="gloo", OMP_NUM_THREADS="4", **(extra_env or {}))
-        procs.append(subprocess.Popen([sys.executable, str(script)] + args, env=env))
-    for p in procs:
-        assert p.wait(timeout=900) == 0
+    from conftest import run_ranks
+    run_ranks([sys.executable, str(script)] + args, world, 900,
+              dict(MPREID_DIST_BACKEND="gloo", OMP_NUM_THREADS="4", **(extra_env or {})), local_rank=lambda r: 0)
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -176,21 +171,16 @@ def test_test_py_under_two_ranks_matches_single_process(tmp_path, rerank):
             "print('RESULT', float(r[0]), float(r[1]))").format(pkg=os.path.join(ROOT, "mp-reid_amd"), rr=rerank)
 
     def run(world):
-        port = str(29900 + (os.getpid() + world) % 90)
-        outs = []
-        procs = []
-        for r in range(world):
+        from conftest import run_ranks
+        if world == 1:   # a plain process: no rank variables at all
             env = dict(os.environ, MPREID_DIST_BACKEND="gloo", OMP_NUM_THREADS="4")
             for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
                 env.pop(k, None)
-            if world > 1:
-                env.update(RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
-            procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, text=True))
-        for p in procs:
-            o, _ = p.communicate(timeout=900)
-            assert p.returncode == 0, o[-2000:]
-            outs.append(o)
-        return outs
+            r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, text=True, timeout=900)
+            assert r.returncode == 0, r.stdout[-2000:]
+            return [r.stdout]
+        return run_ranks([sys.executable, "-c", code], world, 900, dict(MPREID_DIST_BACKEND="gloo", OMP_NUM_THREADS="4"),
+                         local_rank=lambda r: 0, capture_dir=tmp_path)
 
     single = run(1)[0]
     multi = run(2)
@@ -240,7 +230,7 @@ def test_sharded_evaluator_on_the_rccl_backend_one_rank(tmp_path):
     script = tmp_path / "rccl_worker.py"
     script.write_text(RCCL_WORKER.format(root=ROOT, cases=cases))
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-               MASTER_PORT=str(29950 + os.getpid() % 40), MPREID_DIST_FORCE_COLLECTIVES="1")
+               MASTER_PORT=str(__import__("conftest").free_port()), MPREID_DIST_FORCE_COLLECTIVES="1")
     env.pop("MPREID_DIST_BACKEND", None)
     r = subprocess.run([sys.executable, str(script), str(tmp_path)], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
