@@ -730,7 +730,10 @@ def run_rank(a):
                     "gemm_share_of_step": round(sum(c["total_ms"] for c in classes) /
                                                 (dt * 1e3 if instrument_live else step_ms), 3)}
             if sp:
+                # both conventions side by side: `achieved` / `frac` count what the matrix cores execute (three fp16 products
+                # per multiply-add of the fp32-grade algorithm), the *_fp32_equivalent pair counts 2*M*N*K as SURVEY 8(d) does
                 roof["achieved_fp32_equivalent"] = round(top["tflops"] / 3.0, 1)
+                roof["frac_fp32_equivalent"] = round(top["tflops"] / 3.0 / PEAK_F16_TFLOPS, 4)
                 roof["frac_of_sustainable_1250TF"] = round(top["tflops"] / 1250.0, 4)
         desc = {
             "market": "Market-1501 shape on MI355X (BASELINE configs[1]): ViT-B/16 encode of "
