@@ -243,10 +243,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float v = quick_gelu(fmaf(acc[i][j][r], g.oscale, bias));
-                        const _Float16 hi = (_Float16)v;
-                        wreg[(i * 16 + fq * 4 + r) * 72 + j * 16 + frow] = part == 0 ? hi : (_Float16)(v - (float)hi);
+                    for (int rp = 0; rp < 4; rp += 2) {   // (on element pairs, as in the persistent kernel: the same instructions)
+                        typedef float f32x2 __attribute__((ext_vector_type(2)));
+                        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+                        const f32x2 a = {acc[i][j][rp], acc[i][j][rp + 1]};
+                        const f32x2 h = __builtin_elementwise_fma(a, f32x2{g.oscale, g.oscale}, f32x2{bias, bias});
+                        const f32x2 t = h * (-1.702f * 1.44269504088896340736f);
+                        const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + 1.0f;
+                        const f32x2 v = h * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};   // quick_gelu
+                        const f16x2 hi = __builtin_convertvector(v, f16x2);
+                        const f16x2 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x2), f16x2);
+                        wreg[(i * 16 + fq * 4 + rp) * 72 + j * 16 + frow] = part == 0 ? hi[0] : lo[0];
+                        wreg[(i * 16 + fq * 4 + rp + 1) * 72 + j * 16 + frow] = part == 0 ? hi[1] : lo[1];
                     }
             }
             __syncthreads();
@@ -1062,14 +1070,26 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
         for (int j = 0; j < 4; ++j) bias[j] = g.bias[cur_n0 + wc * 64 + j * 16 + frow];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
+            // (the epilogue is vector-ALU bound -- 128 elements per lane and tile, two transcendentals each; written on
+            // element PAIRS so that the fused multiply-add, the products, the sum, the difference and both roundings to
+            // fp16 are packed instructions (v_pk_fma_f32 ... v_cvt_pk_f16_f32): 11 instead of 20 per pair, same bits)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = quick_gelu(fmaf(acc[i][j][r], g.oscale, bias[j]));
-                    const _Float16 hi = (_Float16)v;
-                    whi[(fq * 4 + r) * 72 + j * 16 + frow] = hi;
-                    wlo[(fq * 4 + r) * 72 + j * 16 + frow] = (_Float16)(v - (float)hi);
+                for (int rp = 0; rp < 4; rp += 2) {
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+                    const f32x2 a = {acc[i][j][rp], acc[i][j][rp + 1]};
+                    const f32x2 h = __builtin_elementwise_fma(a, f32x2{g.oscale, g.oscale}, f32x2{bias[j], bias[j]});
+                    const f32x2 t = h * (-1.702f * 1.44269504088896340736f);
+                    const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + 1.0f;
+                    const f32x2 v = h * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};   // quick_gelu
+                    const f16x2 hi = __builtin_convertvector(v, f16x2);
+                    const f16x2 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x2), f16x2);
+                    whi[(fq * 4 + rp) * 72 + j * 16 + frow] = hi[0];
+                    whi[(fq * 4 + rp + 1) * 72 + j * 16 + frow] = hi[1];
+                    wlo[(fq * 4 + rp) * 72 + j * 16 + frow] = lo[0];
+                    wlo[(fq * 4 + rp + 1) * 72 + j * 16 + frow] = lo[1];
                 }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
