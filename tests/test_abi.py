@@ -139,3 +139,18 @@ def test_do_inference_batch_grouping_helpers():
             torch.zeros(n, dtype=torch.int64), torch.zeros(n, dtype=torch.int64), ("p",) * n) for n in (2, 3)]
     img, cam, view = merge_batches(raw, "cpu")
     assert isinstance(img, RawImageBatch) and len(img) == 5
+
+
+def test_shipped_eval_configs_load():
+    """every YAML under mp-reid_amd/configs merges into the default config (test.py's --config_file path) and names a model
+    the build has an encoder for"""
+    import glob
+    from config import cfg_base
+    files = sorted(glob.glob(os.path.join(ROOT, "mp-reid_amd", "configs", "*", "*.yml")))
+    assert len(files) >= 3
+    for f in files:
+        c = cfg_base.clone()
+        c.merge_from_file(f)
+        assert c.MODEL.NAME in ("ViT-B-16", "RN50") and c.TEST.EVAL is True, f
+        assert c.MODEL.ENCODER_PRECISION in ("split", "fp16", "fp32"), f
+        assert list(c.INPUT.SIZE_TEST) == [256, 128] and c.TEST.FEAT_NORM == "yes", f
