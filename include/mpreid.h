@@ -218,7 +218,7 @@ typedef struct {
     int32_t width, layers, heads, out_dim; /* 768, 12, 12, 512 */
     int32_t neck_after;     /* TEST.NECK_FEAT == 'after': apply the eval BatchNorm necks */
     int32_t cls_only_last;  /* 1: last block computes only the CLS row (the only row the output uses) */
-    int32_t precision;      /* MPREID_VIT_F16 or MPREID_VIT_SPLIT (the all-fp32 mode is mpreid_vit_forward_f32) */
+    int32_t precision;      /* MPREID_VIT_F16, MPREID_VIT_SPLIT or MPREID_VIT_SPLIT_LNFOLD (the all-fp32 mode is mpreid_vit_forward_f32) */
 } mpreid_vit_cfg;
 
 /* Arithmetic of the encoder's linear layers and attention products (model/clip/model.py runs them in fp32,
@@ -233,6 +233,12 @@ typedef struct {
  * (mpreid_split_pack_f32 produces the layout). */
 #define MPREID_VIT_F16 0
 #define MPREID_VIT_SPLIT 1
+/* SPLIT with ln_1 / ln_2 of every block folded into the linear layer behind them:
+ *   LN(x) W^T + b = rstd_m (x_m (gamma o W)^T - mu_m c_n) + b'_n,   c_n = sum_k gamma_k W_nk,   b' = beta W^T + b
+ * in_proj_w / fc_w are the pair matrices of (gamma o W) 2^e, in_proj_b / fc_b hold b', in_proj_c / fc_c hold c; ln1_* / ln2_*
+ * are not read.  The GEMMs consume the pairs of the RAW residual stream, which the residual epilogues write together
+ * with per-row partial sums of x and x^2 (no LayerNorm launches inside the blocks; ln_pre and ln_post are unchanged). */
+#define MPREID_VIT_SPLIT_LNFOLD 2
 
 typedef struct { /* device pointers; *_w are fp16 [out][in] row-major (torch Linear layout) */
     const void *in_proj_w;   /* [3*width][width] fp16 */
@@ -245,6 +251,7 @@ typedef struct { /* device pointers; *_w are fp16 [out][in] row-major (torch Lin
     const void *proj_w;      /* [width][4*width] fp16 */
     const float *proj_b;
     float in_proj_s, out_proj_s, fc_s, proj_s;   /* SPLIT mode: 2^-e of the matching weight matrix (ignored in F16 mode) */
+    const float *in_proj_c, *fc_c;               /* SPLIT_LNFOLD: [3*width], [4*width] row sums of the gamma-scaled weights */
 } mpreid_vit_layer;
 
 typedef struct { /* device pointers */

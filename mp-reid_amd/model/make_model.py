@@ -42,6 +42,7 @@ class build_transformer(nn.Module):
         # mAP bound; 'fp16' = single fp16 operands (fastest, ~4e-4 feature error, misses the bound on hard data);
         # 'fp32' = the all-fp32 mode on the exact fp32 matrix instruction (mpreid_vit_forward_f32)
         self.precision = str(getattr(cfg.MODEL, "ENCODER_PRECISION", "split"))
+        self.ln_fold = bool(getattr(cfg.MODEL, "ENCODER_LN_FOLD", False))   # split mode: LayerNorm folded into the GEMMs (opt-in)
         self.in_planes, self.in_planes_proj = (768, 512) if self.model_name == 'ViT-B-16' else (2048, 1024)
         self.num_classes, self.camera_num, self.view_num = num_classes, camera_num, view_num
         self.sie_coe = cfg.MODEL.SIE_COE
@@ -108,7 +109,8 @@ class build_transformer(nn.Module):
             # RN50 has two modes: 'fp32' (parity) and the fp16 tower ('fp16'; also what 'split' -- a ViT mode -- selects)
             return _ops.Rn50Encoder(self.rn_cfg, sd, self.img_hw, neck_after=neck_after, bn=bn,
                                     precision="fp32" if self.precision == "fp32" else "fp16", **kw)
-        return _ops.VitEncoder(self.vit_cfg, sd, self.img_hw, neck_after=neck_after, bn=bn, precision=self.precision, **kw)
+        return _ops.VitEncoder(self.vit_cfg, sd, self.img_hw, neck_after=neck_after, bn=bn, precision=self.precision,
+                               ln_fold=self.ln_fold, **kw)
 
     def _get_encoder(self):
         if self._encoder is None:

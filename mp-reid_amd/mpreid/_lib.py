@@ -57,7 +57,8 @@ class VitCfg(C.Structure):
 class VitLayer(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "ln1_g", "ln1_b",
                                           "ln2_g", "ln2_b", "fc_w", "fc_b", "proj_w", "proj_b")] + \
-               [(k, C.c_float) for k in ("in_proj_s", "out_proj_s", "fc_s", "proj_s")]
+               [(k, C.c_float) for k in ("in_proj_s", "out_proj_s", "fc_s", "proj_s")] + \
+               [(k, C.c_void_p) for k in ("in_proj_c", "fc_c")]
 
 
 class VitWeights(C.Structure):
@@ -111,7 +112,7 @@ GEMM_EPILOGUE_NAMES = {0: "f32", 1: "qkv_bias_f16", 2: "bias_residual", 3: "fc_b
                        5: "euclid", 6: "cosine", 7: "conv1x1_bias_relu", 8: "conv1x1_bias_residual_relu", 9: "candidates",
                        10: "split_qkv_bias_f32", 11: "split_bias_residual", 12: "split_fc_bias_quickgelu",
                        13: "split_patch_embed"}
-VIT_F16, VIT_SPLIT = 0, 1
+VIT_F16, VIT_SPLIT, VIT_SPLIT_LNFOLD = 0, 1, 2
 
 _lib = None
 

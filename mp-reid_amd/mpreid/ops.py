@@ -241,13 +241,20 @@ class VitEncoder:
     """
 
     def __init__(self, cfg: dict, state_dict: dict, img_hw, neck_after: bool = False, bn: Optional[dict] = None,
-                 device=None, cls_only_last: bool = True, ws_tag: str = "vit", precision: str = "fp16"):
+                 device=None, cls_only_last: bool = True, ws_tag: str = "vit", precision: str = "fp16",
+                 ln_fold: bool = False):
         """precision: 'split' = every GEMM operand an fp16 pair hi + lo, products hi.hi' + lo.hi' + hi.lo' on the fp16
         matrix cores with fp32 accumulation -- fp32-grade features (~1e-6) at 3x the matrix work: the mode that meets
         the 1e-4 mAP bound AND is the measured one; 'fp16' = fp16 operands, fp32 accumulate / residual stream (fastest,
         relative feature error ~4e-4: misses the bound on hard data); 'fp32' = every weight and activation fp32, exact
         fp32 matrix instruction (~1e-6, ~1/8 of the fp16 throughput; mpreid_vit_forward_f32)."""
         assert precision in ("fp16", "fp32", "split"), precision
+        # ln_fold (split mode only): ln_1 / ln_2 of every block folded into in_proj / c_fc -- LN(x) W^T + b =
+        # rstd (x (gamma o W)^T - mu c) + b' with c = row sums of gamma o W and b' = beta W^T + b, all folded here in fp64;
+        # the GEMMs then read the pairs of the raw residual stream and a per-row (mean, rstd) table and the blocks contain
+        # no LayerNorm launches (MPREID_VIT_SPLIT_LNFOLD)
+        ln_fold = bool(ln_fold) and precision == "split"
+        self.ln_fold = ln_fold
         self.precision = precision
         self.device = device or _lib.require_gpu()
         self.ws_tag = ws_tag   # encoders that run concurrently on different streams need distinct workspaces
@@ -267,8 +274,8 @@ class VitEncoder:
 
         scales = {}
 
-        def f16(name, shape=None):   # a GEMM weight: fp16 for the MFMA path, fp32 in the all-fp32 mode
-            t = get(name).to(device=dev, dtype=torch.float32)
+        def f16(name, shape=None, tensor=None):   # a GEMM weight: fp16 for the MFMA path, fp32 in the all-fp32 mode
+            t = (get(name) if tensor is None else tensor).to(device=dev, dtype=torch.float32)
             if shape is not None:
                 t = t.reshape(shape)
             if precision == "split":
@@ -289,7 +296,8 @@ class VitEncoder:
         keep = self._keep.append
         self.c_cfg = _lib.VitCfg(self.img_hw[0], self.img_hw[1], cfg["patch"], cfg["stride"], cfg["h_res"],
                                  cfg["w_res"], w, cfg["layers"], cfg["heads"], cfg["out_dim"], int(bool(neck_after)),
-                                 int(bool(cls_only_last)), _lib.VIT_SPLIT if precision == "split" else _lib.VIT_F16)
+                                 int(bool(cls_only_last)),
+                                 (_lib.VIT_SPLIT_LNFOLD if ln_fold else _lib.VIT_SPLIT) if precision == "split" else _lib.VIT_F16)
         layers = (_lib.VitLayer * max(cfg["layers"], 1))()
         for i in range(cfg["layers"]):
             b = f"transformer.resblocks.{i}"
@@ -299,6 +307,16 @@ class VitEncoder:
                      ln2_g=f32(b + ".ln_2.weight"), ln2_b=f32(b + ".ln_2.bias"),
                      fc_w=f16(b + ".mlp.c_fc.weight"), fc_b=f32(b + ".mlp.c_fc.bias"),
                      proj_w=f16(b + ".mlp.c_proj.weight"), proj_b=f32(b + ".mlp.c_proj.bias"))
+            if ln_fold:
+                for ln, wn, bn_, cn in (("ln_1", "attn.in_proj_weight", "attn.in_proj_bias", "in_proj"),
+                                        ("ln_2", "mlp.c_fc.weight", "mlp.c_fc.bias", "fc")):
+                    g64 = get(f"{b}.{ln}.weight").double().cpu()
+                    b64 = get(f"{b}.{ln}.bias").double().cpu()
+                    w64 = get(f"{b}.{wn}").double().cpu()
+                    ws = w64 * g64[None, :]
+                    t[cn + "_w"] = f16(f"{b}.{wn}", tensor=ws.float())   # (gamma o W): rounded to fp32 once, then the pair
+                    t[cn + "_c"] = ws.float().double().sum(1).float().to(dev).contiguous()   # row sums of what the GEMM multiplies by
+                    t[cn + "_b"] = (get(f"{b}.{bn_}").double().cpu() + w64 @ b64).float().to(dev).contiguous()
             for k, v in t.items():
                 keep(v)
                 setattr(layers[i], k, v.data_ptr())

@@ -274,3 +274,36 @@ def test_split_vit_bn_neck_vs_oracle():
     enc = _encoder(SMALL, sd, (64, 32), neck_after=True, bn=bn, precision="split")
     want = orc.vit_features(sd, SMALL, imgs, bn=bn, neck_feat="after")
     assert np.abs(enc(torch.from_numpy(imgs)).cpu().numpy() - want).max() <= 3e-5
+
+
+def test_split_lnfold_mode(golden):
+    """MPREID_VIT_SPLIT_LNFOLD (ops.VitEncoder(precision='split', ln_fold=True)): ln_1 / ln_2 folded into in_proj / c_fc,
+    the GEMMs read the pairs of the raw residual stream that the residual epilogues write, no LayerNorm launch inside the
+    blocks.  Same accuracy bar as the split mode against the reference's goldens (reduced config, ViT-B/16, camera
+    embedding, stride 12), close to the plain split mode, and the same images give the SAME BITS alone (128 x 128 kernel)
+    and inside a batch of 300 (persistent kernel): the per-row statistics are reduced in one fixed tree in both kernels."""
+    from mpreid import synth
+    g = golden("vit.npz")
+    small = dict(h_res=4, w_res=2, patch=16, stride=16, width=128, layers=2, heads=2, out_dim=64)
+    enc = _encoder(small, synth.vit_state_dict(small, seed=7, std=0.05, ln_jitter=0.1), (64, 32), precision="split", ln_fold=True)
+    f = enc(torch.from_numpy(synth.synthetic_images(3, 64, 32, seed=3))).cpu().numpy()
+    assert np.abs(f - g["small_feat"]).max() <= 2e-5
+    big = synth.VIT_B16
+    sd = synth.vit_state_dict(big, seed=7, std=0.02, ln_jitter=0.05)
+    imgs = synth.synthetic_images(4, 256, 128, seed=1234)
+    enc = _encoder(big, sd, (256, 128), precision="split", ln_fold=True)
+    f4 = enc(torch.from_numpy(imgs)).cpu().numpy()
+    assert np.abs(f4 - g["b16_feat"]).max() <= 5e-5
+    assert np.abs(enc(torch.from_numpy(imgs), cv_emb=torch.from_numpy(g["b16_cv"])).cpu().numpy() - g["b16_feat_cv"]).max() <= 5e-5
+    plain = _encoder(big, sd, (256, 128), precision="split")(torch.from_numpy(imgs)).cpu().numpy()
+    assert np.linalg.norm(f4 - plain) / np.linalg.norm(plain) <= 5e-6
+    full = _encoder(big, sd, (256, 128), precision="split", ln_fold=True, cls_only_last=False)(torch.from_numpy(imgs)).cpu().numpy()
+    assert np.abs(full - g["b16_feat"]).max() <= 5e-5
+    more = synth.synthetic_images(300, 256, 128, seed=99)
+    more[100:104] = imgs
+    f300 = enc(torch.from_numpy(more)).cpu().numpy()
+    assert np.array_equal(f300[100:104], f4)
+    assert np.array_equal(enc(torch.from_numpy(more)).cpu().numpy(), f300)   # run to run
+    s12 = dict(big, h_res=21, w_res=10, stride=12)
+    enc = _encoder(s12, synth.vit_state_dict(s12, seed=8, std=0.02, ln_jitter=0.05), (256, 128), precision="split", ln_fold=True)
+    assert np.abs(enc(torch.from_numpy(imgs[:2])).cpu().numpy() - g["b16_s12_feat"]).max() <= 5e-5
