@@ -1432,15 +1432,13 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
             rt[192 + lane] = t3;
         }
         // Fast path: GE_EUCLID on an interior tile (every tile but the last tile row / column) and GE_S_BIAS_F32 (the
-        // split mode's q | k | v output, never ragged).  The general loop below makes eight dependent round trips per
-        // tile -- 16 x 64 block into the wave's one patch, wait, four (LDS read -> wait -> arithmetic -> store), wait --
-        // and was LATENCY-bound: 0.8 us per pass, 8.5 us per 256 x 256 tile (tools/gemm_tile_stamps.py), although one CU
-        // retires a tile's 256 KB of stores in 2.0 us when nothing else holds it up and the whole chip sustains 5.6 TB/s
-        // (tools/probes/store_probe.hip); halving its instruction count (64-bit address arithmetic, bounds, exec
-        // masking) changed nothing.  Here the idle ring gives every wave FOUR patches: half a tile (4 blocks) is laid
-        // down, then its 16 row reads are all issued before the first store needs one -- two round trips per tile
-        // instead of eight.  Addresses: wave-uniform 64-bit base (SGPR pair) + four per-lane 32-bit offsets computed once
-        // per tile; no bounds; the scale test hoisted.  Same arithmetic in the same order: same bits.
+        // split mode's q | k | v output, never ragged).  The general loop below spends ~45 instructions per store on 64-bit
+        // address arithmetic, row / column bounds and exec masking; here: wave-uniform 64-bit base (SGPR pair) + four
+        // per-lane 32-bit offsets computed once per tile, no bounds, the scale test hoisted.  Same arithmetic in the same
+        // order: same bits.  MPREID_FAST_NBLK 16-row blocks are laid into the idle ring per LDS round trip; measured on
+        // one device in one run (20k x 20k x 768 stored distances): 1 block 0.803 ms, 2 blocks 0.813, 4 blocks 0.844 --
+        // batching the round trips only adds live registers (per-tile stamps: epilogue 8.5 -> 10.2 us), the time goes to
+        // the stores themselves.
         bool fast_done = false;
         if constexpr (EPI == GE_EUCLID || EPI == GE_S_BIAS_F32) {
             if (fast_path) {
@@ -1452,7 +1450,10 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
 #pragma unroll
                 for (int it = 0; it < 4; ++it) voff[it] = (unsigned)(it * 4 + (lane >> 4)) * ldo_b + (unsigned)c4 * 4u;
                 const bool scaled = g.rscale != nullptr;
-                constexpr int NBLK = (EPI == GE_S_BIAS_F32 && LNF) ? 1 : 4;
+                #ifndef MPREID_FAST_NBLK
+#define MPREID_FAST_NBLK 1
+#endif
+                constexpr int NBLK = (EPI == GE_S_BIAS_F32 && LNF) ? 1 : MPREID_FAST_NBLK;
                 if constexpr (((DBG >> 7) & 7) == 6) {   // (timing experiment, wrong data) the 32 stores straight from the accumulators
 #pragma unroll
                     for (int e = 0; e < 32; ++e)
