@@ -20,7 +20,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "enc":
     L = _lib.load()
     dev = _lib.require_gpu()
     SH = {"qkv": (2304, 768, 1), "out": (768, 768, 2), "fc1": (3072, 768, 3), "fc2": (768, 3072, 2),
-          "sqkv": (2304, 768, 10), "sout": (768, 768, 11), "sfc1": (3072, 768, 12), "sfc2": (768, 3072, 11)}
+          "sqkv": (2304, 768, 10), "sout": (768, 768, 11), "sfc1": (3072, 768, 12), "sfc2": (768, 3072, 11),
+          # crossed shapes: which of N and the epilogue sets the k-loop time?
+          "sqkv_n3072": (3072, 768, 10), "sfc1_n2304": (2304, 768, 12), "sqkv_n768": (768, 768, 10)}
     M = 65536
     for name in sys.argv[2:]:
         N, K, epi = SH[name]
