@@ -47,6 +47,11 @@ def _stale(target, deps):
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    # objects built with other flags (e.g. a timing-ablation build, MPREID_ABLATION=1) must not survive into this build
+    stamp = os.path.join(OBJ, "flags.txt")
+    flags_now = " ".join(FLAGS) + " | " + repr(sorted(EXTRA_FLAGS.items()))
+    if not os.path.exists(stamp) or open(stamp).read() != flags_now:
+        force = True
     jobs = []
     objs = []
     for src in SOURCES:
@@ -71,6 +76,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 print(warn, file=sys.stderr)
     if force or jobs or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    with open(stamp, "w") as fh:
+        fh.write(flags_now)
     return LIB
 
 
