@@ -234,8 +234,8 @@ def cpu_baseline(n_img):
 
 #: kernels of each re-rank stage as rocprofv3 names them (prefix match) -> used to sum the committed PMC bytes per stage
 RERANK_STAGE_KERNELS = {
-    "rerank.candidates": ("sqnorm_kernel", "rr2_norm_stats_kernel", "_Z20rr2_cast_rows_kernel", "void gemm_f16_big_kernel<5, 0>",
-                          "rr2_threshold_kernel", "void gemm_f16_big_kernel<9, 0>"),
+    "rerank.candidates": ("sqnorm_kernel", "rr2_norm_stats_kernel", "_Z20rr2_cast_rows_kernel", "void gemm_f16_big_kernel<5, 0",
+                          "rr2_threshold_kernel", "void gemm_f16_big_kernel<9, 0"),   # (prefixes: the template list grew a parameter in round 3)
     "rerank.refine": ("void rr2_refine_kernel", "rr2_fb_gather_kernel", "rowmax_topk_kernel", "rr2_fb_scatter_kernel"),
     "rerank.krecip": ("recip_bits_kernel", "void krecip_kernel"),
     "rerank.query_rows": ("void gemm_f32_exact_kernel",),
@@ -356,7 +356,7 @@ def extras(ops, dev, with_widened=True):
     for fn in ("r03_pmc_summary.json", "r02_pmc_summary.json"):
         try:
             per = json.load(open(os.path.join(ROOT, "profiles", fn)))["featgemm_20kx20kx768_fp16_hbm_bytes_per_launch"]
-            fg_traffic = int(sum(v for k, v in per.items() if k.startswith(("void gemm_f16_big_kernel<5, 0>", "void gemm_f16_store"))))
+            fg_traffic = int(sum(v for k, v in per.items() if k.startswith(("void gemm_f16_big_kernel<5, 0", "void gemm_f16_store"))))
             fg_src = fn
             break
         except Exception:
