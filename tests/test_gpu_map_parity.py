@@ -16,8 +16,9 @@ SPREAD (the parity bar).  Weights ~ N(0, 0.05^2): the image content drives the f
   evaluated in fp64 instead of fp32 (features 1.07e-6 apart) moves mAP by 2.7e-5 and no Rank-1 (tools/map_noise_floor.py
   spread).  So 1e-4 is a meaningful bound, and it is ASSERTED for the split
   and the fp32 mode, with and without re-ranking: |dmAP| <= 1e-4, |dRank-1| <= 1e-4 (i.e. not one query differs),
-  features within 2e-5 relative L2 (measured on MI355X: split 3.7e-6 / |dmAP| 2.7e-8 / no query differs; fp32 2.1e-6 /
-  2.2e-8).  The fp16 mode is reported and held to the bound its feature error supports (measured 8.9e-4 / |dmAP| 5.4e-4 /
+  features within 2e-5 relative L2 (measured on MI355X: split 1.5e-6 ... 3.7e-6 / |dmAP| 2.7e-8 ... 5.3e-5 / no query
+  differs; fp32 2.1e-6 / 2.2e-8 ... 5.0e-5 -- the spread is the ORACLE's: the GPU boxes of the pool have different host
+  CPUs and the fp32 torch graph takes different MKL paths on them; both HIP modes move together).  The fp16 mode is reported and held to the bound its feature error supports (measured 8.9e-4 / |dmAP| 5.4e-4 /
   one query: single fp16 operands do NOT meet 1e-4 on realistic geometry either).
 
 DEGENERATE (the round-1/2 set, kept as a stress case).  Weights ~ N(0, 0.02^2): the CLS row barely sees the image, all
@@ -77,8 +78,8 @@ def test_image_to_map_parity(data, name, rerank):
     cmc_o, map_o = orc.eval_func(d_or, pid[:nq], pid[nq:])
     assert 0.2 < map_o < 0.97, map_o   # hard enough to be informative (re-ranking lifts it)
     res = {}
-    for prec in ("split", "fp32", "fp16"):
-        enc = ops.VitEncoder(synth.VIT_B16, sd, (256, 128), precision=prec)
+    for prec in ("split", "split_lnfold", "fp32", "fp16"):   # split_lnfold: the opt-in folded-LayerNorm form of the split mode
+        enc = ops.VitEncoder(synth.VIT_B16, sd, (256, 128), precision=prec.split("_")[0], ln_fold=prec.endswith("lnfold"))
         f = torch.empty((n, enc.feat_dim), device="cuda")
         for s in range(0, n, 508):
             enc(torch.from_numpy(x[s:s + 508]), out=f[s:s + 508])
@@ -90,13 +91,13 @@ def test_image_to_map_parity(data, name, rerank):
           (name, rerank, map_o, cmc_o[0], float(np.median(orc.euclidean_distance(fo[:nq], fo[nq:])))) +
           " | ".join(f"{k}: feat rel-L2 {v[0]:.2e} dmAP {v[1]:.2e} dR1 {v[2]:.2e} max dCMC {v[3]:.2e}" for k, v in res.items()))
     if name == "spread":
-        for prec in ("split", "fp32"):   # north_star's bound: the default (measured) mode and the fp32 mode meet it
+        for prec in ("split", "split_lnfold", "fp32"):   # north_star's bound: the default (measured) mode and the fp32 mode meet it
             rel, dmap, dr1, dcmc = res[prec]
             assert rel <= 2e-5 and dmap <= 1e-4 and dr1 <= 1e-4, (prec, res[prec])
         rel, dmap, dr1, dcmc = res["fp16"]
         assert rel <= 3e-3 and dmap <= 3e-3 and dr1 <= 2.0 / nq + 1e-9, res["fp16"]   # what single fp16 operands support
     else:
-        for prec in ("split", "fp32"):
+        for prec in ("split", "split_lnfold", "fp32"):
             rel, dmap, dr1, dcmc = res[prec]
             assert rel <= 2e-5 and dmap <= 5e-4 and dr1 <= 1.0 / nq + 1e-9, (prec, res[prec])
         rel, dmap, dr1, dcmc = res["fp16"]
