@@ -8,9 +8,14 @@ processes (one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.
 rank 0's JSON line; under `python -m torch.distributed.run` the ranks are the launcher's.  It never re-execs.
 
 Workloads (BASELINE.json configs):
-  market  (default; configs[1], with --rerank the configs[2] stand-in)  ViT-B/16 encode of 3368 query + 15913 gallery
-          images PER GPU SHARD -> L2-normalise -> all-gather of the query features -> [3368, 15913] exact distance
-          block per GPU.  Weak scaling (per-GPU gallery fixed).
+  market  (default; configs[1], with --rerank the configs[2] stand-in)  THE DROP-IN PATH: one step is one call of
+          ``processor.do_inference(cfg, model, val_loader, num_query)`` on a ``make_model(cfg, ...)`` model -- the
+          reference's test.py:58-62 -- over a query-then-gallery loader of 64-image fp32 batches that are resident in HBM:
+          ViT-B/16 encode of 3368 query + 15913 gallery images PER GPU SHARD (grouped, two streams: mpreid/pipeline.py)
+          -> R1_mAP_eval.compute(): L2-normalise -> all-gather of the query features -> [3368, 15913] exact distance
+          block per GPU -> CMC / mAP ranking on the GPU -> matrix and features handed to the host.  Weak scaling
+          (per-GPU gallery fixed).  extras: the same call fed by a HOST fp32 loader (the reference's loader type) and by a
+          RawImageBatch loader (decoded uint8 images), PCIe inclusive.
   synth   (configs[3])  ONE 20 000-query x 80 000-gallery x 768 problem, gallery rows sharded over the N GPUs,
           all-gather of the query features, per-shard [20000, 80000/N] distance blocks; --rerank adds the row-sharded
           k-reciprocal re-ranking of the N = 100 000 problem.  Strong scaling (total work fixed).
@@ -374,8 +379,9 @@ def extras(ops, dev, with_widened=True):
         out["feat_gemm_20kx20k_d768_split3_ms"] = round(ms, 4)
         out["feat_gemm_20kx20k_d768_split3_executed_tflops"] = round(3 * flop / ms / 1e9, 1)
         roofs.append({"stage": "feat_gemm_20kx20k_d768 (3-term fp16 split, |err| <= 1e-6)", "kernel": "gemm_f16_big_kernel<euclid_split3>",
-                      "bound": "mfma", "achieved": round(3 * flop / ms / 1e9, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                      "frac": round(3 * flop / ms / 1e9 / PEAK_F16_TFLOPS, 4), "algorithmic_flop": int(3 * flop),
+                      "bound": "mfma", "achieved": round(flop / ms / 1e9, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                      "frac": round(flop / ms / 1e9 / PEAK_F16_TFLOPS, 4), "algorithmic_flop": int(flop),
+                      "achieved_executed": round(3 * flop / ms / 1e9, 1), "frac_executed": round(3 * flop / ms / 1e9 / PEAK_F16_TFLOPS, 4),
                       "avg_launch_ms": round(ms, 4), "traffic": None})
     ms = timed_ms(lambda: ops.euclidean_distance(ft, ft, mode=ops.GEMM_F32_EXACT, out=buf), 3)
     out["feat_gemm_20kx20k_d768_fp32exact_ms"] = round(ms, 4)
@@ -425,7 +431,6 @@ def extras(ops, dev, with_widened=True):
         fo_ = torch.empty((508, e_.feat_dim), device=dev)
         ms = timed_ms(lambda: e_(img508, out=fo_), reps)
         per_mode[prec] = {"images_per_s": round(508 / ms * 1e3, 1), "ms_per_batch_of_508": round(ms, 3),
-                          "meets_1e-4_map_bound": prec != "fp16",
                           "encode_tflops_algorithmic": round(508 * GFLOP_PER_IMG / ms, 1)}
         del e_, fo_
         ops.release_workspaces()
@@ -508,6 +513,147 @@ def extras(ops, dev, with_widened=True):
 
 
 # ----------------------------------------------------------------------------------------------------------------
+# the drop-in path: make_model -> do_inference -> R1_mAP_eval.compute()   (market workload)
+# ----------------------------------------------------------------------------------------------------------------
+class ValLoader:
+    """Query-then-gallery validation loader with the reference's batch tuple (datasets/make_dataloader.py:39-43):
+    (img, pids, camids, camids_tensor, viewids_tensor, img_paths), `per_batch` samples per batch.  `batches` holds the images of
+    THIS rank's samples (global positions `index`, ascending) batch by batch: fp32 tensors in HBM (headline), pageable
+    fp32 host tensors (the reference's loader type) or RawImageBatch lists of decoded uint8 images."""
+
+    def __init__(self, batches, index, n_total, pids, camids):
+        import torch
+        self.batches, self.index, self.n = batches, list(index), n_total
+        self.meta = []
+        lo = 0
+        for b in batches:
+            k = len(b)
+            idx = self.index[lo:lo + k]
+            cams = tuple(int(camids[i]) for i in idx)
+            self.meta.append((tuple(int(pids[i]) for i in idx), cams, torch.tensor(cams, dtype=torch.int64),
+                              torch.zeros(k, dtype=torch.int64), tuple("synthetic/%07d.jpg" % i for i in idx)))
+            lo += k
+        assert lo == len(self.index)
+
+    def __iter__(self):
+        for img, m in zip(self.batches, self.meta):
+            yield (img,) + m
+
+    def __len__(self):
+        return len(self.batches)
+
+    def shard(self, indices):
+        """processor.shard_val_loader asks for this rank's samples: exactly the ones this loader holds"""
+        assert list(indices) == self.index, "ValLoader holds another shard"
+        return iter(self)
+
+
+def market_cfg(a, nq, ng_total, rerank):
+    from config import cfg_base
+    cfg = cfg_base.clone()
+    cfg.defrost()
+    cfg.merge_from_list(["DATASETS.SYNTH_QUERY", nq, "DATASETS.SYNTH_GALLERY", ng_total, "TEST.RE_RANKING", bool(rerank),
+                         "MODEL.ENCODER_PRECISION", a.encoder_precision, "TEST.DISTANCE_MODE", a.dist_mode,
+                         "TEST.RERANK_ALGO", a.rerank_algo, "TEST.IMS_PER_BATCH", 64])
+    cfg.freeze()
+    return cfg
+
+
+def quiet_do_inference(cfg, model, loader, nq):
+    """do_inference with its prints sent to stderr (stdout carries the ONE JSON line)"""
+    import contextlib
+    from processor.processor import do_inference
+    with contextlib.redirect_stdout(sys.stderr):
+        return do_inference(cfg, model, loader, nq)
+
+
+def timed_do_inference(cfg, model, loader, nq, reps, pipeline_env=None):
+    """wall seconds per call of do_inference (whole call: encode pipeline + compute() + host hand-over), after one warm call"""
+    import torch
+    old = os.environ.get("MPREID_PIPELINE")
+    if pipeline_env is not None:
+        os.environ["MPREID_PIPELINE"] = pipeline_env
+    try:
+        quiet_do_inference(cfg, model, loader, nq)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            quiet_do_inference(cfg, model, loader, nq)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+    finally:
+        if pipeline_env is not None:
+            if old is None:
+                os.environ.pop("MPREID_PIPELINE", None)
+            else:
+                os.environ["MPREID_PIPELINE"] = old
+
+
+def drop_in_extras(a, cfg, model, nq, ng, pids, camids, dev):
+    """the same do_inference call fed from the HOST (PCIe inclusive): (i) 64-image fp32 batches in pageable host memory --
+    the reference's loader type (datasets/make_dataloader.py:103-106: DataLoader without pin_memory, `img.to(device)`
+    in the loop, processor/processor.py:189); (ii) RawImageBatch batches of decoded uint8 images of ragged sizes (Resize +
+    ToTensor + Normalize on the GPU).  Never the headline value."""
+    import numpy as np
+    import torch
+    from datasets.make_dataloader import RawImageBatch
+    from processor.processor import do_inference
+    out = {}
+    n = nq + ng
+    g = torch.Generator(device=dev)
+    g.manual_seed(4321)
+    host = []
+    for s in range(0, n, 64):
+        e = min(n, s + 64)
+        host.append(torch.randn((e - s, 3, H, W), generator=g, device=dev).clamp_(-1.0, 1.0).cpu())   # pageable
+    ld = ValLoader(host, range(n), n, pids, camids)
+    for stage in ("pinned", "direct"):
+        dt = timed_do_inference(cfg, model, ld, nq, 2, pipeline_env=f"stage={stage}")
+        out[f"do_inference_images_per_s_fp32_loader_{stage}"] = round(n / dt, 1)
+    best = max(("pinned", "direct"), key=lambda k: out[f"do_inference_images_per_s_fp32_loader_{k}"])
+    out["do_inference_images_per_s_fp32_loader"] = out[f"do_inference_images_per_s_fp32_loader_pinned"]   # the default stage
+    out["do_inference_fp32_loader_best_stage"] = best
+    out["do_inference_fp32_loader_h2d_gb_per_s"] = round(out["do_inference_images_per_s_fp32_loader"] * 3 * H * W * 4 / 1e9, 2)
+    # the reference's own loop shape on the same loader, for scale: one 64-image batch at a time, pageable .to(device)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    k = 0
+    with torch.no_grad():
+        for img, *_ in ld:
+            model(img.to(dev))
+            k += img.shape[0]
+            if k >= 4096:
+                break
+    torch.cuda.synchronize()
+    out["reference_loop_shape_images_per_s_fp32_loader"] = round(k / (time.perf_counter() - t0), 1)
+    del ld, host
+    rng = np.random.default_rng(77)
+    pool = rng.integers(0, 256, 64 << 20, dtype=np.uint8)   # decoded-image stand-ins cut from one random pool
+    raws, off = [], 0
+    for s in range(0, n, 64):
+        b = []
+        for _ in range(min(n, s + 64) - s):
+            h, w = int(rng.integers(96, 200)), int(rng.integers(48, 100))
+            if off + h * w * 3 > pool.size:
+                off = int(rng.integers(0, 4096))
+            b.append(pool[off:off + h * w * 3].reshape(h, w, 3))
+            off += h * w * 3
+        raws.append(RawImageBatch(b))
+    ld = ValLoader(raws, range(n), n, pids, camids)
+    dt = timed_do_inference(cfg, model, ld, nq, 2)
+    out["do_inference_images_per_s_raw_loader"] = round(n / dt, 1)
+    ev = do_inference.last_evaluator
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):
+        for _ in range(3):
+            ev.compute()
+    out["compute_ms"] = round((time.perf_counter() - t0) / 3 * 1e3, 2)   # R1_mAP_eval.compute(): normalise, distmat, ranking, D2H
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
 # one rank
 # ----------------------------------------------------------------------------------------------------------------
 def run_rank(a):
@@ -543,7 +689,8 @@ def run_rank(a):
     div = 16 if a.small else 1
     wl = a.workload
     enc = None
-    if wl in ("market", "msmt17"):
+    side, encs = [], []
+    if wl == "msmt17":
         enc = ops.VitEncoder(synth.VIT_B16, synth.vit_state_dict(synth.VIT_B16, seed=7), (H, W),
                              precision=a.encoder_precision)
         side = [torch.cuda.Stream(device=dev) for _ in range(nstreams - 1)]
@@ -565,16 +712,30 @@ def run_rank(a):
         for st in side:
             main.wait_stream(st)
 
+    market = None
     if wl == "market":
-        # weak scaling: every rank owns a whole Market-1501-sized gallery shard + 1/world of the queries
+        # weak scaling: every rank owns a whole Market-1501-sized gallery shard + 1/world of the queries.  The step is the
+        # drop-in call itself: do_inference on a make_model model over a loader of HBM-resident 64-image batches
+        from model.make_model import make_model
         nq, ng = NQ // div, NG // div
         q_lo, q_hi = D.shard_range(nq, rank, world)
         nq_local, ng_local = q_hi - q_lo, ng
         ng_total = world * ng
         scaling = "weak"
         imgs = make_images(nq_local + ng_local, 1234 + rank, dev)
-        feat_dim = enc.feat_dim
         images_per_step = nq + ng_total
+        cfg = market_cfg(a, nq, ng_total, a.rerank)
+        model = make_model(cfg, num_class=751, camera_num=6, view_num=1)
+        model.to("cuda")
+        rng = np.random.default_rng(1234)
+        pids_all = rng.integers(0, max(ng_total // 21, 1), size=nq + ng_total)    # ~21 gallery images per identity (Market-1501)
+        cams_all = rng.integers(0, 6, size=nq + ng_total)
+        g_lo, g_hi = D.shard_range(ng_total, rank, world)
+        index = list(range(q_lo, q_hi)) + list(range(nq + g_lo, nq + g_hi))
+        loader = ValLoader(list(torch.split(imgs, 64)), index, nq + ng_total, pids_all, cams_all)
+        market = {"cfg": cfg, "model": model, "loader": loader}
+        feat_dim = 1280
+        enc = model   # (truthy: the workload has an encoder)
     elif wl == "msmt17":
         nq, ng_total = MSMT_NQ // div, MSMT_NG // div
         q_lo, q_hi = D.shard_range(nq, rank, world)
@@ -596,14 +757,20 @@ def run_rank(a):
         del allf
         feat_dim = SYN_D
         images_per_step = nq + ng_total
-    if wl != "synth":
+    if wl == "msmt17":
         feats = torch.empty((nq_local + ng_local, feat_dim), dtype=torch.float32, device=dev)
-    block = torch.empty((nq, ng_local), dtype=torch.float32, device=dev)
+    if wl != "market":
+        block = torch.empty((nq, ng_local), dtype=torch.float32, device=dev)
     rr_holder = {}
 
-    host_concat = a.host_concat == "on" or (a.host_concat == "auto" and wl == "market")
+    host_concat = a.host_concat == "on"   # (market: the hand-over to the host is part of R1_mAP_eval.compute())
+    os.environ["MPREID_PIPELINE"] = f"streams={nstreams}"
 
     def step():
+        if market is not None:
+            r1, _ = quiet_do_inference(market["cfg"], market["model"], market["loader"], nq)
+            rr_holder["rank1"] = float(r1)
+            return
         if wl == "synth":
             fq, fg = fq_local, fg_local
         else:
@@ -658,16 +825,21 @@ def run_rank(a):
         # roofline leg: one more pass of the same work on ONE stream with per-launch hipEvents
         saved = (list(side), list(encs))
         side[:], encs[:] = [], [enc]
+        os.environ["MPREID_PIPELINE"] = "streams=1"
         L.mpreid_profile_enable(1)
         step()
         fence()
         L.mpreid_profile_enable(0)
+        os.environ["MPREID_PIPELINE"] = f"streams={nstreams}"
         side[:], encs[:] = saved
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    assert torch.isfinite(block).all()
+    if market is not None:
+        assert np.isfinite(rr_holder["rank1"])
+    else:
+        assert torch.isfinite(block).all()
 
     if rank == 0:
         ents = (_lib.ProfileEntry * 48)()
@@ -698,7 +870,7 @@ def run_rank(a):
         traffic = None
         traffic_src = None
         if top:
-            for fn in ("r03_gemm_pmc_traffic.json", "r02_gemm_pmc_traffic.json"):
+            for fn in ("r04_gemm_pmc_traffic.json", "r03_gemm_pmc_traffic.json", "r02_gemm_pmc_traffic.json"):
                 try:  # HBM bytes per launch of the dominant kernel: committed rocprofv3 PMC passes (profiles/)
                     tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
                     key = f"{_lib.GEMM_EPILOGUE_NAMES.get(top['epilogue_id'])}:{top['N']}:{top['K']}"
@@ -711,13 +883,15 @@ def run_rank(a):
         if top:
             step_ms = dt / a.steps * 1e3
             sp = top["operand_pairs"]
+            mult = 3.0 if sp else 1.0   # executed fp16 products per multiply-add of the algorithm
+            alg_tf = top["tflops"] / mult
             roof = {"bound": "mfma", "kernel": top["kernel"], "shape": [top["M"], top["N"], top["K"]],
-                    "achieved": top["tflops"], "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                    "algorithmic_gflop_per_launch": top["gflop_per_launch"],
-                    "flop_convention": ("2*M*N*3K: the kernel's algorithm is the 3-product fp16-pair multiply-add "
-                                        "(hi.hi' + lo.hi' + hi.lo'), every product a real fp16 MFMA operation; the fp32-equivalent "
-                                        "rate (2*M*N*K) is `achieved_fp32_equivalent`") if sp else "2*M*N*K",
-                    "frac": round(top["tflops"] / PEAK_F16_TFLOPS, 4), "traffic": traffic,
+                    "achieved": round(alg_tf, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                    "algorithmic_gflop_per_launch": round(top["gflop_per_launch"] / mult, 2),
+                    "flop_convention": "2*M*N*K per launch (SURVEY.md section 8d): ALGORITHMIC flops" +
+                                       ("; the kernel executes three fp16 products per multiply-add (operand pairs hi + lo: "
+                                        "hi.hi' + lo.hi' + hi.lo'), reported as achieved_executed / frac_executed" if sp else ""),
+                    "frac": round(alg_tf / PEAK_F16_TFLOPS, 4), "traffic": traffic,
                     "traffic_source": (f"profiles/{traffic_src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes = "
                                        "(2*FETCH_SIZE + WRITE_SIZE)*1024, same kernel and shape at M=65536") if traffic_src else None,
                     "avg_launch_ms": top["avg_ms"], "launches": top["launches"],
@@ -730,16 +904,26 @@ def run_rank(a):
                     "gemm_share_of_step": round(sum(c["total_ms"] for c in classes) /
                                                 (dt * 1e3 if instrument_live else step_ms), 3)}
             if sp:
-                # both conventions side by side: `achieved` / `frac` count what the matrix cores execute (three fp16 products
-                # per multiply-add of the fp32-grade algorithm), the *_fp32_equivalent pair counts 2*M*N*K as SURVEY 8(d) does
-                roof["achieved_fp32_equivalent"] = round(top["tflops"] / 3.0, 1)
-                roof["frac_fp32_equivalent"] = round(top["tflops"] / 3.0 / PEAK_F16_TFLOPS, 4)
+                # `achieved` / `frac` follow SURVEY 8(d) (2*M*N*K); the executed pair counts what the matrix cores do (three
+                # fp16 products per multiply-add of the fp32-grade algorithm)
+                roof["achieved_executed"] = top["tflops"]
+                roof["frac_executed"] = round(top["tflops"] / PEAK_F16_TFLOPS, 4)
                 roof["frac_of_sustainable_1250TF"] = round(top["tflops"] / 1250.0, 4)
+            try:   # matrix-pipe counters of the same kernel class (committed rocprofv3 --pmc pass, tools/collect_profiles.sh)
+                mj = json.load(open(os.path.join(ROOT, "profiles", "r04_gemm_pmc_mfma.json")))
+                key = f"{_lib.GEMM_EPILOGUE_NAMES.get(top['epilogue_id'])}:{top['N']}:{top['K']}"
+                if key in mj.get("classes", {}):
+                    roof["mfma_busy"] = mj["classes"][key]
+                    roof["mfma_busy_source"] = "profiles/r04_gemm_pmc_mfma.json"
+            except Exception:
+                pass
         desc = {
-            "market": "Market-1501 shape on MI355X (BASELINE configs[1]): ViT-B/16 encode of "
-                      f"{nq} query + {NG // div} gallery 3x256x128 images per GPU shard (seeded random init), "
-                      "L2-normalise, all-gather query features, euclidean distmat "
-                      f"[{nq} x {NG // div}] per GPU ({a.dist_mode})",
+            "market": "Market-1501 shape on MI355X (BASELINE configs[1]) through the drop-in API: one step = "
+                      "processor.do_inference(cfg, make_model(cfg, ...), val_loader, num_query) -- ViT-B/16 encode of "
+                      f"{nq} query + {NG // div} gallery 3x256x128 images per GPU shard (seeded random init; 64-image fp32 "
+                      "loader batches resident in HBM), R1_mAP_eval.compute(): L2-normalise, all-gather query features, "
+                      f"euclidean distmat [{nq} x {NG // div}] per GPU ({a.dist_mode}), CMC/mAP ranking, matrix + "
+                      "features handed to the host",
             "msmt17": f"MSMT17 shape (BASELINE configs[4]): ViT-B/16 encode of {nq} query + {ng_total} gallery "
                       f"images sharded over {world} GPU(s), L2-normalise, all-gather query features, euclidean "
                       f"distmat [{nq} x {ng_total}/{world}] at D=1280 ({a.dist_mode})",
@@ -765,7 +949,8 @@ def run_rank(a):
                      {"exact": "distmat f32 (exact fp32 MFMA)", "f16": "distmat f16 operands one pass, f32 accumulate",
                       "split3": "distmat 3-term f16 split, f32 accumulate"}[a.dist_mode],
             "data": "synthetic",
-            "config": {"workload": desc, "images_per_step": images_per_step, "encoder_batch": a.batch if enc else None,
+            "config": {"workload": desc, "images_per_step": images_per_step,
+                       "encoder_batch": (market["model"].encode_group if market else a.batch) if enc else None,
                        "encoder_precision": a.encoder_precision if enc else None,
                        "encoder_streams": nstreams if enc else None,
                        "sharding": (f"gallery rows over {world} GPU(s), queries 1/{world} each + all-gather")},
@@ -804,13 +989,30 @@ def run_rank(a):
             res["tolerance_check_vs_exact_fp32"] = chk
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.cpu_images)
+        if market is not None:
+            from processor.processor import do_inference as _di
+            res["drop_in"] = {"call": "processor.do_inference(cfg, model.make_model.make_model(cfg, ...), val_loader, num_query)",
+                              "loader_batch": 64, "rank1": rr_holder.get("rank1"),
+                              "pipeline": dict(getattr(_di, "last_pipeline_stats", {}))}
         if world == 1 and not a.no_extras and not a.small:
-            del block
+            drop = {}
+            if market is not None:
+                drop = drop_in_extras(a, market["cfg"], market["model"], nq, ng_total, pids_all, cams_all, dev)
+                market["loader"] = None
+                del loader
+            else:
+                del block
             if wl != "synth":
-                del imgs, feats
+                del imgs
+            if wl == "msmt17":
+                del feats
             ops.release_workspaces()
             torch.cuda.empty_cache()
             res["extras"], roofs = extras(ops, dev, with_widened=(wl == "market"))
+            res["extras"].update(drop)
+            if drop:
+                res["extras"]["do_inference_fp32_loader_over_headline"] = round(drop["do_inference_images_per_s_fp32_loader"] / res["value"], 4)
+                res["extras"]["do_inference_raw_loader_over_headline"] = round(drop["do_inference_images_per_s_raw_loader"] / res["value"], 4)
             enc_roofs = [dict(roof, stage="encoder dominant GEMM class")] if roof else []
             for o in other:   # the HBM-bound encoder kernels of the timed (or single-stream) pass
                 if o["gbps"]:

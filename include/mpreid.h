@@ -26,6 +26,17 @@ extern "C" {
 #define MPREID_ERR_NODEVICE (-4)
 #define MPREID_ERR_RETRY_DENSE (-5) /* sparse re-ranking hit a data-dependent capacity: repeat with MPREID_RERANK_DENSE */
 
+/* Environment: the library reads ONE tuning string, MPREID_TUNE="key=value,key=value" (once per process), that selects
+ * between BIT-IDENTICAL forms of a stage; no other variable changes which kernel runs.  Keys (default):
+ *   gemm_big (1)            0 = never the 256x256 persistent GEMM, 1 = when its grid fills the chip, 2 = whenever divisible
+ *   gemm_order (1)          tile order of the persistent GEMM: 0 = grouped rows over the whole grid, 1 = per-XCD super-tiles
+ *   gemm_stagger, gemm_stagger_all (0)   start delay (ticks) of the persistent workgroups
+ *   jaccard_wave (-1 auto), jaccard_wave_rows (10240), jaccard_table (0)   form of the Jaccard stage
+ *   csc_atomic (0), csc_fill (1)         inverted index: round-1 atomic build; scattered (0) / LDS-bucketed (1) fill
+ *   rerank_overlap (-1 auto)             exact query rows in line (0) / on a side stream (1)
+ *   verbose (0)             occupancy messages on stderr
+ * Unknown keys are reported on stderr and ignored.  Switches that change RESULTS exist only in -DMPREID_ABLATION builds. */
+
 typedef void *mpreid_stream_t; /* hipStream_t */
 
 int mpreid_version(void);

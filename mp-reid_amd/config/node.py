@@ -83,6 +83,7 @@ def make_defaults():
         "DATALOADER": {"NUM_WORKERS": 0},
         "TEST": {"IMS_PER_BATCH": 64, "RE_RANKING": False, "WEIGHT": "", "NECK_FEAT": "before", "FEAT_NORM": "yes",
                  "DIST_MAT": "dist_mat.npy", "EVAL": False,
+                 "DISTANCE_MODE": "exact", "RERANK_ALGO": "exact",   # not reference keys: see processor.do_inference
                  # Uni-Prompt evaluation (reference config/defaults.py:331-344)
                  "TTA_ENABLED": False, "TTPT": {"ENABLED": False, "LR": 0.001, "STEPS": 5, "TEMPERATURE": 0.07}},
         "OUTPUT_DIR": "",

@@ -2,6 +2,9 @@
 #include "common.h"
 
 #include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 
@@ -10,6 +13,42 @@ void mpreid_set_error(const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// MPREID_TUNE="key=value,...": parsed once; see common.h / include/mpreid.h
+namespace {
+struct TuneTable {
+    std::vector<std::pair<std::string, int>> kv;
+    TuneTable() {
+        static const char *known[] = {"gemm_big", "gemm_stagger", "gemm_stagger_all", "jaccard_wave", "jaccard_wave_rows",
+                                      "jaccard_table", "csc_atomic", "rerank_overlap", "verbose", "gemm_order", "csc_fill"};
+        const char *e = getenv("MPREID_TUNE");
+        if (!e) return;
+        std::string s(e);
+        size_t pos = 0;
+        while (pos <= s.size()) {
+            size_t end = s.find(',', pos);
+            if (end == std::string::npos) end = s.size();
+            std::string item = s.substr(pos, end - pos);
+            pos = end + 1;
+            if (item.empty()) continue;
+            const size_t eq = item.find('=');
+            const std::string key = item.substr(0, eq);
+            const int val = eq == std::string::npos ? 1 : atoi(item.c_str() + eq + 1);
+            bool ok = false;
+            for (const char *k : known) ok = ok || key == k;
+            if (!ok) fprintf(stderr, "[mpreid] MPREID_TUNE: unknown key '%s' ignored\n", key.c_str());
+            else kv.emplace_back(key, val);
+        }
+    }
+};
+} // namespace
+
+int mpreid_tune(const char *key, int dflt) {
+    static const TuneTable t;
+    for (const auto &p : t.kv)
+        if (p.first == key) return p.second;
+    return dflt;
 }
 
 extern "C" int mpreid_version(void) { return 100; } /* 0.1.0 */

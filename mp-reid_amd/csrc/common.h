@@ -46,6 +46,12 @@ static inline int mpreid_ablation_env(const char *name) {
 #endif
 }
 
+// Tuning switches between BIT-IDENTICAL forms of a stage (kernel shape selection, side-stream overlap): ONE documented
+// environment string, MPREID_TUNE="key=value,key=value" (include/mpreid.h lists the keys), read once per process.  A key that
+// is absent returns `dflt`; unknown keys are reported once on stderr -- a stray or misspelt variable cannot silently change
+// which kernel is measured.  (Switches that change RESULTS exist only in -DMPREID_ABLATION builds, above.)
+int mpreid_tune(const char *key, int dflt);
+
 // Bijective XCD-aware remap of a 1-D block id: blocks b and b+8 share an XCD (round-robin
 // dispatch), so give each XCD a contiguous chunk of the logical tile order (L2 locality only;
 // correctness never depends on it).  cdna_hip_programming.md §5 "XCD swizzle must be bijective".

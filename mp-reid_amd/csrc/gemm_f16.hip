@@ -1654,14 +1654,10 @@ struct ProfClass {
     int64_t m = 0; // largest M seen in the class
 };
 bool g_prof_on = false;
-// MPREID_GEMM_BIG: 0 = never use the 256x256 kernel, 1 = when the grid fills the chip (default),
+// MPREID_TUNE gemm_big: 0 = never use the 256x256 kernel, 1 = when the grid fills the chip (default),
 // 2 = whenever the shape is divisible (tests)
 int big_mode() {
-    static int mode = -1;
-    if (mode < 0) {
-        const char *e = getenv("MPREID_GEMM_BIG");
-        mode = e ? atoi(e) : 1;
-    }
+    static const int mode = mpreid_tune("gemm_big", 1);
     return mode;
 }
 std::mutex g_prof_mu;
@@ -1719,7 +1715,12 @@ struct ProfToken {
 void *mpreid_prof_begin(hipStream_t stream) {
     if (!g_prof_on) return nullptr;
     ProfToken *t = new ProfToken{};
-    if (hipEventCreate(&t->e0) != hipSuccess || hipEventRecord(t->e0, stream) != hipSuccess) {
+    if (hipEventCreate(&t->e0) != hipSuccess) {
+        delete t;
+        return nullptr;
+    }
+    if (hipEventRecord(t->e0, stream) != hipSuccess) {
+        (void)hipEventDestroy(t->e0);
         delete t;
         return nullptr;
     }
@@ -1735,6 +1736,9 @@ void mpreid_prof_end(void *token, hipStream_t stream, int cls, int64_t m, int n,
         pc.ev.emplace_back(t->e0, e1);
         pc.m = std::max<int64_t>(pc.m, m);
         pc.flops_total += work;
+    } else {   // not filed: both events are ours to destroy
+        if (e1) (void)hipEventDestroy(e1);
+        (void)hipEventDestroy(t->e0);
     }
     delete t;
 }
@@ -1810,7 +1814,7 @@ static int launch_one(const GemmArgs &a_in, hipStream_t stream) {
                     HIP_TRY(hipDeviceGetAttribute(&cus_of[slot], hipDeviceAttributeMultiprocessorCount, dev));
                 big_cus = cus_of[slot];
             }
-            static const int stag_all = getenv("MPREID_GEMM_STAGGER_ALL") ? atoi(getenv("MPREID_GEMM_STAGGER_ALL")) : 0;
+            static const int stag_all = mpreid_tune("gemm_stagger_all", 0);
             GemmArgs a = a_in;
             if (stag_all > 0) {
                 a.stagger = stag_all;
@@ -2102,12 +2106,11 @@ __global__ __launch_bounds__(256) void split3_pack_kernel(const float *__restric
     }
 }
 
-// start stagger of the persistent distance GEMM (see GemmArgs::stagger); MPREID_GEMM_STAGGER overrides (ticks, 0 = off)
+// start stagger of the persistent distance GEMM (see GemmArgs::stagger); MPREID_TUNE gemm_stagger = ticks (default 0 = off)
 static int euclid_stagger_ticks(int M, int N, int K) {
-    static const char *e = getenv("MPREID_GEMM_STAGGER");
-    if (e) return atoi(e);
+    static const int ticks = mpreid_tune("gemm_stagger", 0);
     (void)M; (void)N; (void)K;
-    return 0;
+    return ticks;
 }
 
 size_t mpreid_distance_split3_ws_bytes(int64_t nq, int64_t ng, int d) {

@@ -67,8 +67,8 @@ struct JaccardPlan {
 };
 static JaccardPlan jaccard_plan(int64_t N) {   // N = number of INDEXED rows (the gallery rows)
     constexpr int B = 256;   // = CSC_B
-    static const int jwave = getenv("MPREID_JACCARD_WAVE") ? atoi(getenv("MPREID_JACCARD_WAVE")) : -1;
-    static const int jrows = getenv("MPREID_JACCARD_WAVE_ROWS") ? atoi(getenv("MPREID_JACCARD_WAVE_ROWS")) : 10240;
+    static const int jwave = mpreid_tune("jaccard_wave", -1);
+    static const int jrows = mpreid_tune("jaccard_wave_rows", 10240);
     JaccardPlan p;
     p.rpb = (int)((N + B - 1) / B);
     // 256-thread form: at most ~24 K rows per chunk (48 KB of accumulators: two workgroups per CU beside the tables)
@@ -2109,7 +2109,7 @@ __global__ __launch_bounds__(1024) void max_i32_kernel(const int *__restrict__ x
 // exact sub-ranges per row chunk); otherwise the round-1 atomic build.
 static int launch_csc(int64_t N, int64_t nq, const int *fcnt, const int *fidx, const uint16_t *fval, int qcap, unsigned *ccnt,
                       unsigned *chist, long long *cptr, int *crow, uint16_t *cval, hipStream_t stream, bool *blocked) {
-    static const bool csc_atomic = getenv("MPREID_CSC_ATOMIC") != nullptr;   // A/B switch: the round-1 atomic build
+    static const bool csc_atomic = mpreid_tune("csc_atomic", 0) != 0;   // A/B switch: the round-1 atomic build
     const bool blocked_csc = chist && !csc_atomic && (uint64_t)N * (uint64_t)qcap < (1ull << 32);
     *blocked = blocked_csc;
     const int64_t M = N - nq;   // indexed rows
@@ -2180,7 +2180,7 @@ static int launch_jaccard(int64_t N, int64_t nq, int q0, int64_t qrows, const fl
     // (multi-wave form, N = 20 000 / Market shape: 512 threads <2, 4> 1.58 / 1.42 ms, 256 threads <3, 4> 1.36 / 1.21,
     // <3, 8> the same, <2, 4> 2.05 (columns longer than 512 entries take the direct path), 128 threads <5, 4> 1.72 / 1.50)
     // blocked index = packed entries (csc2_fill_kernel); the atomic build keeps (row, value) in two arrays
-    static const int jtab = getenv("MPREID_JACCARD_TABLE") ? atoi(getenv("MPREID_JACCARD_TABLE")) : 0;   // A/B: LDS table form
+    static const int jtab = mpreid_tune("jaccard_table", 0);   // A/B: LDS table form
     const size_t wl = align_up((size_t)rch * 2 + 16, 16);   // table-free kernels: the accumulators only
     if (threads == 64 && !jtab) {
         int rc = set_dyn_lds(jaccard_wave_kernel<64, 2, 8>, wl);
@@ -2682,7 +2682,7 @@ static int rerank_sparse(const float *q, const float *g, int64_t nq, int64_t ng,
         return mpreid_distance_launch(feat + (size_t)q0 * d, feat + (size_t)nq * d, rows, N - nq, d, sqn + q0, sqn + nq,
                                       dq + (size_t)q0 * L.ld + nq, L.ld, 0, s);
     };
-    // Overlap of the fp32 matrix work with the rest (MPREID_RERANK_OVERLAP = 0 / 1 forces it off / on): one launch on
+    // Overlap of the fp32 matrix work with the rest (MPREID_TUNE rerank_overlap = 0 / 1 forces it off / on): one launch on
     // the side stream, forked AFTER the fused GEMM (a persistent kernel that owns every CU's LDS: forked before it, the
     // two GEMMs only take turns).  Nearly zero-sum wherever it was measured: N = 20 000 6.06 vs 6.04 ms, N = 100 000
     // 87.7 -> 86.2 ms, MSMT17 shape 77.7 -> 76.7 ms (on by default only from N = 50 000).  Also measured at N = 100 000
@@ -2690,8 +2690,8 @@ static int rerank_sparse(const float *q, const float *g, int64_t nq, int64_t ng,
     // beside the rows of block b + 1 -- 87.0 ms as launched (the GEMM's workgroups take every slot that frees up and
     // the partner starves), 90.2 ms against 90.7 in line with the GEMM made persistent at two workgroups per CU so that
     // both kernels are resident (both then run at half speed: they share each CU's load path and LDS).
-    static const char *ov_env = getenv("MPREID_RERANK_OVERLAP");
-    const int ov_mode = ov_env ? (atoi(ov_env) != 0) : (N < 50000 ? 0 : 1);
+    static const int ov_tune = mpreid_tune("rerank_overlap", -1);
+    const int ov_mode = ov_tune >= 0 ? (ov_tune != 0) : (N < 50000 ? 0 : 1);
     const bool no_overlap = ov_mode == 0;
     SideStream *ss = nullptr;
     if (ov_mode != 0) {

@@ -967,7 +967,7 @@ static int launch_attention(const _Float16 *qkv, int B, int L, int W, int heads,
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
                 &occ, reinterpret_cast<const void *>(attention_kernel<KTP, NW, EXACT>), 64 * NW, lds));
             blocks_per_cu_dev[slot] = occ > 0 ? occ : 1;
-            if (getenv("MPREID_DEBUG"))
+            if (mpreid_tune("verbose", 0))
                 fprintf(stderr, "[mpreid] attention<%d,%d> on device %d: %d workgroups/CU by the occupancy API (lds %zu B, %d threads)\n",
                         KTP, NW, dev, occ, lds, 64 * NW);
         }
@@ -1140,7 +1140,7 @@ static int vit_forward_impl(const mpreid_vit_cfg *cfg, const mpreid_vit_weights 
         const bool tail = cls_last && (l == cfg->layers - 1);
         GemmArgs g{};
         // x = x + out_proj(attn(ln_1(x)))
-        void *ptok = mpreid_prof_begin(stream);
+        void *ptok = fold ? nullptr : mpreid_prof_begin(stream);   // folded mode: no LayerNorm launch, nothing to file
         if (fold) {
             // (xp / st hold the pairs and statistics of x: from pair_stats_kernel or the previous block's last epilogue)
         } else if (split)

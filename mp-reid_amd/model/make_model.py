@@ -106,11 +106,28 @@ class build_transformer(nn.Module):
                       self._modules[n].running_var) for n in ("bottleneck", "bottleneck_proj")}
         kw = {} if ws_tag is None else {"ws_tag": ws_tag}
         if self.model_name == 'RN50':
-            # RN50 has two modes: 'fp32' (parity) and the fp16 tower ('fp16'; also what 'split' -- a ViT mode -- selects)
-            return _ops.Rn50Encoder(self.rn_cfg, sd, self.img_hw, neck_after=neck_after, bn=bn,
-                                    precision="fp32" if self.precision == "fp32" else "fp16", **kw)
+            # RN50 has two modes: 'fp32' (parity-grade, 4.7e-6 from the reference's features) and the fp16 tower ('fp16':
+            # 11x faster, 2.6e-3).  'split' -- the default, a ViT mode -- means "parity-grade" and selects 'fp32' here, so
+            # that a default-config RN50 run meets the same bound as a default ViT run; the fast tower must be asked for.
+            prec = "fp16" if self.precision == "fp16" else "fp32"
+            if self.precision == "split":
+                import logging
+                logging.getLogger("transreid.test").info(
+                    "MODEL.NAME RN50 has no split-precision tower: ENCODER_PRECISION 'split' runs the all-fp32 tower "
+                    "(parity-grade); set MODEL.ENCODER_PRECISION fp16 for the fast fp16 tower (feature error 2.6e-3)")
+            return _ops.Rn50Encoder(self.rn_cfg, sd, self.img_hw, neck_after=neck_after, bn=bn, precision=prec, **kw)
         return _ops.VitEncoder(self.vit_cfg, sd, self.img_hw, neck_after=neck_after, bn=bn, precision=self.precision,
                                ln_fold=self.ln_fold, **kw)
+
+    @property
+    def encode_group(self):
+        """images per encoder call that fill the chip without a ragged last round: the persistent GEMMs walk 256-row tiles on
+        256 CUs, so the largest batch whose token rows fit 256 * 256 (508 images of 129 tokens); 256 images for RN50
+        (processor.do_inference groups the loader's batches to this size)"""
+        if self.model_name == 'RN50':
+            return 256
+        tokens = self.h_resolution * self.w_resolution + 1
+        return max(64, 65536 // tokens)
 
     def _get_encoder(self):
         if self._encoder is None:
@@ -139,7 +156,7 @@ class build_transformer(nn.Module):
         list of decoded uint8 [h,w,3] images (Resize, ToTensor and Normalize run on the GPU with INPUT.PIXEL_MEAN /
         PIXEL_STD).  view: a test-time-augmentation view id (mpreid.ops.VIEW_*)."""
         enc = self._get_encoder()
-        if isinstance(x, (list, tuple)):
+        if isinstance(x, (list, tuple, _ops.PackedRawImages)):
             x = _ops.resize_bilinear_u8(x, self.img_hw)
         if self.model_name == 'RN50':
             if view != 0:

@@ -51,7 +51,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
     stamp = os.path.join(OBJ, "flags.txt")
     flags_now = " ".join(FLAGS) + " | " + repr(sorted(EXTRA_FLAGS.items()))
     if not os.path.exists(stamp) or open(stamp).read() != flags_now:
+        # a different (or unknown) flag set: no object of the old set may be linked.  The objects and the stamp are
+        # removed BEFORE anything is compiled, so an interrupted build leaves no stamp and the next one starts over.
         force = True
+        for f in os.listdir(OBJ):
+            if f.endswith(".o") or f == "flags.txt":
+                os.remove(os.path.join(OBJ, f))
     jobs = []
     objs = []
     for src in SOURCES:
@@ -76,7 +81,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 print(warn, file=sys.stderr)
     if force or jobs or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-    with open(stamp, "w") as fh:
+    with open(stamp, "w") as fh:   # only a complete object set of ONE flag set is ever stamped (git-ignored: csrc/_obj/)
         fh.write(flags_now)
     return LIB
 

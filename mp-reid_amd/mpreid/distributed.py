@@ -135,15 +135,28 @@ def _gather_blocks_to_host(block: torch.Tensor, dim: int, dst: int, reuse_buffer
     dist.gather(pad, parts, dst=dst)
     if rank != dst:
         return None
+    return _concat_parts_to_host(parts, sizes, dim, block.shape[other], reuse_buffer)
+
+
+def _concat_parts_to_host(parts, sizes, dim: int, other_len: int, reuse_buffer: bool = False):
+    """the gathered (padded) pieces -> ONE page-locked host matrix.  Device pieces are first laid side by side in one
+    contiguous DEVICE matrix (a strided D2D copy per piece, HBM speed) so that a single contiguous D2H copy lands in the
+    pinned matrix: a non_blocking copy_ into a strided view of a CPU tensor would make torch allocate a pageable
+    temporary per piece and finish with a CPU-to-CPU copy (the ragged column-block case, dim = 1)."""
     total = sum(sizes)
-    host = _pinned_matrix(block.shape[other] if dim == 1 else total, total if dim == 1 else block.shape[other],
-                          block.dtype, f"cat{dim}")
+    dtype = parts[0].dtype
+    rows, cols = (other_len, total) if dim == 1 else (total, other_len)
+    host = _pinned_matrix(rows, cols, dtype, f"cat{dim}")
+    on_dev = parts[0].is_cuda
+    dst = torch.empty((rows, cols), dtype=dtype, device=parts[0].device) if on_dev else host
     lo = 0
     for p, n in zip(parts, sizes):
         if n:
-            host.narrow(dim, lo, n).copy_(p.narrow(dim, 0, n), non_blocking=p.is_cuda)
+            dst.narrow(dim, lo, n).copy_(p.narrow(dim, 0, n))
         lo += n
-    if not staged and block.is_cuda:
+    if on_dev:
+        assert dst.is_contiguous() and host.is_contiguous()
+        host.copy_(dst, non_blocking=True)
         torch.cuda.current_stream().synchronize()
     return host.numpy() if reuse_buffer else host.numpy().copy()
 

@@ -18,8 +18,10 @@ _ws_cache: Dict[tuple, torch.Tensor] = {}
 
 
 def _workspace(tag: str, nbytes: int, device) -> torch.Tensor:
-    """Grow-only cached byte buffer per (device, tag); the caller owns nothing."""
-    key = (str(device), tag)
+    """Grow-only cached byte buffer per (device, tag, current stream); the caller owns nothing.  The stream is part of
+    the key: a workspace is scratch memory of ONE in-flight call, and calls issued on different streams may overlap on
+    the device (processor.do_inference alternates its encoder calls over two streams)."""
+    key = (str(device), tag, int(torch.cuda.current_stream(device).cuda_stream))
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         if buf is not None:
@@ -198,35 +200,57 @@ class _HostStager:
 _stager = _HostStager()
 
 
-def resize_bilinear_u8(images, out_hw) -> torch.Tensor:
-    """T.Resize(cfg.INPUT.SIZE_TEST) of val_transforms (datasets/make_dataloader.py:57-58) on the GPU, bit-exact with
-    PIL.Image.resize(BILINEAR): images = sequence of uint8 [h, w, 3] arrays / tensors of any sizes (decoded RGB);
-    returns uint8 [B, out_h, out_w, 3] on the device -- the input of VitEncoder.forward_u8.  One H2D copy of the packed
-    bytes (pinned staging), two kernels."""
-    dev = _lib.require_gpu()
-    L = _lib.load()
+def raw_image_layout(images):
+    """(contiguous uint8 [h, w, 3] arrays, hw int32 [B, 2], byte offsets int64 [B], total bytes) of a sequence of decoded
+    RGB images laid back to back"""
     arrs = [np.ascontiguousarray(im.cpu().numpy() if isinstance(im, torch.Tensor) else im, dtype=np.uint8) for im in images]
-    B = len(arrs)
-    assert B > 0 and all(a.ndim == 3 and a.shape[2] == 3 for a in arrs)
+    assert len(arrs) > 0 and all(a.ndim == 3 and a.shape[2] == 3 for a in arrs)
     hw = np.array([a.shape[:2] for a in arrs], dtype=np.int32)
     sizes = hw[:, 0].astype(np.int64) * hw[:, 1] * 3
-    offsets = np.zeros(B, np.int64)
+    offsets = np.zeros(len(arrs), np.int64)
     offsets[1:] = np.cumsum(sizes)[:-1]
-    packed, slot = _stager.stage(int(sizes.sum()))
-    pk = packed.numpy()
-    for a, o, n in zip(arrs, offsets, sizes):
-        pk[o:o + n] = a.reshape(-1)
+    return arrs, hw, offsets, int(sizes.sum())
+
+
+class PackedRawImages:
+    """A batch of decoded uint8 RGB images of ragged sizes ALREADY on the device, packed back to back: data uint8 [bytes],
+    offsets int64 [B], hw int32 [B, 2] (device tensors), max_h = tallest image.  What mpreid.pipeline uploads for a
+    RawImageBatch loader; ``resize_packed_u8`` turns it into the uint8 [B, H, W, 3] input of forward_u8."""
+
+    def __init__(self, data, offsets, hw, count, max_h):
+        self.data, self.offsets, self.hw, self.count, self.max_h = data, offsets, hw, int(count), int(max_h)
+
+    def __len__(self):
+        return self.count
+
+
+def resize_packed_u8(packed: PackedRawImages, out_hw) -> torch.Tensor:
+    """the two resize kernels on images that are already packed in device memory (no host work, no copy)"""
+    dev = _lib.require_gpu()
+    L = _lib.load()
+    B, oh, ow = packed.count, int(out_hw[0]), int(out_hw[1])
+    dst = torch.empty((B, oh, ow, 3), dtype=torch.uint8, device=dev)
+    ws = _workspace("resize", L.mpreid_resize_workspace_bytes(B, packed.max_h, ow), dev)
+    _lib.check(L.mpreid_resize_bilinear_u8(_ptr(packed.data), _ptr(packed.offsets), _ptr(packed.hw), B, packed.max_h, oh, ow,
+                                           _ptr(dst), _ptr(ws), ws.numel(), _lib.stream_ptr()), "mpreid_resize_bilinear_u8")
+    return dst
+
+
+def resize_bilinear_u8(images, out_hw) -> torch.Tensor:
+    """T.Resize(cfg.INPUT.SIZE_TEST) of val_transforms (datasets/make_dataloader.py:57-58) on the GPU, bit-exact with
+    PIL.Image.resize(BILINEAR): images = sequence of uint8 [h, w, 3] arrays / tensors of any sizes (decoded RGB), or a
+    PackedRawImages; returns uint8 [B, out_h, out_w, 3] on the device -- the input of VitEncoder.forward_u8.  One H2D
+    copy of the packed bytes (pinned staging), two kernels."""
+    if isinstance(images, PackedRawImages):
+        return resize_packed_u8(images, out_hw)
+    dev = _lib.require_gpu()
+    arrs, hw, offsets, total = raw_image_layout(images)
+    packed, slot = _stager.stage(total)
+    np.concatenate([a.reshape(-1) for a in arrs], out=packed.numpy())
     src = packed.to(dev, non_blocking=True)
     _stager.copied(slot)
-    offs_d = torch.from_numpy(offsets).to(dev)
-    hw_d = torch.from_numpy(hw).to(dev)
-    oh, ow = int(out_hw[0]), int(out_hw[1])
-    max_h = int(hw[:, 0].max())
-    dst = torch.empty((B, oh, ow, 3), dtype=torch.uint8, device=dev)
-    ws = _workspace("resize", L.mpreid_resize_workspace_bytes(B, max_h, ow), dev)
-    _lib.check(L.mpreid_resize_bilinear_u8(_ptr(src), _ptr(offs_d), _ptr(hw_d), B, max_h, oh, ow, _ptr(dst), _ptr(ws),
-                                           ws.numel(), _lib.stream_ptr()), "mpreid_resize_bilinear_u8")
-    return dst
+    return resize_packed_u8(PackedRawImages(src, torch.from_numpy(offsets).to(dev), torch.from_numpy(hw).to(dev),
+                                            len(arrs), int(hw[:, 0].max())), out_hw)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -241,9 +265,9 @@ class VitEncoder:
     """
 
     def __init__(self, cfg: dict, state_dict: dict, img_hw, neck_after: bool = False, bn: Optional[dict] = None,
-                 device=None, cls_only_last: bool = True, ws_tag: str = "vit", precision: str = "fp16",
+                 device=None, cls_only_last: bool = True, ws_tag: str = "vit", precision: str = "split",
                  ln_fold: bool = False):
-        """precision: 'split' = every GEMM operand an fp16 pair hi + lo, products hi.hi' + lo.hi' + hi.lo' on the fp16
+        """precision: 'split' (default: the parity-grade mode, as in config/node.py and bench.py) = every GEMM operand an fp16 pair hi + lo, products hi.hi' + lo.hi' + hi.lo' on the fp16
         matrix cores with fp32 accumulation -- fp32-grade features (~1e-6) at 3x the matrix work: the mode that meets
         the 1e-4 mAP bound AND is the measured one; 'fp16' = fp16 operands, fp32 accumulate / residual stream (fastest,
         relative feature error ~4e-4: misses the bound on hard data); 'fp32' = every weight and activation fp32, exact

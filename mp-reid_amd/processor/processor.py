@@ -10,10 +10,12 @@ all-gather of the query features, per-shard distance blocks, sharded ranking sta
 Every rank returns the same (Rank-1, Rank-5); rank 0 logs the results.
 """
 import logging
+import os
 
 import torch
 
 from mpreid import distributed as _D
+from mpreid.pipeline import EncodePipeline
 from utils.metrics import R1_mAP_eval
 
 
@@ -78,11 +80,12 @@ def shard_val_loader(val_loader, num_query, n_total=None):
     return _ShardedLoader(val_loader, list(range(q_lo, q_hi)) + list(range(num_query + g_lo, num_query + g_hi)))
 
 
-#: images encoded per model call.  The reference encodes one loader batch (TEST.IMS_PER_BATCH = 64 in every shipped
-#: YAML) at a time; the persistent GEMMs want ~65 000 token rows to fill 256 CUs without a ragged last round
-#: (22 k images/s at 64 per call, 36 k at 512), and a feature row does not depend on which images share its batch
-#: (tests/test_gpu_vit.py: bit for bit), so consecutive loader batches are encoded together and handed to the
-#: evaluator one loader batch at a time, exactly as before.
+#: images encoded per model call when the model does not say (``model.encode_group``).  The reference encodes one
+#: loader batch (TEST.IMS_PER_BATCH = 64 in every shipped YAML) at a time; the persistent GEMMs want ~65 000 token rows
+#: to fill 256 CUs without a ragged last round (22 k images/s at 64 per call, 36 k at 512), and a feature row does not
+#: depend on which images share its batch (tests/test_gpu_vit.py: bit for bit), so consecutive loader batches are
+#: encoded together -- cut at group boundaries, not batch boundaries -- and handed to the evaluator one loader batch at
+#: a time, exactly as before.
 ENCODE_GROUP = 512
 
 
@@ -118,6 +121,14 @@ def do_inference(cfg, model, val_loader, num_query):
 
     reranking = bool(getattr(cfg.TEST, "RE_RANKING", False))  # upstream defines the key but never reads it
     evaluator = R1_mAP_eval(num_query, max_rank=50, feat_norm=cfg.TEST.FEAT_NORM, reranking=reranking)
+    # TEST.DISTANCE_MODE / TEST.RERANK_ALGO (not reference keys): arithmetic of the distance matrix -- 'exact' (default: the
+    # bit-parity fp32 chain), 'split3' (fp16 matrix cores, |err| <= 1e-6), 'f16' (one pass, ~1e-4) -- and of the re-ranking
+    # ('exact' | 'split3': blend-term distance rows from the fp16 matrix cores, ranks identical, outputs within 1e-6)
+    from mpreid import ops as _ops
+    evaluator.distance_mode = {"exact": _ops.GEMM_F32_EXACT, "split3": _ops.GEMM_F16_SPLIT3, "f16": _ops.GEMM_F16_FAST}[
+        str(getattr(cfg.TEST, "DISTANCE_MODE", "exact"))]
+    evaluator.rerank_algo = {"exact": _ops.RERANK_AUTO, "split3": _ops.RERANK_SPARSE_SPLIT3}[
+        str(getattr(cfg.TEST, "RERANK_ALGO", "exact"))]
     evaluator.reset()
 
     model.to(device)
@@ -127,19 +138,22 @@ def do_inference(cfg, model, val_loader, num_query):
     if world > 1:
         logger.info("rank {} of {}: encoding 1/{} of the queries and its gallery shard".format(rank, world, world))
         val_loader = shard_val_loader(val_loader, num_query)
-    for group in grouped_batches(val_loader, ENCODE_GROUP):
-        with torch.no_grad():
-            img, camids, target_view = merge_batches(group, device)
-            camids = camids if cfg.MODEL.SIE_CAMERA else None
-            target_view = target_view if cfg.MODEL.SIE_VIEW else None
-            feat = model(img, cam_label=camids, view_label=target_view)
-            lo = 0
-            for (_, pid, camid, _, _, imgpath) in group:      # the evaluator sees the loader's own batches
-                evaluator.update((feat[lo:lo + len(pid)], pid, camid))
-                img_path_list.extend(imgpath)
-                lo += len(pid)
+    # the reference's loop body (`img = img.to(device); feat = model(img, ...); evaluator.update(...)`, :187-198) as a
+    # pipeline: a stager thread drains the loader into pinned group buffers and uploads them on a copy stream while
+    # earlier groups are encoded on two alternating streams (mpreid/pipeline.py); the evaluator sees the loader's own
+    # batches, in order.  MPREID_PIPELINE="stage=direct,streams=1,slots=4" overrides the defaults (measurements).
+    opts = dict(kv.split("=", 1) for kv in os.environ.get("MPREID_PIPELINE", "").split(",") if "=" in kv)
+    pipe = EncodePipeline(model, group=int(opts.get("group", getattr(model, "encode_group", ENCODE_GROUP))),
+                          sie_camera=bool(cfg.MODEL.SIE_CAMERA), sie_view=bool(cfg.MODEL.SIE_VIEW),
+                          streams=int(opts.get("streams", 2)), slots=int(opts.get("slots", 3)),
+                          stage=opts.get("stage", "pinned"))
+    for feat, (_, pid, camid, _, _, imgpath) in pipe.run(val_loader):
+        evaluator.update((feat, pid, camid))
+        img_path_list.extend(imgpath)
+    do_inference.last_pipeline_stats = pipe.stats
 
     cmc, mAP, _, _, _, _, _ = evaluator.compute()
+    do_inference.last_evaluator = evaluator   # (measurements: bench.py times compute() again on the same features)
     if rank == 0:
         logger.info("Validation Results ")
         logger.info("mAP: {:.1%}".format(mAP))

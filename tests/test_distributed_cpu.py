@@ -168,3 +168,24 @@ def test_rank_launcher_terminates_survivors_when_a_rank_dies(tmp_path):
     ok.write_text("import os\nprint('rank', os.environ['RANK'], os.environ['MASTER_ADDR'])\n")
     outs = run_ranks([sys.executable, str(ok)], 2, 60, capture_dir=tmp_path)
     assert [o.strip() for o in outs] == ["rank 0 127.0.0.1", "rank 1 127.0.0.1"]
+
+
+def _ragged_parts(dim, device):
+    import torch
+    sizes = [5, 0, 3, 4]
+    other = 7
+    mx = max(sizes)
+    g = torch.Generator().manual_seed(3)
+    shape = (other, mx) if dim == 1 else (mx, other)
+    parts = [torch.randn(shape, generator=g).to(device) for _ in sizes]
+    want = np.concatenate([p.cpu().numpy()[:, :n] if dim == 1 else p.cpu().numpy()[:n] for p, n in zip(parts, sizes)], axis=dim)
+    return parts, sizes, other, want
+
+
+@pytest.mark.parametrize("dim", [0, 1])
+def test_concat_parts_to_host_ragged_cpu(dim):
+    """the host concatenation of padded ragged pieces (mpreid.distributed._concat_parts_to_host), host tensors"""
+    from mpreid import distributed as D
+    parts, sizes, other, want = _ragged_parts(dim, "cpu")
+    got = D._concat_parts_to_host(parts, sizes, dim, other)
+    assert got.shape == want.shape and np.array_equal(got, want)

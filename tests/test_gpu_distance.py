@@ -111,7 +111,7 @@ def test_gemm_f16_exact_integers(ops):
 
 @pytest.mark.parametrize("m,n,k", [(256, 256, 64), (512, 768, 192), (1024, 512, 768), (256, 1024, 3072)])
 def test_gemm_f16_big_kernel_exact_integers(m, n, k):
-    """the 256x256 ring-pipelined kernel (forced with MPREID_GEMM_BIG=2 in a child process)"""
+    """the 256x256 ring-pipelined kernel (forced with MPREID_TUNE=gemm_big=2 in a child process)"""
     import os, subprocess, sys, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = textwrap.dedent(f"""
@@ -127,7 +127,7 @@ def test_gemm_f16_big_kernel_exact_integers(m, n, k):
             assert np.array_equal(c, a @ b.T), np.abs(c - a @ b.T).max()
         print("ok")
     """)
-    env = dict(os.environ, MPREID_GEMM_BIG="2")
+    env = dict(os.environ, MPREID_TUNE="gemm_big=2")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
@@ -175,7 +175,7 @@ def test_gemm_kernels_agree_across_variants(epi):
     outs = []
     for mode in ("0", "2", "3"):
         path = f"/tmp/gemm_variant_{epi}_{mode}.npy"
-        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, MPREID_GEMM_BIG=mode),
+        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, MPREID_TUNE="gemm_big=" + mode),
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
         outs.append(np.load(path))
@@ -244,7 +244,7 @@ def test_split3_gives_the_oracles_neighbour_tables_on_the_goldens(ops, golden, c
 
 def test_stored_distance_kernels_bit_identical():
     """the persistent 256 x 256 kernel's stored-distance path (paired DMA, early prologue with store-tolerant waits,
-    interior-tile fast epilogue + the general one on ragged edges) against the 128 x 128 kernel (MPREID_GEMM_BIG=0, latched
+    interior-tile fast epilogue + the general one on ragged edges) against the 128 x 128 kernel (MPREID_TUNE=gemm_big=0, latched
     per process: child processes): same k order inside every accumulator => the outputs must agree bit for bit.  Shapes:
     Market-1501 (ragged rows and columns), K = 128 and K = 64 (pipelines shorter than the early-prologue threshold), the
     3-term split (row / column scales, K = 3 d), a single tile row, and a 20k-class square"""
@@ -272,7 +272,7 @@ def test_stored_distance_kernels_bit_identical():
     """)
     outs = []
     for big in ("0", "2"):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MPREID_GEMM_BIG=big), capture_output=True,
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MPREID_TUNE="gemm_big=" + big), capture_output=True,
                            text=True, timeout=900)
         assert r.returncode == 0, r.stdout + r.stderr
         outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("HASHES ")][0].split()[1:])

@@ -245,3 +245,17 @@ def test_sharded_evaluator_on_the_rccl_backend_one_rank(tmp_path):
         assert np.array_equal(got[f"cmc{ci}"], cmc) and float(got[f"map{ci}"]) == float(mAP), ci
         assert np.array_equal(got[f"dist{ci}"], distmat), ci
         assert np.array_equal(got[f"qf{ci}"], qf.numpy()) and np.array_equal(got[f"gf{ci}"], gf.numpy()), ci
+
+
+@pytest.mark.parametrize("dim", [0, 1])
+def test_concat_parts_to_host_ragged_device_pieces(dim):
+    """what rank 0 does with the pieces an RCCL gather delivered: ragged, padded DEVICE tensors -> one contiguous device
+    matrix -> ONE contiguous D2H copy into the pinned host matrix (dim = 1 used to copy into strided host views)"""
+    import torch
+    from mpreid import distributed as D
+    from test_distributed_cpu import _ragged_parts
+    parts, sizes, other, want = _ragged_parts(dim, torch.device("cuda", 0))
+    got = D._concat_parts_to_host(parts, sizes, dim, other)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    view = D._concat_parts_to_host(parts, sizes, dim, other, reuse_buffer=True)
+    assert np.array_equal(view, want)

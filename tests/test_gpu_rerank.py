@@ -300,12 +300,12 @@ np.savez(sys.argv[1], **res)
 
 
 @pytest.mark.parametrize("env", [
-    {"MPREID_JACCARD_WAVE": "1", "MPREID_JACCARD_WAVE_ROWS": "1024"},   # one-wave Jaccard form, 3-4 row chunks
-    {"MPREID_JACCARD_WAVE": "1", "MPREID_JACCARD_WAVE_ROWS": "256"},    # ... 12-16 chunks of ~250 rows
-    {"MPREID_JACCARD_WAVE": "1", "MPREID_JACCARD_WAVE_ROWS": "512", "MPREID_JACCARD_TABLE": "1"},   # ... with the LDS table
-    {"MPREID_JACCARD_WAVE": "0"},                                         # 256-thread form
-    {"MPREID_CSC_ATOMIC": "1"},                                           # round-1 atomic inverted index + unchunked Jaccard
-    {"MPREID_RERANK_OVERLAP": "1"},                                       # exact query rows on the side stream
+    {"MPREID_TUNE": "jaccard_wave=1,jaccard_wave_rows=1024"},   # one-wave Jaccard form, 3-4 row chunks
+    {"MPREID_TUNE": "jaccard_wave=1,jaccard_wave_rows=256"},    # ... 12-16 chunks of ~250 rows
+    {"MPREID_TUNE": "jaccard_wave=1,jaccard_wave_rows=512,jaccard_table=1"},   # ... with the LDS table
+    {"MPREID_TUNE": "jaccard_wave=0"},                                         # 256-thread form
+    {"MPREID_TUNE": "csc_atomic=1"},                                           # round-1 atomic inverted index + unchunked Jaccard
+    {"MPREID_TUNE": "rerank_overlap=1"},                                       # exact query rows on the side stream
 ])
 def test_rerank_kernel_forms_against_oracle(tmp_path, env):
     """The large-N forms of the Jaccard stage (and the A/B switches of the inverted index / the side stream) are
@@ -412,7 +412,7 @@ def test_sparse_rerank_concurrent_streams(tmp_path, overlap):
     cases = [(4100, 700, 128, 50, 15), (3300, 500, 256, 20, 6)]
     script = tmp_path / "cw.py"
     script.write_text(_CONCURRENT_WORKER.format(root=root, cases=cases))
-    r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, MPREID_RERANK_OVERLAP=overlap), capture_output=True,
+    r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, MPREID_TUNE="rerank_overlap=" + overlap), capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0 and "CONCURRENT OK" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
 

@@ -24,6 +24,7 @@ def _close(got, want, rel=4e-3, mx=3e-2):
 
 def _encoder(cfg, sd, hw, **kw):
     from mpreid.ops import VitEncoder
+    kw.setdefault("precision", "fp16")   # these tests pin the fp16-operand mode unless they name another (VitEncoder's default is 'split')
     return VitEncoder(cfg, sd, hw, **kw)
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """feat x feat^T distance GEMM timings (north_star: 20k x 20k x 768): exact fp32 MFMA, one-pass fp16, 3-term split.
-Usage: python tools/distgemm_bench.py [nq ng d] ; MPREID_GEMM_STAGGER=<ticks> to try the start stagger."""
+Usage: python tools/distgemm_bench.py [nq ng d] ; MPREID_TUNE=gemm_stagger=<ticks> to try the start stagger."""
 import os
 import sys
 
@@ -34,4 +34,4 @@ for name in modes:
         best = min(best, e0.elapsed_time(e1) / 3)
     mult = 3 if name == "split3" else 1
     print(f"{name:6s} {nq}x{ng}x{d}: {best:.4f} ms  algorithmic {flop/best/1e9:.1f} TF  executed {mult*flop/best/1e9:.1f} TF  "
-          f"store {4.0*nq*ng/best/1e6:.0f} GB/s  stagger={os.environ.get('MPREID_GEMM_STAGGER','0')}", flush=True)
+          f"store {4.0*nq*ng/best/1e6:.0f} GB/s  tune={os.environ.get('MPREID_TUNE','')}", flush=True)

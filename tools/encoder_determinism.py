@@ -39,7 +39,7 @@ def main():
     base = torch.from_numpy(synth.synthetic_images(64, 256, 128, seed=3)).cuda()
     img = base.repeat(8, 1, 1, 1)[:508].contiguous()
     sd = synth.vit_state_dict(synth.VIT_B16, seed=7)
-    bad = check("ViT-B/16 fp16 mode, batch 508", lambda t: ops.VitEncoder(synth.VIT_B16, sd, (256, 128), ws_tag="det_" + t), img, a.reps)
+    bad = check("ViT-B/16 fp16 mode, batch 508", lambda t: ops.VitEncoder(synth.VIT_B16, sd, (256, 128), ws_tag="det_" + t, precision="fp16"), img, a.reps)
     bad += check("ViT-B/16 split mode (default), batch 508",
                  lambda t: ops.VitEncoder(synth.VIT_B16, sd, (256, 128), ws_tag="dets_" + t, precision="split"), img, a.reps)
     bad += check("ViT-B/16 split mode with folded LayerNorm, batch 508",

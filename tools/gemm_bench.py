@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GEMM micro-benchmark on random data: the encoder's GEMM shapes through the C ABI
-(mpreid_gemm_f16_nt_ex), interleaved rounds in one process.  MPREID_GEMM_BIG=0/1/2 selects the
+(mpreid_gemm_f16_nt_ex), interleaved rounds in one process.  MPREID_TUNE=gemm_big=0/1/2 selects the
 kernel.  Usage: python tools/gemm_bench.py [--m 65536] [--reps 20] [--only fc1]"""
 import argparse
 import ctypes as C
@@ -71,7 +71,7 @@ def main():
         _, _, _, _, N, K, epi = bufs[n]
         ms = sorted(res[n])[len(res[n]) // 2]
         mult = 3.0 if epi >= 10 else 1.0   # executed products per logical multiply-add
-        print(f"{n:4s} M={a.m} N={N} K={K} epi={epi} big={os.environ.get('MPREID_GEMM_BIG', '1')}: {ms*1e3:8.1f} us  "
+        print(f"{n:4s} M={a.m} N={N} K={K} epi={epi} tune={os.environ.get('MPREID_TUNE', '')}: {ms*1e3:8.1f} us  "
               f"{mult*2.0*a.m*N*K/ms/1e9:7.1f} TFLOP/s executed (min {mult*2.0*a.m*N*K/min(res[n])/1e9:.1f})")
 
 

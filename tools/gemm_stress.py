@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Race screen for the persistent GEMM's epilogues (counted-vmcnt LDS queues, ring reuse across tiles): the big
 kernel is run many times per shape -- alone and with a second stream hammering HBM beside it -- and every FULL result
-is compared bit for bit with the 128x128 kernel's (computed by a child process under MPREID_GEMM_BIG=0: the kernel
+is compared bit for bit with the 128x128 kernel's (computed by a child process under MPREID_TUNE=gemm_big=0: the kernel
 choice is latched per process).  Usage: python tools/gemm_stress.py [--iters 40]"""
 import argparse
 import ctypes as C
@@ -63,7 +63,7 @@ def main():
     L = _lib.load()
     dev = _lib.require_gpu()
     if a.ref_dir:   # child: reference outputs with the 128x128 kernel only
-        assert os.environ.get("MPREID_GEMM_BIG") == "0"
+        assert os.environ.get("MPREID_TUNE") == "gemm_big=0"
         for name, N, K, epi in SHAPES:
             for Mb in MS:
                 A, W, bias, init = inputs(name, N, K, epi, Mb, dev)
@@ -71,10 +71,10 @@ def main():
                 torch.cuda.synchronize()
                 torch.save(init.cpu(), os.path.join(a.ref_dir, f"{name}_{Mb}.pt"))
         return
-    assert os.environ.get("MPREID_GEMM_BIG") == "2", "run with MPREID_GEMM_BIG=2"
+    assert os.environ.get("MPREID_TUNE") == "gemm_big=2", "run with MPREID_TUNE=gemm_big=2"
     tmp = tempfile.mkdtemp(prefix="gemm_stress_")
     subprocess.check_call([sys.executable, os.path.abspath(__file__), "--ref-dir", tmp],
-                          env=dict(os.environ, MPREID_GEMM_BIG="0"))
+                          env=dict(os.environ, MPREID_TUNE="gemm_big=0"))
     side = torch.cuda.Stream()
     noise_a = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
     noise_b = torch.empty_like(noise_a)

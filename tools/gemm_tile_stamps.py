@@ -15,7 +15,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "enc":
     # the encoder's GEMM classes instead (M = 65536): python tools/gemm_tile_stamps.py enc sqkv|sout|sfc1|sfc2|qkv|out|fc1|fc2
     import ctypes as C
     os.environ["MPREID_GEMM_DBG"] = "32"
-    os.environ["MPREID_GEMM_BIG"] = "2"
+    os.environ["MPREID_TUNE"] = "gemm_big=2"
     from mpreid import _lib
     L = _lib.load()
     dev = _lib.require_gpu()
