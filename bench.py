@@ -673,17 +673,8 @@ def run_rank(a):
     comm = {"bytes": 0, "ms": 0.0, "calls": 0}
 
     def gather_rows(x, n_total):
-        """all_gather_rows with its bytes and (event-timed) duration recorded"""
-        if world == 1:
-            return x
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        y = D.all_gather_rows(x, n_total)
-        e1.record()
-        comm["ev"] = comm.get("ev", []) + [(e0, e1)]
-        comm["bytes"] += y.numel() * y.element_size()
-        comm["calls"] += 1
-        return y
+        """(bytes and event-timed duration are recorded inside mpreid.distributed: D.comm_stats)"""
+        return D.all_gather_rows(x, n_total)
 
     nstreams = max(1, a.streams)
     div = 16 if a.small else 1
@@ -807,7 +798,8 @@ def run_rank(a):
     for _ in range(a.warmup):
         step()
     fence()
-    comm.update(bytes=0, calls=0, ev=[], host_ms=0.0)
+    comm.update(host_ms=0.0)
+    D.comm_stats_reset(timing=True)
     instrument_live = nstreams == 1 or enc is None   # event pairs on one stream also span other streams' kernels
     L.mpreid_profile_reset()
     if instrument_live:
@@ -818,8 +810,9 @@ def run_rank(a):
     fence()
     dt = time.perf_counter() - t0
     L.mpreid_profile_enable(0)
-    comm_ms = sum(e0.elapsed_time(e1) for e0, e1 in comm.get("ev", []))
-    comm_bytes, comm_calls = comm["bytes"], comm["calls"]
+    comm_ms = sum(e0.elapsed_time(e1) for e0, e1 in D.comm_stats["events"])
+    comm_bytes, comm_calls = D.comm_stats["bytes"], D.comm_stats["calls"]
+    D.comm_stats_reset()
     host_concat_ms = comm.get("host_ms", 0.0) / max(a.steps, 1)
     if not instrument_live:
         # roofline leg: one more pass of the same work on ONE stream with per-launch hipEvents

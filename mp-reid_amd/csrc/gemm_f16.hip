@@ -676,8 +676,11 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
         }
         m0 = tm * BBM;
         n0 = tn * BBN;
-        a_src = g.A + (int64_t)(m0 + wave * 32 + drow) * K + dchunk * 8;
-        b_src = g.W + (int64_t)(n0 + wave * 32 + drow) * K + dchunk * 8;
+        // (ablation DBG 64, wrong results: every tile reads operand panels 0-1 -- 2 x 2 panels stay resident in each XCD's
+        // L2, so nothing is fetched from beyond it: the upper bound of what a better tile order could win)
+        const int ma = (DBG == 64) ? (tm & 1) * BBM : m0, na = (DBG == 64) ? (tn & 1) * BBN : n0;
+        a_src = g.A + (int64_t)(ma + wave * 32 + drow) * K + dchunk * 8;
+        b_src = g.W + (int64_t)(na + wave * 32 + drow) * K + dchunk * 8;
     };
     auto dma_stage = [&](int st) {
         unsigned char *abase = smem + (st & (B_NSTAGE - 1)) * B_STAGE_BYTES + wave * 2048;
@@ -1826,7 +1829,11 @@ static int launch_one(const GemmArgs &a_in, hipStream_t stream) {
 #endif
             const dim3 grid(total_tiles < (unsigned)big_cus ? total_tiles : (unsigned)big_cus);
 #ifdef MPREID_ABLATION
-            if (dbg == 32 && EPI != GE_EUCLID && EPI != GE_BIAS_GELU) {   // per-tile phase stamps for any epilogue (tools/gemm_tile_stamps.py)
+            if (dbg == 64 && gemm_epi_is_split(EPI)) {   // operand panels aliased onto two (L2-resident): see set_tile
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_big_kernel<EPI, 64>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_TOTAL));
+                hipLaunchKernelGGL((gemm_f16_big_kernel<EPI, 64>), grid, dim3(512), B_LDS_TOTAL, stream, a, tiles_m, tiles_n);
+            } else if (dbg == 32 && EPI != GE_EUCLID && EPI != GE_BIAS_GELU) {   // per-tile phase stamps for any epilogue (tools/gemm_tile_stamps.py)
                 GemmArgs as = a;
                 const char *sp = getenv("MPREID_GEMM_STAMPS");
                 as.stamps = sp ? reinterpret_cast<unsigned long long *>(strtoull(sp, nullptr, 16)) : nullptr;

@@ -12,8 +12,11 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
-OBJ = os.path.join(CSRC, "_obj")
-LIB = os.path.join(HERE, "libmpreid_hip.so")
+# MPREID_BUILD_TAG=<tag>: a second build beside the product one (objects under csrc/_obj_<tag>/, library
+# libmpreid_hip_<tag>.so) -- e.g. the timing-ablation library for a same-device A/B through MPREID_LIB
+_TAG = os.environ.get("MPREID_BUILD_TAG", "")
+OBJ = os.path.join(CSRC, "_obj" + ("_" + _TAG if _TAG else ""))
+LIB = os.path.join(HERE, "libmpreid_hip" + ("_" + _TAG if _TAG else "") + ".so")
 SOURCES = ["api.cpp", "distance.hip", "rerank.hip", "gemm_f16.hip", "vit.hip", "evalrank.hip", "preprocess.hip", "conv_f16.hip", "rn50.hip", "rn50_f32.hip"]
 # -ffp-contract=off: the rounding sequence of the re-ranking path is part of the contract
 # (include/mpreid_numerics.h); fused multiply-adds are written as explicit fmaf().

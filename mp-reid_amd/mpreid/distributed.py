@@ -45,6 +45,15 @@ def shard_sizes(n: int, world: int) -> List[int]:
     return [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
 
 
+#: accounting of the row all-gathers (the data-path collective of the evaluation): bytes gathered per rank, calls and --
+#: while comm_stats["timing"] is set -- hipEvent pairs around each call on its launch stream (bench.py reads them)
+comm_stats = {"bytes": 0, "calls": 0, "events": [], "timing": False}
+
+
+def comm_stats_reset(timing: bool = False):
+    comm_stats.update(bytes=0, calls=0, events=[], timing=bool(timing))
+
+
 def all_gather_rows(x: torch.Tensor, n_total: int) -> torch.Tensor:
     """Concatenate the row shards of every rank (shard sizes from shard_sizes(n_total, world)).
     Ragged shards are padded to the largest one for the collective and trimmed afterwards."""
@@ -53,6 +62,20 @@ def all_gather_rows(x: torch.Tensor, n_total: int) -> torch.Tensor:
     if x.dtype == torch.int16:   # fp16 bit patterns: neither NCCL/RCCL nor gloo has a 16-bit integer type
         x2 = x.contiguous().view(torch.uint8)
         return all_gather_rows(x2, n_total).view(torch.int16)
+    timed = comm_stats["timing"] and x.is_cuda
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    out = _all_gather_rows(x, n_total)
+    if timed:
+        e1.record()
+        comm_stats["events"].append((e0, e1))
+    comm_stats["bytes"] += out.numel() * out.element_size()
+    comm_stats["calls"] += 1
+    return out
+
+
+def _all_gather_rows(x: torch.Tensor, n_total: int) -> torch.Tensor:
     world = dist.get_world_size()
     sizes = shard_sizes(n_total, world)
     mx = max(sizes)

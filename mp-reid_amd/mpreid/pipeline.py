@@ -150,7 +150,8 @@ class EncodePipeline:
                 raw = isinstance(img, (list, tuple))
                 if raw:
                     kind, shape, dtype = "raw", None, None
-                    arrs, hw, _, _ = ops.raw_image_layout(img)
+                    if n:
+                        arrs, hw, _, _ = ops.raw_image_layout(img)
                 else:
                     assert torch.is_tensor(img) and img.shape[0] == n, "loader batch: images must be a tensor [b, ...] or a list"
                     img = img.detach()

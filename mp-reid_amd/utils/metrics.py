@@ -164,6 +164,22 @@ def eval_func_sharded(dist_rows, q_pids_local, g_pids, max_rank=50):
     return hits / float(num_valid), np.mean(ap)
 
 
+def _check_finite(feats, collective=False):
+    """An encoder whose fp16 operand halves overflowed (|activation| > 65 504 in the 'split' / 'fp16' precision modes:
+    include/mpreid.h, mpreid_vit_forward) hands over NaN / inf feature rows; ranking them would print a plausible-looking
+    mAP.  Refuse loudly instead (one reduction over [N, D]; compute() synchronises anyway)."""
+    bad = int((~torch.isfinite(feats).all(dim=1)).sum()) if feats.numel() else 0
+    if collective:   # every rank must take the same branch: a rank that raised alone would leave the others in a collective
+        import torch.distributed as tdist
+        t = torch.tensor([bad], dtype=torch.int64, device="cpu" if tdist.get_backend() == "gloo" else feats.device)
+        tdist.all_reduce(t)
+        bad = int(t.item())
+    if bad:
+        raise RuntimeError(f"R1_mAP_eval.compute(): {bad} feature rows are non-finite -- the encoder's "
+                           "fp16 operands overflowed (or the model produced NaN); use MODEL.ENCODER_PRECISION fp32 for "
+                           "this checkpoint / input range")
+
+
 _d2h_streams = {}
 
 
@@ -219,6 +235,7 @@ class R1_mAP_eval():
         if D.sharded_active():
             return self._compute_sharded()
         feats = torch.cat(self.feats, dim=0)
+        _check_finite(feats)
         if self.feat_norm:
             print("The test feature is normalized")
             feats = _ops.l2_normalize(feats)
@@ -270,6 +287,7 @@ class R1_mAP_eval():
                            device="cpu" if tdist.get_backend() == "gloo" else dev)
         tdist.all_reduce(dim, op=tdist.ReduceOp.MAX)
         feats = torch.cat(self.feats, dim=0) if self.feats else torch.empty((0, int(dim.item())), device=dev)
+        _check_finite(feats, collective=True)
         if self.feat_norm:
             if rank == 0:
                 print("The test feature is normalized")

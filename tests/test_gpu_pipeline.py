@@ -452,3 +452,140 @@ def test_head_vs_reference_golden(golden, mode, neck):
     want = g[f"{mode}_{neck}"]
     assert got.shape == want.shape == (6, 1280)
     assert np.abs(got - want).max() <= 5e-5, np.abs(got - want).max()
+
+
+# ---- mpreid.pipeline.EncodePipeline: the staged encode loop behind do_inference ------------------------------------
+class _TinyModel:
+    """stands in for build_transformer: a reduced ViT on 64x32 images; counts its calls and their sizes"""
+
+    def __init__(self, sie=False):
+        from mpreid import ops, synth
+        self.cfg = dict(h_res=4, w_res=2, patch=16, stride=16, width=128, layers=2, heads=2, out_dim=64)
+        self.enc = ops.VitEncoder(self.cfg, synth.vit_state_dict(self.cfg, seed=7, std=0.05, ln_jitter=0.1), (64, 32))
+        self.calls = []
+        self.sie = sie
+        self.table = torch.randn(6, 128, generator=torch.Generator().manual_seed(1)).cuda() if sie else None
+
+    def __call__(self, x, cam_label=None, view_label=None):
+        from mpreid import ops
+        self.calls.append(len(x))
+        cv = None
+        if self.sie:
+            assert cam_label is not None and cam_label.is_cuda and len(cam_label) == len(x)
+            cv = self.table[cam_label]
+        if isinstance(x, (list, tuple, ops.PackedRawImages)):
+            return self.enc.forward_u8(ops.resize_bilinear_u8(x, (64, 32)), cv_emb=cv)
+        assert x.is_cuda
+        return self.enc.forward_u8(x, cv_emb=cv) if x.dtype == torch.uint8 else self.enc(x, cv)
+
+
+def _batches(kind, sizes, seed=0):
+    from datasets.make_dataloader import RawImageBatch
+    from mpreid import synth
+    rng = np.random.default_rng(seed)
+    out, base = [], 0
+    for n in sizes:
+        if kind == "raw":
+            img = RawImageBatch([rng.integers(0, 256, (int(rng.integers(40, 90)), int(rng.integers(20, 50)), 3), dtype=np.uint8)
+                                 for _ in range(n)])
+        else:
+            img = torch.from_numpy(synth.synthetic_images(n, 64, 32, seed=seed + base)) if n else torch.empty((0, 3, 64, 32))
+            if kind == "device":
+                img = img.cuda()
+            elif kind == "pinned":
+                img = img.pin_memory()
+            elif kind == "u8":
+                img = torch.from_numpy(rng.integers(0, 256, (n, 64, 32, 3), dtype=np.uint8))
+        cams = tuple(int(c) for c in rng.integers(0, 6, n))
+        out.append((img, tuple(range(base, base + n)), cams, torch.tensor(cams, dtype=torch.int64),
+                    torch.zeros(n, dtype=torch.int64), tuple(f"p{i}" for i in range(base, base + n))))
+        base += n
+    return out
+
+
+@pytest.mark.parametrize("kind,stage", [("host", "pinned"), ("host", "direct"), ("pinned", "pinned"), ("device", "pinned"),
+                                        ("raw", "pinned"), ("u8", "pinned")])
+@pytest.mark.parametrize("sie", [False, True])
+def test_encode_pipeline_equals_plain_loop_bitwise(kind, stage, sie):
+    """every loader type through the staged pipeline (groups of 10 images cut across ragged loader batches, 3 slots
+    recycled several times, two encode streams) gives, per loader batch and in order, the bits of model(batch) called
+    directly -- the reference's loop shape (processor/processor.py:187-198)"""
+    from mpreid.pipeline import EncodePipeline
+    sizes = [7, 3, 0, 12, 1, 9, 25, 4, 6, 2, 11]
+    batches = _batches(kind, sizes, seed=5)
+    model = _TinyModel(sie=sie)
+    want = []
+    for b in batches:
+        if len(b[1]):
+            x = b[0] if kind == "raw" else b[0].cuda()
+            want.append(model(x, cam_label=b[3].cuda() if sie else None).cpu())
+        else:
+            want.append(None)
+    model.calls.clear()
+    pipe = EncodePipeline(model, group=10, sie_camera=sie, streams=2, slots=3, stage=stage)
+    got = list(pipe.run(iter(batches)))
+    torch.cuda.synchronize()
+    assert [b[1] for _, b in got] == [b[1] for b in batches]            # the loader's own batches, in order
+    for (f, b), w in zip(got, want):
+        if w is None:
+            assert f.shape[0] == 0
+        else:
+            assert torch.equal(f.cpu(), w), b[1][:2]
+    total = sum(sizes)
+    assert sum(model.calls) == total and model.calls == [10] * (total // 10) + ([total % 10] if total % 10 else [])
+    assert pipe.stats["images"] == total and pipe.stats["groups"] == len(model.calls)
+    if kind in ("host", "raw", "u8"):
+        assert pipe.stats["h2d_bytes"] > 0
+
+
+def test_encode_pipeline_surfaces_loader_and_model_errors():
+    from mpreid.pipeline import EncodePipeline
+
+    def bad_loader():
+        yield from _batches("host", [4, 4])
+        raise ValueError("loader broke")
+
+    model = _TinyModel()
+    with pytest.raises(ValueError, match="loader broke"):
+        list(EncodePipeline(model, group=6).run(bad_loader()))
+
+    class Boom(_TinyModel):
+        def __call__(self, x, **k):
+            raise RuntimeError("model broke")
+
+    with pytest.raises(RuntimeError, match="model broke"):
+        list(EncodePipeline(Boom(), group=6).run(iter(_batches("host", [4, 4, 4]))))
+    # the pipeline is reusable after a failure and leaves no thread behind
+    import threading
+    assert not [t for t in threading.enumerate() if t.name == "mpreid-stager" and t.is_alive()]
+    assert len(list(EncodePipeline(model, group=6).run(iter(_batches("host", [4, 4]))))) == 2
+
+
+def test_do_inference_host_and_raw_loaders_match_direct_calls():
+    """do_inference over the reference's loader type (pageable fp32 batches) and over a RawImageBatch loader: Rank-1 / Rank-5
+    equal the evaluator fed by direct model calls, for both staging modes (MPREID_PIPELINE)"""
+    import os
+    from datasets.make_dataloader import make_dataloader
+    from model.make_model import make_model
+    from processor.processor import do_inference
+    from utils.metrics import R1_mAP_eval
+    for raw in (False, True):
+        cfg = _cfg(nq=20, ng=50, batch=16)
+        cfg.defrost()
+        cfg.merge_from_list(["DATASETS.SYNTH_RAW", raw])
+        cfg.freeze()
+        _, _, loader, nq, ncls, ncam, nview = make_dataloader(cfg)
+        model = make_model(cfg, num_class=ncls, camera_num=ncam, view_num=nview)
+        ev = R1_mAP_eval(nq, feat_norm=cfg.TEST.FEAT_NORM)
+        ev.reset()
+        for img, pid, camid, *_ in loader:
+            ev.update((model(img if raw else img.cuda()), pid, camid))
+        cmc = ev.compute()[0]
+        for stage in ("pinned", "direct"):
+            os.environ["MPREID_PIPELINE"] = f"stage={stage},group=24"
+            try:
+                r1, r5 = do_inference(cfg, model, loader, nq)
+            finally:
+                del os.environ["MPREID_PIPELINE"]
+            assert (float(r1), float(r5)) == (float(cmc[0]), float(cmc[4])), (raw, stage)
+            assert do_inference.last_pipeline_stats["images"] == 70

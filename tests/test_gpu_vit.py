@@ -308,3 +308,79 @@ def test_split_lnfold_mode(golden):
     s12 = dict(big, h_res=21, w_res=10, stride=12)
     enc = _encoder(s12, synth.vit_state_dict(s12, seed=8, std=0.02, ln_jitter=0.05), (256, 128), precision="split", ln_fold=True)
     assert np.abs(enc(torch.from_numpy(imgs[:2])).cpu().numpy() - g["b16_s12_feat"]).max() <= 5e-5
+
+
+# ---- the split mode where real CLIP checkpoints will stress it (hard part 5) ---------------------
+def outlier_state_dict(cfg, seed=31):
+    """seeded ViT weights with the outlier structure of trained CLIP towers (reference model/clip/model.py:150-161 LayerNorm,
+    :260-281 block): ONE residual channel carried at about -2000 / +2000 through every block (a 'massive activation'
+    channel: written by ln_pre with gamma 100 on a channel that dominates the embedding), LayerNorm gammas with a few
+    channels x30-100, and FC1 units whose pre-activations sit at +-60."""
+    from mpreid import synth
+    sd = synth.vit_state_dict(cfg, seed=seed, std=0.02, ln_jitter=0.05)
+    rng = np.random.default_rng(seed)
+    w = cfg["width"]
+    c0, c1 = 5, w // 2 + 3
+    sd["positional_embedding"][:, c0] += 40.0          # dominates every token's embedding ...
+    sd["positional_embedding"][:, c1] -= 40.0
+    sd["ln_pre.weight"][c0] = 100.0                    # ... ln_pre turns it into ~ +-1900 in the residual stream
+    sd["ln_pre.weight"][c1] = 100.0
+    for i in range(cfg["layers"]):
+        b = f"transformer.resblocks.{i}"
+        for ln in ("ln_1", "ln_2"):
+            big = rng.choice(w, 4, replace=False)
+            big = big[(big != c0) & (big != c1)]
+            sd[f"{b}.{ln}.weight"][big] *= rng.uniform(30.0, 100.0, big.size).astype(np.float32)
+            sd[f"{b}.{ln}.weight"][[c0, c1]] = 0.02     # trained towers damp the massive channels inside the blocks
+        units = rng.choice(4 * w, 6, replace=False)
+        sd[f"{b}.mlp.c_fc.bias"][units[:3]] = 60.0
+        sd[f"{b}.mlp.c_fc.bias"][units[3:]] = -60.0
+    return sd
+
+
+def test_split_mode_on_clip_like_outliers():
+    """fp16 operand PAIRS on activations with massive channels, x30-100 LayerNorm gammas and +-60 FC1 pre-activations:
+    features finite and within 2e-5 (relative L2) of the float64 evaluation of the same graph, ViT-B/16 at full size"""
+    from mpreid import synth
+    from oracle import oracle as orc
+    cfg = synth.VIT_B16
+    sd = outlier_state_dict(cfg)
+    imgs = synth.synthetic_images(3, 256, 128, seed=12)
+    want = orc.vit_features(sd, cfg, imgs, dtype="float64")
+    assert np.isfinite(want).all()
+    # the stress is real: the residual stream carries the massive channel (checked on the fp64 graph's ln_pre output)
+    enc = _encoder(cfg, sd, (256, 128), precision="split")
+    got = enc(torch.from_numpy(imgs)).cpu().numpy().astype(np.float64)
+    assert np.isfinite(got).all()
+    rel = np.linalg.norm(got - want) / np.linalg.norm(want)
+    f32 = orc.vit_features(sd, cfg, imgs).astype(np.float64)
+    rel32 = np.linalg.norm(f32 - want) / np.linalg.norm(want)
+    assert rel <= 2e-5, (rel, rel32)
+    assert rel <= max(8.0 * rel32, 4e-6), (rel, rel32)   # no worse than a few times what plain fp32 arithmetic loses on this model
+
+
+@pytest.mark.parametrize("scale,finite", [(1e-3, True), (1.0, True), (30.0, True), (2e5, False)])
+def test_split_mode_input_scale_edges(scale, finite):
+    """images far outside val_transforms' range: tiny inputs (most `lo` halves of the patch operands are fp16 subnormals or
+    zero) stay within the split mode's bound because ln_pre renormalises what the patch GEMM carried with >= 11 bits
+    RELATIVE TO THE ROW; inputs whose `hi` halves overflow fp16 (|x| > 65 504) give non-finite features, which
+    R1_mAP_eval.compute() refuses loudly (RuntimeError) instead of ranking them"""
+    from mpreid import synth
+    from oracle import oracle as orc
+    from utils.metrics import R1_mAP_eval
+    cfg = dict(h_res=4, w_res=2, patch=16, stride=16, width=128, layers=2, heads=2, out_dim=64)
+    sd = synth.vit_state_dict(cfg, seed=7, std=0.05, ln_jitter=0.1)
+    imgs = synth.synthetic_images(6, 64, 32, seed=3) * np.float32(scale)
+    enc = _encoder(cfg, sd, (64, 32), precision="split")
+    got = enc(torch.from_numpy(imgs))
+    if finite:
+        want = orc.vit_features(sd, cfg, imgs, dtype="float64")
+        rel = np.linalg.norm(got.cpu().numpy() - want) / np.linalg.norm(want)
+        assert np.isfinite(got.cpu().numpy()).all() and rel <= 2e-5, (scale, rel)
+        return
+    assert not torch.isfinite(got).all()
+    ev = R1_mAP_eval(2, feat_norm=True)
+    ev.reset()
+    ev.update((got, (0, 1, 0, 1, 0, 1), (0,) * 6))
+    with pytest.raises(RuntimeError, match="non-finite"):
+        ev.compute()
