@@ -395,10 +395,13 @@ static int distance_common(const float *q, const float *g, int64_t nq, int64_t n
         return MPREID_ERR_WORKSPACE;
     }
     hipStream_t stream = (hipStream_t)stream_;
-    float *qn = (float *)ws, *gn = qn + nq;
+    // all-pairs distances of ONE set (same pointer): one norm vector serves rows and columns (mpreid_distance_launch and the
+    // fp16 kernels recognise the case by the same test and compute the tiles on or above the diagonal only)
+    const bool same = (q == g && nq == ng);
+    float *qn = (float *)ws, *gn = same ? qn : qn + nq;
     const int nmode = (epi == EPI_COSINE) ? 1 : 0;
     hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, q, nq, d, qn, nmode);
-    hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)((ng + 3) / 4)), dim3(256), 0, stream, g, ng, d, gn, nmode);
+    if (!same) hipLaunchKernelGGL(sqnorm_kernel, dim3((unsigned)((ng + 3) / 4)), dim3(256), 0, stream, g, ng, d, gn, nmode);
     LAUNCH_CHECK();
     if (mode == MPREID_GEMM_F16_FAST) {
         char *rest = (char *)ws + align_up((size_t)(nq + ng) * sizeof(float), 256);

@@ -567,6 +567,12 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
     const int K = g.K;
     // split precision mode (GE_S_*): rows are [hi | lo], K = 2 * kseg halfs; the stages walk hi.hi', lo.hi', hi.lo'
     constexpr bool SPLIT = gemm_epi_is_split(EPI);
+    // epilogues that know symmetric problems (GemmArgs::sym: A == W, square): only tiles on or above the diagonal are
+    // computed; GE_CAND tests the mirrored pair, GE_EUCLID stores every off-diagonal tile a second time, transposed
+    // (the mirrored stores live in their own instance, <GE_EUCLID, 0, true>: the third template flag -- LNF for the split
+    // epilogues -- selects it, so the plain distance kernel carries none of its registers)
+    constexpr bool SYM_STORE = (EPI == GE_EUCLID) && LNF;
+    constexpr bool SYM_EPI = (EPI == GE_CAND) || SYM_STORE;
     const int nseg = SPLIT ? g.kseg / BBK : 0;
     const int nst = SPLIT ? 3 * nseg : K / BBK; // even (K, kseg are multiples of 64)
     // SPLIT stage order is k-block major: stage 3r + s works on the 32-wide k block r with
@@ -606,12 +612,50 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
     const int xcd = (int)(blockIdx.x & 7), per_xcd = nb >> 3, per_group = 8 * tiles_n, ngroups = tiles_m >> 3;
     const int bc_w = per_xcd >> 3;                                   // tile columns per block (blocked mode)
     const int nbc = blocked ? (tiles_n + bc_w - 1) / bc_w : 1, nbr = (tiles_m + 7) >> 3;
-    int pos = owned ? (int)(blockIdx.x >> 3) : (blocked ? 0 : (int)blockIdx.x); // position in this CU's tile list
-    const int pos_step = owned ? per_xcd : (blocked ? 1 : nb);
+    // SYM_STORE on the blocked walk: COMPACTED.  The blocks that straddle the diagonal (and the edge blocks) have unused
+    // slots; a CU tied to one slot of every block then gets 11-14 tiles at N = 20 000 (79 x 79 tiles) where the mean is 12.3.
+    // Instead the XCD's blocks form one list of VALID tiles (block order, slot order inside a block) and the CU in slot s
+    // takes items s, s + 32, s + 64, ...: 12 or 13 tiles each, and 32 consecutive items still share one or two blocks'
+    // operand panels.  (GE_CAND keeps the slot walk: its candidate lists must not change order between builds.)
+    const bool symc = SYM_STORE && blocked && g.sym != 0;
+    int pos = (owned || symc) ? (int)(blockIdx.x >> 3) : (blocked ? 0 : (int)blockIdx.x); // position in this CU's tile list
+    const int pos_step = (owned || symc) ? per_xcd : (blocked ? 1 : nb);
+    int sy_p = 0, sy_cum = 0;   // symc: cursor into the XCD's block list and the number of valid tiles before it
+    auto sym_tile_at = [&](int k) -> int {   // k-th valid tile of this XCD's list (k never decreases), -1 when exhausted
+        for (;;) {
+            int b = sy_p * 8 + xcd, br = 0, bcol = 0;
+            for (;; ++br) {   // block row br holds the block columns from ceil((8 br - bc_w + 1) / bc_w) on
+                if (br >= nbr) return -1;
+                int fb = (br * 8 - bc_w + 1 + bc_w - 1) / bc_w;
+                fb = fb < 0 ? 0 : fb;
+                const int cnt = nbc - fb;
+                if (cnt > 0 && b < cnt) {
+                    bcol = fb + b;
+                    break;
+                }
+                b -= cnt > 0 ? cnt : 0;
+            }
+            const int c_lo = bcol * bc_w, c_hi = min(tiles_n, c_lo + bc_w);
+            int cnt = 0;
+            for (int r = 0; r < 8; ++r) {
+                const int tm = br * 8 + r;
+                if (tm < tiles_m) cnt += max(0, c_hi - max(tm, c_lo));
+            }
+            if (k < sy_cum + cnt) {
+                int want = k - sy_cum;
+                for (int sl = 0; sl < 8 * bc_w; ++sl) {
+                    const int tm = br * 8 + (sl & 7), tn = c_lo + (sl >> 3);
+                    if (tm < tiles_m && tn < tiles_n && tn >= tm && want-- == 0) return tm * tiles_n + tn;
+                }
+            }
+            sy_cum += cnt;
+            ++sy_p;
+        }
+    };
     auto tile_at_raw = [&](int p) -> int { // -1 when the list is exhausted, -2 for an unused slot of an edge block
         if (blocked) {
             int b = p * 8 + xcd, br, bcol;
-            if (EPI == GE_CAND && g.sym) {
+            if (SYM_EPI && g.sym) {
                 // symmetric problem: only blocks with a tile on or above the diagonal are enumerated (block row br
                 // starts at block column ceil((8 br - bc_w + 1) / bc_w)), so the eight XCDs get the same number of
                 // blocks to within one
@@ -634,12 +678,12 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
             if (br >= nbr) return -1;
             const int slot = (int)(blockIdx.x >> 3);
             const int tm = br * 8 + (slot & 7), tn = bcol * bc_w + (slot >> 3);
-            if (EPI == GE_CAND && g.sym && tn < tm) return -2;   // symmetric problem: upper-triangular tiles only
+            if (SYM_EPI && g.sym && tn < tm) return -2;   // symmetric problem: upper-triangular tiles only
             return (tm < tiles_m && tn < tiles_n) ? tm * tiles_n + tn : -2;
         }
         if (!owned) {
             if (p >= ntiles) return -1;
-            if (EPI == GE_CAND && g.sym) {
+            if (SYM_EPI && g.sym) {
                 int tm, tn;
                 tile_coords((unsigned)p, tiles_m, tiles_n, 8, tm, tn);
                 if (tn < tm) return -2;
@@ -649,10 +693,13 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
         const int grp = xcd + 8 * (p / per_group);
         if (grp >= ngroups) return -1;
         const int within = p % per_group;
-        if (EPI == GE_CAND && g.sym && (within >> 3) < grp * 8 + (within & 7)) return -2;
+        if (SYM_EPI && g.sym && (within >> 3) < grp * 8 + (within & 7)) return -2;
         return (grp * 8 + (within & 7)) * tiles_n + (within >> 3); // row-major tile id
     };
     auto tile_at = [&](int &p) -> int {    // advances p past unused slots
+        if constexpr (SYM_STORE) {
+            if (symc) return sym_tile_at(p);
+        }
         int t = tile_at_raw(p);
         while (t == -2) {
             p += pos_step;
@@ -1628,6 +1675,97 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
             __builtin_amdgcn_wave_barrier();
         }
         }
+        if constexpr (SYM_STORE) {
+            if (g.sym && cur_m0 != cur_n0) {
+                // SYMMETRIC problem (all-pairs distances of one set), off-diagonal tile: the tile (tn, tm) is never computed --
+                // its values are this tile's, transposed (same fp16 products in the same k order, |q_m|^2 + |q_n|^2 commutes:
+                // the bits the other tile would have produced, tests/test_gpu_distance.py).  The wave's 128 x 64 block leaves
+                // as 64 rows x 128 columns in two halves of 64 x 64: the finished values go into the wave's 16 KB of the idle
+                // ring TRANSPOSED ([n][m], 16-byte chunks XOR-swizzled by n & 15: the b128 writes of a 16-lane group and the
+                // b128 reads of a row both touch 16 different chunk banks) and leave as whole 256-byte row pieces, like the
+                // direct copy.  (Straight from the accumulators a store instruction would cover 16 rows x 64 bytes: half
+                // lines, measured slower in round 3.)
+                float *T = reinterpret_cast<float *>(smem + wave * 16384);
+                float *rtm = reinterpret_cast<float *>(patch + wave * 4096);
+                if (!fast_path) {   // the general path kept its row table in the ring slice: move it above the ring
+                    const float t0 = rt[lane], t1 = rt[64 + lane], t2 = rt[128 + lane], t3 = rt[192 + lane];
+                    __builtin_amdgcn_wave_barrier();
+                    rtm[lane] = t0;
+                    rtm[64 + lane] = t1;
+                    rtm[128 + lane] = t2;
+                    rtm[192 + lane] = t3;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
+                const bool scaledT = g.rscale != nullptr;
+                float bnT[4], csT[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = nbase + j * 16 + frow;
+                    bnT[j] = (n < g.n_valid) ? g.aux2[n] : 0.f;
+                    csT[j] = scaledT ? g.cscale[n] : 1.0f;
+                }
+                const bool interior = vec_ok && cur_m0 + BBM <= g.m_valid && cur_n0 + BBN <= g.n_valid;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) {
+                        const int i = hf * 4 + ii;
+                        const float4 am4 = *reinterpret_cast<const float4 *>(rtm + i * 16 + fq * 4);
+                        const float4 rs4 = *reinterpret_cast<const float4 *>(rtm + 128 + i * 16 + fq * 4);
+                        const float amr[4] = {am4.x, am4.y, am4.z, am4.w}, rsr[4] = {rs4.x, rs4.y, rs4.z, rs4.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            f32x4 o;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float a = acc[i][j][r];
+                                o[r] = scaledT ? fmaf(-2.0f, a * (rsr[r] * csT[j]), amr[r] + bnT[j])
+                                               : fmaf(-2.0f, a, amr[r] + bnT[j]);
+                            }
+                            *reinterpret_cast<f32x4 *>(T + (j * 16 + frow) * 64 + (((ii * 4 + fq) ^ frow) << 2)) = o;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const int l16 = lane & 15;
+                    const int mcol = cur_m0 + wr * 128 + hf * 64 + l16 * 4;
+                    // wave-uniform 64-bit base + one 32-bit lane offset (as the direct fast path): row nl = e * 4 + (lane >> 4)
+                    const uint64_t tbase = reinterpret_cast<uint64_t>(outp + (int64_t)nbase * g.ldo + cur_m0 + wr * 128 + hf * 64);
+                    const unsigned ldo_bT = (unsigned)g.ldo * 4u;
+                    const unsigned voffT = (unsigned)(lane >> 4) * ldo_bT + (unsigned)l16 * 16u;
+                    if (interior) {
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            const int nl = e * 4 + (lane >> 4);
+                            const f32x4 v = *reinterpret_cast<const f32x4 *>(T + nl * 64 + ((l16 ^ (nl & 15)) << 2));
+                            store16_nt_sv(tbase + (uint64_t)(e * 4) * ldo_bT, voffT, v);
+                        }
+                    } else {   // last tile row / column: bounds per row and per 16-byte piece (rolled: 158 of 3160 tiles at N = 20 000)
+#pragma unroll 1
+                        for (int e = 0; e < 16; ++e) {
+                            const int nl = e * 4 + (lane >> 4);
+                            const f32x4 v = *reinterpret_cast<const f32x4 *>(T + nl * 64 + ((l16 ^ (nl & 15)) << 2));
+                            const int n = nbase + nl;
+                            float *dst = outp + (int64_t)n * g.ldo + mcol;
+                            if (n < g.n_valid) {
+                                if (vec_ok && mcol + 3 < g.m_valid) {
+                                    store_nt(dst, make_float4(v[0], v[1], v[2], v[3]));
+                                } else {
+                                    if (mcol + 0 < g.m_valid) dst[0] = v[0];
+                                    if (mcol + 1 < g.m_valid) dst[1] = v[1];
+                                    if (mcol + 2 < g.m_valid) dst[2] = v[2];
+                                    if (mcol + 3 < g.m_valid) dst[3] = v[3];
+                                }
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
         // the fast path's patches alias the ring, which the next tile's prologue fills: all waves done first
         if constexpr (EPI == GE_EUCLID || EPI == GE_S_BIAS_F32) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
@@ -1886,6 +2024,17 @@ static int launch_one(const GemmArgs &a_in, hipStream_t stream) {
                     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_big_kernel<EPI, 16>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_TOTAL));
                     hipLaunchKernelGGL((gemm_f16_big_kernel<EPI, 16>), grid, dim3(512), B_LDS_TOTAL, stream, a, tiles_m, tiles_n);
+                } else if (EPI == GE_EUCLID && a.sym) {   // symmetric problem: the instance with the mirrored stores
+                    if constexpr (EPI == GE_EUCLID) {
+                        static PerDeviceOnce sym_once;
+                        const int rc = sym_once.run([]() -> int {
+                            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_big_kernel<EPI, 0, true>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_TOTAL));
+                            return MPREID_OK;
+                        });
+                        if (rc) return rc;
+                        hipLaunchKernelGGL((gemm_f16_big_kernel<EPI, 0, true>), grid, dim3(512), B_LDS_TOTAL, stream, a, tiles_m, tiles_n);
+                    }
                 } else {
                     hipLaunchKernelGGL(gemm_f16_big_kernel<EPI>, grid, dim3(512), B_LDS_TOTAL, stream, a, tiles_m, tiles_n);
                 }
@@ -2161,6 +2310,10 @@ int mpreid_distance_f16_split3(const float *q, const float *g, int64_t nq, int64
     a.n_valid = (int)ng;
     a.rscale = qs;
     a.cscale = gs;
+    // all-pairs distances of ONE set (same pointer, utils.metrics.euclidean_distance(f, f)): the persistent kernel computes
+    // the tiles on or above the diagonal and stores the others as transposed copies -- half the matrix work (the 3-term sum
+    // is not bit-symmetric computed both ways; either value is within the mode's 1e-6, and the copies are what they copy)
+    a.sym = (epi == 0 && q == g && nq == ng) ? 1 : 0;
     a.stagger = euclid_stagger_ticks(a.M, a.N, a.K);
     return launch_gemm_f16(a, epi == 0 ? GE_EUCLID : GE_COSINE, stream);
 }
@@ -2179,10 +2332,14 @@ int mpreid_distance_f16_fast(const float *q, const float *g, int64_t nq, int64_t
     }
     const int dp = (int)align_up((size_t)d, GBK);
     const int64_t mp = (int64_t)align_up((size_t)nq, BBM), np = (int64_t)align_up((size_t)ng, BBN);
+    // all-pairs distances of ONE set (same pointer): one cast serves both operands and the kernel computes the tiles on or
+    // above the diagonal only, storing each off-diagonal tile twice (the fp16 dot products are bit-symmetric: same bits
+    // as the full computation)
+    const bool sym = epi == 0 && q == g && nq == ng;
     _Float16 *qh = (_Float16 *)ws;
-    _Float16 *gh = (_Float16 *)((char *)ws + align_up((size_t)mp * dp * 2, 256));
+    _Float16 *gh = sym ? qh : (_Float16 *)((char *)ws + align_up((size_t)mp * dp * 2, 256));
     hipLaunchKernelGGL(cast_pad_kernel, dim3((unsigned)mp), dim3(256), 0, stream, q, nq, d, qh, mp, dp);
-    hipLaunchKernelGGL(cast_pad_kernel, dim3((unsigned)np), dim3(256), 0, stream, g, ng, d, gh, np, dp);
+    if (!sym) hipLaunchKernelGGL(cast_pad_kernel, dim3((unsigned)np), dim3(256), 0, stream, g, ng, d, gh, np, dp);
     LAUNCH_CHECK();
     GemmArgs a{};
     a.A = qh;
@@ -2196,6 +2353,7 @@ int mpreid_distance_f16_fast(const float *q, const float *g, int64_t nq, int64_t
     a.aux2 = gn;
     a.m_valid = (int)nq;
     a.n_valid = (int)ng;
+    a.sym = sym ? 1 : 0;
     a.stagger = euclid_stagger_ticks(a.M, a.N, a.K);
     return launch_gemm_f16(a, epi == 0 ? GE_EUCLID : GE_COSINE, stream);
 }

@@ -277,3 +277,45 @@ def test_stored_distance_kernels_bit_identical():
         assert r.returncode == 0, r.stdout + r.stderr
         outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("HASHES ")][0].split()[1:])
     assert outs[0] == outs[1], list(zip(outs[0], outs[1]))
+
+
+# ---- all-pairs distances of ONE set: euclidean_distance(f, f) computes the upper-triangular tiles and mirrors them ----
+@pytest.mark.parametrize("n,d,big", [(20000, 768, "1"), (16384, 128, "1"), (1000, 192, "2"), (1000, 192, "1"), (4133, 1280, "2")])
+def test_all_pairs_symmetric_path_same_bits_as_full_computation(n, d, big):
+    """euclidean_distance(f, f, F16_FAST) -- same pointer, so the persistent kernel takes its symmetric form (tiles on or
+    above the diagonal, every off-diagonal tile stored twice) -- equals euclidean_distance(f, copy of f) -- the full
+    computation -- bit for bit: 79 x 79 tiles with ragged edges (blocked walk), 64 x 64 tiles (XCD-owned walk), a grid
+    smaller than the chip (strided walk; also the 128 x 128 kernel, which ignores the flag), and a matrix embedded in a
+    wider one (ldo > n).  The 3-term split mode: within 1e-6 of the exact chain, off-diagonal tiles exactly mirrored."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent(f"""
+        import sys, numpy as np, torch
+        sys.path[:0] = [{root!r}, {root!r} + "/mp-reid_amd"]
+        from mpreid import ops, synth
+        f, _ = synth.clustered_features({n}, {d}, 3.0, seed=11)
+        ft = torch.from_numpy(f).cuda()
+        ft2 = ft.clone()
+        full = ops.euclidean_distance(ft, ft2, mode=ops.GEMM_F16_FAST)
+        for rep in range(2):
+            sym = ops.euclidean_distance(ft, ft, mode=ops.GEMM_F16_FAST)
+            assert torch.equal(sym, full), float((sym - full).abs().max())
+        assert torch.equal(sym, sym.t())
+        wide = torch.full(({n}, {n} + 40), -7.0, device="cuda")
+        ops.euclidean_distance(ft, ft, mode=ops.GEMM_F16_FAST, out=wide, col_offset=24)
+        assert torch.equal(wide[:, 24:24 + {n}], full) and bool((wide[:, :24] == -7).all()) and bool((wide[:, 24 + {n}:] == -7).all())
+        s3 = ops.euclidean_distance(ft, ft, mode=ops.GEMM_F16_SPLIT3)
+        assert float((s3 - s3.t()).abs().max()) <= 5e-7     # exactly mirrored off the diagonal tiles; inside them the 3-term sum is computed both ways
+        if {n} >= 4096 or "{big}" == "2":   # the persistent kernel ran (the 128 x 128 kernel computes every tile)
+            assert torch.equal(s3[512:768, 0:256], s3[0:256, 512:768].t())
+        m = min({n}, 3000)
+        ex = ops.euclidean_distance(ft[:m].contiguous(), ft)
+        s3f = ops.euclidean_distance(ft, ft2, mode=ops.GEMM_F16_SPLIT3)
+        e_sym, e_full = float((s3[:m] - ex).abs().max()), float((s3f[:m] - ex).abs().max())
+        assert e_sym <= max(1e-6, 1.1 * e_full), (e_sym, e_full)     # (the tail of 6e7 entries can pass 1e-6 by a hair, either way)
+        assert float((s3 - s3f).abs().max()) <= 5e-7
+        print("ok")
+    """)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MPREID_TUNE="gemm_big=" + big), capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """feat x feat^T distance GEMM timings (north_star: 20k x 20k x 768): exact fp32 MFMA, one-pass fp16, 3-term split.
-Usage: python tools/distgemm_bench.py [nq ng d] ; MPREID_TUNE=gemm_stagger=<ticks> to try the start stagger."""
+Usage: python tools/distgemm_bench.py [nq ng d [modes [full]]] ; with nq == ng the two operands are the SAME tensor (all-pairs
+distances of one set: the fp16 kernels take their symmetric form) unless the fifth argument is "full" (a copy as the second
+operand: the full computation).  MPREID_TUNE=gemm_stagger=<ticks> to try the start stagger."""
 import os
 import sys
 
@@ -16,6 +18,9 @@ modes = sys.argv[4].split(",") if len(sys.argv) > 4 else ["f16", "split3", "exac
 f, _ = synth.clustered_features(max(nq, ng), d, 3.0, seed=1234)
 ft = torch.from_numpy(f).cuda()
 q, g = ft[:nq], ft[:ng]
+full = len(sys.argv) > 5 and sys.argv[5] == "full"
+if full:
+    g = g.clone()
 out = torch.empty((nq, ng), device="cuda")
 flop = 2.0 * nq * ng * d
 for name in modes:
@@ -34,4 +39,4 @@ for name in modes:
         best = min(best, e0.elapsed_time(e1) / 3)
     mult = 3 if name == "split3" else 1
     print(f"{name:6s} {nq}x{ng}x{d}: {best:.4f} ms  algorithmic {flop/best/1e9:.1f} TF  executed {mult*flop/best/1e9:.1f} TF  "
-          f"store {4.0*nq*ng/best/1e6:.0f} GB/s  tune={os.environ.get('MPREID_TUNE','')}", flush=True)
+          f"store {4.0*nq*ng/best/1e6:.0f} GB/s  {'full' if full or nq != ng else 'same-tensor (symmetric form for f16 / split3)'}  tune={os.environ.get('MPREID_TUNE','')}", flush=True)
