@@ -1707,26 +1707,37 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
                     csT[j] = scaledT ? g.cscale[n] : 1.0f;
                 }
                 const bool interior = vec_ok && cur_m0 + BBM <= g.m_valid && cur_n0 + BBN <= g.n_valid;
+                // the accumulators become the finished values IN PLACE, one 16-row block at a time (short live ranges: the
+                // direct copy above is done with the raw sums)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float4 am4 = *reinterpret_cast<const float4 *>(rtm + i * 16 + fq * 4);
+                    const float amr[4] = {am4.x, am4.y, am4.z, am4.w};
+                    if (scaledT) {
+                        const float4 rs4 = *reinterpret_cast<const float4 *>(rtm + 128 + i * 16 + fq * 4);
+                        const float rsr[4] = {rs4.x, rs4.y, rs4.z, rs4.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                acc[i][j][r] = fmaf(-2.0f, acc[i][j][r] * (rsr[r] * csT[j]), amr[r] + bnT[j]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaf(-2.0f, acc[i][j][r], amr[r] + bnT[j]);
+                    }
+                    asm volatile("" ::: "memory");
+                }
+                float *Trow = T + frow * 64;                      // + j * 1024: row n = j * 16 + frow of the transposed patch
+                const int cx = fq ^ frow;                         // chunk (ii * 4 + fq) ^ frow = (ii * 4) ^ cx  (ii * 4 has no low bits)
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
 #pragma unroll
-                    for (int ii = 0; ii < 4; ++ii) {
-                        const int i = hf * 4 + ii;
-                        const float4 am4 = *reinterpret_cast<const float4 *>(rtm + i * 16 + fq * 4);
-                        const float4 rs4 = *reinterpret_cast<const float4 *>(rtm + 128 + i * 16 + fq * 4);
-                        const float amr[4] = {am4.x, am4.y, am4.z, am4.w}, rsr[4] = {rs4.x, rs4.y, rs4.z, rs4.w};
+                    for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            f32x4 o;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float a = acc[i][j][r];
-                                o[r] = scaledT ? fmaf(-2.0f, a * (rsr[r] * csT[j]), amr[r] + bnT[j])
-                                               : fmaf(-2.0f, a, amr[r] + bnT[j]);
-                            }
-                            *reinterpret_cast<f32x4 *>(T + (j * 16 + frow) * 64 + (((ii * 4 + fq) ^ frow) << 2)) = o;
-                        }
-                    }
+                        for (int j = 0; j < 4; ++j)
+                            *reinterpret_cast<f32x4 *>(Trow + j * 1024 + ((((ii * 4) ^ cx) & 15) << 2)) = acc[hf * 4 + ii][j];
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

@@ -641,7 +641,14 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8 || XKEY) ? 2 : 1) void attention_
                 x_request(nxt);
             }
         }
-        for (int qt = wave; qt < ((dbg & 2) ? 0 : nqt); qt += NW) {
+        // XKEY, all query tiles wanted: the tiles 0 .. KTP-1 are full, tile KTP holds ONE query (token L-1).  Handed to one
+        // wave as a tile of its own (round 3) that wave did three tiles per pair where the others did two, and everybody
+        // waited for it at the next barrier: a third of the compute phase for 1/129 of the rows.  Now the waves share it BY
+        // KEYS (below, after the main tiles): every wave scores the query against its own two key tiles, the partial
+        // (max, sum, O) leave through LDS and wave 0 merges them -- a quarter tile per wave instead of a whole one for one.
+        const bool tail = XKEY && nqt == KTP + 1;
+        const int nmain = tail ? KTP : nqt;
+        for (int qt = wave; qt < ((dbg & 2) ? 0 : nmain); qt += NW) {
             f16x8 qh[2], ql[2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -665,7 +672,8 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8 || XKEY) ? 2 : 1) void attention_
                 }
                 sx = xor16_32_sum(sx);
             }
-            if (qt + NW < nqt) q_request(qt + NW);
+            if (qt + NW < nmain) q_request(qt + NW);
+            else if (tail) q_request(KTP);   // (every column of that tile clamps to token L-1: sixteen copies of the one query)
             f32x4 s[KTP];
             float mx = -3.0e38f;
             const int nkt = XKEY ? KTP : (L + 15) >> 4;   // key tiles that hold a valid key
@@ -787,6 +795,150 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8 || XKEY) ? 2 : 1) void attention_
                 }
             }
         } // query tiles
+        if constexpr (XKEY) {
+            if (tail && !(dbg & 2)) {
+                static_assert(!XKEY || KTP == 2 * NW, "the tail query is shared by keys: two key tiles (one PV step) per wave");
+                f16x8 qh[2], ql[2];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const float4 a0 = qraw[2 * ks], a1 = qraw[2 * ks + 1];
+                    const float qv[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        qh[ks][e] = (_Float16)qv[e];
+                        ql[ks][e] = (_Float16)(qv[e] - (float)qh[ks][e]);
+                    }
+                }
+                f32x4 s2t[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int kt = 2 * wave + t;
+                    s2t[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const int ko = (kt * 16 + fr) * 128 + (((ks * 4 + fq) ^ (lane & 7)) << 4);
+                        const f16x8 kh = *reinterpret_cast<const f16x8 *>(Kh + ko);
+                        const f16x8 kl = *reinterpret_cast<const f16x8 *>(Kl + ko);
+                        s2t[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[ks], s2t[t], 0, 0, 0);
+                        s2t[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[ks], s2t[t], 0, 0, 0);
+                        s2t[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[ks], s2t[t], 0, 0, 0);
+                    }
+                }
+                float mx = fmaxf(fmaxf(fmaxf(s2t[0][0], s2t[0][1]), fmaxf(s2t[0][2], s2t[0][3])),
+                                 fmaxf(fmaxf(s2t[1][0], s2t[1][1]), fmaxf(s2t[1][2], s2t[1][3])));
+                mx = xor16_32_max(mx);
+                float sx = 0.f;
+                if (wave == 0) {   // the extra key (token L-1 as a KEY) belongs to wave 0's share
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float4 kx = *reinterpret_cast<const float4 *>(Xk + (c >> 1) * 32 + fq * 8 + (c & 1) * 4);
+                        sx = fmaf(qraw[c].x, kx.x, sx);
+                        sx = fmaf(qraw[c].y, kx.y, sx);
+                        sx = fmaf(qraw[c].z, kx.z, sx);
+                        sx = fmaf(qraw[c].w, kx.w, sx);
+                    }
+                    sx = xor16_32_sum(sx);
+                    mx = fmaxf(mx, sx);
+                }
+                const float nmx = fmaf(-mx, scale_log2e, 10.0f);
+                float sum = 0.f;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(fmaf(s2t[t][r], scale_log2e, nmx));
+                        s2t[t][r] = pv;
+                        sum += pv;
+                    }
+                sum = xor16_32_sum(sum);
+                float px = 0.f;
+                if (wave == 0) {
+                    px = __builtin_amdgcn_exp2f(fmaf(sx, scale_log2e, nmx));
+                    sum += px;
+                }
+                f32x4 o[4];
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                {
+                    f16x8 ph, pl;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        ph[j] = (_Float16)s2t[0][j];
+                        pl[j] = (_Float16)(s2t[0][j] - (float)ph[j]);
+                        ph[4 + j] = (_Float16)s2t[1][j];
+                        pl[4 + j] = (_Float16)(s2t[1][j] - (float)ph[4 + j]);
+                    }
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        const int trq = fr >> 2, trp = fr & 3;
+                        const int row0 = wave * 32 + fq * 4 + trq, row1 = row0 + 16;
+                        const int chunk = dt * 2 + (trp >> 1);
+                        const int o0 = row0 * 128 + ((chunk ^ (((row0 >> 1) & 3) << 1)) << 4) + (trp & 1) * 8;
+                        const int o1 = row1 * 128 + ((chunk ^ (((row1 >> 1) & 3) << 1)) << 4) + (trp & 1) * 8;
+                        typedef short s8_t __attribute__((ext_vector_type(8)));
+                        const att_s4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((att_lds_s4 *)(Vh + o0));
+                        const att_s4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((att_lds_s4 *)(Vh + o1));
+                        const att_s4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((att_lds_s4 *)(Vl + o0));
+                        const att_s4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((att_lds_s4 *)(Vl + o1));
+                        const s8_t vh8 = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+                        const s8_t vl8 = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+                        const f16x8 vh = __builtin_bit_cast(f16x8, vh8), vl = __builtin_bit_cast(f16x8, vl8);
+                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph, o[dt], 0, 0, 0);
+                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph, o[dt], 0, 0, 0);
+                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl, o[dt], 0, 0, 0);
+                    }
+                }
+                if (wave == 0) {
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) {
+                        const float4 vx = *reinterpret_cast<const float4 *>(Xk + 64 + dt * 16 + fq * 4);
+                        o[dt][0] = fmaf(px, vx.x, o[dt][0]);
+                        o[dt][1] = fmaf(px, vx.y, o[dt][1]);
+                        o[dt][2] = fmaf(px, vx.z, o[dt][2]);
+                        o[dt][3] = fmaf(px, vx.w, o[dt][3]);
+                    }
+                }
+                // partials of query column 0 (= token L-1; the other fifteen columns are copies): the wave's own patch holds
+                // O[64] | max | sum as fp32
+                float *pt = reinterpret_cast<float *>(Ot + wave * (16 * OS));
+                if (fr == 0) {
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt)
+                        *reinterpret_cast<float4 *>(pt + dt * 16 + fq * 4) = make_float4(o[dt][0], o[dt][1], o[dt][2], o[dt][3]);
+                    if (fq == 0) {
+                        pt[64] = mx;
+                        pt[65] = sum;
+                    }
+                }
+                __syncthreads();
+                if (wave == 0) {   // merge in wave order (fixed: the result does not depend on timing), lane = output dimension d
+                    float mw[NW], lw[NW], M = -3.0e38f;
+#pragma unroll
+                    for (int w2 = 0; w2 < NW; ++w2) {
+                        const float *pw = reinterpret_cast<const float *>(Ot + w2 * (16 * OS));
+                        mw[w2] = pw[64];
+                        lw[w2] = pw[65];
+                        M = fmaxf(M, mw[w2]);
+                    }
+                    float den = 0.f, num = 0.f;
+#pragma unroll
+                    for (int w2 = 0; w2 < NW; ++w2) {
+                        const float *pw = reinterpret_cast<const float *>(Ot + w2 * (16 * OS));
+                        const float sc = __builtin_amdgcn_exp2f((mw[w2] - M) * scale_log2e);
+                        den = fmaf(lw[w2], sc, den);
+                        num = fmaf(pw[lane], sc, num);
+                    }
+                    const float v = num / den;
+                    const _Float16 hi = (_Float16)v;
+                    const _Float16 lo = (_Float16)(v - (float)hi);
+                    if (!(dbg & 4)) {
+                        _Float16 *orow = out + ((int64_t)b * L + (L - 1)) * 2 * W + h * 64 + lane;
+                        orow[0] = hi;
+                        orow[W] = lo;
+                    }
+                }
+            }
+        }
     }     // (image, head) pairs
 }
 
