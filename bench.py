@@ -254,7 +254,7 @@ RERANK_STAGE_KERNELS = {
 def _pmc_stage_bytes():
     """HBM bytes per launch of every re-rank stage at N = 20 000 from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE in separate runs, gfx950 corrections applied by tools/pmc_summary.py): {stage: (bytes, source file)}"""
-    for fn in ("r03_pmc_summary.json", "r02_pmc_summary.json"):
+    for fn in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json"):
         try:
             per = json.load(open(os.path.join(ROOT, "profiles", fn)))["rerank_N20000_hbm_bytes_per_launch"]
         except Exception:

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Collect the round's evidence on the GPU box (run through gpurun from the repo root):
-#   bash tools/collect_profiles.sh r03
+#   bash tools/collect_profiles.sh r04
 # Writes everything under gpurun_out/profiles_<tag>/; the summaries are then copied into profiles/ (tracked).
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
@@ -33,5 +33,8 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_e_write -o e -- pytho
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_g_fetch -o g -- python3 $R/tools/gemm_bench.py --reps 3 --rounds 2 --only qkv,out,fc1,fc2,sqkv,sout,sfc1,sfc2 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_g_write -o g -- python3 $R/tools/gemm_bench.py --reps 3 --rounds 2 --only qkv,out,fc1,fc2,sqkv,sout,sfc1,sfc2 > /dev/null 2>&1
 python3 $R/tools/pmc_traffic.py $OUT/pmc_g_fetch $OUT/pmc_g_write $OUT/${TAG}_gemm_pmc_traffic.json > /dev/null 2>&1
+# 5b. matrix-pipe counters of the same classes (the dominant kernel of the headline step is split_fc_bias_quickgelu): one SQ / GRBM pass
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_g_mfma -o g -- python3 $R/tools/gemm_bench.py --reps 3 --rounds 2 --only qkv,out,fc1,fc2,sqkv,sout,sfc1,sfc2 > /dev/null 2>&1
+python3 $R/tools/pmc_mfma.py $OUT/pmc_g_mfma $OUT/${TAG}_gemm_pmc_mfma.json > $OUT/pmc_mfma.log 2>&1
 python3 $R/tools/pmc_summary.py $OUT $TAG > $OUT/${TAG}_pmc_summary.json 2> $OUT/pmc_summary.err
 ls -la $OUT | head -40
