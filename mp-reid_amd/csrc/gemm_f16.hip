@@ -616,8 +616,9 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
     // slots; a CU tied to one slot of every block then gets 11-14 tiles at N = 20 000 (79 x 79 tiles) where the mean is 12.3.
     // Instead the XCD's blocks form one list of VALID tiles (block order, slot order inside a block) and the CU in slot s
     // takes items s, s + 32, s + 64, ...: 12 or 13 tiles each, and 32 consecutive items still share one or two blocks'
-    // operand panels.  (GE_CAND keeps the slot walk: its candidate lists must not change order between builds.)
-    const bool symc = SYM_STORE && blocked && g.sym != 0;
+    // operand panels.  (GE_CAND too: its candidate lists are appended through atomics and sorted by the refinement, so
+    // the order in which tiles are visited never reaches a result.)
+    const bool symc = SYM_EPI && blocked && g.sym != 0;
     int pos = (owned || symc) ? (int)(blockIdx.x >> 3) : (blocked ? 0 : (int)blockIdx.x); // position in this CU's tile list
     const int pos_step = (owned || symc) ? per_xcd : (blocked ? 1 : nb);
     int sy_p = 0, sy_cum = 0;   // symc: cursor into the XCD's block list and the number of valid tiles before it
@@ -697,7 +698,7 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
         return (grp * 8 + (within & 7)) * tiles_n + (within >> 3); // row-major tile id
     };
     auto tile_at = [&](int &p) -> int {    // advances p past unused slots
-        if constexpr (SYM_STORE) {
+        if constexpr (SYM_EPI) {
             if (symc) return sym_tile_at(p);
         }
         int t = tile_at_raw(p);

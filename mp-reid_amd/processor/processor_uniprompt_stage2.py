@@ -119,20 +119,21 @@ def do_inference_ttpt_option_a(cfg, model, val_loader, num_query):
                 if processed_samples % 1000 == 0:
                     logger.info(f"Processed {processed_samples}/{getattr(val_loader, 'n', '?')} samples...")
 
-    end_time = time.time()
-    logger.info(f"Feature extraction finished in {end_time - start_time:.2f} seconds.")
+    logger.info("Feature extraction finished in %.2f seconds." % (time.time() - start_time))
 
-    cmc, mAP, _, _, _, _, _ = evaluator.compute()
+    cmc, mAP = evaluator.compute()[:2]
+    return _report_option_a(logger, cmc, mAP, limit=getattr(evaluator, "max_rank", 50))
+
+
+def _report_option_a(logger, cmc, mAP, limit=50):
+    """the result lines of the TTA evaluation (same text as the reference's, processor_uniprompt_stage2.py:676-692: a rank
+    that the curve does not reach is reported as such instead of indexed) and its (Rank-1, Rank-5) return value"""
+    have = min(len(cmc), limit)
     logger.info("Validation Results (TTPT Option A - Image Features)")
     logger.info("mAP: {:.1%}".format(mAP))
-    for r in [1, 5, 10]:
-        eval_max_rank = getattr(evaluator, 'max_rank', 50)
-        if r <= eval_max_rank and r <= len(cmc):
-            logger.info("CMC curve, Rank-{:<3}:{:.1%}".format(r, cmc[r - 1]))
-        else:
-            logger.info(f"Rank-{r} exceeds max_rank ({eval_max_rank}) or CMC length ({len(cmc)}) ")
-
-    rank1 = cmc[0] if len(cmc) > 0 else 0.0
-    rank5 = cmc[4] if len(cmc) > 4 else 0.0
-    logger.info(f"Returning Rank-1: {rank1:.1%}, Rank-5: {rank5:.1%}")
-    return rank1, rank5
+    for r in (1, 5, 10):
+        logger.info("CMC curve, Rank-{:<3}:{:.1%}".format(r, cmc[r - 1]) if r <= have else
+                    f"Rank-{r} exceeds max_rank ({limit}) or CMC length ({len(cmc)}) ")
+    top = [float(cmc[r - 1]) if len(cmc) >= r else 0.0 for r in (1, 5)]
+    logger.info("Returning Rank-1: {:.1%}, Rank-5: {:.1%}".format(*top))
+    return top[0], top[1]
