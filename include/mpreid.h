@@ -29,10 +29,9 @@ extern "C" {
 /* Environment: the library reads ONE tuning string, MPREID_TUNE="key=value,key=value" (once per process), that selects
  * between BIT-IDENTICAL forms of a stage; no other variable changes which kernel runs.  Keys (default):
  *   gemm_big (1)            0 = never the 256x256 persistent GEMM, 1 = when its grid fills the chip, 2 = whenever divisible
- *   gemm_order (1)          tile order of the persistent GEMM: 0 = grouped rows over the whole grid, 1 = per-XCD super-tiles
  *   gemm_stagger, gemm_stagger_all (0)   start delay (ticks) of the persistent workgroups
  *   jaccard_wave (-1 auto), jaccard_wave_rows (10240), jaccard_table (0)   form of the Jaccard stage
- *   csc_atomic (0), csc_fill (1)         inverted index: round-1 atomic build; scattered (0) / LDS-bucketed (1) fill
+ *   csc_atomic (0)                       inverted index: the round-1 atomic build
  *   rerank_overlap (-1 auto)             exact query rows in line (0) / on a side stream (1)
  *   verbose (0)             occupancy messages on stderr
  * Unknown keys are reported on stderr and ignored.  Switches that change RESULTS exist only in -DMPREID_ABLATION builds. */
@@ -123,9 +122,13 @@ size_t mpreid_rerank_workspace_bytes_ex(int64_t nq, int64_t ng, int d, int k1, i
  * float16 and lambda to float32.  The call synchronises `stream` internally (sizes of the sparse
  * structures are read back) and returns after the result is complete.
  * stats may be NULL; with timing != 0 per-stage times are measured with hipEvents on `stream`.
- * Limits: max(k1 + 1, k2) <= 256 (the neighbour selection sorts its winners in one 256-entry LDS network; the
- * reference is called with k1 = 50, k2 = 15, utils/metrics.py:127) -> MPREID_ERR_UNSUPPORTED above that;
- * N = nq + ng < 2^31 - 64. */
+ * Limits (the reference has none, utils/reranking.py:53-54; it is called with k1 = 50, k2 = 15, utils/metrics.py:127):
+ *   max(k1 + 1, k2) <= 256 -- the neighbour selection sorts its winners in one 256-entry LDS network and the reciprocity
+ *   masks are 256 bits per row -> MPREID_ERR_UNSUPPORTED above that;
+ *   the expansion lists of one row live in LDS: 8 * min(N, (k1 + 1) * (1 + ceil(k1 / 2))) + N / 8 + 8 * (k1 + 1) + 2 KB must
+ *   fit a workgroup's 160 KB, i.e. k1 <= ~190 at N >= 20 000 (k1 <= 255 for N <= 18 000) -> hipErrorInvalidValue from the
+ *   launch configuration above that (a loud failure, never a wrong result);
+ *   N = nq + ng < 2^31 - 64. */
 /* mpreid_rerank_f32 (+ mpreid_rerank_workspace_bytes, mpreid_rerank_debug_copy) is the DENSE algorithm: it never returns
  * the data-dependent MPREID_ERR_RETRY_DENSE.  mpreid_rerank_f32_ex takes the algorithm (AUTO / SPARSE: faster, may ask for
  * the dense retry with a workspace from mpreid_rerank_workspace_bytes_ex(..., MPREID_RERANK_DENSE)). */
@@ -241,7 +244,18 @@ typedef struct {
  *          feature error ~1e-6, |dmAP| <= 1e-4) at 3x the matrix work.  The parity mode that is also the measured mode.
  * In SPLIT mode every *_w pointer of the weight structs is an fp16 pair matrix [out][2*in] = [hi(in) | lo(in)] of
  * W * 2^e (e per matrix, so that the largest |entry| is in [2^9, 2^10)), and the matching *_s field is 2^-e
- * (mpreid_split_pack_f32 produces the layout). */
+ * (mpreid_split_pack_f32 produces the layout).
+ * Range of the fp16 modes (both): ACTIVATIONS are split / rounded unscaled, so every GEMM input -- the normalised pixels, the
+ * LayerNorm outputs, q / k / v, the softmax-weighted values, the QuickGELU outputs -- must stay below 65 504 in magnitude.
+ * Above that a `hi` half is +-inf, the products turn into NaN and the NaN reaches the image's feature row through the
+ * residual stream (it is NOT clamped or hidden): R1_mAP_eval.compute() tests the features and raises RuntimeError
+ * ("non-finite") instead of ranking them; use the all-fp32 mode for such a checkpoint / input range.  Trained CLIP towers
+ * stay 1-2 orders of magnitude below the bound where it applies: the +-2000 "massive activation" channels live in the
+ * fp32 residual stream, which is never an fp16 operand; LayerNorm outputs are at most sqrt(width) * max|gamma| + max|beta|.
+ * Small values: an element below 2^-3 in magnitude keeps an ABSOLUTE error of 2^-25 (its `lo` half is an fp16 subnormal),
+ * which is the level of fp32 rounding noise relative to O(1) activations; tests/test_gpu_vit.py pins both edges
+ * (test_split_mode_on_clip_like_outliers: x30-100 LayerNorm gammas, +-1900 residual channels, +-60 FC1 pre-activations within
+ * 2e-5 of the float64 graph and within a few times plain fp32's own error; test_split_mode_input_scale_edges). */
 #define MPREID_VIT_F16 0
 #define MPREID_VIT_SPLIT 1
 /* SPLIT with ln_1 / ln_2 of every block folded into the linear layer behind them:
