@@ -232,7 +232,7 @@ typedef struct {
     int32_t width, layers, heads, out_dim; /* 768, 12, 12, 512 */
     int32_t neck_after;     /* TEST.NECK_FEAT == 'after': apply the eval BatchNorm necks */
     int32_t cls_only_last;  /* 1: last block computes only the CLS row (the only row the output uses) */
-    int32_t precision;      /* MPREID_VIT_F16, MPREID_VIT_SPLIT or MPREID_VIT_SPLIT_LNFOLD (the all-fp32 mode is mpreid_vit_forward_f32) */
+    int32_t precision;      /* MPREID_VIT_F16 or MPREID_VIT_SPLIT (the all-fp32 mode is mpreid_vit_forward_f32) */
 } mpreid_vit_cfg;
 
 /* Arithmetic of the encoder's linear layers and attention products (model/clip/model.py runs them in fp32,
@@ -258,12 +258,10 @@ typedef struct {
  * 2e-5 of the float64 graph and within a few times plain fp32's own error; test_split_mode_input_scale_edges). */
 #define MPREID_VIT_F16 0
 #define MPREID_VIT_SPLIT 1
-/* SPLIT with ln_1 / ln_2 of every block folded into the linear layer behind them:
- *   LN(x) W^T + b = rstd_m (x_m (gamma o W)^T - mu_m c_n) + b'_n,   c_n = sum_k gamma_k W_nk,   b' = beta W^T + b
- * in_proj_w / fc_w are the pair matrices of (gamma o W) 2^e, in_proj_b / fc_b hold b', in_proj_c / fc_c hold c; ln1_* / ln2_*
- * are not read.  The GEMMs consume the pairs of the RAW residual stream, which the residual epilogues write together
- * with per-row partial sums of x and x^2 (no LayerNorm launches inside the blocks; ln_pre and ln_post are unchanged). */
-#define MPREID_VIT_SPLIT_LNFOLD 2
+/* (precision 2 was MPREID_VIT_SPLIT_LNFOLD in round 3: the LayerNorms folded into the linear layers behind them.  Removed in
+ * round 4 -- measured 0.5 % SLOWER than MPREID_VIT_SPLIT, and tools/ws_poison_check.py found its 128 x 128-kernel form not
+ * reproducible run to run at small batches; mpreid_vit_forward returns MPREID_ERR_UNSUPPORTED for it.  The in_proj_c / fc_c
+ * fields below are kept for layout compatibility and are not read.) */
 
 typedef struct { /* device pointers; *_w are fp16 [out][in] row-major (torch Linear layout) */
     const void *in_proj_w;   /* [3*width][width] fp16 */
@@ -276,7 +274,7 @@ typedef struct { /* device pointers; *_w are fp16 [out][in] row-major (torch Lin
     const void *proj_w;      /* [width][4*width] fp16 */
     const float *proj_b;
     float in_proj_s, out_proj_s, fc_s, proj_s;   /* SPLIT mode: 2^-e of the matching weight matrix (ignored in F16 mode) */
-    const float *in_proj_c, *fc_c;               /* SPLIT_LNFOLD: [3*width], [4*width] row sums of the gamma-scaled weights */
+    const float *in_proj_c, *fc_c;               /* not read (see MPREID_VIT_SPLIT above) */
 } mpreid_vit_layer;
 
 typedef struct { /* device pointers */
@@ -406,6 +404,27 @@ typedef struct {
 size_t mpreid_rn50_workspace_bytes_f32(const mpreid_rn50_cfg *cfg, int batch);
 int mpreid_rn50_forward_f32(const mpreid_rn50_cfg *cfg, const mpreid_rn50_weights_f32 *w, const float *img_f32_dev, int batch,
                             float *out_dev, void *ws_dev, size_t ws_bytes, mpreid_stream_t stream);
+
+/* SPLIT-precision mode of the RN50 tower (MODEL.NAME 'RN50' + MODEL.ENCODER_PRECISION 'split', the default): fp32 NHWC
+ * activations; the convolutions of layer1-4 and the attention pool's k / v projections run on the fp16 matrix cores over
+ * fp16 PAIRS hi + lo, three products per multiply-add with fp32 accumulation (the GE_S_* GEMMs of the ViT's split mode):
+ * fp32-grade features at several times the all-fp32 mode's throughput.  The stem's first convolution (K = 27), the one-query attention and the 1-row
+ * projections q / c stay on the exact fp32 path (`f32`: stem1_*, pos_emb, q_*, c_*, bn_* are read; its stem2 / stem3 /
+ * blocks / k_* / v_* are not).  A split convolution: w = fp16 pair matrix [npad][2 * kseg] = [hi(kseg) | lo(kseg)] of the
+ * BatchNorm-folded weights [cout][taps * cin] (k order (kh, kw, c)) times 2^e, zero-padded to kseg = taps * cin rounded up to
+ * 64 columns and npad = cout rounded up to 128 rows (mpreid_split_pack_f32); bias fp32 [npad] (zero past cout);
+ * oscale = 2^-e.  cin % 4 == 0.  Range: as for the ViT's split mode (activations below 65 504). */
+typedef struct { const void *w; const float *bias; int32_t cin, cout, taps, kseg, npad; float oscale; } mpreid_rn50_conv_split;
+typedef struct { mpreid_rn50_conv_split conv1, conv2, conv3, down; int32_t stride; } mpreid_rn50_block_split;   /* down.w NULL: none */
+typedef struct {
+    mpreid_rn50_weights_f32 f32;
+    const mpreid_rn50_block_split *blocks;       /* HOST array of n_blocks entries */
+    mpreid_rn50_conv_split k, v;                 /* attention pool k_proj / v_proj as 1x1 "convolutions" over the tokens */
+    mpreid_rn50_conv_split stem2, stem3;         /* the stem's second and third convolution (f32.stem2 / stem3 are not read) */
+} mpreid_rn50_weights_split;
+size_t mpreid_rn50_workspace_bytes_split(const mpreid_rn50_cfg *cfg, int batch);
+int mpreid_rn50_forward_split(const mpreid_rn50_cfg *cfg, const mpreid_rn50_weights_split *w, const float *img_f32_dev, int batch,
+                              float *out_dev, void *ws_dev, size_t ws_bytes, mpreid_stream_t stream);
 
 /* One convolution layer of the RN50 tower as the encoder runs it (unit tests, micro-benchmarks):
  * NHWC fp16 in [batch][h][w][cin] (cin % 64 == 0), stride 1, taps = 1 (1x1) or 9 (3x3, pad 1); weights fp16

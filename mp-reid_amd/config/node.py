@@ -72,7 +72,7 @@ def make_defaults():
     return CfgNode({
         "MODEL": {"NAME": "ViT-B-16", "DEVICE": "cuda", "DEVICE_ID": "0", "STRIDE_SIZE": [16, 16],
                   "SIE_CAMERA": False, "SIE_VIEW": False, "SIE_COE": 3.0, "NECK": "bnneck", "COS_LAYER": False,
-                  "DIST_TRAIN": False, "INIT_SEED": 7, "ENCODER_PRECISION": "split", "ENCODER_LN_FOLD": False},
+                  "DIST_TRAIN": False, "INIT_SEED": 7, "ENCODER_PRECISION": "split"},
         "INPUT": {"SIZE_TRAIN": [256, 128], "SIZE_TEST": [256, 128], "PIXEL_MEAN": [0.5, 0.5, 0.5],
                   "PIXEL_STD": [0.5, 0.5, 0.5]},
         "DATASETS": {"NAMES": "synthetic", "ROOT_DIR": "", "EXP_SETTING": "", "SYNTH_QUERY": 3368,

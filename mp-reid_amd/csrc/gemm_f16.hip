@@ -2050,41 +2050,16 @@ static int launch_one(const GemmArgs &a_in, hipStream_t stream) {
                 } else {
                     hipLaunchKernelGGL(gemm_f16_big_kernel<EPI>, grid, dim3(512), B_LDS_TOTAL, stream, a, tiles_m, tiles_n);
                 }
-            } else if constexpr (EPI == GE_S_BIAS_F32 || EPI == GE_S_BIAS_RES || EPI == GE_S_BIAS_GELU) {
-                if (a.rowstat || a.pair_out) {   // folded-LayerNorm instance
-                    static PerDeviceOnce lnf_once;
-                    const int rc = lnf_once.run([]() -> int {
-                        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_big_kernel<EPI, 0, true>),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, B_LDS_TOTAL));
-                        return MPREID_OK;
-                    });
-                    if (rc) return rc;
-                    hipLaunchKernelGGL((gemm_f16_big_kernel<EPI, 0, true>), grid, dim3(512), B_LDS_TOTAL, stream, a, tiles_m, tiles_n);
-                } else {
-                    hipLaunchKernelGGL(gemm_f16_big_kernel<EPI>, grid, dim3(512), B_LDS_TOTAL, stream, a, tiles_m, tiles_n);
-                }
             } else {
                 hipLaunchKernelGGL(gemm_f16_big_kernel<EPI>, grid, dim3(512), B_LDS_TOTAL, stream, a, tiles_m, tiles_n);
             }
         }
     } else {
-        bool launched = false;
-        if constexpr (EPI == GE_S_BIAS_F32 || EPI == GE_S_BIAS_RES || EPI == GE_S_BIAS_GELU) {
-            if (a.rowstat || a.pair_out) {
-                static PerDeviceOnce lnf_small_once;
-                const int rc = lnf_small_once.run([]() -> int {
-                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f16_kernel<EPI, true>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES));
-                    return MPREID_OK;
-                });
-                if (rc) return rc;
-                hipLaunchKernelGGL((gemm_f16_kernel<EPI, true>), dim3((unsigned)tiles_m * (unsigned)tiles_n), dim3(256), G_LDS_BYTES,
-                                   stream, a, tiles_m, tiles_n);
-                launched = true;
-            }
+        if (a.rowstat || a.pair_out) {   // the folded-LayerNorm instances (rounds 3) are no longer built: see include/mpreid.h
+            mpreid_set_error("gemm_f16: GemmArgs::rowstat / pair_out (LayerNorm folding) is not supported any more");
+            return MPREID_ERR_UNSUPPORTED;
         }
-        if (!launched)
-            hipLaunchKernelGGL(gemm_f16_kernel<EPI>, dim3((unsigned)tiles_m * (unsigned)tiles_n), dim3(256), G_LDS_BYTES,
+        hipLaunchKernelGGL(gemm_f16_kernel<EPI>, dim3((unsigned)tiles_m * (unsigned)tiles_n), dim3(256), G_LDS_BYTES,
                                stream, a, tiles_m, tiles_n);
     }
     LAUNCH_CHECK();

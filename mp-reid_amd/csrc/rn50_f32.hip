@@ -13,6 +13,7 @@
 // (explicit q / k / v projections, one query per image: token 0 is the only output the reference uses) in fp32.
 // A parity / debugging mode (~1/10 of the fp16 tower's throughput), the RN50 counterpart of mpreid_vit_forward_f32.
 #include "common.h"
+#include "gemm_f16.h"   // the split-precision tower (below) runs its layer1-4 convolutions on the fp16 matrix cores
 
 int mpreid_gemm_f32_linear(const float *A, const float *Wt, int64_t M, int64_t N, int K, const float *bias, float *C,
                            int64_t ldc, int epi, hipStream_t stream);
@@ -40,6 +41,69 @@ __global__ __launch_bounds__(256) void stem1_f32_kernel(const float *__restrict_
             }
     const float v = acc + bias[n];
     out[gid] = v < 0.0f ? 0.0f : v;
+}
+
+// the same convolution, one thread per OUTPUT PIXEL (all COUT channels): the 27 inputs are read once instead of once per
+// output channel, the folded weights sit in LDS ([27][COUT], broadcast reads), the pixel's COUT results leave as one
+// contiguous run.  Same arithmetic per output (fmaf chain over (c, kh, kw) ascending, + bias, ReLU): same bits as
+// stem1_f32_kernel, which stays for channel counts other than 32 / 16 / 8.
+template <int COUT>
+__global__ __launch_bounds__(256) void stem1_px_kernel(const float *__restrict__ img, const float *__restrict__ w,
+                                                       const float *__restrict__ bias, int B, int H, int W,
+                                                       float *__restrict__ out) {
+    __shared__ float ws[27 * COUT + COUT];
+    for (int t = threadIdx.x; t < 27 * COUT; t += 256) ws[(t % 27) * COUT + t / 27] = w[t];   // [n][27] -> [27][n]
+    for (int t = threadIdx.x; t < COUT; t += 256) ws[27 * COUT + t] = bias[t];
+    __syncthreads();
+    const int OH = H / 2, OW = W / 2;
+    const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= (int64_t)B * OH * OW) return;
+    const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), b = (int)(pix / ((int64_t)OW * OH));
+    float acc[COUT];
+#pragma unroll
+    for (int n = 0; n < COUT; ++n) acc[n] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iy = oy * 2 + kh - 1, ix = ox * 2 + kw - 1;
+                const float x = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? img[(((int64_t)b * 3 + c) * H + iy) * W + ix] : 0.0f;
+                const float *wr = ws + (c * 9 + kh * 3 + kw) * COUT;
+#pragma unroll
+                for (int n = 0; n < COUT; ++n) acc[n] = fmaf(x, wr[n], acc[n]);
+            }
+    float *o = out + pix * COUT;
+#pragma unroll
+    for (int n = 0; n < COUT; n += 4) {
+        float4 v;
+        v.x = acc[n] + ws[27 * COUT + n];
+        v.y = acc[n + 1] + ws[27 * COUT + n + 1];
+        v.z = acc[n + 2] + ws[27 * COUT + n + 2];
+        v.w = acc[n + 3] + ws[27 * COUT + n + 3];
+        v.x = v.x < 0.0f ? 0.0f : v.x;
+        v.y = v.y < 0.0f ? 0.0f : v.y;
+        v.z = v.z < 0.0f ? 0.0f : v.z;
+        v.w = v.w < 0.0f ? 0.0f : v.w;
+        *reinterpret_cast<float4 *>(o + n) = v;
+    }
+}
+
+static int launch_stem1(const float *img, const float *w, const float *bias, int c1, int B, int H, int W, float *out,
+                        hipStream_t stream) {
+    const int64_t px = (int64_t)B * (H / 2) * (W / 2);
+    const dim3 gp((unsigned)((px + 255) / 256));
+    if (c1 == 32) hipLaunchKernelGGL(stem1_px_kernel<32>, gp, dim3(256), 0, stream, img, w, bias, B, H, W, out);
+    else if (c1 == 16) hipLaunchKernelGGL(stem1_px_kernel<16>, gp, dim3(256), 0, stream, img, w, bias, B, H, W, out);
+    else if (c1 == 8) hipLaunchKernelGGL(stem1_px_kernel<8>, gp, dim3(256), 0, stream, img, w, bias, B, H, W, out);
+    else {
+        const int64_t threads = px * c1;
+        hipLaunchKernelGGL(stem1_f32_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, img, w, bias, c1, B, H, W,
+                           out);
+    }
+    LAUNCH_CHECK();
+    return 0;
 }
 
 // [B][H][W][C] -> [B*H*W][9*C], k = (kh*3 + kw)*C + c, zero padded (pad 1, stride 1); C % 4 == 0
@@ -230,13 +294,7 @@ extern "C" int mpreid_rn50_forward_f32(const mpreid_rn50_cfg *cfg, const mpreid_
 
     // ---- stem (model/clip/model.py:128-134) ----
     int H = cfg->img_h / 2, W = cfg->img_w / 2;
-    {
-        const int c1 = cfg->width / 2;
-        const int64_t threads = (int64_t)B * H * W * c1;
-        hipLaunchKernelGGL(stem1_f32_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, img, w->stem1_w,
-                           w->stem1_b, c1, B, cfg->img_h, cfg->img_w, buf[0]);
-        LAUNCH_CHECK();
-    }
+    if ((rc = launch_stem1(img, w->stem1_w, w->stem1_b, cfg->width / 2, B, cfg->img_h, cfg->img_w, buf[0], stream))) return rc;
     ARG_CHECK(w->stem2.taps == 9 && w->stem3.taps == 9 && w->stem2.cin % 4 == 0 && w->stem3.cin % 4 == 0);
     if ((rc = conv_f32(w->stem2, buf[0], B, H, W, 1, 0, buf[1], col, stream))) return rc;
     if ((rc = conv_f32(w->stem3, buf[1], B, H, W, 1, 0, buf[0], col, stream))) return rc;
@@ -300,6 +358,353 @@ extern "C" int mpreid_rn50_forward_f32(const mpreid_rn50_cfg *cfg, const mpreid_
     LAUNCH_CHECK();
     if ((rc = mpreid_gemm_f32_linear(att, w->c_w, B, cfg->out_dim, v.E, w->c_b, proj, cfg->out_dim, F32_LIN, stream))) return rc;
     hipLaunchKernelGGL(head_f32_kernel, dim3(B), dim3(256), 0, stream, mean, proj, v.E, cfg->out_dim, w->bn_scale, w->bn_shift, out);
+    LAUNCH_CHECK();
+    return 0;
+}
+
+
+// =============================================================================================================
+// SPLIT-precision mode of the RN50 tower (MODEL.NAME 'RN50' + MODEL.ENCODER_PRECISION 'split', round 4): the ViT's recipe
+// carried over.  Activations stay fp32 NHWC in HBM (the "residual stream" of a ResNet is every tensor); every convolution
+// of layer1-4 and the attention pool's k / v projections -- 95 % of the tower's FLOPs -- run as GEMMs over fp16 PAIRS
+// x = hi + lo on the fp16 matrix cores, three products hi.hi' + lo.hi' + hi.lo' per multiply-add with fp32 accumulation
+// (gemm_f16.hip GE_S_BIAS_F32 / GE_S_BIAS_RES: the kernels the ViT's split mode uses, unchanged):
+//   1x1 convolution   pack_pairs_kernel: fp32 [M][C] -> pairs [Mp][hi(kseg) | lo(kseg)] (ReLU of the producer applied on the
+//                     way), then out fp32 = acc * 2^-e + bias'                      (BatchNorm folded into W 2^e and bias')
+//   3x3 convolution   im2col3x3_pairs_kernel: the same with the nine taps gathered (k order (kh, kw, c), zero padding)
+//   conv3 + identity  GE_S_BIAS_RES: the identity (block input, or the downsample branch's output) sits in the destination,
+//                     dst += acc * 2^-e + bias'; the block's closing ReLU is applied by whoever reads dst next (and written
+//                     back by the next block's first pack, because dst is that block's identity)
+// The stem's first convolution (K = 27: direct fp32 FMAs), the one-query attention and the 1-row projections q / c stay on
+// the exact fp32 path above.  Channel counts are padded to the GEMM's granularity (kseg to 64, cout to 128: the stem's and
+// layer1's 32 / 64-channel tensors are stored with a row stride of 128).
+// =============================================================================================================
+namespace {
+
+// fp32 [rows][ld_in] (first C channels real) -> fp16 pairs [rows_pad][2 * kseg]: hi at k, lo at kseg + k, zeros for k >= C
+// and for rows >= rows.  RELU: max(x, 0) first; WB: the ReLU-ed value is also written back in place (the tensor is the
+// next block's identity).  One thread per 4 channels of kseg.
+template <bool RELU, bool WB>
+__global__ __launch_bounds__(256) void pack_pairs_kernel(float *__restrict__ in, int64_t rows, int64_t rows_pad, int C, int ld_in,
+                                                         int kseg, _Float16 *__restrict__ out) {
+    const int k4n = kseg / 4;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= rows_pad * k4n) return;
+    const int k4 = (int)(gid % k4n);
+    const int64_t r = gid / k4n;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r < rows && k4 * 4 < C) {   // C % 4 == 0
+        const float4 x = *reinterpret_cast<const float4 *>(in + r * ld_in + k4 * 4);
+        v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+        if (RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];
+            if (WB) *reinterpret_cast<float4 *>(in + r * ld_in + k4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    h4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        hi[e] = (_Float16)v[e];
+        lo[e] = (_Float16)(v[e] - (float)hi[e]);
+    }
+    _Float16 *o = out + r * 2 * kseg + k4 * 4;
+    *reinterpret_cast<h4 *>(o) = hi;
+    *reinterpret_cast<h4 *>(o + kseg) = lo;
+}
+
+// fp32 NHWC [B][H][W][ld_in] (C real channels), ReLU on read -> pairs [rows_pad][2 * kseg], k = (kh * 3 + kw) * C + c.
+// One workgroup per 4 output rows (pixels): the row's kseg / 8 chunks of 8 channels are walked by 64 lanes -- 32-byte reads,
+// two 16-byte writes per chunk, one division per chunk instead of five per 4 channels.  C % 8 == 0 (else CH4: 4 channels).
+template <int CH>
+__global__ __launch_bounds__(256) void im2col3x3_pairs_kernel(const float *__restrict__ in, int B, int H, int W, int C, int ld_in,
+                                                              int64_t rows_pad, int kseg, _Float16 *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pix = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pix >= rows_pad) return;
+    const bool live = pix < (int64_t)B * H * W;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H);
+    const int64_t b = pix / ((int64_t)W * H);
+    const float *img = in + b * H * W * ld_in;
+    _Float16 *orow = out + pix * 2 * kseg;
+    typedef _Float16 hv __attribute__((ext_vector_type(CH)));
+    for (int k = lane * CH; k < kseg; k += 64 * CH) {
+        float v[CH];
+#pragma unroll
+        for (int e = 0; e < CH; ++e) v[e] = 0.f;
+        if (live && k < 9 * C) {
+            const int tap = k / C, c = k - tap * C;   // C % CH == 0: the channels of a chunk share a tap
+            const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                const float *p = img + ((int64_t)iy * W + ix) * ld_in + c;
+#pragma unroll
+                for (int q = 0; q < CH / 4; ++q) {
+                    const float4 t = *reinterpret_cast<const float4 *>(p + q * 4);
+                    v[q * 4 + 0] = t.x < 0.f ? 0.f : t.x;
+                    v[q * 4 + 1] = t.y < 0.f ? 0.f : t.y;
+                    v[q * 4 + 2] = t.z < 0.f ? 0.f : t.z;
+                    v[q * 4 + 3] = t.w < 0.f ? 0.f : t.w;
+                }
+            }
+        }
+        hv hi, lo;
+#pragma unroll
+        for (int e = 0; e < CH; ++e) {
+            hi[e] = (_Float16)v[e];
+            lo[e] = (_Float16)(v[e] - (float)hi[e]);
+        }
+        *reinterpret_cast<hv *>(orow + k) = hi;
+        *reinterpret_cast<hv *>(orow + kseg + k) = lo;
+    }
+}
+
+// AvgPool2d(2) on NHWC fp32 with channel strides (ld_in -> ld_out), optional ReLU on read
+template <bool RELU>
+__global__ __launch_bounds__(256) void avgpool2_ld_kernel(const float *__restrict__ in, int B, int H, int W, int C, int ld_in,
+                                                          int ld_out, float *__restrict__ out) {
+    const int OH = H / 2, OW = W / 2;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (int64_t)B * OH * OW * C) return;
+    const int c = (int)(gid % C);
+    const int64_t pix = gid / C;
+    const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), b = (int)(pix / ((int64_t)OW * OH));
+    const float *p = in + (((int64_t)b * H + oy * 2) * W + ox * 2) * ld_in + c;
+    float a0 = p[0], a1 = p[ld_in], a2 = p[(int64_t)W * ld_in], a3 = p[(int64_t)W * ld_in + ld_in];
+    if (RELU) {
+        a0 = a0 < 0.f ? 0.f : a0;
+        a1 = a1 < 0.f ? 0.f : a1;
+        a2 = a2 < 0.f ? 0.f : a2;
+        a3 = a3 < 0.f ? 0.f : a3;
+    }
+    out[pix * ld_out + c] = (((a0 + a1) + a2) + a3) * 0.25f;
+}
+
+__global__ __launch_bounds__(256) void relu_inplace_kernel(float *__restrict__ x, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] = x[i] < 0.f ? 0.f : x[i];
+}
+
+struct LayoutSplit {
+    LayoutF32 f;           // the fp32 part: five activation buffers (sized for padded channel strides), stem im2col, pool buffers
+    size_t pairs, total;   // one pair matrix (the GEMM A operand of the layer in flight)
+    size_t act_elems;
+};
+
+inline int64_t pad_rows(int64_t m) { return (int64_t)align_up((size_t)m, 256); }
+
+LayoutSplit layout_split(const mpreid_rn50_cfg *cfg, int B) {
+    LayoutSplit v{};
+    const int fh = cfg->img_h / 16, fw = cfg->img_w / 16;
+    const int S = fh * fw, T = S + 1, E = cfg->width * 32;
+    const int wd = cfg->width;
+    auto np = [](int c) { return (int64_t)align_up((size_t)c, 128); };
+    // activation buffers: the widest tensors are the stem's (H/2 x W/2 x width), layer1's (H/4 x W/4 x 4 width, strides padded to
+    // 128) and -- per pixel count -- nothing later is larger
+    const int64_t px2 = (int64_t)(cfg->img_h / 2) * (cfg->img_w / 2), px4 = px2 / 4;
+    // GEMM outputs have their rows padded to 256 and their channel stride to 128.  Widest tensor per resolution: the stem's
+    // (H/2 x W/2 x width); H/4: layer1's output 4 width; H/8: layer2's 8 width; H/16: layer4's 32 width
+    int64_t a = pad_rows((int64_t)B * px2) * np(wd);
+    a = std::max<int64_t>(a, pad_rows((int64_t)B * px4) * np(wd * 4));
+    a = std::max<int64_t>(a, pad_rows((int64_t)B * px4 / 4) * np(wd * 8));
+    a = std::max<int64_t>(a, pad_rows((int64_t)B * S) * np(wd * 32));
+    v.act_elems = (size_t)a;
+    // pair matrix: the largest A operand.  A block's conv1 / conv2 run at the block's INPUT resolution (the stride is an
+    // average pool behind conv2): H/4: 1x1 over <= 4 width, 3x3 over <= 2 width; H/8: 8 width / 4 width; H/16: 32 width / 8 width
+    auto kseg = [](int64_t k) { return (int64_t)align_up((size_t)k, 64); };
+    int64_t pe = pad_rows((int64_t)B * px4) * 2 * std::max(kseg(9 * wd * 2), kseg(wd * 4));
+    pe = std::max<int64_t>(pe, pad_rows((int64_t)B * px2) * 2 * kseg(9 * (wd / 2)));   // the stem's conv2 / conv3
+    pe = std::max<int64_t>(pe, pad_rows((int64_t)B * px4 / 4) * 2 * std::max(kseg(9 * wd * 4), kseg(wd * 8)));
+    pe = std::max<int64_t>(pe, pad_rows((int64_t)B * S) * 2 * std::max(kseg(9 * wd * 8), kseg(wd * 32)));
+    pe = std::max<int64_t>(pe, pad_rows((int64_t)B * T) * 2 * kseg(E));
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off += align_up(bytes, 256);
+        return o;
+    };
+    for (int i = 0; i < 5; ++i) v.f.act[i] = take(v.act_elems * 4);
+    v.f.col = take(256);   // (the fp32 path's im2col buffer is not used by this mode)
+    v.f.S = S; v.f.T = T; v.f.E = E;
+    v.f.mean = take((size_t)B * E * 4);
+    v.f.tok = take((size_t)pad_rows((int64_t)B * T) * E * 4);
+    v.f.tok0 = take((size_t)B * E * 4);
+    v.f.q = take((size_t)B * E * 4);
+    v.f.k = take((size_t)pad_rows((int64_t)B * T) * E * 4);
+    v.f.v = take((size_t)pad_rows((int64_t)B * T) * E * 4);
+    v.f.att = take((size_t)B * E * 4);
+    v.f.proj = take((size_t)B * cfg->out_dim * 4);
+    v.pairs = take((size_t)pe * 2);
+    v.total = off;
+    return v;
+}
+
+struct ActView { float *p; int C, ld; bool dirty; };   // fp32 NHWC tensor: C real channels, row stride ld, ReLU pending?
+
+// one folded convolution of the split tower: pairs of `in` (ReLU applied on read when in.dirty) -> GEMM; res != 0: out += (GE_S_BIAS_RES)
+int conv_split(const mpreid_rn50_conv_split &c, ActView &in, int B, int H, int W, int res, float *out, _Float16 *pairs,
+               hipStream_t stream, bool writeback) {
+    const int64_t M = (int64_t)B * H * W, Mp = pad_rows(M);
+    ARG_CHECK(c.w && c.bias && c.cin == in.C && c.cin % 4 == 0 && c.kseg % 64 == 0 && c.kseg >= c.taps * c.cin &&
+              c.npad % 128 == 0 && c.npad >= c.cout && (c.taps == 1 || c.taps == 9));
+    const int64_t threads = Mp * (c.kseg / 4);
+    const dim3 grid((unsigned)((threads + 255) / 256));
+    if (c.taps == 9) {
+        const dim3 g9((unsigned)((Mp + 3) / 4));
+        if (in.C % 8 == 0 && c.kseg % 8 == 0)
+            hipLaunchKernelGGL(im2col3x3_pairs_kernel<8>, g9, dim3(256), 0, stream, in.p, B, H, W, in.C, in.ld, Mp, c.kseg, pairs);
+        else
+            hipLaunchKernelGGL(im2col3x3_pairs_kernel<4>, g9, dim3(256), 0, stream, in.p, B, H, W, in.C, in.ld, Mp, c.kseg, pairs);
+    } else if (in.dirty && writeback) {
+        hipLaunchKernelGGL((pack_pairs_kernel<true, true>), grid, dim3(256), 0, stream, in.p, M, Mp, in.C, in.ld, c.kseg, pairs);
+        in.dirty = false;
+    } else if (in.dirty) {
+        hipLaunchKernelGGL((pack_pairs_kernel<true, false>), grid, dim3(256), 0, stream, in.p, M, Mp, in.C, in.ld, c.kseg, pairs);
+    } else {
+        hipLaunchKernelGGL((pack_pairs_kernel<false, false>), grid, dim3(256), 0, stream, in.p, M, Mp, in.C, in.ld, c.kseg, pairs);
+    }
+    LAUNCH_CHECK();
+    GemmArgs g{};
+    g.A = pairs;
+    g.W = (const _Float16 *)c.w;
+    g.M = (int)Mp;
+    g.N = c.npad;
+    g.K = 2 * c.kseg;
+    g.kseg = c.kseg;
+    g.oscale = c.oscale;
+    g.out = out;
+    g.ldo = c.npad;
+    g.bias = c.bias;
+    return launch_gemm_f16(g, res ? GE_S_BIAS_RES : GE_S_BIAS_F32, stream);
+}
+
+} // namespace
+
+extern "C" size_t mpreid_rn50_workspace_bytes_split(const mpreid_rn50_cfg *cfg, int batch) {
+    if (check_cfg_f32(cfg) || batch <= 0) return 0;
+    return layout_split(cfg, batch).total;
+}
+
+extern "C" int mpreid_rn50_forward_split(const mpreid_rn50_cfg *cfg, const mpreid_rn50_weights_split *w, const float *img, int B,
+                                         float *out, void *ws, size_t ws_bytes, mpreid_stream_t stream_) {
+    int rc = check_cfg_f32(cfg);
+    if (rc) return rc;
+    ARG_CHECK(w && img && out && B > 0 && w->blocks && w->f32.stem1_w && w->f32.stem1_b && w->f32.q_w && w->f32.c_w && w->k.w && w->v.w &&
+              w->stem2.w && w->stem3.w);
+    const LayoutSplit v = layout_split(cfg, B);
+    if (!ws || ws_bytes < v.total) {
+        mpreid_set_error("rn50 split workspace too small: %zu < %zu", ws_bytes, v.total);
+        return MPREID_ERR_WORKSPACE;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    char *base = (char *)ws;
+    float *buf[5];
+    for (int i = 0; i < 5; ++i) buf[i] = (float *)(base + v.f.act[i]);
+    float *col = (float *)(base + v.f.col);
+    _Float16 *pairs = (_Float16 *)(base + v.pairs);
+    const mpreid_rn50_weights_f32 &wf = w->f32;
+
+    // ---- stem on the exact fp32 path (ReLU applied by its GEMM epilogues) ----
+    int H = cfg->img_h / 2, W = cfg->img_w / 2;
+    if ((rc = launch_stem1(img, wf.stem1_w, wf.stem1_b, cfg->width / 2, B, cfg->img_h, cfg->img_w, buf[0], stream))) return rc;
+    // stem conv2 / conv3 (3x3 over width/2 channels): pair GEMMs like the layers' (their outputs are stored with a channel
+    // stride of 128; on the exact fp32 path these two narrow layers -- N = 32 and 64 in 128-wide tiles -- cost 4.7 ms of a
+    // 25 ms forward at B = 256)
+    ARG_CHECK(w->stem2.taps == 9 && w->stem3.taps == 9);
+    {
+        ActView s1{buf[0], cfg->width / 2, cfg->width / 2, true};   // (stem1 applied its ReLU already: max(x, 0) again is the identity)
+        if ((rc = conv_split(w->stem2, s1, B, H, W, 0, buf[1], pairs, stream, false))) return rc;
+        ActView s2{buf[1], w->stem2.cout, w->stem2.npad, true};
+        if ((rc = conv_split(w->stem3, s2, B, H, W, 0, buf[2], pairs, stream, false))) return rc;
+        const int64_t threads = (int64_t)B * (H / 2) * (W / 2) * w->stem3.cout;
+        hipLaunchKernelGGL((avgpool2_ld_kernel<true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, buf[2], B, H, W,
+                           w->stem3.cout, w->stem3.npad, w->stem3.cout, buf[1]);
+        LAUNCH_CHECK();
+    }
+    (void)col;
+    H /= 2;
+    W /= 2;
+    int xi = 1;
+    ActView x{buf[1], w->stem3.cout, w->stem3.cout, false};
+
+    // ---- residual layers on the fp16 matrix cores (pairs) ----
+    for (int bi = 0; bi < cfg->n_blocks; ++bi) {
+        const mpreid_rn50_block_split &blk = w->blocks[bi];
+        ARG_CHECK(blk.stride == 1 || blk.stride == 2);
+        ARG_CHECK(blk.conv1.taps == 1 && blk.conv2.taps == 9 && blk.conv3.taps == 1);
+        int free_i[4], nf = 0;
+        for (int i = 0; i < 5; ++i)
+            if (i != xi) free_i[nf++] = i;
+        float *t1 = buf[free_i[0]], *t2 = buf[free_i[1]], *t3 = buf[free_i[2]], *t4 = buf[free_i[3]];
+        // conv1 reads x (ReLU of the previous block's sum applied on the way AND written back: x is an identity below)
+        if ((rc = conv_split(blk.conv1, x, B, H, W, 0, t1, pairs, stream, true))) return rc;
+        ActView a1{t1, blk.conv1.cout, blk.conv1.npad, true};
+        if ((rc = conv_split(blk.conv2, a1, B, H, W, 0, t2, pairs, stream, false))) return rc;
+        ActView a2{t2, blk.conv2.cout, blk.conv2.npad, true};
+        int OH = H, OW = W;
+        if (blk.stride == 2) {
+            const int64_t threads = (int64_t)B * (H / 2) * (W / 2) * a2.C;
+            hipLaunchKernelGGL((avgpool2_ld_kernel<true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, a2.p, B, H, W,
+                               a2.C, a2.ld, a2.C, t1);
+            LAUNCH_CHECK();
+            a2 = ActView{t1, a2.C, a2.C, false};
+            OH = H / 2;
+            OW = W / 2;
+        }
+        float *dst;
+        if (blk.down.w) {
+            ActView xin = x;   // (clean: conv1's pack wrote the ReLU back)
+            if (blk.stride == 2) {
+                const int64_t threads = (int64_t)B * OH * OW * x.C;
+                hipLaunchKernelGGL((avgpool2_ld_kernel<false>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, x.p, B, H,
+                                   W, x.C, x.ld, x.C, t3);
+                LAUNCH_CHECK();
+                xin = ActView{t3, x.C, x.C, false};
+            }
+            // conv3's operand must be packed AFTER the downsample GEMM has consumed the pair buffer: order matters (one buffer)
+            if ((rc = conv_split(blk.down, xin, B, OH, OW, 0, t4, pairs, stream, false))) return rc;
+            dst = t4;
+            xi = free_i[3];
+        } else {
+            ARG_CHECK(blk.stride == 1 && blk.conv3.cout == x.C && blk.conv3.npad == x.ld);
+            dst = x.p;      // x itself is the identity (clean) and is not needed afterwards
+        }
+        if ((rc = conv_split(blk.conv3, a2, B, OH, OW, 1, dst, pairs, stream, false))) return rc;
+        x = ActView{dst, blk.conv3.cout, blk.conv3.npad, true};
+        H = OH;
+        W = OW;
+    }
+    ARG_CHECK(H * W == v.f.S && x.C == v.f.E && x.ld == v.f.E);
+    {
+        const int64_t n = (int64_t)B * v.f.S * v.f.E;
+        hipLaunchKernelGGL(relu_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x.p, n);
+        LAUNCH_CHECK();
+    }
+
+    // ---- attention pool: k / v projections of the B * T tokens as pair GEMMs, the rest on the fp32 path ----
+    float *mean = (float *)(base + v.f.mean), *tok = (float *)(base + v.f.tok), *tok0 = (float *)(base + v.f.tok0);
+    float *q = (float *)(base + v.f.q), *k = (float *)(base + v.f.k), *vv = (float *)(base + v.f.v);
+    float *att = (float *)(base + v.f.att), *proj = (float *)(base + v.f.proj);
+    hipLaunchKernelGGL(tokens_f32_kernel, dim3(B), dim3(256), 0, stream, x.p, wf.pos_emb, v.f.S, v.f.E, mean, tok);
+    hipLaunchKernelGGL(gather_tok0_f32_kernel, dim3(B), dim3(256), 0, stream, tok, v.f.T, v.f.E, tok0);
+    LAUNCH_CHECK();
+    if ((rc = mpreid_gemm_f32_linear(tok0, wf.q_w, B, v.f.E, v.f.E, wf.q_b, q, v.f.E, F32_LIN, stream))) return rc;
+    {
+        ActView tk{tok, v.f.E, v.f.E, false};
+        ARG_CHECK(w->k.npad == v.f.E && w->v.npad == v.f.E);
+        // one pack serves both projections: conv_split packs per call, so pack once by hand and launch the two GEMMs
+        if ((rc = conv_split(w->k, tk, B * v.f.T, 1, 1, 0, k, pairs, stream, false))) return rc;
+        GemmArgs g{};
+        g.A = pairs; g.W = (const _Float16 *)w->v.w; g.M = (int)pad_rows((int64_t)B * v.f.T); g.N = w->v.npad; g.K = 2 * w->v.kseg;
+        g.kseg = w->v.kseg; g.oscale = w->v.oscale; g.out = vv; g.ldo = w->v.npad; g.bias = w->v.bias;
+        ARG_CHECK(w->v.kseg == w->k.kseg);
+        if ((rc = launch_gemm_f16(g, GE_S_BIAS_F32, stream))) return rc;
+    }
+    hipLaunchKernelGGL(pool_attend_f32_kernel, dim3((unsigned)(B * cfg->heads)), dim3(64), (size_t)v.f.T * 4, stream, q, k, vv, v.f.T,
+                       v.f.E, cfg->heads, att);
+    LAUNCH_CHECK();
+    if ((rc = mpreid_gemm_f32_linear(att, wf.c_w, B, cfg->out_dim, v.f.E, wf.c_b, proj, cfg->out_dim, F32_LIN, stream))) return rc;
+    hipLaunchKernelGGL(head_f32_kernel, dim3(B), dim3(256), 0, stream, mean, proj, v.f.E, cfg->out_dim, wf.bn_scale, wf.bn_shift, out);
     LAUNCH_CHECK();
     return 0;
 }

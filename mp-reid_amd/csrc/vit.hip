@@ -202,76 +202,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
-// LayerNorm folded into the linear layer behind it (MPREID_VIT_SPLIT_LNFOLD): the GEMM consumes the fp16 pairs of the RAW
-// residual stream and a per-row (mean, 1 / sqrt(var + eps)) table (gemm_f16.h GemmArgs::rowstat).
-//   pair_stats_kernel      x fp32 -> pairs [hi(W) | lo(W)] + the row's statistics, two-pass as the LayerNorm kernel computes
-//                          them (after ln_pre, and for the CLS rows of the last block); one wave per row
-//   stats_finalize_kernel  the residual epilogues' per-row partial sums of x and x^2 over 64-column groups -> (mean, rstd);
-//                          groups are combined in ascending order (deterministic); var = E[x^2] - mean^2, the difference taken
-//                          in fp64 (the partial sums themselves are fp32: relative error of var ~1e-7 * E[x^2] / var)
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pair_stats_kernel(const float *__restrict__ x, int64_t rows, int W, _Float16 *__restrict__ xp,
-                                                         float *__restrict__ st) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float *xr = x + row * W;
-    float4 v[4];
-    bool act[4];
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        act[i] = (i * 256 + lane * 4) < W;
-        v[i] = act[i] ? *reinterpret_cast<const float4 *>(xr + i * 256 + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
-    const float mean = s / (float)W;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (act[i]) {
-            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
-            q += (a * a + b * b) + (c * c + d * d);
-        }
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
-    const float rstd = 1.0f / __fsqrt_rn(q / (float)W + 1e-5f);
-    if (lane == 0) *reinterpret_cast<float2 *>(st + row * 2) = make_float2(mean, rstd);
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-    _Float16 *orow = xp + row * 2 * (int64_t)W;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (!act[i]) continue;
-        const int k = i * 256 + lane * 4;
-        const h4 hi = {(_Float16)v[i].x, (_Float16)v[i].y, (_Float16)v[i].z, (_Float16)v[i].w};
-        const h4 lo = {(_Float16)(v[i].x - (float)hi[0]), (_Float16)(v[i].y - (float)hi[1]), (_Float16)(v[i].z - (float)hi[2]),
-                       (_Float16)(v[i].w - (float)hi[3])};
-        *reinterpret_cast<h4 *>(orow + k) = hi;
-        *reinterpret_cast<h4 *>(orow + W + k) = lo;
-    }
-}
-
-__global__ __launch_bounds__(256) void stats_finalize_kernel(const float *__restrict__ part, int groups, int64_t mstride, int64_t rows,
-                                                             int W, float *__restrict__ st) {
-    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (row >= rows) return;
-    float s = 0.f, q = 0.f;
-    for (int gidx = 0; gidx < groups; ++gidx) {
-        const float2 p = *reinterpret_cast<const float2 *>(part + ((int64_t)gidx * mstride + row) * 2);
-        s += p.x;
-        q += p.y;
-    }
-    const float mean = s / (float)W;
-    double var = (double)q / (double)W - (double)mean * (double)mean;
-    var = var < 0.0 ? 0.0 : var;
-    const float rstd = 1.0f / __fsqrt_rn((float)var + 1e-5f);
-    *reinterpret_cast<float2 *>(st + row * 2) = make_float2(mean, rstd);
-}
-
-// ---------------------------------------------------------------------------------------------
 // attention: softmax(q k^T / sqrt(64)) v per (image, head); L <= 16*KTP keys live in LDS.
 //
 // One workgroup per (image, head); each wave owns 16-query tiles.  Computed "key on the lane":
@@ -1026,7 +956,7 @@ __global__ __launch_bounds__(256) void gather_cls_kernel(const float *__restrict
 // ---------------------------------------------------------------------------------------------
 struct VitLayout {
     int L, P, M, Mpad, MPpad, Kp, Bpad;
-    size_t patches, x, a, qkv, hbuf, x_cls, a_cls, h_cls, y_cls, xp, xp_cls, st, part, total;   // xp ..: LNFOLD only
+    size_t patches, x, a, qkv, hbuf, x_cls, a_cls, h_cls, y_cls, total;
 };
 
 static VitLayout vit_layout(const mpreid_vit_cfg *c, int B) {
@@ -1056,12 +986,6 @@ static VitLayout vit_layout(const mpreid_vit_cfg *c, int B) {
     v.a_cls = take((size_t)v.Bpad * W * 2 * pr);
     v.h_cls = take((size_t)v.Bpad * 4 * W * 2 * pr);
     v.y_cls = take((size_t)v.Bpad * W * 4);
-    if (c->precision == MPREID_VIT_SPLIT_LNFOLD) {   // pairs of the raw residual stream, row statistics and their partials
-        v.xp = take((size_t)v.Mpad * W * 4);
-        v.xp_cls = take((size_t)v.Bpad * W * 4);
-        v.st = take((size_t)v.Mpad * 2 * 4);
-        v.part = take((size_t)(W / 64) * v.Mpad * 2 * 4);
-    }
     v.total = off;
     return v;
 }
@@ -1069,7 +993,12 @@ static VitLayout vit_layout(const mpreid_vit_cfg *c, int B) {
 static int vit_check_cfg(const mpreid_vit_cfg *c) {
     ARG_CHECK(c != nullptr);
     ARG_CHECK(c->width > 0 && c->heads > 0 && c->layers >= 0 && c->out_dim > 0);
-    ARG_CHECK(c->precision == MPREID_VIT_F16 || c->precision == MPREID_VIT_SPLIT || c->precision == MPREID_VIT_SPLIT_LNFOLD);
+    if (c->precision == 2) {   // MPREID_VIT_SPLIT_LNFOLD of rounds 3: see include/mpreid.h
+        mpreid_set_error("the folded-LayerNorm form of the split mode was removed in round 4 (not faster than MPREID_VIT_SPLIT, and not "
+                         "reproducible run to run at small batches); use MPREID_VIT_SPLIT");
+        return MPREID_ERR_UNSUPPORTED;
+    }
+    ARG_CHECK(c->precision == MPREID_VIT_F16 || c->precision == MPREID_VIT_SPLIT);
     if (c->width != c->heads * 64) {
         mpreid_set_error("head dim must be 64 (width %d, heads %d)", c->width, c->heads);
         return MPREID_ERR_UNSUPPORTED;
@@ -1224,12 +1153,6 @@ static int vit_forward_impl(const mpreid_vit_cfg *cfg, const mpreid_vit_weights 
     const bool cls_last = cfg->cls_only_last != 0 && cfg->layers > 0;
     // split precision mode: every linear layer runs hi.hi' + lo.hi' + hi.lo' over fp16 pairs (gemm_f16.h GE_S_*)
     const bool split = cfg->precision != MPREID_VIT_F16;
-    // LNFOLD: ln_1 / ln_2 of every block are folded into in_proj / c_fc (weights gamma-scaled, bias' = beta.W^T + b and
-    // c = row sums of the scaled weights prepared by the caller); the GEMMs read the pairs of the raw residual stream (xp)
-    // and a (mean, rstd) table per row; xp and the statistics' partial sums leave the residual epilogues
-    const bool fold = cfg->precision == MPREID_VIT_SPLIT_LNFOLD;
-    _Float16 *xp = fold ? (_Float16 *)(base + v.xp) : nullptr, *xp_cls = fold ? (_Float16 *)(base + v.xp_cls) : nullptr;
-    float *st = fold ? (float *)(base + v.st) : nullptr, *part = fold ? (float *)(base + v.part) : nullptr;
     const int pr = split ? 2 : 1;   // halfs per logical element of a GEMM operand row
     auto linear = [&](GemmArgs &g, int kdim, float wscale, int epi_f16, int epi_split) -> int {
         g.K = pr * kdim;
@@ -1279,23 +1202,15 @@ static int vit_forward_impl(const mpreid_vit_cfg *cfg, const mpreid_vit_weights 
                            B, L, W, x);
         hipLaunchKernelGGL(layernorm_kernel<0>, dim3((unsigned)((v.M + 3) / 4)), dim3(256), 0, stream, x,
                            (int64_t)v.M, W, w->ln_pre_g, w->ln_pre_b, (void *)x, (int64_t)W);
-        if (fold)
-            hipLaunchKernelGGL(pair_stats_kernel, dim3((unsigned)((v.M + 3) / 4)), dim3(256), 0, stream, x, (int64_t)v.M, W, xp, st);
         LAUNCH_CHECK();
     }
-    auto finalize = [&](int64_t rows, int64_t mstride) {
-        hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, part, W / 64, mstride,
-                           rows, W, st);
-    };
     for (int l = 0; l < cfg->layers; ++l) {
         const mpreid_vit_layer &ly = w->layers[l];
         const bool tail = cls_last && (l == cfg->layers - 1);
         GemmArgs g{};
         // x = x + out_proj(attn(ln_1(x)))
-        void *ptok = fold ? nullptr : mpreid_prof_begin(stream);   // folded mode: no LayerNorm launch, nothing to file
-        if (fold) {
-            // (xp / st hold the pairs and statistics of x: from pair_stats_kernel or the previous block's last epilogue)
-        } else if (split)
+        void *ptok = mpreid_prof_begin(stream);
+        if (split)
             hipLaunchKernelGGL(layernorm_kernel<2>, dim3((unsigned)((v.M + 3) / 4)), dim3(256), 0, stream, x,
                                (int64_t)v.M, W, ly.ln1_g, ly.ln1_b, (void *)a, (int64_t)W);
         else
@@ -1304,9 +1219,8 @@ static int vit_forward_impl(const mpreid_vit_cfg *cfg, const mpreid_vit_weights 
         mpreid_prof_end(ptok, stream, MPREID_PROF_LAYERNORM, v.M, W, pr, (double)v.M * W * (4.0 + 2.0 * pr));
         LAUNCH_CHECK();
         g = GemmArgs{};
-        g.A = fold ? xp : a; g.W = (const _Float16 *)ly.in_proj_w; g.M = v.Mpad; g.N = 3 * W;
+        g.A = a; g.W = (const _Float16 *)ly.in_proj_w; g.M = v.Mpad; g.N = 3 * W;
         g.out = qkv; g.ldo = 3 * W; g.bias = ly.in_proj_b;
-        if (fold) { g.rowstat = st; g.colc = ly.in_proj_c; }
         if ((rc = linear(g, W, ly.in_proj_s, GE_BIAS_F16, GE_S_BIAS_F32))) return rc;
         // in the last block only the CLS row reaches the output (model/make_model.py:98-100): the
         // attention runs the first query tile only and everything after it runs on the B CLS rows.
@@ -1320,23 +1234,19 @@ static int vit_forward_impl(const mpreid_vit_cfg *cfg, const mpreid_vit_weights 
                         ((double)v.M * 2.0 * W + (tail ? (double)B * 16 : (double)v.M) * 2.0 * W) * 2.0 * pr);
         if (rc) return rc;
         float *xr = x;
-        _Float16 *ar = a, *hr = hbuf, *xpr = xp;
+        _Float16 *ar = a, *hr = hbuf;
         int rows = v.M, rows_pad = v.Mpad;
         if (tail) {
             hipLaunchKernelGGL(gather_cls_kernel, dim3((unsigned)B), dim3(256), 0, stream, x, a, B, L, W, pr * W, x_cls, a_cls);
             LAUNCH_CHECK();
-            xr = x_cls; ar = a_cls; hr = h_cls; rows = B; rows_pad = v.Bpad; xpr = xp_cls;
+            xr = x_cls; ar = a_cls; hr = h_cls; rows = B; rows_pad = v.Bpad;
         }
         g = GemmArgs{};
         g.A = ar; g.W = (const _Float16 *)ly.out_proj_w; g.M = rows_pad; g.N = W;
         g.out = xr; g.ldo = W; g.bias = ly.out_proj_b;
-        if (fold) { g.pair_out = xpr; g.ldp = 2 * W; g.stat_part = part; }
         if ((rc = linear(g, W, ly.out_proj_s, GE_BIAS_RES, GE_S_BIAS_RES))) return rc;
         // x = x + c_proj(quickgelu(c_fc(ln_2(x))))
-        if (fold) {
-            finalize(rows_pad, rows_pad);
-            LAUNCH_CHECK();
-        } else if (split)
+        if (split)
             hipLaunchKernelGGL(layernorm_kernel<2>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, xr,
                                (int64_t)rows, W, ly.ln2_g, ly.ln2_b, (void *)ar, (int64_t)W);
         else
@@ -1344,20 +1254,13 @@ static int vit_forward_impl(const mpreid_vit_cfg *cfg, const mpreid_vit_weights 
                                (int64_t)rows, W, ly.ln2_g, ly.ln2_b, (void *)ar, (int64_t)W);
         LAUNCH_CHECK();
         g = GemmArgs{};
-        g.A = fold ? xpr : ar; g.W = (const _Float16 *)ly.fc_w; g.M = rows_pad; g.N = 4 * W;
+        g.A = ar; g.W = (const _Float16 *)ly.fc_w; g.M = rows_pad; g.N = 4 * W;
         g.out = hr; g.ldo = pr * 4 * W; g.bias = ly.fc_b;
-        if (fold) { g.rowstat = st; g.colc = ly.fc_c; }
         if ((rc = linear(g, W, ly.fc_s, GE_BIAS_GELU, GE_S_BIAS_GELU))) return rc;
         g = GemmArgs{};
         g.A = hr; g.W = (const _Float16 *)ly.proj_w; g.M = rows_pad; g.N = W;
         g.out = xr; g.ldo = W; g.bias = ly.proj_b;
-        const bool more = fold && l + 1 < cfg->layers;   // the next block's in_proj reads xp / st
-        if (more) { g.pair_out = xpr; g.ldp = 2 * W; g.stat_part = part; }
         if ((rc = linear(g, 4 * W, ly.proj_s, GE_BIAS_RES, GE_S_BIAS_RES))) return rc;
-        if (more) {
-            finalize(rows_pad, rows_pad);
-            LAUNCH_CHECK();
-        }
     }
     const bool neck = cfg->neck_after != 0 && w->bn_scale && w->bn_proj_scale;
     hipLaunchKernelGGL(cls_ln_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, cls_last ? x_cls : x,

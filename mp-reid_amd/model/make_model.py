@@ -42,7 +42,6 @@ class build_transformer(nn.Module):
         # mAP bound; 'fp16' = single fp16 operands (fastest, ~4e-4 feature error, misses the bound on hard data);
         # 'fp32' = the all-fp32 mode on the exact fp32 matrix instruction (mpreid_vit_forward_f32)
         self.precision = str(getattr(cfg.MODEL, "ENCODER_PRECISION", "split"))
-        self.ln_fold = bool(getattr(cfg.MODEL, "ENCODER_LN_FOLD", False))   # split mode: LayerNorm folded into the GEMMs (opt-in)
         self.in_planes, self.in_planes_proj = (768, 512) if self.model_name == 'ViT-B-16' else (2048, 1024)
         self.num_classes, self.camera_num, self.view_num = num_classes, camera_num, view_num
         self.sie_coe = cfg.MODEL.SIE_COE
@@ -106,18 +105,12 @@ class build_transformer(nn.Module):
                       self._modules[n].running_var) for n in ("bottleneck", "bottleneck_proj")}
         kw = {} if ws_tag is None else {"ws_tag": ws_tag}
         if self.model_name == 'RN50':
-            # RN50 has two modes: 'fp32' (parity-grade, 4.7e-6 from the reference's features) and the fp16 tower ('fp16':
-            # 11x faster, 2.6e-3).  'split' -- the default, a ViT mode -- means "parity-grade" and selects 'fp32' here, so
-            # that a default-config RN50 run meets the same bound as a default ViT run; the fast tower must be asked for.
-            prec = "fp16" if self.precision == "fp16" else "fp32"
-            if self.precision == "split":
-                import logging
-                logging.getLogger("transreid.test").info(
-                    "MODEL.NAME RN50 has no split-precision tower: ENCODER_PRECISION 'split' runs the all-fp32 tower "
-                    "(parity-grade); set MODEL.ENCODER_PRECISION fp16 for the fast fp16 tower (feature error 2.6e-3)")
-            return _ops.Rn50Encoder(self.rn_cfg, sd, self.img_hw, neck_after=neck_after, bn=bn, precision=prec, **kw)
-        return _ops.VitEncoder(self.vit_cfg, sd, self.img_hw, neck_after=neck_after, bn=bn, precision=self.precision,
-                               ln_fold=self.ln_fold, **kw)
+            # RN50 modes: 'split' (default: fp32 activations, layer1-4 and the attention pool's k / v projections over fp16
+            # pairs on the fp16 matrix cores -- fp32-grade features), 'fp32' (everything on the exact fp32 matrix instruction)
+            # and 'fp16' (fp16 activations: the throughput tower, feature error 2.6e-3, misses the 1e-4 mAP bound)
+            assert self.precision in ("split", "fp32", "fp16"), self.precision
+            return _ops.Rn50Encoder(self.rn_cfg, sd, self.img_hw, neck_after=neck_after, bn=bn, precision=self.precision, **kw)
+        return _ops.VitEncoder(self.vit_cfg, sd, self.img_hw, neck_after=neck_after, bn=bn, precision=self.precision, **kw)
 
     @property
     def encode_group(self):

@@ -32,6 +32,7 @@ SYMBOLS = [
     "mpreid_vit_workspace_bytes_f32", "mpreid_vit_forward_f32",
     "mpreid_tta_mean_f32", "mpreid_resize_workspace_bytes", "mpreid_resize_bilinear_u8", "mpreid_conv_f16_nhwc",
     "mpreid_rn50_workspace_bytes", "mpreid_rn50_forward", "mpreid_rn50_workspace_bytes_f32", "mpreid_rn50_forward_f32",
+    "mpreid_rn50_workspace_bytes_split", "mpreid_rn50_forward_split",
     "mpreid_gemm_f16_nt", "mpreid_gemm_f16_nt_ex", "mpreid_gemm_f16_split_nt", "mpreid_split_pack_f32",
     "mpreid_cast_f32_to_f16", "mpreid_profile_enable", "mpreid_profile_reset", "mpreid_profile_query",
 ]
@@ -103,6 +104,21 @@ class Rn50WeightsF32(C.Structure):
                 ("c_b", C.c_void_p), ("bn_scale", C.c_void_p), ("bn_shift", C.c_void_p)]
 
 
+class Rn50ConvSplit(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("bias", C.c_void_p), ("cin", C.c_int32), ("cout", C.c_int32), ("taps", C.c_int32),
+                ("kseg", C.c_int32), ("npad", C.c_int32), ("oscale", C.c_float)]
+
+
+class Rn50BlockSplit(C.Structure):
+    _fields_ = [("conv1", Rn50ConvSplit), ("conv2", Rn50ConvSplit), ("conv3", Rn50ConvSplit), ("down", Rn50ConvSplit),
+                ("stride", C.c_int32)]
+
+
+class Rn50WeightsSplit(C.Structure):
+    _fields_ = [("f32", Rn50WeightsF32), ("blocks", C.POINTER(Rn50BlockSplit)), ("k", Rn50ConvSplit), ("v", Rn50ConvSplit),
+                ("stem2", Rn50ConvSplit), ("stem3", Rn50ConvSplit)]
+
+
 class ProfileEntry(C.Structure):
     _fields_ = [("epilogue", C.c_int32), ("n", C.c_int32), ("k", C.c_int32), ("m", C.c_int64),
                 ("launches", C.c_int64), ("total_ms", C.c_double), ("flops_total", C.c_double)]
@@ -112,7 +128,7 @@ GEMM_EPILOGUE_NAMES = {0: "f32", 1: "qkv_bias_f16", 2: "bias_residual", 3: "fc_b
                        5: "euclid", 6: "cosine", 7: "conv1x1_bias_relu", 8: "conv1x1_bias_residual_relu", 9: "candidates",
                        10: "split_qkv_bias_f32", 11: "split_bias_residual", 12: "split_fc_bias_quickgelu",
                        13: "split_patch_embed"}
-VIT_F16, VIT_SPLIT, VIT_SPLIT_LNFOLD = 0, 1, 2
+VIT_F16, VIT_SPLIT = 0, 1
 
 _lib = None
 
@@ -220,6 +236,10 @@ def load():
     L.mpreid_rn50_workspace_bytes_f32.argtypes = [C.POINTER(Rn50Cfg), i32]
     L.mpreid_rn50_forward_f32.restype = i32
     L.mpreid_rn50_forward_f32.argtypes = [C.POINTER(Rn50Cfg), C.POINTER(Rn50WeightsF32), vp, i32, vp, vp, sz, vp]
+    L.mpreid_rn50_workspace_bytes_split.restype = sz
+    L.mpreid_rn50_workspace_bytes_split.argtypes = [C.POINTER(Rn50Cfg), i32]
+    L.mpreid_rn50_forward_split.restype = i32
+    L.mpreid_rn50_forward_split.argtypes = [C.POINTER(Rn50Cfg), C.POINTER(Rn50WeightsSplit), vp, i32, vp, vp, sz, vp]
     L.mpreid_conv_f16_nhwc.restype = i32
     L.mpreid_conv_f16_nhwc.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, vp, i32, vp, vp, vp]
     L.mpreid_gemm_f16_nt.restype = i32

@@ -273,12 +273,9 @@ class VitEncoder:
         relative feature error ~4e-4: misses the bound on hard data); 'fp32' = every weight and activation fp32, exact
         fp32 matrix instruction (~1e-6, ~1/8 of the fp16 throughput; mpreid_vit_forward_f32)."""
         assert precision in ("fp16", "fp32", "split"), precision
-        # ln_fold (split mode only): ln_1 / ln_2 of every block folded into in_proj / c_fc -- LN(x) W^T + b =
-        # rstd (x (gamma o W)^T - mu c) + b' with c = row sums of gamma o W and b' = beta W^T + b, all folded here in fp64;
-        # the GEMMs then read the pairs of the raw residual stream and a per-row (mean, rstd) table and the blocks contain
-        # no LayerNorm launches (MPREID_VIT_SPLIT_LNFOLD)
-        ln_fold = bool(ln_fold) and precision == "split"
-        self.ln_fold = ln_fold
+        if ln_fold:
+            raise ValueError("ln_fold: the folded-LayerNorm form of the split mode was removed in round 4 (0.5 % slower than the plain "
+                             "split mode and not reproducible run to run at small batches: include/mpreid.h)")
         self.precision = precision
         self.device = device or _lib.require_gpu()
         self.ws_tag = ws_tag   # encoders that run concurrently on different streams need distinct workspaces
@@ -321,7 +318,7 @@ class VitEncoder:
         self.c_cfg = _lib.VitCfg(self.img_hw[0], self.img_hw[1], cfg["patch"], cfg["stride"], cfg["h_res"],
                                  cfg["w_res"], w, cfg["layers"], cfg["heads"], cfg["out_dim"], int(bool(neck_after)),
                                  int(bool(cls_only_last)),
-                                 (_lib.VIT_SPLIT_LNFOLD if ln_fold else _lib.VIT_SPLIT) if precision == "split" else _lib.VIT_F16)
+                                 _lib.VIT_SPLIT if precision == "split" else _lib.VIT_F16)
         layers = (_lib.VitLayer * max(cfg["layers"], 1))()
         for i in range(cfg["layers"]):
             b = f"transformer.resblocks.{i}"
@@ -331,16 +328,6 @@ class VitEncoder:
                      ln2_g=f32(b + ".ln_2.weight"), ln2_b=f32(b + ".ln_2.bias"),
                      fc_w=f16(b + ".mlp.c_fc.weight"), fc_b=f32(b + ".mlp.c_fc.bias"),
                      proj_w=f16(b + ".mlp.c_proj.weight"), proj_b=f32(b + ".mlp.c_proj.bias"))
-            if ln_fold:
-                for ln, wn, bn_, cn in (("ln_1", "attn.in_proj_weight", "attn.in_proj_bias", "in_proj"),
-                                        ("ln_2", "mlp.c_fc.weight", "mlp.c_fc.bias", "fc")):
-                    g64 = get(f"{b}.{ln}.weight").double().cpu()
-                    b64 = get(f"{b}.{ln}.bias").double().cpu()
-                    w64 = get(f"{b}.{wn}").double().cpu()
-                    ws = w64 * g64[None, :]
-                    t[cn + "_w"] = f16(f"{b}.{wn}", tensor=ws.float())   # (gamma o W): rounded to fp32 once, then the pair
-                    t[cn + "_c"] = ws.float().double().sum(1).float().to(dev).contiguous()   # row sums of what the GEMM multiplies by
-                    t[cn + "_b"] = (get(f"{b}.{bn_}").double().cpu() + w64 @ b64).float().to(dev).contiguous()
             for k, v in t.items():
                 keep(v)
                 setattr(layers[i], k, v.data_ptr())
@@ -561,15 +548,17 @@ class Rn50Encoder:
                  device=None, ws_tag: str = "rn50", precision: str = "fp16"):
         """precision: 'fp16' = fp16 NHWC activations, implicit-GEMM convolutions on the fp16 matrix cores (the throughput
         path, relative feature error 2.6e-3); 'fp32' = everything fp32 on the exact fp32 matrix instruction
-        (mpreid_rn50_forward_f32: ~1e-6, the parity mode)."""
-        assert precision in ("fp16", "fp32"), precision
+        (mpreid_rn50_forward_f32: ~1e-6); 'split' = fp32 activations, the convolutions of layer1-4 and the attention pool's
+        k / v projections over fp16 PAIRS on the fp16 matrix cores (mpreid_rn50_forward_split: fp32-grade features -- the
+        parity-grade mode that is also fast)."""
+        assert precision in ("fp16", "fp32", "split"), precision
         self.precision = precision
         self.device = dev = device or _lib.require_gpu()
         self.ws_tag, self.cfg, self.img_hw = ws_tag, dict(cfg), tuple(img_hw)
         width, layers = cfg["width"], tuple(cfg["layers"])
         assert self.img_hw[0] // 16 == cfg["h_res"] and self.img_hw[1] // 16 == cfg["w_res"], (img_hw, cfg)
-        if precision == "fp32":
-            self._init_f32(cfg, state_dict, neck_after, bn)
+        if precision in ("fp32", "split"):
+            self._init_f32(cfg, state_dict, neck_after, bn, split=precision == "split")
             return
 
         def get(name):
@@ -661,8 +650,10 @@ class Rn50Encoder:
         self.c_w.c_w, self.c_w.c_b = _ptr(cw), _ptr(cb)
         self.c_w.bn_scale, self.c_w.bn_shift = _ptr(scale), _ptr(shift)
 
-    def _init_f32(self, cfg, state_dict, neck_after, bn):
-        """fp32 mode: BatchNorm folded in fp64 and rounded once to fp32; real channel counts; [cout][kh][kw][cin] rows"""
+    def _init_f32(self, cfg, state_dict, neck_after, bn, split=False):
+        """fp32 mode: BatchNorm folded in fp64 and rounded once to fp32; real channel counts; [cout][kh][kw][cin] rows.
+        split: the same folded fp32 matrices, those of layer1-4 and of k_proj / v_proj additionally as fp16 pair matrices
+        [cout_pad128][hi(kseg) | lo(kseg)] of W * 2^e (mpreid_split_pack_f32; include/mpreid.h mpreid_rn50_conv_split)"""
         dev = self.device
         width, layers = cfg["width"], tuple(cfg["layers"])
 
@@ -692,6 +683,29 @@ class Rn50Encoder:
             wk = dev32(w.transpose(0, 2, 3, 1).reshape(cout, kh * kw * cin))   # k order (kh, kw, c)
             return _lib.Rn50ConvF32(_ptr(wk), _ptr(dev32(b)), cin, cout, kh * kw)
 
+        def pairs_of(w2d, bias, cin, taps):
+            """folded fp32 matrix [cout][taps * cin] + bias -> Rn50ConvSplit (zero-padded pair matrix of W * 2^e)"""
+            cout, k = w2d.shape
+            kseg, npad = _pad_to(k, 64), _pad_to(cout, 128)
+            wp = np.zeros((npad, kseg), np.float32)
+            wp[:cout, :k] = w2d.astype(np.float32)
+            bp = np.zeros(npad, np.float32)
+            bp[:cout] = bias
+            amax = float(np.abs(wp).max())
+            e = 9 - int(np.floor(np.log2(amax))) if amax > 0 and np.isfinite(amax) else 0
+            wt = torch.from_numpy(wp).to(dev)
+            pair = torch.empty((npad, 2 * kseg), dtype=torch.float16, device=dev)
+            _lib.check(_lib.load().mpreid_split_pack_f32(_ptr(wt), npad, kseg, float(2.0 ** e), _ptr(pair), _lib.stream_ptr()),
+                       "mpreid_split_pack_f32")
+            torch.cuda.current_stream().synchronize()   # wt is a temporary of this call
+            self._keep.append(pair)
+            return _lib.Rn50ConvSplit(_ptr(pair), _ptr(dev32(bp)), cin, cout, taps, kseg, npad, float(2.0 ** -e))
+
+        def conv_s(cname, bname):
+            w, b = fold(cname, bname)
+            cout, cin, kh, kw = w.shape
+            return pairs_of(w.transpose(0, 2, 3, 1).reshape(cout, kh * kw * cin), b, cin, kh * kw)
+
         s1w, s1b = fold("conv1", "bn1")
         blocks = []
         inplanes = width
@@ -711,6 +725,28 @@ class Rn50Encoder:
         self.feat_dim = E + od
         self.c_cfg = _lib.Rn50Cfg(self.img_hw[0], self.img_hw[1], width, len(blocks), cfg["heads"], od)
         cw = self.c_w = _lib.Rn50WeightsF32()
+        if split:
+            sblocks = []
+            inpl = width
+            for li, (planes, nb, stride) in enumerate(zip((width, width * 2, width * 4, width * 8), layers, (1, 2, 2, 1)), 1):
+                for b in range(nb):
+                    pre = f"layer{li}.{b}"
+                    sb = _lib.Rn50BlockSplit()
+                    sb.conv1, sb.conv2, sb.conv3 = conv_s(pre + ".conv1", pre + ".bn1"), conv_s(pre + ".conv2", pre + ".bn2"), \
+                        conv_s(pre + ".conv3", pre + ".bn3")
+                    sb.stride = stride if b == 0 else 1
+                    if sb.stride > 1 or inpl != planes * 4:
+                        sb.down = conv_s(pre + ".downsample.0", pre + ".downsample.1")
+                    sblocks.append(sb)
+                    inpl = planes * 4
+            self.c_sblocks = (_lib.Rn50BlockSplit * len(sblocks))(*sblocks)
+            self.c_ws = _lib.Rn50WeightsSplit()
+            cw = self.c_ws.f32
+            self.c_ws.blocks = C.cast(self.c_sblocks, C.POINTER(_lib.Rn50BlockSplit))
+            self.c_ws.stem2, self.c_ws.stem3 = conv_s("conv2", "bn2"), conv_s("conv3", "bn3")
+            for n in ("k", "v"):
+                setattr(self.c_ws, n, pairs_of(get(f"attnpool.{n}_proj.weight").astype(np.float64),
+                                               get(f"attnpool.{n}_proj.bias").astype(np.float64), E, 1))
         cw.stem1_w, cw.stem1_b = _ptr(dev32(s1w)), _ptr(dev32(s1b))
         cw.stem2, cw.stem3 = conv("conv2", "bn2"), conv("conv3", "bn3")
         cw.blocks = C.cast(self.c_blocks, C.POINTER(_lib.Rn50BlockF32))
@@ -734,7 +770,8 @@ class Rn50Encoder:
         """img: fp32 [B,3,H,W] (val_transforms applied) or uint8 [B,H,W,3] (after Resize).  cv_emb is ignored: the
         reference's RN50 branch has no SIE embedding (model/make_model.py:82-86)."""
         L = _lib.load()
-        if self.precision == "fp32":
+        if self.precision in ("fp32", "split"):
+            split = self.precision == "split"
             if img.dtype == torch.uint8:   # ToTensor + Normalize of val_transforms with tensor ops, then the fp32 tower
                 t = img.detach().to(self.device).permute(0, 3, 1, 2).to(torch.float32).div(255)
                 mean = torch.tensor(pixel_mean, dtype=torch.float32, device=self.device)[None, :, None, None]
@@ -745,9 +782,15 @@ class Rn50Encoder:
             B = img.shape[0]
             if out is None:
                 out = torch.empty((B, self.feat_dim), dtype=torch.float32, device=self.device)
-            step = 64    # fp32 activations and the im2col matrix: 4x-36x the bytes per image
+            step = 256 if split else 64    # fp32 activations and the im2col matrix: 4x-36x the bytes per image
             for s0 in range(0, B, step):
                 e0 = min(B, s0 + step)
+                if split:
+                    ws = _workspace(self.ws_tag + "_split", L.mpreid_rn50_workspace_bytes_split(C.byref(self.c_cfg), e0 - s0), self.device)
+                    _lib.check(L.mpreid_rn50_forward_split(C.byref(self.c_cfg), C.byref(self.c_ws), _ptr(img[s0:e0]), e0 - s0,
+                                                           _ptr(out[s0:e0]), _ptr(ws), ws.numel(), _lib.stream_ptr()),
+                               "mpreid_rn50_forward_split")
+                    continue
                 ws = _workspace(self.ws_tag + "_f32", L.mpreid_rn50_workspace_bytes_f32(C.byref(self.c_cfg), e0 - s0), self.device)
                 _lib.check(L.mpreid_rn50_forward_f32(C.byref(self.c_cfg), C.byref(self.c_w), _ptr(img[s0:e0]), e0 - s0,
                                                      _ptr(out[s0:e0]), _ptr(ws), ws.numel(), _lib.stream_ptr()),

@@ -18,8 +18,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--precision", default="fp16", choices=("fp16", "split", "fp32"))
     a = ap.parse_args()
-    enc = ops.Rn50Encoder(synth.RN50, synth.rn50_state_dict(synth.RN50, seed=11), (256, 128))
+    enc = ops.Rn50Encoder(synth.RN50, synth.rn50_state_dict(synth.RN50, seed=11), (256, 128), precision=a.precision)
     img = torch.from_numpy(synth.synthetic_images(min(a.batch, 64), 256, 128, seed=1)).cuda()
     img = img.repeat((a.batch + img.shape[0] - 1) // img.shape[0], 1, 1, 1)[:a.batch].contiguous()
     out = torch.empty((a.batch, enc.feat_dim), device="cuda")
@@ -30,7 +31,7 @@ def main():
         enc(img, out=out)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
-    print(f"rn50 batch {a.batch}: {dt*1e3:.2f} ms/batch  {a.batch/dt:.0f} img/s  {a.batch*GFLOP_PER_IMG/dt/1e3:.1f} TFLOP/s")
+    print(f"rn50 {a.precision} batch {a.batch}: {dt*1e3:.2f} ms/batch  {a.batch/dt:.0f} img/s  {a.batch*GFLOP_PER_IMG/dt/1e3:.1f} TFLOP/s")
 
 
 if __name__ == "__main__":
