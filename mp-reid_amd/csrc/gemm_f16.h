@@ -78,16 +78,6 @@ struct GemmArgs {
                           // real-time counter late, so that the CUs reach their store-heavy epilogues at different
                           // times instead of all at once (0 = off)
     int stagger_mode;     // 1: eight phases by the CU's slot inside its XCD instead ((b >> 3) mod 8) / 8
-    // LayerNorm folded into the linear layer that follows it (split mode):
-    //   consumer (GE_S_BIAS_F32 / GE_S_BIAS_GELU): rowstat != null -> out = rstd[m] * (acc * oscale - mu[m] * colc[n]) + bias[n]
-    //     (A = pairs of the RAW residual stream, W = gamma-scaled weights, colc[n] = sum_k gamma_k W[n][k], bias = beta.W^T + b)
-    //   producer (GE_S_BIAS_RES): pair_out != null -> the updated x also leaves as fp16 pair rows [hi(N) | lo(N)] (row stride
-    //     ldp halfs) and per-row partial sums of x and x^2 over each 64-column group go to stat_part[(n / 64)][m][2]
-    const float *rowstat;   // [M][2]: mean, 1 / sqrt(var + eps)
-    const float *colc;      // [N]
-    _Float16 *pair_out;
-    int64_t ldp;
-    float *stat_part;       // [N / 64][M][2]
     unsigned long long *stamps;   // ablation builds (DBG bit 32): [workgroup][32 tiles][8] real-time stamps, else null
 };
 

@@ -86,56 +86,7 @@ __device__ __forceinline__ void store_nt(float *p, const float4 &v) {
     __builtin_nontemporal_store(nv, reinterpret_cast<f32x4_t *>(p));
 }
 
-// sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15), valid in the row's LAST lane: a balanced binary tree in lane
-// order -- ((l0 + l1) + (l2 + l3)) + ... -- so that every kernel that reduces 64 consecutive columns this way (4 per lane,
-// then this) produces the same bits
-__device__ __forceinline__ float row16_sum_last(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));   // row_shr:1
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));   // row_shr:2
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));   // row_shr:4
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));   // row_shr:8
-    return v;
-}
-// LayerNorm folded into the following linear layer (GemmArgs::rowstat): rstd * (acc * oscale - mu * c) + bias
-__device__ __forceinline__ float ln_fold(float acc, float oscale, float mu, float rstd, float c, float bias) {
-    return fmaf(fmaf(acc, oscale, -(mu * c)), rstd, bias);
-}
-// the residual epilogues' second output (GemmArgs::pair_out / stat_part) for one row piece: o = 4 consecutive columns
-// (c4 .. c4+3, c4 = 4 * (lane & 15)) of row m held by each lane of a 16-lane DPP row.  Pairs: even lanes store the hi halves
-// of their own and their right neighbour's columns (16 bytes), odd lanes the lo halves of their left neighbour's and their
-// own; statistics: sum and sum of squares over the row's 64 columns, written by the row's last lane.
-typedef _Float16 gemm_h2 __attribute__((ext_vector_type(2)));
-typedef float gemm_f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void res_second_output(const GemmArgs &g, int lane, int64_t m, int nbase, const float (&o)[4]) {
-    const gemm_f2 v01 = {o[0], o[1]}, v23 = {o[2], o[3]};
-    const gemm_h2 h01 = __builtin_convertvector(v01, gemm_h2), h23 = __builtin_convertvector(v23, gemm_h2);
-    const gemm_h2 l01 = __builtin_convertvector(v01 - __builtin_convertvector(h01, gemm_f2), gemm_h2);
-    const gemm_h2 l23 = __builtin_convertvector(v23 - __builtin_convertvector(h23, gemm_f2), gemm_h2);
-    const int hi0 = __builtin_bit_cast(int, h01), hi1 = __builtin_bit_cast(int, h23);
-    const int lo0 = __builtin_bit_cast(int, l01), lo1 = __builtin_bit_cast(int, l23);
-    // neighbour exchange inside lane pairs (quad_perm [1,0,3,2] = 0xb1)
-    const int nhi0 = __builtin_amdgcn_update_dpp(0, hi0, 0xb1, 0xf, 0xf, true), nhi1 = __builtin_amdgcn_update_dpp(0, hi1, 0xb1, 0xf, 0xf, true);
-    const int nlo0 = __builtin_amdgcn_update_dpp(0, lo0, 0xb1, 0xf, 0xf, true), nlo1 = __builtin_amdgcn_update_dpp(0, lo1, 0xb1, 0xf, 0xf, true);
-    const bool odd = (lane & 1) != 0;
-    const int c4e = ((lane & 15) & ~1) * 4;   // first column of the lane pair
-    uint4 pk;
-    pk.x = odd ? (unsigned)nlo0 : (unsigned)hi0;
-    pk.y = odd ? (unsigned)nlo1 : (unsigned)hi1;
-    pk.z = odd ? (unsigned)lo0 : (unsigned)nhi0;
-    pk.w = odd ? (unsigned)lo1 : (unsigned)nhi1;
-    _Float16 *dst = g.pair_out + m * g.ldp + (odd ? g.N : 0) + nbase + c4e;
-    store_nt(dst, pk);
-    float s = (o[0] + o[1]) + (o[2] + o[3]);
-    float q = (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
-    s = row16_sum_last(s);
-    q = row16_sum_last(q);
-    if ((lane & 15) == 15) *reinterpret_cast<float2 *>(g.stat_part + ((int64_t)(nbase >> 6) * g.M + m) * 2) = make_float2(s, q);
-}
-
-
-// LNF: the folded-LayerNorm variants of GE_S_BIAS_F32 / GE_S_BIAS_GELU (GemmArgs::rowstat) and GE_S_BIAS_RES (pair_out):
-// separate instances, so that the plain ones carry none of their registers or branches
-template <int EPI, bool LNF = false>
+template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -301,16 +252,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
                         typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
                         const f32x2 a = {acc[i][j][rp], acc[i][j][rp + 1]};
                         f32x2 h;
-                        if constexpr (LNF) {   // LayerNorm folded in: rstd * (acc * oscale - mu * c) + bias
-                            const int64_t mr = m0 + wm * 64 + i * 16 + fq * 4 + rp;
-                            const float2 s0 = *reinterpret_cast<const float2 *>(g.rowstat + mr * 2);
-                            const float2 s1 = *reinterpret_cast<const float2 *>(g.rowstat + mr * 2 + 2);
-                            const float cj = g.colc[n0 + wn * 64 + j * 16 + frow];
-                            const f32x2 u = __builtin_elementwise_fma(a, f32x2{g.oscale, g.oscale}, -(f32x2{s0.x, s1.x} * cj));
-                            h = __builtin_elementwise_fma(u, f32x2{s0.y, s1.y}, f32x2{bias, bias});
-                        } else {
-                            h = __builtin_elementwise_fma(a, f32x2{g.oscale, g.oscale}, f32x2{bias, bias});
-                        }
+                        h = __builtin_elementwise_fma(a, f32x2{g.oscale, g.oscale}, f32x2{bias, bias});
                         const f32x2 t = h * (-1.702f * 1.44269504088896340736f);
                         const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + 1.0f;
                         const f32x2 v = h * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};   // quick_gelu
@@ -366,15 +308,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
         }
     } else if constexpr (EPI == GE_S_BIAS_F32 || EPI == GE_S_BIAS_RES) {
         // split mode, fp32 outputs: out = acc * oscale + bias, or x += that; whole 256-byte row pieces, each lane four
-        // consecutive columns (the layout of the persistent kernel's epilogues: the LayerNorm-folding variants -- see
-        // GemmArgs::rowstat / pair_out -- reduce and exchange inside 16-lane rows and must give that kernel's bits)
+        // consecutive columns (the layout of the persistent kernel's epilogues)
         __syncthreads();
         float *wreg = reinterpret_cast<float *>(smem) + wave * (32 * 68);
         float *outp = reinterpret_cast<float *>(g.out);
         const int nbase = n0 + wn * 64, c4 = (lane & 15) * 4;
         const float4 bias4 = *reinterpret_cast<const float4 *>(g.bias + nbase + c4);
-        float4 cc4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (EPI == GE_S_BIAS_F32 && LNF) cc4 = *reinterpret_cast<const float4 *>(g.colc + nbase + c4);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -393,18 +332,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
                 const float4 a = *reinterpret_cast<const float4 *>(wreg + lr * 68 + c4);
                 float *dst = outp + m * g.ldo + nbase + c4;
                 float o[4];
-                if (EPI == GE_S_BIAS_F32 && LNF) {
-                    const float2 st = *reinterpret_cast<const float2 *>(g.rowstat + m * 2);
-                    o[0] = ln_fold(a.x, g.oscale, st.x, st.y, cc4.x, bias4.x);
-                    o[1] = ln_fold(a.y, g.oscale, st.x, st.y, cc4.y, bias4.y);
-                    o[2] = ln_fold(a.z, g.oscale, st.x, st.y, cc4.z, bias4.z);
-                    o[3] = ln_fold(a.w, g.oscale, st.x, st.y, cc4.w, bias4.w);
-                } else {
-                    o[0] = fmaf(a.x, g.oscale, bias4.x);
-                    o[1] = fmaf(a.y, g.oscale, bias4.y);
-                    o[2] = fmaf(a.z, g.oscale, bias4.z);
-                    o[3] = fmaf(a.w, g.oscale, bias4.w);
-                }
+                o[0] = fmaf(a.x, g.oscale, bias4.x);
+                o[1] = fmaf(a.y, g.oscale, bias4.y);
+                o[2] = fmaf(a.z, g.oscale, bias4.z);
+                o[3] = fmaf(a.w, g.oscale, bias4.w);
                 if (EPI == GE_S_BIAS_RES) {
                     const float4 x = *reinterpret_cast<const float4 *>(dst);
                     o[0] = x.x + o[0];
@@ -413,7 +344,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
                     o[3] = x.w + o[3];
                 }
                 *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-                if (EPI == GE_S_BIAS_RES && LNF) res_second_output(g, lane, m, nbase, o);
             }
             __syncthreads();
         }
@@ -558,7 +488,7 @@ constexpr int B_LDS_TOTAL = B_LDS_BYTES + 8 * 4096;   // + 32 KB of epilogue pat
 
 // DBG (timing-only ablation builds, never used by the product path): 1 no DMA in the steady loop,
 // 2 no MFMA, 4 no fragment reads in the steady loop, 8 no epilogue
-template <int EPI, int DBG = 0, bool LNF = false>   // LNF: see gemm_f16_kernel
+template <int EPI, int DBG = 0, bool SYM = false>   // SYM (GE_EUCLID only): the instance with the mirrored stores, see SYM_STORE
 __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -569,9 +499,9 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
     constexpr bool SPLIT = gemm_epi_is_split(EPI);
     // epilogues that know symmetric problems (GemmArgs::sym: A == W, square): only tiles on or above the diagonal are
     // computed; GE_CAND tests the mirrored pair, GE_EUCLID stores every off-diagonal tile a second time, transposed
-    // (the mirrored stores live in their own instance, <GE_EUCLID, 0, true>: the third template flag -- LNF for the split
-    // epilogues -- selects it, so the plain distance kernel carries none of its registers)
-    constexpr bool SYM_STORE = (EPI == GE_EUCLID) && LNF;
+    // (the mirrored stores live in their own instance, <GE_EUCLID, 0, true>, so the plain distance kernel carries none of
+    // its registers)
+    constexpr bool SYM_STORE = (EPI == GE_EUCLID) && SYM;
     constexpr bool SYM_EPI = (EPI == GE_CAND) || SYM_STORE;
     const int nseg = SPLIT ? g.kseg / BBK : 0;
     const int nst = SPLIT ? 3 * nseg : K / BBK; // even (K, kseg are multiples of 64)
@@ -1207,30 +1137,11 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
         _Float16 *whi = reinterpret_cast<_Float16 *>(patch + wave * 4096);
         _Float16 *wlo = reinterpret_cast<_Float16 *>(smem + wave * 4096);
         _Float16 *out = reinterpret_cast<_Float16 *>(g.out);
-        float bias[4], colc[4] = {0.f, 0.f, 0.f, 0.f};
+        float bias[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) bias[j] = g.bias[cur_n0 + wc * 64 + j * 16 + frow];
-        // LayerNorm folded in (GemmArgs::rowstat): the wave's 128 (mean, rstd) pairs sit behind the hi patch
-        float *rst = reinterpret_cast<float *>(patch + wave * 4096 + 2304);   // [128][2]
-        constexpr bool fold = LNF;
-        if (fold) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) colc[j] = g.colc[cur_n0 + wc * 64 + j * 16 + frow];
-            const int64_t r0 = cur_m0 + wr * 128;
-            *reinterpret_cast<float4 *>(rst + lane * 4) = *reinterpret_cast<const float4 *>(g.rowstat + (r0 + lane * 2) * 2);
-        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            float4 st01 = make_float4(0.f, 1.f, 0.f, 1.f), st23 = st01;   // (mean, rstd) of rows fq*4 + 0..3 of this pass
-            if (fold) {
-                if (i == 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                }
-                st01 = *reinterpret_cast<const float4 *>(rst + (i * 16 + fq * 4) * 2);
-                st23 = *reinterpret_cast<const float4 *>(rst + (i * 16 + fq * 4 + 2) * 2);
-            }
             // (the epilogue is vector-ALU bound -- 128 elements per lane and tile, two transcendentals each; written on
             // element PAIRS so that the fused multiply-add, the products, the sum, the difference and both roundings to
             // fp16 are packed instructions (v_pk_fma_f32 ... v_cvt_pk_f16_f32): 11 instead of 20 per pair, same bits)
@@ -1241,14 +1152,7 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
                     typedef float f32x2 __attribute__((ext_vector_type(2)));
                     typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
                     const f32x2 a = {acc[i][j][rp], acc[i][j][rp + 1]};
-                    f32x2 h;
-                    if (fold) {   // rstd * (acc * oscale - mu * c) + bias, the 128 x 128 kernel's instructions
-                        const float4 sp = rp == 0 ? st01 : st23;
-                        const f32x2 u = __builtin_elementwise_fma(a, f32x2{g.oscale, g.oscale}, -(f32x2{sp.x, sp.z} * colc[j]));
-                        h = __builtin_elementwise_fma(u, f32x2{sp.y, sp.w}, f32x2{bias[j], bias[j]});
-                    } else {
-                        h = __builtin_elementwise_fma(a, f32x2{g.oscale, g.oscale}, f32x2{bias[j], bias[j]});
-                    }
+                    const f32x2 h = __builtin_elementwise_fma(a, f32x2{g.oscale, g.oscale}, f32x2{bias[j], bias[j]});
                     const f32x2 t = h * (-1.702f * 1.44269504088896340736f);
                     const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + 1.0f;
                     const f32x2 v = h * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};   // quick_gelu
@@ -1369,11 +1273,9 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
                 for (int r = 0; r < 4; ++r) wreg[(efq * 4 + r) * 64 + j * 16 + efrow] = acc[i][j][r];
             asm volatile("" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            // younger than pass i's block: 4 DMAs per queued pass behind it + S stores per finished pass since (S = 4, or 12
-            // with the second output: per row piece one 16-byte pair store and one statistics store more):
-            // i <= 3: 12 + S i, i >= 4: 3 S + 4 (7 - i)
-            if (EPI == GE_S_BIAS_RES && LNF) wait_vmcnt(i < 4 ? 12 + 12 * i : 36 + 4 * (7 - i));   // 12 24 36 48 | 48 44 40 36
-            else wait_vmcnt(i < 4 ? 12 + 4 * i : 24 - 4 * (i - 4));                                      // 12 16 20 24 | 24 20 16 12
+            // younger than pass i's block: 4 DMAs per queued pass behind it + 4 stores per finished pass since:
+            // i <= 3: 12 + 4 i, i >= 4: 12 + 4 (7 - i)
+            wait_vmcnt(i < 4 ? 12 + 4 * i : 24 - 4 * (i - 4));                                      // 12 16 20 24 | 24 20 16 12
             f32x4_t a[4], x[4];
             asm volatile("ds_read_b128 %0, %8\n\t"
                          "ds_read_b128 %1, %8 offset:1024\n\t"
@@ -1403,10 +1305,6 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
                     o[3] = x[it][3] + (a[it][3] + bias4.w);
                 }
                 store16_sv(x_base(i * 16 + it * 4), x_loff, o);
-                if constexpr (EPI == GE_S_BIAS_RES && LNF) {
-                    const float ov[4] = {o[0], o[1], o[2], o[3]};
-                    res_second_output(g, el, (int64_t)(cur_m0 + wr * 128 + i * 16 + it * 4 + efq), nbase, ov);
-                }
             }
             if (i + 4 < 8) x_dma(i + 4);
             __builtin_amdgcn_wave_barrier();
@@ -1457,17 +1355,6 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
                         (EPI == GE_S_BIAS_F32 || (cur_m0 + BBM <= g.m_valid && cur_n0 + BBN <= g.n_valid));
         float *rt = fast_path ? reinterpret_cast<float *>(patch + wave * 4096)
                               : reinterpret_cast<float *>(smem + wave * 16384);   // [128] |q|^2, then [128] row scales
-        // GE_S_BIAS_F32 with the LayerNorm folded in (GemmArgs::rowstat; fast path only, the launcher checks): the wave's
-        // 128 (mean, rstd) pairs take the table's place, colc the column scales' registers
-        [[maybe_unused]] bool fold_f32 = false;
-        if constexpr (EPI == GE_S_BIAS_F32) {
-            if (LNF && fast_path) {
-                fold_f32 = true;
-                cs4 = *reinterpret_cast<const float4 *>(g.colc + nbase + c4);
-                *reinterpret_cast<float4 *>(rt + lane * 4) =
-                    *reinterpret_cast<const float4 *>(g.rowstat + ((int64_t)(cur_m0 + wr * 128) + lane * 2) * 2);
-            }
-        }
         if constexpr (EPI == GE_EUCLID) {
             const int r0 = cur_m0 + wr * 128;
             const float t0 = (r0 + lane < g.m_valid) ? g.aux[r0 + lane] : 0.f;
@@ -1504,7 +1391,7 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
                 #ifndef MPREID_FAST_NBLK
 #define MPREID_FAST_NBLK 1
 #endif
-                constexpr int NBLK = (EPI == GE_S_BIAS_F32 && LNF) ? 1 : MPREID_FAST_NBLK;
+                constexpr int NBLK = MPREID_FAST_NBLK;
                 if constexpr (((DBG >> 7) & 7) == 6) {   // (timing experiment, wrong data) the 32 stores straight from the accumulators
 #pragma unroll
                     for (int e = 0; e < 32; ++e)
@@ -1532,10 +1419,6 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
                         if constexpr (EPI == GE_EUCLID) {
                             amv[e] = rt[(h * NBLK + ii) * 16 + lr];
                             rsv[e] = scaled ? rt[128 + (h * NBLK + ii) * 16 + lr] : 1.0f;
-                        } else if constexpr (LNF) {
-                            const float2 st = *reinterpret_cast<const float2 *>(rt + ((h * NBLK + ii) * 16 + lr) * 2);
-                            amv[e] = st.x;   // mean
-                            rsv[e] = st.y;   // 1 / sqrt(var + eps)
                         }
                     }
 #pragma unroll
@@ -1545,17 +1428,10 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
                         const float4 a = av[e];
                         f32x4 o;
                         if constexpr (EPI == GE_S_BIAS_F32) {
-                            if constexpr (LNF) {
-                                o[0] = ln_fold(a.x, g.oscale, amv[e], rsv[e], cs4.x, bias4.x);
-                                o[1] = ln_fold(a.y, g.oscale, amv[e], rsv[e], cs4.y, bias4.y);
-                                o[2] = ln_fold(a.z, g.oscale, amv[e], rsv[e], cs4.z, bias4.z);
-                                o[3] = ln_fold(a.w, g.oscale, amv[e], rsv[e], cs4.w, bias4.w);
-                            } else {
-                                o[0] = fmaf(a.x, g.oscale, bias4.x);
-                                o[1] = fmaf(a.y, g.oscale, bias4.y);
-                                o[2] = fmaf(a.z, g.oscale, bias4.z);
-                                o[3] = fmaf(a.w, g.oscale, bias4.w);
-                            }
+                            o[0] = fmaf(a.x, g.oscale, bias4.x);
+                            o[1] = fmaf(a.y, g.oscale, bias4.y);
+                            o[2] = fmaf(a.z, g.oscale, bias4.z);
+                            o[3] = fmaf(a.w, g.oscale, bias4.w);
                         } else if (scaled) {
                             const float rs = rsv[e], am = amv[e];
                             o[0] = fmaf(-2.0f, a.x * (rs * cs4.x), am + bn4.x);
@@ -1918,16 +1794,6 @@ static int launch_one(const GemmArgs &a_in, hipStream_t stream) {
             return MPREID_ERR_ARG;
         }
     }
-    if (a.rowstat || a.pair_out) {
-        const bool ok = (a.rowstat == nullptr || ((EPI == GE_S_BIAS_F32 || EPI == GE_S_BIAS_GELU) && a.colc)) &&
-                        (a.pair_out == nullptr || (EPI == GE_S_BIAS_RES && a.stat_part && a.ldp >= 2 * (int64_t)a.N && a.ldp % 8 == 0 &&
-                                                   (reinterpret_cast<uintptr_t>(a.pair_out) & 15) == 0)) &&
-                        a.ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
-        if (!ok) {
-            mpreid_set_error("gemm_f16: folded-LayerNorm arguments do not fit epilogue %d", EPI);
-            return MPREID_ERR_ARG;
-        }
-    }
     if constexpr (EPI == GE_CAND) {
         if (a.M % BBM || a.N % BBN) {
             mpreid_set_error("gemm_f16: the candidate epilogue needs M, N multiples of %d", BBM);
@@ -2055,10 +1921,6 @@ static int launch_one(const GemmArgs &a_in, hipStream_t stream) {
             }
         }
     } else {
-        if (a.rowstat || a.pair_out) {   // the folded-LayerNorm instances (rounds 3) are no longer built: see include/mpreid.h
-            mpreid_set_error("gemm_f16: GemmArgs::rowstat / pair_out (LayerNorm folding) is not supported any more");
-            return MPREID_ERR_UNSUPPORTED;
-        }
         hipLaunchKernelGGL(gemm_f16_kernel<EPI>, dim3((unsigned)tiles_m * (unsigned)tiles_n), dim3(256), G_LDS_BYTES,
                                stream, a, tiles_m, tiles_n);
     }
