@@ -637,7 +637,7 @@ def drop_in_extras(a, cfg, model, nq, ng, pids, camids, dev):
         host.append(torch.randn((e - s, 3, H, W), generator=g, device=dev).clamp_(-1.0, 1.0).cpu())   # pageable
     ld = ValLoader(host, range(n), n, pids, camids)
     for stage in ("pinned", "direct"):
-        dt = timed_do_inference(cfg, model, ld, nq, 2, pipeline_env=f"stage={stage}")
+        dt = timed_do_inference(cfg, model, ld, nq, 2, pipeline_env=f"stage={stage},streams={max(1, a.streams)}")
         out[f"do_inference_images_per_s_fp32_loader_{stage}"] = round(n / dt, 1)
     best = max(("pinned", "direct"), key=lambda k: out[f"do_inference_images_per_s_fp32_loader_{k}"])
     out["do_inference_images_per_s_fp32_loader"] = out[f"do_inference_images_per_s_fp32_loader_pinned"]   # the default stage
@@ -669,7 +669,7 @@ def drop_in_extras(a, cfg, model, nq, ng, pids, camids, dev):
             off += h * w * 3
         raws.append(RawImageBatch(b))
     ld = ValLoader(raws, range(n), n, pids, camids)
-    dt = timed_do_inference(cfg, model, ld, nq, 2)
+    dt = timed_do_inference(cfg, model, ld, nq, 2, pipeline_env=f"streams={max(1, a.streams)}")
     out["do_inference_images_per_s_raw_loader"] = round(n / dt, 1)
     ev = do_inference.last_evaluator
     torch.cuda.synchronize()
