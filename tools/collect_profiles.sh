@@ -17,7 +17,9 @@ python3 $R/bench.py --workload msmt17 --rerank --steps 1 --warmup 1 --no-cpu-bas
 python3 $R/bench.py --rerank --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_market_rerank.json 2>> $OUT/bench.err
 # 2. kernel trace + stats of the same bench command (--streams 1 is honoured by every leg, also the host-loader ones of
 #    `extras`: no two kernels of the process overlap, so a kernel's average duration here is its launch duration)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_bench -o b -- python3 $R/bench.py --steps 1 --warmup 1 --streams 1 --no-cpu-baseline > $OUT/${TAG}_bench_under_rocprof.json 2>/dev/null
+#    --no-extras: only the headline step's launches are in the trace (the extras run the same kernels at other shapes -- the
+#    reference-loop leg encodes 64 images per call -- and rocprofv3 --stats averages per kernel NAME)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_bench -o b -- python3 $R/bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_under_rocprof.json 2>/dev/null
 cp $OUT/kt_bench/b_kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv
 # 3. re-ranking alone (N = 20 000): kernel stats and the FETCH / WRITE passes (separate runs)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_rr -o rr -- python3 $R/tools/rerank_bench.py 20000 4000 768 > $OUT/rr.log 2>&1
