@@ -24,6 +24,27 @@ def golden():
     return load
 
 
+def map_noise_envelope(orc, feats, rel, pid, nq, rerank, k1, k2, seeds=6):
+    """How far do mAP / Rank-1 move when `feats` carry a RANDOM error of relative size `rel` (Gaussian, relative L2 = rel)?
+    The largest |dmAP| and |dRank-1| over `seeds` perturbations, through the oracle's normalise -> distance / re-ranking ->
+    eval_func pipeline.  The image -> mAP tests hold an encoder whose measured feature error is `rel` to a small multiple
+    of this envelope: on nearly parallel features (the "degenerate" sets) a 1e-6 feature error legitimately moves mAP by
+    1e-4 ... 1e-3, and the envelope says how much WITHOUT relying on one lucky realisation of the reference's own rounding."""
+    base = orc.l2_normalize(np.asarray(feats, np.float32))
+    d0 = orc.re_ranking(base[:nq], base[nq:], k1, k2, 0.3) if rerank else orc.euclidean_distance(base[:nq], base[nq:])
+    cmc0, map0 = orc.eval_func(d0, pid[:nq], pid[nq:])
+    scale = rel * float(np.linalg.norm(feats)) / np.sqrt(feats.size)
+    dmap = dr1 = 0.0
+    for s in range(seeds):
+        rng = np.random.default_rng(1000 + s)
+        f = (np.asarray(feats, np.float64) + scale * rng.standard_normal(feats.shape)).astype(np.float32)
+        fn = orc.l2_normalize(f)
+        d = orc.re_ranking(fn[:nq], fn[nq:], k1, k2, 0.3) if rerank else orc.euclidean_distance(fn[:nq], fn[nq:])
+        cmc, mp = orc.eval_func(d, pid[:nq], pid[nq:])
+        dmap, dr1 = max(dmap, abs(mp - map0)), max(dr1, abs(float(cmc[0]) - float(cmc0[0])))
+    return dmap, dr1
+
+
 def free_port():
     """a port the kernel just handed out (bound to port 0, then released)"""
     import socket
