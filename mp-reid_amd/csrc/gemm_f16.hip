@@ -1669,6 +1669,280 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
 }
 
 // ---------------------------------------------------------------------------------------------
+// Symmetric stored distance matrix (all-pairs distances of ONE set: A == W), "p2" schedule: PERSISTENT, TWO independent
+// 4-wave workgroups per CU walking tiles out of phase.
+//   Why: in the one-workgroup-per-CU kernel above ~45 % of a tile of this problem is its epilogue -- 2 x 256 KB of fp32
+//   leaving through the CU's ~16 B/clk store path with the matrix pipe idle.  That kernel owns the
+//   CU's whole LDS and half of its registers, so nothing else can run beside its stores.  Here a workgroup is half the
+//   size (tile 256 x 128, waves 2 x 2 of 128 x 64 -- the same fragment code -- and a 3-slot ring of 24 KB stages = 72 KB),
+//   two of them share a CU, and while one drains its stores the other runs its k-loop.
+//   Tiles: only those that reach the upper triangle (tn >= 2 tm in units of the 256 x 128 tile) are computed; a tile
+//   entirely above the diagonal (tn >= 2 tm + 2) also stores its transpose, through the same swizzled LDS transposition
+//   as the kernel above.  Order: strips of 8 tile rows, column-major inside a strip, so that 64 consecutive tiles -- the
+//   64 workgroups of an XCD at one time -- are an 8 x 8 block sharing 8 + 8 operand panels in that XCD's L2; the list is
+//   cut into eight EQUAL contiguous ranges, one per XCD (closed-form position -> tile map, no list in memory).
+//   Same products in the same k order as the kernels above: same bits (tests/test_gpu_distance.py).
+// ---------------------------------------------------------------------------------------------
+constexpr int PBM = 256, PBN = 128, PBK = 32, P_NSTAGE = 3;
+constexpr int P_A_BYTES = PBM * PBK * 2;                 // 16 KB
+constexpr int P_B_BYTES = PBN * PBK * 2;                 // 8 KB
+constexpr int P_STAGE_BYTES = P_A_BYTES + P_B_BYTES;     // 24 KB
+constexpr int P_RING_BYTES = P_NSTAGE * P_STAGE_BYTES;   // 72 KB
+constexpr int P_LDS_BYTES = P_RING_BYTES + 4 * 1024;     // + the four waves' row tables: 76 KB, two workgroups per CU
+
+// number of tiles of strip br (tile rows 8 br .. 8 br + R - 1, tile columns 16 br .. tiles_n - 1): column j of the strip
+// holds min(R, j / 2 + 1) tiles
+__device__ __forceinline__ int p2_strip_size(int R, int ncol, int &ramp) {
+    ramp = min(ncol, 2 * (R - 1));
+    const int p = ramp >> 1;
+    return p * (p + 1) + ((ramp & 1) ? (p + 1) : 0) + (ncol - ramp) * R;
+}
+__device__ __forceinline__ int p2_total_tiles(int tiles_m, int tiles_n) {
+    int T = 0, ramp;
+    for (int br = 0; 8 * br < tiles_m; ++br) T += p2_strip_size(min(8, tiles_m - 8 * br), tiles_n - 16 * br, ramp);
+    return T;
+}
+__device__ __forceinline__ void p2_tile_at(int k, int tiles_m, int tiles_n, int &tm, int &tn) {   // k < total
+    int br = 0, R, ramp;
+    for (;; ++br) {
+        R = min(8, tiles_m - 8 * br);
+        const int S = p2_strip_size(R, tiles_n - 16 * br, ramp);
+        if (k < S) break;
+        k -= S;
+    }
+    int j = 0;
+    for (; j < ramp; ++j) {
+        const int c = (j >> 1) + 1;
+        if (k < c) break;
+        k -= c;
+    }
+    if (j == ramp) {
+        j += k / R;
+        k = k % R;
+    }
+    tm = 8 * br + k;
+    tn = 16 * br + j;
+}
+
+__global__ __launch_bounds__(256, 2) void dist_sym_p2_kernel(GemmArgs g, int tiles_m, int tiles_n, int naps, int abl) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int K = g.K;
+    const int nst = (abl & 2) ? 1 : K / PBK;
+    const int per_xcd = (int)gridDim.x >> 3;                      // the grid is a multiple of 8
+    const int xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3);
+    const int total = p2_total_tiles(tiles_m, tiles_n);
+    const int lo = (int)((int64_t)xcd * total / 8), hi = (int)((int64_t)(xcd + 1) * total / 8);
+
+    // the second workgroup of every CU (in practice: the second half of an XCD's workgroups) starts half a k-loop late,
+    // once: from then on the two alternate between the k-loop and the store-bound epilogue
+    if (slot >= (per_xcd >> 1))
+        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(8);
+
+    // DMA geometry: one piece = 16 rows x 64 B.  A part: 16 pieces, wave w takes 4w..4w+3; B part: 8 pieces, wave w takes
+    // 2w, 2w+1.  Rows 8..15 of a piece hold their four 16-byte chunks reversed (the read side undoes it): the b128
+    // fragment reads of a 16-lane group then touch all banks
+    const int drow = lane >> 2;
+    const int dchunk = (lane & 3) ^ (((drow >> 3) & 1) * 3);
+    const int frow = lane & 15, fq = lane >> 4;
+    const int fsw = (fq ^ (((lane >> 3) & 1) * 3)) << 4;
+    const int a_off = (wr * 128 + frow) * 64 + fsw;                // + i * 1024
+    const int b_off = P_A_BYTES + (wc * 64 + frow) * 64 + fsw;     // + j * 1024
+    float *outp = reinterpret_cast<float *>(g.out);
+    const bool vec_ok = (g.ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(outp) & 15) == 0) && g.ldo < (1 << 24);
+    const bool scaled = g.rscale != nullptr;
+    float *rt = reinterpret_cast<float *>(smem + P_RING_BYTES + wave * 1024);   // [128] |x_m|^2, [128] row scales
+    float *T = reinterpret_cast<float *>(smem + wave * (P_RING_BYTES / 4));     // 18 KB of the idle ring per wave
+
+    for (int it = lo + slot; it < hi; it += per_xcd) {
+        int tm, tn;
+        p2_tile_at(it, tiles_m, tiles_n, tm, tn);
+        const int m0 = tm * PBM, n0 = tn * PBN;
+        const _Float16 *a_src = g.A + (int64_t)(m0 + wave * 64 + drow) * K + dchunk * 8;
+        const _Float16 *b_src = g.W + (int64_t)(n0 + wave * 32 + drow) * K + dchunk * 8;
+        auto dma_stage = [&](int st) {
+            unsigned char *sb = smem + (st % P_NSTAGE) * P_STAGE_BYTES;
+            const int koff = st * PBK;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dma16(a_src + (int64_t)t * 16 * K + koff, sb + wave * 4096 + t * 1024);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) dma16(b_src + (int64_t)t * 16 * K + koff, sb + P_A_BYTES + wave * 2048 + t * 1024);
+        };
+
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // the previous tile's epilogue is done with the ring (LDS reads only: its stores drain behind the first stages)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        dma_stage(0);
+        if (nst > 1) dma_stage(1);
+        for (int t = 0; t < nst; ++t) {
+            // stage t landed everywhere (stage t+1 may stay in flight); slot (t+2)%3 = slot of stage t-1 is free
+            if (t + 1 < nst) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (t + 2 < nst) dma_stage(t + 2);
+            const unsigned char *sb = smem + (t % P_NSTAGE) * P_STAGE_BYTES;
+            f16x8 fa[8], fb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const f16x8 *>(sb + b_off + j * 1024);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const f16x8 *>(sb + a_off + i * 1024);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+
+        // ---- epilogue ----
+        const int r0 = m0 + wr * 128, nbase = n0 + wc * 64;
+        {   // row tables of the wave (above the ring: no hazard with the other waves' last fragment reads)
+            const float t0 = (r0 + lane < g.m_valid) ? g.aux[r0 + lane] : 0.f;
+            const float t1 = (r0 + 64 + lane < g.m_valid) ? g.aux[r0 + 64 + lane] : 0.f;
+            float t2 = 1.f, t3 = 1.f;
+            if (scaled) {
+                t2 = g.rscale[r0 + lane];           // (padded to the tile size)
+                t3 = g.rscale[r0 + 64 + lane];
+            }
+            rt[lane] = t0;
+            rt[64 + lane] = t1;
+            rt[128 + lane] = t2;
+            rt[192 + lane] = t3;
+        }
+        float bnT[4], csT[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = nbase + j * 16 + frow;
+            bnT[j] = (n < g.n_valid) ? g.aux2[n] : 0.f;
+            csT[j] = scaled ? g.cscale[n] : 1.0f;
+        }
+        // every wave is past its last fragment reads: the ring becomes the waves' patches
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // the accumulators become the finished values in place, one 16-row block at a time
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float4 am4 = *reinterpret_cast<const float4 *>(rt + i * 16 + fq * 4);
+            const float amr[4] = {am4.x, am4.y, am4.z, am4.w};
+            if (scaled) {
+                const float4 rs4 = *reinterpret_cast<const float4 *>(rt + 128 + i * 16 + fq * 4);
+                const float rsr[4] = {rs4.x, rs4.y, rs4.z, rs4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        acc[i][j][r] = fmaf(-2.0f, acc[i][j][r] * (rsr[r] * csT[j]), amr[r] + bnT[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaf(-2.0f, acc[i][j][r], amr[r] + bnT[j]);
+            }
+            asm volatile("" ::: "memory");
+        }
+        const bool interior = vec_ok && m0 + PBM <= g.m_valid && n0 + PBN <= g.n_valid;
+        const int l16 = lane & 15;
+        if (abl & 1) continue;
+        // (1) the block itself: 16 rows at a time through a [16][68] patch (row stride 68 floats: the four row groups of
+        // a b32 write land in different banks), out as whole 256-byte row pieces
+        {
+            const uint64_t obase = reinterpret_cast<uint64_t>(outp + (int64_t)r0 * g.ldo + nbase);
+            const unsigned ldo_b = (unsigned)g.ldo * 4u;
+            const unsigned voff = (unsigned)(lane >> 4) * ldo_b + (unsigned)l16 * 16u;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) T[(fq * 4 + r) * 68 + j * 16 + frow] = acc[i][j][r];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (interior) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const f32x4 v = *reinterpret_cast<const f32x4 *>(T + (e * 4 + (lane >> 4)) * 68 + l16 * 4);
+                        store16_nt_sv(obase + (uint64_t)(i * 16 + e * 4) * ldo_b, voff, v);
+                    }
+                } else {
+#pragma unroll 1
+                    for (int e = 0; e < 4; ++e) {
+                        const int lr = e * 4 + (lane >> 4);
+                        const f32x4 v = *reinterpret_cast<const f32x4 *>(T + lr * 68 + l16 * 4);
+                        const int m = r0 + i * 16 + lr, n = nbase + l16 * 4;
+                        float *dst = outp + (int64_t)m * g.ldo + n;
+                        if (m < g.m_valid) {
+                            if (vec_ok && n + 3 < g.n_valid) {
+                                store_nt(dst, make_float4(v[0], v[1], v[2], v[3]));
+                            } else {
+                                if (n + 0 < g.n_valid) dst[0] = v[0];
+                                if (n + 1 < g.n_valid) dst[1] = v[1];
+                                if (n + 2 < g.n_valid) dst[2] = v[2];
+                                if (n + 3 < g.n_valid) dst[3] = v[3];
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        // (2) its transpose, when the tile lies entirely above the diagonal: 64 rows x 128 columns in two halves, each
+        // through a [64 n][64 m] patch whose 16-byte chunks are XOR-swizzled by n & 15 (b128 writes of a 16-lane group
+        // and b128 reads of a row both touch 16 different chunk banks)
+        if (tn >= 2 * tm + 2 && !(abl & 4)) {
+            float *Trow = T + frow * 64;                      // + j * 1024: row n = j * 16 + frow
+            const int cx = fq ^ frow;                         // chunk (ii * 4 + fq) ^ frow = (ii * 4) ^ cx
+            const unsigned ldo_bT = (unsigned)g.ldo * 4u;
+            const unsigned voffT = (unsigned)(lane >> 4) * ldo_bT + (unsigned)l16 * 16u;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        *reinterpret_cast<f32x4 *>(Trow + j * 1024 + ((((ii * 4) ^ cx) & 15) << 2)) = acc[hf * 4 + ii][j];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int mcol = r0 + hf * 64 + l16 * 4;
+                const uint64_t tbase = reinterpret_cast<uint64_t>(outp + (int64_t)nbase * g.ldo + r0 + hf * 64);
+                if (interior) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int nl = e * 4 + (lane >> 4);
+                        const f32x4 v = *reinterpret_cast<const f32x4 *>(T + nl * 64 + ((l16 ^ (nl & 15)) << 2));
+                        store16_nt_sv(tbase + (uint64_t)(e * 4) * ldo_bT, voffT, v);
+                    }
+                } else {
+#pragma unroll 1
+                    for (int e = 0; e < 16; ++e) {
+                        const int nl = e * 4 + (lane >> 4);
+                        const f32x4 v = *reinterpret_cast<const f32x4 *>(T + nl * 64 + ((l16 ^ (nl & 15)) << 2));
+                        const int n = nbase + nl;
+                        float *dst = outp + (int64_t)n * g.ldo + mcol;
+                        if (n < g.n_valid) {
+                            if (vec_ok && mcol + 3 < g.m_valid) {
+                                store_nt(dst, make_float4(v[0], v[1], v[2], v[3]));
+                            } else {
+                                if (mcol + 0 < g.m_valid) dst[0] = v[0];
+                                if (mcol + 1 < g.m_valid) dst[1] = v[1];
+                                if (mcol + 2 < g.m_valid) dst[2] = v[2];
+                                if (mcol + 3 < g.m_valid) dst[3] = v[3];
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // optional per-launch event timing (bench.py's roofline leg): hipEvents recorded on the launch
 // stream around every GEMM launch while enabled, aggregated per (epilogue, M, N, K) class.
 // ---------------------------------------------------------------------------------------------
@@ -1819,7 +2093,35 @@ static int launch_one(const GemmArgs &a_in, hipStream_t stream) {
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, stream));
     }
-    if (use_big) {
+    // MPREID_TUNE dist_sym_p2: 0 = never, 1 = symmetric stored distance problems of at least 16 tile rows (default),
+    // 2 = every symmetric problem whose padded size allows it (tests)
+    bool use_p2 = false;
+    if constexpr (EPI == GE_EUCLID) {
+        static const int p2_mode = mpreid_tune("dist_sym_p2", 1);
+        use_p2 = a.sym && p2_mode > 0 && a.M == a.N && a.A == a.W && (a.M % PBM == 0) && (a.K % PBK == 0) &&
+                 (p2_mode >= 2 || a.M / PBM >= 16);
+    }
+    if (use_p2) {
+        if constexpr (EPI == GE_EUCLID) {
+            static PerDeviceOnce p2_once;
+            const int rc = p2_once.run([]() -> int {
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(dist_sym_p2_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES));
+                return MPREID_OK;
+            });
+            if (rc) return rc;
+            int dev = 0, cus = 0;
+            HIP_TRY(hipGetDevice(&dev));
+            HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            const int grid = std::max(8, (2 * cus) & ~7);
+            static const int naps_tune = mpreid_tune("dist_sym_p2_naps", -1);
+            const int naps = naps_tune >= 0 ? naps_tune : (a.K / PBK) / 2;   // s_sleep 8 ~ 512 clocks ~ one k stage
+            static const int abl = mpreid_tune("dist_sym_p2_abl", 0);
+            static const int gridt = mpreid_tune("dist_sym_p2_grid", 0);
+            hipLaunchKernelGGL(dist_sym_p2_kernel, dim3((unsigned)(gridt ? gridt : grid)), dim3(256), P_LDS_BYTES, stream, a, a.M / PBM, a.N / PBN,
+                               naps, abl);
+        }
+    } else if (use_big) {
         if constexpr (HAS_BIG) {
             static const int dbg = mpreid_ablation_env("MPREID_GEMM_DBG");
             // persistent: one workgroup per CU (the kernel owns the CU's whole LDS), each walking tiles

@@ -280,8 +280,10 @@ def test_stored_distance_kernels_bit_identical():
 
 
 # ---- all-pairs distances of ONE set: euclidean_distance(f, f) computes the upper-triangular tiles and mirrors them ----
-@pytest.mark.parametrize("n,d,big", [(20000, 768, "1"), (16384, 128, "1"), (1000, 192, "2"), (1000, 192, "1"), (4133, 1280, "2")])
-def test_all_pairs_symmetric_path_same_bits_as_full_computation(n, d, big):
+@pytest.mark.parametrize("n,d,big,p2", [(20000, 768, "1", "1"), (20000, 768, "1", "0"), (16384, 128, "1", "1"), (16384, 128, "1", "0"),
+                                         (1000, 192, "2", "2"), (1000, 192, "2", "0"), (1000, 192, "1", "1"), (4133, 1280, "2", "2"),
+                                         (4133, 1280, "2", "0"), (300, 96, "2", "2"), (6000, 2048, "1", "1")])
+def test_all_pairs_symmetric_path_same_bits_as_full_computation(n, d, big, p2):
     """euclidean_distance(f, f, F16_FAST) -- same pointer, so the persistent kernel takes its symmetric form (tiles on or
     above the diagonal, every off-diagonal tile stored twice) -- equals euclidean_distance(f, copy of f) -- the full
     computation -- bit for bit: 79 x 79 tiles with ragged edges (blocked walk), 64 x 64 tiles (XCD-owned walk), a grid
@@ -306,7 +308,7 @@ def test_all_pairs_symmetric_path_same_bits_as_full_computation(n, d, big):
         assert torch.equal(wide[:, 24:24 + {n}], full) and bool((wide[:, :24] == -7).all()) and bool((wide[:, 24 + {n}:] == -7).all())
         s3 = ops.euclidean_distance(ft, ft, mode=ops.GEMM_F16_SPLIT3)
         assert float((s3 - s3.t()).abs().max()) <= 5e-7     # exactly mirrored off the diagonal tiles; inside them the 3-term sum is computed both ways
-        if {n} >= 4096 or "{big}" == "2":   # the persistent kernel ran (the 128 x 128 kernel computes every tile)
+        if {n} >= 4096 or "{big}" == "2" or "{p2}" == "2":   # a symmetric kernel ran (the 128 x 128 kernel computes every tile)
             assert torch.equal(s3[512:768, 0:256], s3[0:256, 512:768].t())
         m = min({n}, 3000)
         ex = ops.euclidean_distance(ft[:m].contiguous(), ft)
@@ -316,6 +318,8 @@ def test_all_pairs_symmetric_path_same_bits_as_full_computation(n, d, big):
         assert float((s3 - s3f).abs().max()) <= 5e-7
         print("ok")
     """)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MPREID_TUNE="gemm_big=" + big), capture_output=True,
-                       text=True, timeout=900)
+    # dist_sym_p2: 0 = the one-workgroup-per-CU kernel's symmetric instance, 1 = the two-workgroups-per-CU kernel from 16
+    # tile rows on (the default), 2 = always
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MPREID_TUNE="gemm_big=" + big + ",dist_sym_p2=" + p2),
+                       capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
