@@ -1724,7 +1724,9 @@ __device__ __forceinline__ void p2_tile_at(int k, int tiles_m, int tiles_n, int 
     tn = 16 * br + j;
 }
 
-__global__ __launch_bounds__(256, 2) void dist_sym_p2_kernel(GemmArgs g, int tiles_m, int tiles_n, int naps, int abl) {
+template <int abl>   // ablation variants (MPREID_ABLATION builds): bit 0 no stores, 1 no k-loop, 2 no mirrored stores, 3 operands aliased
+                     // onto two L2-resident panels, 4 stores straight from the accumulators (wrong data)
+__global__ __launch_bounds__(256, 2) void dist_sym_p2_kernel(GemmArgs g, int tiles_m, int tiles_n, int naps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1736,8 +1738,10 @@ __global__ __launch_bounds__(256, 2) void dist_sym_p2_kernel(GemmArgs g, int til
     const int total = p2_total_tiles(tiles_m, tiles_n);
     const int lo = (int)((int64_t)xcd * total / 8), hi = (int)((int64_t)(xcd + 1) * total / 8);
 
-    // the second workgroup of every CU (in practice: the second half of an XCD's workgroups) starts half a k-loop late,
-    // once: from then on the two alternate between the k-loop and the store-bound epilogue
+    // (experiments) the second workgroup of every CU -- blocks b and b + gridDim/2 share a CU, tools/probes/hwid_probe.hip --
+    // can be started late.  Neither that nor a per-CU token that lets only one of the two store at a time (perfect
+    // alternation, checked with per-tile stamps) helps: a tile's 256 KB take ~20 us to leave while the neighbour runs its
+    // k-loop, 12 us when nothing else uses the CU's vector-memory path.
     if (slot >= (per_xcd >> 1))
         for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(8);
 
@@ -1756,12 +1760,20 @@ __global__ __launch_bounds__(256, 2) void dist_sym_p2_kernel(GemmArgs g, int til
     float *rt = reinterpret_cast<float *>(smem + P_RING_BYTES + wave * 1024);   // [128] |x_m|^2, [128] row scales
     float *T = reinterpret_cast<float *>(smem + wave * (P_RING_BYTES / 4));     // 18 KB of the idle ring per wave
 
+    [[maybe_unused]] int stamp_tile = 0;
+    auto stamp = [&](int which) {   // (ablation builds) per-tile phase stamps of the 100 MHz counter, tools/p2_stamps.py
+#ifdef MPREID_ABLATION
+        if (g.stamps && tid == 0 && stamp_tile < 32)
+            g.stamps[((size_t)blockIdx.x * 32 + stamp_tile) * 8 + which] = __builtin_amdgcn_s_memrealtime();
+#endif
+    };
     for (int it = lo + slot; it < hi; it += per_xcd) {
         int tm, tn;
         p2_tile_at(it, tiles_m, tiles_n, tm, tn);
         const int m0 = tm * PBM, n0 = tn * PBN;
-        const _Float16 *a_src = g.A + (int64_t)(m0 + wave * 64 + drow) * K + dchunk * 8;
-        const _Float16 *b_src = g.W + (int64_t)(n0 + wave * 32 + drow) * K + dchunk * 8;
+        const int ma = (abl & 8) ? (tm & 1) * PBM : m0, na = (abl & 8) ? (tn & 1) * PBN : n0;   // (experiment) L2-resident operands
+        const _Float16 *a_src = g.A + (int64_t)(ma + wave * 64 + drow) * K + dchunk * 8;
+        const _Float16 *b_src = g.W + (int64_t)(na + wave * 32 + drow) * K + dchunk * 8;
         auto dma_stage = [&](int st) {
             unsigned char *sb = smem + (st % P_NSTAGE) * P_STAGE_BYTES;
             const int koff = st * PBK;
@@ -1781,10 +1793,16 @@ __global__ __launch_bounds__(256, 2) void dist_sym_p2_kernel(GemmArgs g, int til
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         dma_stage(0);
         if (nst > 1) dma_stage(1);
+        // One barrier per stage: stage t has landed everywhere (stage t+1 may stay in flight), every wave is done with stage
+        // t-1, whose slot takes the DMA of stage t+2; then 12 fragment reads and 32 matrix instructions.  The other
+        // workgroup of the CU fills the gaps.  (A software-pipelined version -- fragments of stage t+1 and the DMA of stage
+        // t+3 spread between the matrix instructions of stage t, as in the 256 x 256 kernel -- runs the k-loop ALONE 7 %
+        // faster and the whole kernel slower, 0.62 against 0.54-0.59 ms at N = 20 000 on one device: this kernel's
+        // k-loop is bound by the CU's vector-memory path, which its stores share)
         for (int t = 0; t < nst; ++t) {
-            // stage t landed everywhere (stage t+1 may stay in flight); slot (t+2)%3 = slot of stage t-1 is free
             if (t + 1 < nst) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (t == 0) stamp(0);
             if (t + 2 < nst) dma_stage(t + 2);
             const unsigned char *sb = smem + (t % P_NSTAGE) * P_STAGE_BYTES;
             f16x8 fa[8], fb[4];
@@ -1800,6 +1818,7 @@ __global__ __launch_bounds__(256, 2) void dist_sym_p2_kernel(GemmArgs g, int til
         }
 
         // ---- epilogue ----
+        stamp(1);
         const int r0 = m0 + wr * 128, nbase = n0 + wc * 64;
         {   // row tables of the wave (above the ring: no hazard with the other waves' last fragment reads)
             const float t0 = (r0 + lane < g.m_valid) ? g.aux[r0 + lane] : 0.f;
@@ -1823,6 +1842,7 @@ __global__ __launch_bounds__(256, 2) void dist_sym_p2_kernel(GemmArgs g, int til
         }
         // every wave is past its last fragment reads: the ring becomes the waves' patches
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        stamp(2);
         // the accumulators become the finished values in place, one 16-row block at a time
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -1846,13 +1866,24 @@ __global__ __launch_bounds__(256, 2) void dist_sym_p2_kernel(GemmArgs g, int til
         }
         const bool interior = vec_ok && m0 + PBM <= g.m_valid && n0 + PBN <= g.n_valid;
         const int l16 = lane & 15;
-        if (abl & 1) continue;
+        if constexpr (!(abl & 1)) {
         // (1) the block itself: 16 rows at a time through a [16][68] patch (row stride 68 floats: the four row groups of
         // a b32 write land in different banks), out as whole 256-byte row pieces
         {
             const uint64_t obase = reinterpret_cast<uint64_t>(outp + (int64_t)r0 * g.ldo + nbase);
             const unsigned ldo_b = (unsigned)g.ldo * 4u;
             const unsigned voff = (unsigned)(lane >> 4) * ldo_b + (unsigned)l16 * 16u;
+            if constexpr ((abl & 16) != 0) {   // (timing experiment, wrong data) straight from the accumulators, no LDS round trips
+                if (interior)
+#pragma unroll
+                for (int e = 0; e < 32; ++e) store16_nt_sv(obase + (uint64_t)(e * 4) * ldo_b, voff, acc[e >> 2][e & 3]);
+                if (interior && tn >= 2 * tm + 2) {
+                    const uint64_t tb = reinterpret_cast<uint64_t>(outp + (int64_t)nbase * g.ldo + r0);
+#pragma unroll
+                    for (int e = 0; e < 32; ++e)
+                        store16_nt_sv(tb + (uint64_t)((e & 15) * 4) * ldo_b + (e >> 4) * 256, voff, acc[e >> 2][e & 3]);
+                }
+            } else
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
 #pragma unroll
@@ -1893,7 +1924,7 @@ __global__ __launch_bounds__(256, 2) void dist_sym_p2_kernel(GemmArgs g, int til
         // (2) its transpose, when the tile lies entirely above the diagonal: 64 rows x 128 columns in two halves, each
         // through a [64 n][64 m] patch whose 16-byte chunks are XOR-swizzled by n & 15 (b128 writes of a 16-lane group
         // and b128 reads of a row both touch 16 different chunk banks)
-        if (tn >= 2 * tm + 2 && !(abl & 4)) {
+        if (tn >= 2 * tm + 2 && !(abl & (4 | 16))) {
             float *Trow = T + frow * 64;                      // + j * 1024: row n = j * 16 + frow
             const int cx = fq ^ frow;                         // chunk (ii * 4 + fq) ^ frow = (ii * 4) ^ cx
             const unsigned ldo_bT = (unsigned)g.ldo * 4u;
@@ -1939,6 +1970,13 @@ __global__ __launch_bounds__(256, 2) void dist_sym_p2_kernel(GemmArgs g, int til
                 __builtin_amdgcn_wave_barrier();
             }
         }
+        }
+        stamp(3);
+#ifdef MPREID_ABLATION
+        if (g.stamps) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+        stamp(4);
+        ++stamp_tile;
     }
 }
 
@@ -2105,7 +2143,7 @@ static int launch_one(const GemmArgs &a_in, hipStream_t stream) {
         if constexpr (EPI == GE_EUCLID) {
             static PerDeviceOnce p2_once;
             const int rc = p2_once.run([]() -> int {
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(dist_sym_p2_kernel),
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(dist_sym_p2_kernel<0>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES));
                 return MPREID_OK;
             });
@@ -2115,11 +2153,29 @@ static int launch_one(const GemmArgs &a_in, hipStream_t stream) {
             HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
             const int grid = std::max(8, (2 * cus) & ~7);
             static const int naps_tune = mpreid_tune("dist_sym_p2_naps", -1);
-            const int naps = naps_tune >= 0 ? naps_tune : (a.K / PBK) / 2;   // s_sleep 8 ~ 512 clocks ~ one k stage
-            static const int abl = mpreid_tune("dist_sym_p2_abl", 0);
+            const int naps = naps_tune >= 0 ? naps_tune : 0;   // (experiments) late start of every CU's second workgroup, units of s_sleep 8
+            [[maybe_unused]] static const int abl = mpreid_tune("dist_sym_p2_abl", 0);
+            GemmArgs a = a_in;
             static const int gridt = mpreid_tune("dist_sym_p2_grid", 0);
-            hipLaunchKernelGGL(dist_sym_p2_kernel, dim3((unsigned)(gridt ? gridt : grid)), dim3(256), P_LDS_BYTES, stream, a, a.M / PBM, a.N / PBN,
-                               naps, abl);
+            const dim3 gdim((unsigned)(gridt ? gridt : grid));
+#ifdef MPREID_ABLATION
+            if (const char *sp = getenv("MPREID_GEMM_STAMPS")) a.stamps = reinterpret_cast<unsigned long long *>(strtoull(sp, nullptr, 16));
+#define MPREID_P2_CASE(V)                                                                                      \
+    case V:                                                                                                    \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(dist_sym_p2_kernel<V>),                     \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES));                 \
+        hipLaunchKernelGGL(dist_sym_p2_kernel<V>, gdim, dim3(256), P_LDS_BYTES, stream, a, a.M / PBM, a.N / PBN, naps); \
+        break;
+            switch (abl) {
+                MPREID_P2_CASE(1) MPREID_P2_CASE(2) MPREID_P2_CASE(3) MPREID_P2_CASE(4) MPREID_P2_CASE(8) MPREID_P2_CASE(9)
+                MPREID_P2_CASE(16) MPREID_P2_CASE(24)
+            default:
+                hipLaunchKernelGGL(dist_sym_p2_kernel<0>, gdim, dim3(256), P_LDS_BYTES, stream, a, a.M / PBM, a.N / PBN, naps);
+            }
+#undef MPREID_P2_CASE
+#else
+            hipLaunchKernelGGL(dist_sym_p2_kernel<0>, gdim, dim3(256), P_LDS_BYTES, stream, a, a.M / PBM, a.N / PBN, naps);
+#endif
         }
     } else if (use_big) {
         if constexpr (HAS_BIG) {
