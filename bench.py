@@ -368,7 +368,7 @@ def extras(ops, dev, with_widened=True):
     for fn in ("r04_pmc_summary.json",):
         try:
             per = json.load(open(os.path.join(ROOT, "profiles", fn)))["featgemm_20kx20kx768_fp16_hbm_bytes_per_launch"]
-            fg_traffic = int(sum(v for k, v in per.items() if k.startswith(("void gemm_f16_big_kernel<5, 0", "void gemm_f16_store"))))
+            fg_traffic = int(sum(v for k, v in per.items() if k.startswith(("void gemm_f16_big_kernel<5, 0", "void dist_sym_p2_kernel", "void gemm_f16_store"))))
             fg_src = fn
             break
         except Exception:
@@ -378,7 +378,7 @@ def extras(ops, dev, with_widened=True):
                   "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(flop / ms_full / 1e9 / PEAK_F16_TFLOPS, 4),
                   "algorithmic_flop": int(flop), "avg_launch_ms": round(ms_full, 4), "traffic": None})
     roofs.append({"stage": "feat_gemm_20kx20k_d768 (fp16 one pass, fp32 N x N stored; all pairs of one tensor: symmetric form)",
-                  "kernel": "gemm_f16_big_kernel<euclid, sym>",
+                  "kernel": "dist_sym_p2_kernel (two workgroups per CU, 256 x 128 tiles; MPREID_TUNE dist_sym_p2=0: gemm_f16_big_kernel<euclid, sym>)",
                   "bound": "mfma", "achieved": round(flop / ms / 1e9, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                   "frac": round(flop / ms / 1e9 / PEAK_F16_TFLOPS, 4), "frac_of_sustainable_1250TF": round(flop / ms / 1e9 / 1250.0, 4),
                   "algorithmic_flop": int(flop),
@@ -391,7 +391,7 @@ def extras(ops, dev, with_widened=True):
         ms = timed_ms(lambda: ops.euclidean_distance(ft, ft, mode=ops.GEMM_F16_SPLIT3, out=buf), 10, warm=3)
         out["feat_gemm_20kx20k_d768_split3_ms"] = round(ms, 4)
         out["feat_gemm_20kx20k_d768_split3_executed_tflops"] = round(3 * flop / ms / 1e9, 1)
-        roofs.append({"stage": "feat_gemm_20kx20k_d768 (3-term fp16 split, |err| <= 1e-6; all pairs of one tensor: symmetric form)", "kernel": "gemm_f16_big_kernel<euclid_split3, sym>",
+        roofs.append({"stage": "feat_gemm_20kx20k_d768 (3-term fp16 split, |err| <= 1e-6; all pairs of one tensor: symmetric form)", "kernel": "dist_sym_p2_kernel (split3 operands)",
                       "bound": "mfma", "achieved": round(flop / ms / 1e9, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                       "frac": round(flop / ms / 1e9 / PEAK_F16_TFLOPS, 4), "algorithmic_flop": int(flop),
                       "achieved_executed": round(3 * flop / ms / 1e9, 1), "frac_executed": round(3 * flop / ms / 1e9 / PEAK_F16_TFLOPS, 4),

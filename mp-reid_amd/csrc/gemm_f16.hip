@@ -1777,6 +1777,16 @@ __global__ __launch_bounds__(256, 2) void dist_sym_p2_kernel(GemmArgs g, int til
         auto dma_stage = [&](int st) {
             unsigned char *sb = smem + (st % P_NSTAGE) * P_STAGE_BYTES;
             const int koff = st * PBK;
+            if constexpr ((abl & 32) != 0) {   // (timing experiment, wrong data) the same bytes requested as WHOLE 128-byte lines:
+                // even stages the first half of the rows, odd stages the second half, both k slabs of a line at once
+                const _Float16 *aw = g.A + (int64_t)(ma + (st & 1) * 128 + wave * 32 + (lane >> 3)) * K + (st >> 1) * 64 + (lane & 7) * 8;
+                const _Float16 *bw = g.W + (int64_t)(na + (st & 1) * 64 + wave * 16 + (lane >> 3)) * K + (st >> 1) * 64 + (lane & 7) * 8;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dma16(aw + (int64_t)t * 8 * K, sb + wave * 4096 + t * 1024);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) dma16(bw + (int64_t)t * 8 * K, sb + P_A_BYTES + wave * 2048 + t * 1024);
+                return;
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t) dma16(a_src + (int64_t)t * 16 * K + koff, sb + wave * 4096 + t * 1024);
 #pragma unroll
@@ -2168,7 +2178,7 @@ static int launch_one(const GemmArgs &a_in, hipStream_t stream) {
         break;
             switch (abl) {
                 MPREID_P2_CASE(1) MPREID_P2_CASE(2) MPREID_P2_CASE(3) MPREID_P2_CASE(4) MPREID_P2_CASE(8) MPREID_P2_CASE(9)
-                MPREID_P2_CASE(16) MPREID_P2_CASE(24)
+                MPREID_P2_CASE(16) MPREID_P2_CASE(24) MPREID_P2_CASE(32) MPREID_P2_CASE(33)
             default:
                 hipLaunchKernelGGL(dist_sym_p2_kernel<0>, gdim, dim3(256), P_LDS_BYTES, stream, a, a.M / PBM, a.N / PBN, naps);
             }
