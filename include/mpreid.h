@@ -31,7 +31,8 @@ extern "C" {
  *   gemm_big (1)            0 = never the 256x256 persistent GEMM, 1 = when its grid fills the chip, 2 = whenever divisible
  *   gemm_stagger, gemm_stagger_all (0)   start delay (ticks) of the persistent workgroups
  *   dist_sym_p2 (1)         all-pairs distances of ONE tensor (q == g), fp16 modes: 0 = the 256x256 kernel's symmetric form,
- *                           1 = the two-workgroups-per-CU kernel from 16 tile rows on (N >= 3841), 2 = whenever the padded size allows;
+ *                           1 = the two-workgroups-per-CU kernel from 16 tile rows on (N >= 3841; one-pass fp16 mode only: the 3-term
+ *                           split operands stay on the first), 2 = whenever the padded size allows, 3 = also the 3-term split;
  *                           dist_sym_p2_naps / dist_sym_p2_grid (0): late start of every CU's second workgroup / grid size
  *                           (experiments); dist_sym_p2_abl: ablation variants, -DMPREID_ABLATION builds only
  *   jaccard_wave (-1 auto), jaccard_wave_rows (10240), jaccard_table (0)   form of the Jaccard stage

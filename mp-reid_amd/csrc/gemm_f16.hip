@@ -2094,6 +2094,22 @@ void mpreid_prof_end(void *token, hipStream_t stream, int cls, int64_t m, int n,
     delete t;
 }
 
+// CU count of the current device (cached per device ordinal; benign race: every writer stores the same value)
+static int current_device_cus(int *cus) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    static int cus_of[64] = {0};
+    if (dev >= 0 && dev < 64 && cus_of[dev] > 0) {
+        *cus = cus_of[dev];
+        return MPREID_OK;
+    }
+    int n = 0;
+    HIP_TRY(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    if (dev >= 0 && dev < 64) cus_of[dev] = n;
+    *cus = n;
+    return MPREID_OK;
+}
+
 template <int EPI>
 static int launch_one(const GemmArgs &a_in, hipStream_t stream) {
     const GemmArgs &a = a_in;
@@ -2146,8 +2162,8 @@ static int launch_one(const GemmArgs &a_in, hipStream_t stream) {
     bool use_p2 = false;
     if constexpr (EPI == GE_EUCLID) {
         static const int p2_mode = mpreid_tune("dist_sym_p2", 1);
-        use_p2 = a.sym && p2_mode > 0 && a.M == a.N && a.A == a.W && (a.M % PBM == 0) && (a.K % PBK == 0) &&
-                 (p2_mode >= 2 || a.M / PBM >= 16);
+        use_p2 = a.sym && p2_mode > 0 && a.M == a.N && (a.A == a.W || p2_mode >= 3) && (a.M % PBM == 0) && (a.K % PBK == 0) &&
+                 (p2_mode >= 2 || a.M / PBM >= 16);   // (3: also the 3-term split operands, A != W: measured slower, see DESIGN)
     }
     if (use_p2) {
         if constexpr (EPI == GE_EUCLID) {
@@ -2158,9 +2174,8 @@ static int launch_one(const GemmArgs &a_in, hipStream_t stream) {
                 return MPREID_OK;
             });
             if (rc) return rc;
-            int dev = 0, cus = 0;
-            HIP_TRY(hipGetDevice(&dev));
-            HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            int cus = 0;
+            if (const int rcc = current_device_cus(&cus)) return rcc;
             const int grid = std::max(8, (2 * cus) & ~7);
             static const int naps_tune = mpreid_tune("dist_sym_p2_naps", -1);
             const int naps = naps_tune >= 0 ? naps_tune : 0;   // (experiments) late start of every CU's second workgroup, units of s_sleep 8
@@ -2192,15 +2207,7 @@ static int launch_one(const GemmArgs &a_in, hipStream_t stream) {
             static const int dbg = mpreid_ablation_env("MPREID_GEMM_DBG");
             // persistent: one workgroup per CU (the kernel owns the CU's whole LDS), each walking tiles
             int big_cus = 0;
-            {
-                int dev = 0;
-                HIP_TRY(hipGetDevice(&dev));
-                static int cus_of[64] = {0};   // benign race: every writer stores the same value
-                const int slot = (dev >= 0 && dev < 64) ? dev : 0;
-                if (cus_of[slot] == 0 || slot != dev)
-                    HIP_TRY(hipDeviceGetAttribute(&cus_of[slot], hipDeviceAttributeMultiprocessorCount, dev));
-                big_cus = cus_of[slot];
-            }
+            if (const int rcc = current_device_cus(&big_cus)) return rcc;
             static const int stag_all = mpreid_tune("gemm_stagger_all", 0);
             GemmArgs a = a_in;
             if (stag_all > 0) {

@@ -282,7 +282,7 @@ def test_stored_distance_kernels_bit_identical():
 # ---- all-pairs distances of ONE set: euclidean_distance(f, f) computes the upper-triangular tiles and mirrors them ----
 @pytest.mark.parametrize("n,d,big,p2", [(20000, 768, "1", "1"), (20000, 768, "1", "0"), (16384, 128, "1", "1"), (16384, 128, "1", "0"),
                                          (1000, 192, "2", "2"), (1000, 192, "2", "0"), (1000, 192, "1", "1"), (4133, 1280, "2", "2"),
-                                         (4133, 1280, "2", "0"), (300, 96, "2", "2"), (6000, 2048, "1", "1")])
+                                         (4133, 1280, "2", "0"), (300, 96, "2", "2"), (6000, 2048, "1", "1"), (6000, 768, "1", "3")])
 def test_all_pairs_symmetric_path_same_bits_as_full_computation(n, d, big, p2):
     """euclidean_distance(f, f, F16_FAST) -- same pointer, so the persistent kernel takes its symmetric form (tiles on or
     above the diagonal, every off-diagonal tile stored twice) -- equals euclidean_distance(f, copy of f) -- the full
@@ -319,7 +319,7 @@ def test_all_pairs_symmetric_path_same_bits_as_full_computation(n, d, big, p2):
         print("ok")
     """)
     # dist_sym_p2: 0 = the one-workgroup-per-CU kernel's symmetric instance, 1 = the two-workgroups-per-CU kernel from 16
-    # tile rows on (the default), 2 = always
+    # tile rows on (the default), 2 = always, 3 = also for the 3-term split operands (which stay on the first by default)
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MPREID_TUNE="gemm_big=" + big + ",dist_sym_p2=" + p2),
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
