@@ -299,7 +299,7 @@ def test_all_pairs_symmetric_path_same_bits_as_full_computation(n, d, big, p2):
         ft = torch.from_numpy(f).cuda()
         ft2 = ft.clone()
         full = ops.euclidean_distance(ft, ft2, mode=ops.GEMM_F16_FAST)
-        for rep in range(2):
+        for rep in range(12):   # (also a race screen: the two workgroups of a CU drift through every relative phase)
             sym = ops.euclidean_distance(ft, ft, mode=ops.GEMM_F16_FAST)
             assert torch.equal(sym, full), float((sym - full).abs().max())
         assert torch.equal(sym, sym.t())
