@@ -1697,16 +1697,16 @@ __device__ __forceinline__ int p2_strip_size(int R, int ncol, int &ramp) {
     const int p = ramp >> 1;
     return p * (p + 1) + ((ramp & 1) ? (p + 1) : 0) + (ncol - ramp) * R;
 }
-__device__ __forceinline__ int p2_total_tiles(int tiles_m, int tiles_n) {
+__device__ __forceinline__ int p2_total_tiles(int tiles_m, int tiles_n, int SH) {   // SH = tile rows per strip
     int T = 0, ramp;
-    for (int br = 0; 8 * br < tiles_m; ++br) T += p2_strip_size(min(8, tiles_m - 8 * br), tiles_n - 16 * br, ramp);
+    for (int br = 0; SH * br < tiles_m; ++br) T += p2_strip_size(min(SH, tiles_m - SH * br), tiles_n - 2 * SH * br, ramp);
     return T;
 }
-__device__ __forceinline__ void p2_tile_at(int k, int tiles_m, int tiles_n, int &tm, int &tn) {   // k < total
+__device__ __forceinline__ void p2_tile_at(int k, int tiles_m, int tiles_n, int SH, int &tm, int &tn) {   // k < total
     int br = 0, R, ramp;
     for (;; ++br) {
-        R = min(8, tiles_m - 8 * br);
-        const int S = p2_strip_size(R, tiles_n - 16 * br, ramp);
+        R = min(SH, tiles_m - SH * br);
+        const int S = p2_strip_size(R, tiles_n - 2 * SH * br, ramp);
         if (k < S) break;
         k -= S;
     }
@@ -1720,13 +1720,13 @@ __device__ __forceinline__ void p2_tile_at(int k, int tiles_m, int tiles_n, int 
         j += k / R;
         k = k % R;
     }
-    tm = 8 * br + k;
-    tn = 16 * br + j;
+    tm = SH * br + k;
+    tn = 2 * SH * br + j;
 }
 
 template <int abl>   // ablation variants (MPREID_ABLATION builds): bit 0 no stores, 1 no k-loop, 2 no mirrored stores, 3 operands aliased
                      // onto two L2-resident panels, 4 stores straight from the accumulators (wrong data)
-__global__ __launch_bounds__(256, 2) void dist_sym_p2_kernel(GemmArgs g, int tiles_m, int tiles_n, int naps) {
+__global__ __launch_bounds__(256, 2) void dist_sym_p2_kernel(GemmArgs g, int tiles_m, int tiles_n, int naps, int SH) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1735,7 +1735,7 @@ __global__ __launch_bounds__(256, 2) void dist_sym_p2_kernel(GemmArgs g, int til
     const int nst = (abl & 2) ? 1 : K / PBK;
     const int per_xcd = (int)gridDim.x >> 3;                      // the grid is a multiple of 8
     const int xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3);
-    const int total = p2_total_tiles(tiles_m, tiles_n);
+    const int total = p2_total_tiles(tiles_m, tiles_n, SH);
     const int lo = (int)((int64_t)xcd * total / 8), hi = (int)((int64_t)(xcd + 1) * total / 8);
 
     // (experiments) the second workgroup of every CU -- blocks b and b + gridDim/2 share a CU, tools/probes/hwid_probe.hip --
@@ -1769,7 +1769,7 @@ __global__ __launch_bounds__(256, 2) void dist_sym_p2_kernel(GemmArgs g, int til
     };
     for (int it = lo + slot; it < hi; it += per_xcd) {
         int tm, tn;
-        p2_tile_at(it, tiles_m, tiles_n, tm, tn);
+        p2_tile_at(it, tiles_m, tiles_n, SH, tm, tn);
         const int m0 = tm * PBM, n0 = tn * PBN;
         const int ma = (abl & 8) ? (tm & 1) * PBM : m0, na = (abl & 8) ? (tn & 1) * PBN : n0;   // (experiment) L2-resident operands
         const _Float16 *a_src = g.A + (int64_t)(ma + wave * 64 + drow) * K + dchunk * 8;
@@ -2182,6 +2182,7 @@ static int launch_one(const GemmArgs &a_in, hipStream_t stream) {
             [[maybe_unused]] static const int abl = mpreid_tune("dist_sym_p2_abl", 0);
             GemmArgs a = a_in;
             static const int gridt = mpreid_tune("dist_sym_p2_grid", 0);
+            static const int strip = std::max(1, mpreid_tune("dist_sym_p2_strip", 8));   // tile rows per strip of the walk
             const dim3 gdim((unsigned)(gridt ? gridt : grid));
 #ifdef MPREID_ABLATION
             if (const char *sp = getenv("MPREID_GEMM_STAMPS")) a.stamps = reinterpret_cast<unsigned long long *>(strtoull(sp, nullptr, 16));
@@ -2189,17 +2190,17 @@ static int launch_one(const GemmArgs &a_in, hipStream_t stream) {
     case V:                                                                                                    \
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(dist_sym_p2_kernel<V>),                     \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES));                 \
-        hipLaunchKernelGGL(dist_sym_p2_kernel<V>, gdim, dim3(256), P_LDS_BYTES, stream, a, a.M / PBM, a.N / PBN, naps); \
+        hipLaunchKernelGGL(dist_sym_p2_kernel<V>, gdim, dim3(256), P_LDS_BYTES, stream, a, a.M / PBM, a.N / PBN, naps, strip); \
         break;
             switch (abl) {
                 MPREID_P2_CASE(1) MPREID_P2_CASE(2) MPREID_P2_CASE(3) MPREID_P2_CASE(4) MPREID_P2_CASE(8) MPREID_P2_CASE(9)
                 MPREID_P2_CASE(16) MPREID_P2_CASE(24) MPREID_P2_CASE(32) MPREID_P2_CASE(33)
             default:
-                hipLaunchKernelGGL(dist_sym_p2_kernel<0>, gdim, dim3(256), P_LDS_BYTES, stream, a, a.M / PBM, a.N / PBN, naps);
+                hipLaunchKernelGGL(dist_sym_p2_kernel<0>, gdim, dim3(256), P_LDS_BYTES, stream, a, a.M / PBM, a.N / PBN, naps, strip);
             }
 #undef MPREID_P2_CASE
 #else
-            hipLaunchKernelGGL(dist_sym_p2_kernel<0>, gdim, dim3(256), P_LDS_BYTES, stream, a, a.M / PBM, a.N / PBN, naps);
+            hipLaunchKernelGGL(dist_sym_p2_kernel<0>, gdim, dim3(256), P_LDS_BYTES, stream, a, a.M / PBM, a.N / PBN, naps, strip);
 #endif
         }
     } else if (use_big) {
