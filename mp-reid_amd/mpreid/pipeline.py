@@ -15,7 +15,8 @@ Loader batch images, by type:
     ONE asynchronous H2D per group; ``stage='direct'`` hands the pageable memory to the HIP runtime batch by batch (the
     runtime pins or stages it itself; host-synchronous, which is harmless in the stager thread).  Already-pinned batches
     are always copied directly.
-  * tensors already on the device: gathered into the group buffer by D2D copies on the copy stream.
+  * tensors already on the device: read in place when a group's batches are back-to-back slices of one allocation (a
+    device-resident dataset cut into batches), else gathered into the group buffer by D2D copies on the copy stream.
   * ``RawImageBatch`` (decoded uint8 RGB images of ragged sizes): packed back to back into a pinned byte buffer, one H2D
     per group, then Resize + ToTensor + Normalize inside the model call (ops.PackedRawImages).
 No host ``torch.cat``, no per-batch synchronisation; the host runs at most ``slots`` groups ahead of the device.
@@ -65,7 +66,8 @@ class _Slot:
 
 
 class _Group:
-    __slots__ = ("slot", "count", "kind", "shape", "dtype", "pieces", "cams", "views", "raw_total", "raw_max_h", "error")
+    __slots__ = ("slot", "count", "kind", "shape", "dtype", "pieces", "cams", "views", "raw_total", "raw_max_h", "error",
+                 "dev_parts", "direct")
 
     def __init__(self, slot):
         self.slot, self.count, self.kind = slot, 0, None
@@ -75,9 +77,28 @@ class _Group:
         self.views: List[torch.Tensor] = []
         self.raw_total, self.raw_max_h = 0, 0
         self.error = None
+        self.dev_parts: List[torch.Tensor] = []   # kind "device": the loader's own tensors, in group order
+        self.direct = None                        # ... and, when they turn out to be one contiguous range, a view of it
 
 
 _END = object()
+
+
+def _contiguous_view(parts, count, shape, dtype):
+    """the tensors of `parts` as ONE tensor [count, *shape] when they are back-to-back slices of the same allocation, else None"""
+    if not parts:
+        return None
+    first = parts[0]
+    st = first.untyped_storage()
+    at = first.data_ptr()
+    for t in parts:
+        if t.data_ptr() != at or t.untyped_storage().data_ptr() != st.data_ptr() or not t.is_contiguous():
+            return None
+        at += t.numel() * t.element_size()
+    off = first.data_ptr() - st.data_ptr()
+    if off % first.element_size() or at > st.data_ptr() + st.nbytes() or first.data_ptr() % 16:
+        return None
+    return torch.empty(0, dtype=dtype, device=first.device).set_(st, off // first.element_size(), (count,) + tuple(shape))
 
 
 class EncodePipeline:
@@ -130,6 +151,22 @@ class EncodePipeline:
                         nb = g.count * int(np.prod(g.shape)) * g.dtype.itemsize
                         slot.devbuf(nb)[:nb].copy_(slot.pin[:nb], non_blocking=True)
                         self.stats["h2d_bytes"] += nb
+                    elif g.kind == "device":
+                        # Batches that are consecutive slices of ONE allocation (a device-resident dataset cut into batches) are
+                        # read where they lie: no copy.  Anything else is gathered into the group buffer by D2D copies.
+                        g.direct = _contiguous_view(g.dev_parts, g.count, g.shape, g.dtype)
+                        if g.direct is None:
+                            sb = int(np.prod(g.shape)) * g.dtype.itemsize
+                            buf, at = slot.devbuf(self.group * sb), 0
+                            for t in g.dev_parts:
+                                nb = t.shape[0] * sb
+                                buf[at:at + nb].copy_(t.reshape(-1).view(torch.uint8), non_blocking=True)
+                                t.record_stream(copy_s)
+                                at += nb
+                            self.stats["d2d_bytes"] = self.stats.get("d2d_bytes", 0) + at
+                        else:
+                            self.stats["zero_copy_groups"] = self.stats.get("zero_copy_groups", 0) + 1
+                            g.dev_parts = []
                     elif g.kind == "raw":
                         nb = g.raw_total
                         slot.devbuf(nb)[:nb].copy_(slot.pin[:nb], non_blocking=True)
@@ -202,13 +239,12 @@ class EncodePipeline:
                         src = img[lo:lo + take].reshape(-1).view(torch.uint8)
                         if kind == "host_pinned":
                             slot.host(self.group * sb)[cur.count * sb:(cur.count + take) * sb].copy_(src)
-                        else:   # pageable / pinned host memory straight to the device, or device to device
+                        elif kind == "device":   # decided when the group closes: read in place or gathered
+                            cur.dev_parts.append(img[lo:lo + take])
+                        else:   # pageable / pinned host memory straight to the device
                             with torch.cuda.stream(copy_s):
                                 slot.devbuf(self.group * sb)[cur.count * sb:(cur.count + take) * sb].copy_(src, non_blocking=True)
-                            if kind == "host_direct":
-                                self.stats["h2d_bytes"] += take * sb
-                            if kind == "device":
-                                img.record_stream(copy_s)
+                            self.stats["h2d_bytes"] += take * sb
                     cur.pieces.append((bi, lo, lo + take, cur.count))
                     if self.sie_camera:
                         cur.cams.append(batch[3][lo:lo + take])
@@ -236,6 +272,8 @@ class EncodePipeline:
             offs = slot.meta_dev[:G * 8].view(torch.int64)[:g.count]
             hw = slot.meta_dev[G * 8:G * 16].view(torch.int32).view(G, 2)[:g.count]
             return ops.PackedRawImages(slot.dev[:g.raw_total], offs, hw, g.count, g.raw_max_h)
+        if g.direct is not None:
+            return g.direct
         nb = g.count * int(np.prod(g.shape)) * g.dtype.itemsize
         return slot.dev[:nb].view(g.dtype).view((g.count,) + g.shape)
 
@@ -286,6 +324,8 @@ class EncodePipeline:
                 with torch.cuda.stream(s):
                     s.wait_event(g.slot.ready)
                     x = self._input_of(g)
+                    if g.direct is not None:
+                        x.record_stream(s)        # the loader's memory, read on this stream
                     cam = torch.cat(g.cams).to(dev, non_blocking=True) if self.sie_camera else None
                     view = torch.cat(g.views).to(dev, non_blocking=True) if self.sie_view else None
                     with torch.no_grad():

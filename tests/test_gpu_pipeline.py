@@ -484,6 +484,10 @@ def _batches(kind, sizes, seed=0):
     from mpreid import synth
     rng = np.random.default_rng(seed)
     out, base = [], 0
+    resident = None
+    if kind == "device_slices":   # a device-resident dataset cut into batches: consecutive slices of ONE allocation
+        resident = torch.cat([torch.from_numpy(synth.synthetic_images(n, 64, 32, seed=seed + sum(sizes[:i]))) for i, n in enumerate(sizes)
+                              if n]).cuda()
     for n in sizes:
         if kind == "raw":
             img = RawImageBatch([rng.integers(0, 256, (int(rng.integers(40, 90)), int(rng.integers(20, 50)), 3), dtype=np.uint8)
@@ -492,6 +496,8 @@ def _batches(kind, sizes, seed=0):
             img = torch.from_numpy(synth.synthetic_images(n, 64, 32, seed=seed + base)) if n else torch.empty((0, 3, 64, 32))
             if kind == "device":
                 img = img.cuda()
+            elif kind == "device_slices":
+                img = resident[base:base + n]
             elif kind == "pinned":
                 img = img.pin_memory()
             elif kind == "u8":
@@ -504,7 +510,7 @@ def _batches(kind, sizes, seed=0):
 
 
 @pytest.mark.parametrize("kind,stage", [("host", "pinned"), ("host", "direct"), ("pinned", "pinned"), ("device", "pinned"),
-                                        ("raw", "pinned"), ("u8", "pinned")])
+                                        ("device_slices", "pinned"), ("raw", "pinned"), ("u8", "pinned")])
 @pytest.mark.parametrize("sie", [False, True])
 def test_encode_pipeline_equals_plain_loop_bitwise(kind, stage, sie):
     """every loader type through the staged pipeline (groups of 10 images cut across ragged loader batches, 3 slots
@@ -536,6 +542,11 @@ def test_encode_pipeline_equals_plain_loop_bitwise(kind, stage, sie):
     assert pipe.stats["images"] == total and pipe.stats["groups"] == len(model.calls)
     if kind in ("host", "raw", "u8"):
         assert pipe.stats["h2d_bytes"] > 0
+    if kind == "device_slices":      # read in place: no copy at all
+        assert pipe.stats.get("zero_copy_groups", 0) == pipe.stats["groups"] and pipe.stats.get("d2d_bytes", 0) == 0
+    if kind == "device":             # separately allocated batches: gathered (a group that lies inside ONE batch is read in place)
+        assert 0 < pipe.stats.get("d2d_bytes", 0) <= total * 3 * 64 * 32 * 4
+        assert 0 < pipe.stats.get("zero_copy_groups", 0) < pipe.stats["groups"]
 
 
 def test_encode_pipeline_surfaces_loader_and_model_errors():
