@@ -42,7 +42,7 @@ constexpr int conv_lds_bytes(int BN) { return 2 * conv_stage_bytes(BN); }       
 
 // BN = output channels per tile: 128 (2 x 2 waves of 64 x 64) or 64 (4 x 1 waves of 32 x 64) for the layers with
 // <= 64 output channels (stem, layer1): a 128-wide tile would spend half of its MFMAs on zero weight rows
-template <int TAPS, bool RELU, int BN>
+template <int TAPS, bool RELU, int BN, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs g, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int C_STAGE_BYTES = conv_stage_bytes(BN);
@@ -55,8 +55,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs g, int tiles
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = (BN == 128) ? (wave >> 1) : wave, wn = (BN == 128) ? (wave & 1) : 0;
-    const int C = g.C, K = TAPS * C;
-    const int cpt = C / CBK; // K-steps per tap
+    const int C = g.C;
+    const int cpt = C / CBK;                       // 64-channel blocks per tap
+    const int AS = SPLIT ? 2 * C : C;              // row stride of the activations in halfs (pairs: hi | lo)
+    const int K = TAPS * C * (SPLIT ? 3 : 1);      // row length of the weights: one 64-half slab per k step
 
     // ---- staging: wave w moves rows [32w, 32w+32) of both tiles, 8 rows per DMA instruction ----
     const int srow = lane >> 3;
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs g, int tiles
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int m = m0 + wave * 32 + t * 8 + srow;
-        a_row[t] = g.act + (int64_t)m * C + gchunk * 8;
+        a_row[t] = g.act + (int64_t)m * AS + gchunk * 8;
         unsigned mask = 0;
         if (m < g.M) {
             if (TAPS == 1) {
@@ -87,9 +89,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs g, int tiles
     auto stage = [&](int s, int kt) {
         unsigned char *abase = smem + s * C_STAGE_BYTES + wave * 4096;
         unsigned char *bbase = smem + s * C_STAGE_BYTES + C_TILE_BYTES + wave * (BROWS * 128);
-        const int tap = (TAPS == 1) ? 0 : kt / cpt;
-        const int c0 = (kt - tap * cpt) * CBK;
-        const int64_t shift = (TAPS == 1) ? (int64_t)c0 : (int64_t)((tap / 3 - 1) * g.W + (tap % 3 - 1)) * C + c0;
+        int tap, c0;
+        if constexpr (SPLIT) {   // k step = (tap, 64-channel block, product): 0 hi.hi', 1 lo.hi', 2 hi.lo' (the weight slabs are laid out in this order)
+            const int kb = kt / 3, kind = kt - 3 * kb;
+            tap = (TAPS == 1) ? 0 : kb / cpt;
+            c0 = (kb - tap * cpt) * CBK + (kind == 1 ? C : 0);
+        } else {
+            tap = (TAPS == 1) ? 0 : kt / cpt;
+            c0 = (kt - tap * cpt) * CBK;
+        }
+        const int64_t shift = (TAPS == 1) ? (int64_t)c0 : (int64_t)((tap / 3 - 1) * g.W + (tap % 3 - 1)) * AS + c0;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const _Float16 *src = ((tapmask[t] >> tap) & 1u) ? a_row[t] + shift : zero;
@@ -169,7 +178,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs g, int tiles
             const float4 v0 = *reinterpret_cast<const float4 *>(wreg + lr * 68 + ch * 8);
             const float4 v1 = *reinterpret_cast<const float4 *>(wreg + lr * 68 + ch * 8 + 4);
             float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            if (m < g.M && n < g.N) {
+            if constexpr (SPLIT) {
+                if (m < g.M && n < g.Npad) {
+                    float *o = g.out32 + (int64_t)m * g.ldo + n;
+                    *reinterpret_cast<float4 *>(o) = make_float4(fmaf(v[0], g.oscale, bias[0]), fmaf(v[1], g.oscale, bias[1]),
+                                                                 fmaf(v[2], g.oscale, bias[2]), fmaf(v[3], g.oscale, bias[3]));
+                    *reinterpret_cast<float4 *>(o + 4) = make_float4(fmaf(v[4], g.oscale, bias[4]), fmaf(v[5], g.oscale, bias[5]),
+                                                                     fmaf(v[6], g.oscale, bias[6]), fmaf(v[7], g.oscale, bias[7]));
+                }
+            } else if (m < g.M && n < g.N) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = v[e] + bias[e];
                 if (g.identity) {
@@ -189,25 +206,31 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs g, int tiles
 
 } // namespace
 
-template <int TAPS, bool RELU, int BN>
+template <int TAPS, bool RELU, int BN, bool SPLIT = false>
 static int launch_conv_variant(const ConvArgs &a, hipStream_t stream) {
     const int tiles_m = (a.M + CBM - 1) / CBM, tiles_n = (a.N + BN - 1) / BN;
     static PerDeviceOnce attr_once;
     {
         const int rc = attr_once.run([]() -> int {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm_kernel<TAPS, RELU, BN>),
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(conv_gemm_kernel<TAPS, RELU, BN, SPLIT>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_bytes(BN)));
             return MPREID_OK;
         });
         if (rc) return rc;
     }
-    hipLaunchKernelGGL((conv_gemm_kernel<TAPS, RELU, BN>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), conv_lds_bytes(BN),
+    hipLaunchKernelGGL((conv_gemm_kernel<TAPS, RELU, BN, SPLIT>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), conv_lds_bytes(BN),
                        stream, a, tiles_m, tiles_n);
     LAUNCH_CHECK();
     return 0;
 }
 
 int launch_conv_f16(const ConvArgs &a, hipStream_t stream) {
+    if (a.split) {   // the pair form: 3x3 only, fp32 out
+        ARG_CHECK(a.act && a.wgt && a.bias && a.out32 && a.zero_page && a.taps == 9 && a.C > 0 && a.C % CBK == 0 && a.M > 0);
+        ARG_CHECK(a.Npad % 128 == 0 && a.N > 0 && a.Npad >= a.N && a.ldo % 4 == 0 && a.ldo >= a.Npad && a.H > 0 && a.W > 0 &&
+                  a.M % (a.H * a.W) == 0);
+        return a.N <= 64 ? launch_conv_variant<9, false, 64, true>(a, stream) : launch_conv_variant<9, false, 128, true>(a, stream);
+    }
     ARG_CHECK(a.act && a.wgt && a.bias && a.out && a.zero_page);
     ARG_CHECK((a.taps == 1 || a.taps == 9) && a.C > 0 && a.C % CBK == 0 && a.M > 0 && a.N > 0);
     ARG_CHECK(a.Npad % 128 == 0 && a.Npad >= a.N && a.N % 8 == 0 && a.ldo % 8 == 0 && a.ldo >= a.N);

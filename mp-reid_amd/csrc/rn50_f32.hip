@@ -13,6 +13,7 @@
 // (explicit q / k / v projections, one query per image: token 0 is the only output the reference uses) in fp32.
 // A parity / debugging mode (~1/10 of the fp16 tower's throughput), the RN50 counterpart of mpreid_vit_forward_f32.
 #include "common.h"
+#include "conv_f16.h"   // ... and its 3x3 convolutions as implicit GEMMs over fp16 pairs
 #include "gemm_f16.h"   // the split-precision tower (below) runs its layer1-4 convolutions on the fp16 matrix cores
 
 int mpreid_gemm_f32_linear(const float *A, const float *Wt, int64_t M, int64_t N, int K, const float *bias, float *C,
@@ -56,12 +57,17 @@ __global__ __launch_bounds__(256) void stem1_px_kernel(const float *__restrict__
     for (int t = threadIdx.x; t < COUT; t += 256) ws[27 * COUT + t] = bias[t];
     __syncthreads();
     const int OH = H / 2, OW = W / 2;
-    const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (pix >= (int64_t)B * OH * OW) return;
+    const int64_t npix = (int64_t)B * OH * OW;
+    const int64_t pix_raw = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t pix = pix_raw < npix ? pix_raw : npix - 1;   // (the lanes past the end compute the last pixel again and store nothing)
     const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), b = (int)(pix / ((int64_t)OW * OH));
     float acc[COUT];
 #pragma unroll
     for (int n = 0; n < COUT; ++n) acc[n] = 0.0f;
+    // the 27 inputs first (27 loads in flight), then tap by tap: COUT weights from LDS (broadcast reads), COUT FMAs.  The
+    // scheduling barrier per tap keeps the compiler from hoisting all 27 x COUT weight reads to the top: it did, and the
+    // kernel ran with 384 spilled registers at one wave per SIMD (1.5 ms at B = 256).
+    float xin[27];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -69,12 +75,23 @@ __global__ __launch_bounds__(256) void stem1_px_kernel(const float *__restrict__
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const int iy = oy * 2 + kh - 1, ix = ox * 2 + kw - 1;
-                const float x = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? img[(((int64_t)b * 3 + c) * H + iy) * W + ix] : 0.0f;
-                const float *wr = ws + (c * 9 + kh * 3 + kw) * COUT;
-#pragma unroll
-                for (int n = 0; n < COUT; ++n) acc[n] = fmaf(x, wr[n], acc[n]);
+                xin[c * 9 + kh * 3 + kw] =
+                    (iy >= 0 && iy < H && ix >= 0 && ix < W) ? img[(((int64_t)b * 3 + c) * H + iy) * W + ix] : 0.0f;
             }
-    float *o = out + pix * COUT;
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {   // t = c * 9 + kh * 3 + kw: the accumulation order of the reference chain
+        const float *wr = ws + t * COUT;
+#pragma unroll
+        for (int n = 0; n < COUT; ++n) acc[n] = fmaf(xin[t], wr[n], acc[n]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // The pixel's COUT results go through a wave-private LDS patch so that a store instruction covers 1 KB of consecutive
+    // bytes (lane = 16-byte piece of the wave's 64 x COUT block): written straight from the registers every instruction
+    // touched 64 different lines, 16 bytes each, and the kernel ran at 180 GB/s of output (1.46 ms at B = 256).
+    constexpr int PS = COUT + 4;   // patch row stride in floats (16-byte aligned rows, spread over the banks)
+    __shared__ __attribute__((aligned(16))) float patch[4][64 * PS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *pw = patch[wave];
 #pragma unroll
     for (int n = 0; n < COUT; n += 4) {
         float4 v;
@@ -86,7 +103,19 @@ __global__ __launch_bounds__(256) void stem1_px_kernel(const float *__restrict__
         v.y = v.y < 0.0f ? 0.0f : v.y;
         v.z = v.z < 0.0f ? 0.0f : v.z;
         v.w = v.w < 0.0f ? 0.0f : v.w;
-        *reinterpret_cast<float4 *>(o + n) = v;
+        *reinterpret_cast<float4 *>(pw + lane * PS + n) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    constexpr int CPP = COUT / 4;                               // 16-byte pieces per pixel
+    const int64_t pix0 = (int64_t)blockIdx.x * 256 + wave * 64;   // first pixel of the wave
+#pragma unroll
+    for (int it = 0; it < CPP; ++it) {
+        const int idx = it * 64 + lane;
+        const int p = idx / CPP, ch = idx - p * CPP;
+        if (pix0 + p < npix)
+            *reinterpret_cast<float4 *>(out + (pix0 + p) * COUT + ch * 4) = *reinterpret_cast<const float4 *>(pw + p * PS + ch * 4);
     }
 }
 
@@ -371,7 +400,10 @@ extern "C" int mpreid_rn50_forward_f32(const mpreid_rn50_cfg *cfg, const mpreid_
 // (gemm_f16.hip GE_S_BIAS_F32 / GE_S_BIAS_RES: the kernels the ViT's split mode uses, unchanged):
 //   1x1 convolution   pack_pairs_kernel: fp32 [M][C] -> pairs [Mp][hi(kseg) | lo(kseg)] (ReLU of the producer applied on the
 //                     way), then out fp32 = acc * 2^-e + bias'                      (BatchNorm folded into W 2^e and bias')
-//   3x3 convolution   im2col3x3_pairs_kernel: the same with the nine taps gathered (k order (kh, kw, c), zero padding)
+//   3x3 convolution   the same pack (channels padded to 64), then an IMPLICIT GEMM over the nine shifted views of the pair
+//                     tensor (conv_f16.hip, pair form: per (tap, 64 channels) the three products; padding pixels read a page
+//                     of zeros) -- the materialised im2col pair matrix of the first version cost 9x the activation bytes,
+//                     written and read: 21 % of the forward
 //   conv3 + identity  GE_S_BIAS_RES: the identity (block input, or the downsample branch's output) sits in the destination,
 //                     dst += acc * 2^-e + bias'; the block's closing ReLU is applied by whoever reads dst next (and written
 //                     back by the next block's first pack, because dst is that block's identity)
@@ -412,51 +444,6 @@ __global__ __launch_bounds__(256) void pack_pairs_kernel(float *__restrict__ in,
     _Float16 *o = out + r * 2 * kseg + k4 * 4;
     *reinterpret_cast<h4 *>(o) = hi;
     *reinterpret_cast<h4 *>(o + kseg) = lo;
-}
-
-// fp32 NHWC [B][H][W][ld_in] (C real channels), ReLU on read -> pairs [rows_pad][2 * kseg], k = (kh * 3 + kw) * C + c.
-// One workgroup per 4 output rows (pixels): the row's kseg / 8 chunks of 8 channels are walked by 64 lanes -- 32-byte reads,
-// two 16-byte writes per chunk, one division per chunk instead of five per 4 channels.  C % 8 == 0 (else CH4: 4 channels).
-template <int CH>
-__global__ __launch_bounds__(256) void im2col3x3_pairs_kernel(const float *__restrict__ in, int B, int H, int W, int C, int ld_in,
-                                                              int64_t rows_pad, int kseg, _Float16 *__restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int64_t pix = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (pix >= rows_pad) return;
-    const bool live = pix < (int64_t)B * H * W;
-    const int x = (int)(pix % W), y = (int)((pix / W) % H);
-    const int64_t b = pix / ((int64_t)W * H);
-    const float *img = in + b * H * W * ld_in;
-    _Float16 *orow = out + pix * 2 * kseg;
-    typedef _Float16 hv __attribute__((ext_vector_type(CH)));
-    for (int k = lane * CH; k < kseg; k += 64 * CH) {
-        float v[CH];
-#pragma unroll
-        for (int e = 0; e < CH; ++e) v[e] = 0.f;
-        if (live && k < 9 * C) {
-            const int tap = k / C, c = k - tap * C;   // C % CH == 0: the channels of a chunk share a tap
-            const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-                const float *p = img + ((int64_t)iy * W + ix) * ld_in + c;
-#pragma unroll
-                for (int q = 0; q < CH / 4; ++q) {
-                    const float4 t = *reinterpret_cast<const float4 *>(p + q * 4);
-                    v[q * 4 + 0] = t.x < 0.f ? 0.f : t.x;
-                    v[q * 4 + 1] = t.y < 0.f ? 0.f : t.y;
-                    v[q * 4 + 2] = t.z < 0.f ? 0.f : t.z;
-                    v[q * 4 + 3] = t.w < 0.f ? 0.f : t.w;
-                }
-            }
-        }
-        hv hi, lo;
-#pragma unroll
-        for (int e = 0; e < CH; ++e) {
-            hi[e] = (_Float16)v[e];
-            lo[e] = (_Float16)(v[e] - (float)hi[e]);
-        }
-        *reinterpret_cast<hv *>(orow + k) = hi;
-        *reinterpret_cast<hv *>(orow + kseg + k) = lo;
-    }
 }
 
 // AvgPool2d(2) on NHWC fp32 with channel strides (ld_in -> ld_out), optional ReLU on read
@@ -511,11 +498,12 @@ LayoutSplit layout_split(const mpreid_rn50_cfg *cfg, int B) {
     v.act_elems = (size_t)a;
     // pair matrix: the largest A operand.  A block's conv1 / conv2 run at the block's INPUT resolution (the stride is an
     // average pool behind conv2): H/4: 1x1 over <= 4 width, 3x3 over <= 2 width; H/8: 8 width / 4 width; H/16: 32 width / 8 width
+    // (a 3x3 convolution's A operand is the plain pair tensor too: the nine taps are shifted views of it)
     auto kseg = [](int64_t k) { return (int64_t)align_up((size_t)k, 64); };
-    int64_t pe = pad_rows((int64_t)B * px4) * 2 * std::max(kseg(9 * wd * 2), kseg(wd * 4));
-    pe = std::max<int64_t>(pe, pad_rows((int64_t)B * px2) * 2 * kseg(9 * (wd / 2)));   // the stem's conv2 / conv3
-    pe = std::max<int64_t>(pe, pad_rows((int64_t)B * px4 / 4) * 2 * std::max(kseg(9 * wd * 4), kseg(wd * 8)));
-    pe = std::max<int64_t>(pe, pad_rows((int64_t)B * S) * 2 * std::max(kseg(9 * wd * 8), kseg(wd * 32)));
+    int64_t pe = pad_rows((int64_t)B * px4) * 2 * std::max(kseg(wd * 2), kseg(wd * 4));
+    pe = std::max<int64_t>(pe, pad_rows((int64_t)B * px2) * 2 * kseg(wd));             // the stem's conv2 / conv3
+    pe = std::max<int64_t>(pe, pad_rows((int64_t)B * px4 / 4) * 2 * std::max(kseg(wd * 4), kseg(wd * 8)));
+    pe = std::max<int64_t>(pe, pad_rows((int64_t)B * S) * 2 * std::max(kseg(wd * 8), kseg(wd * 32)));
     pe = std::max<int64_t>(pe, pad_rows((int64_t)B * T) * 2 * kseg(E));
     size_t off = 0;
     auto take = [&](size_t bytes) {
@@ -543,18 +531,37 @@ struct ActView { float *p; int C, ld; bool dirty; };   // fp32 NHWC tensor: C re
 
 // one folded convolution of the split tower: pairs of `in` (ReLU applied on read when in.dirty) -> GEMM; res != 0: out += (GE_S_BIAS_RES)
 int conv_split(const mpreid_rn50_conv_split &c, ActView &in, int B, int H, int W, int res, float *out, _Float16 *pairs,
-               hipStream_t stream, bool writeback) {
+               hipStream_t stream, bool writeback, const _Float16 *zero_page = nullptr) {
     const int64_t M = (int64_t)B * H * W, Mp = pad_rows(M);
-    ARG_CHECK(c.w && c.bias && c.cin == in.C && c.cin % 4 == 0 && c.kseg % 64 == 0 && c.kseg >= c.taps * c.cin &&
-              c.npad % 128 == 0 && c.npad >= c.cout && (c.taps == 1 || c.taps == 9));
+    // kseg: 1x1 -- the padded K of the pair matrix; 3x3 -- the padded channel count of ONE tap (the weights are laid out
+    // for the implicit GEMM, include/mpreid.h)
+    ARG_CHECK(c.w && c.bias && c.cin == in.C && c.cin % 4 == 0 && c.kseg % 64 == 0 && c.kseg >= c.cin &&
+              (c.taps == 9 || c.kseg >= c.taps * c.cin) && c.npad % 128 == 0 && c.npad >= c.cout && (c.taps == 1 || c.taps == 9));
     const int64_t threads = Mp * (c.kseg / 4);
     const dim3 grid((unsigned)((threads + 255) / 256));
     if (c.taps == 9) {
-        const dim3 g9((unsigned)((Mp + 3) / 4));
-        if (in.C % 8 == 0 && c.kseg % 8 == 0)
-            hipLaunchKernelGGL(im2col3x3_pairs_kernel<8>, g9, dim3(256), 0, stream, in.p, B, H, W, in.C, in.ld, Mp, c.kseg, pairs);
+        // 3x3: the input as pairs [pixel][hi(C) | lo(C)] (ReLU applied on the way), then the implicit GEMM over the nine shifted
+        // views of it (conv_f16.hip, pair form) -- no im2col matrix (it cost 9x the activation bytes, written and read)
+        ARG_CHECK(res == 0 && zero_page != nullptr);
+        if (in.dirty)
+            hipLaunchKernelGGL((pack_pairs_kernel<true, false>), grid, dim3(256), 0, stream, in.p, M, Mp, in.C, in.ld, c.kseg, pairs);
         else
-            hipLaunchKernelGGL(im2col3x3_pairs_kernel<4>, g9, dim3(256), 0, stream, in.p, B, H, W, in.C, in.ld, Mp, c.kseg, pairs);
+            hipLaunchKernelGGL((pack_pairs_kernel<false, false>), grid, dim3(256), 0, stream, in.p, M, Mp, in.C, in.ld, c.kseg, pairs);
+        LAUNCH_CHECK();
+        ConvArgs a{};
+        a.act = pairs;
+        a.wgt = (const _Float16 *)c.w;
+        a.bias = c.bias;
+        a.zero_page = zero_page;
+        a.H = H; a.W = W; a.C = c.kseg;
+        a.M = (int)M;
+        a.N = c.cout; a.Npad = c.npad;
+        a.ldo = c.npad;
+        a.taps = 9;
+        a.split = 1;
+        a.oscale = c.oscale;
+        a.out32 = out;
+        return launch_conv_f16(a, stream);
     } else if (in.dirty && writeback) {
         hipLaunchKernelGGL((pack_pairs_kernel<true, true>), grid, dim3(256), 0, stream, in.p, M, Mp, in.C, in.ld, c.kseg, pairs);
         in.dirty = false;
@@ -600,7 +607,8 @@ extern "C" int mpreid_rn50_forward_split(const mpreid_rn50_cfg *cfg, const mprei
     char *base = (char *)ws;
     float *buf[5];
     for (int i = 0; i < 5; ++i) buf[i] = (float *)(base + v.f.act[i]);
-    float *col = (float *)(base + v.f.col);
+    const _Float16 *zero_page = (const _Float16 *)(base + v.f.col);   // 256 bytes of zeros: the padding pixels of the 3x3 convolutions
+    HIP_TRY(hipMemsetAsync(base + v.f.col, 0, 256, (hipStream_t)stream_));
     _Float16 *pairs = (_Float16 *)(base + v.pairs);
     const mpreid_rn50_weights_f32 &wf = w->f32;
 
@@ -613,15 +621,14 @@ extern "C" int mpreid_rn50_forward_split(const mpreid_rn50_cfg *cfg, const mprei
     ARG_CHECK(w->stem2.taps == 9 && w->stem3.taps == 9);
     {
         ActView s1{buf[0], cfg->width / 2, cfg->width / 2, true};   // (stem1 applied its ReLU already: max(x, 0) again is the identity)
-        if ((rc = conv_split(w->stem2, s1, B, H, W, 0, buf[1], pairs, stream, false))) return rc;
+        if ((rc = conv_split(w->stem2, s1, B, H, W, 0, buf[1], pairs, stream, false, zero_page))) return rc;
         ActView s2{buf[1], w->stem2.cout, w->stem2.npad, true};
-        if ((rc = conv_split(w->stem3, s2, B, H, W, 0, buf[2], pairs, stream, false))) return rc;
+        if ((rc = conv_split(w->stem3, s2, B, H, W, 0, buf[2], pairs, stream, false, zero_page))) return rc;
         const int64_t threads = (int64_t)B * (H / 2) * (W / 2) * w->stem3.cout;
         hipLaunchKernelGGL((avgpool2_ld_kernel<true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, buf[2], B, H, W,
                            w->stem3.cout, w->stem3.npad, w->stem3.cout, buf[1]);
         LAUNCH_CHECK();
     }
-    (void)col;
     H /= 2;
     W /= 2;
     int xi = 1;
@@ -639,7 +646,7 @@ extern "C" int mpreid_rn50_forward_split(const mpreid_rn50_cfg *cfg, const mprei
         // conv1 reads x (ReLU of the previous block's sum applied on the way AND written back: x is an identity below)
         if ((rc = conv_split(blk.conv1, x, B, H, W, 0, t1, pairs, stream, true))) return rc;
         ActView a1{t1, blk.conv1.cout, blk.conv1.npad, true};
-        if ((rc = conv_split(blk.conv2, a1, B, H, W, 0, t2, pairs, stream, false))) return rc;
+        if ((rc = conv_split(blk.conv2, a1, B, H, W, 0, t2, pairs, stream, false, zero_page))) return rc;
         ActView a2{t2, blk.conv2.cout, blk.conv2.npad, true};
         int OH = H, OW = W;
         if (blk.stride == 2) {

@@ -701,9 +701,31 @@ class Rn50Encoder:
             self._keep.append(pair)
             return _lib.Rn50ConvSplit(_ptr(pair), _ptr(dev32(bp)), cin, cout, taps, kseg, npad, float(2.0 ** -e))
 
+        def pairs_of_3x3(w, bias):
+            """folded [cout][cin][3][3] -> Rn50ConvSplit for the implicit GEMM (csrc/conv_f16.hip, pair form): fp16 slabs
+            [cout_pad128][tap][cin_pad64 / 64][hi(64) | hi(64) | lo(64)] of W * 2^e -- one 64-half slab per k step, in the
+            order of the three products hi.hi', lo.hi', hi.lo'; kseg = cin_pad64"""
+            cout, cin = w.shape[:2]
+            cp, npad = _pad_to(cin, 64), _pad_to(cout, 128)
+            wp = np.zeros((npad, 9, cp), np.float32)
+            wp[:cout, :, :cin] = w.transpose(0, 2, 3, 1).reshape(cout, 9, cin).astype(np.float32)
+            bp = np.zeros(npad, np.float32)
+            bp[:cout] = bias
+            amax = float(np.abs(wp).max())
+            e = 9 - int(np.floor(np.log2(amax))) if amax > 0 and np.isfinite(amax) else 0
+            wt = torch.from_numpy(wp).to(dev) * float(2.0 ** e)          # exact: a power of two
+            hi = wt.half()
+            lo = (wt - hi.float()).half()
+            hi, lo = hi.view(npad, 9, cp // 64, 1, 64), lo.view(npad, 9, cp // 64, 1, 64)
+            slab = torch.cat([hi, hi, lo], dim=3).reshape(npad, 9 * (cp // 64) * 3 * 64).contiguous()
+            self._keep.append(slab)
+            return _lib.Rn50ConvSplit(_ptr(slab), _ptr(dev32(bp)), cin, cout, 9, cp, npad, float(2.0 ** -e))
+
         def conv_s(cname, bname):
             w, b = fold(cname, bname)
             cout, cin, kh, kw = w.shape
+            if kh * kw == 9:
+                return pairs_of_3x3(w, b)
             return pairs_of(w.transpose(0, 2, 3, 1).reshape(cout, kh * kw * cin), b, cin, kh * kw)
 
         s1w, s1b = fold("conv1", "bn1")
