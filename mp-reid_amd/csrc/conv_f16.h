@@ -22,6 +22,8 @@ struct ConvArgs {
     int split;
     float oscale;
     float *out32;
+    _Float16 *out_pairs;       // SPLIT, optional (then out32 is not written): relu(acc * oscale + bias) as fp16 pairs
+    int pair_c;                // [M][hi(pair_c) | lo(pair_c)] -- the A operand of the next layer's pair GEMM; pair_c % 64 == 0, >= N
 };
 
 int launch_conv_f16(const ConvArgs &a, hipStream_t stream);

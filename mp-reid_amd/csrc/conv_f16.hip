@@ -179,7 +179,21 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs g, int tiles
             const float4 v1 = *reinterpret_cast<const float4 *>(wreg + lr * 68 + ch * 8 + 4);
             float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
             if constexpr (SPLIT) {
-                if (m < g.M && n < g.Npad) {
+                if (g.out_pairs) {   // the consumer is a pair GEMM: its operand directly (ReLU applied), no fp32 round trip
+                    if (m < g.M && n < g.pair_c) {
+                        f16x8 hi, lo;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            float y = fmaf(v[e], g.oscale, bias[e]);
+                            y = (n + e < g.N && y > 0.f) ? y : 0.f;
+                            hi[e] = (_Float16)y;
+                            lo[e] = (_Float16)(y - (float)hi[e]);
+                        }
+                        _Float16 *o = g.out_pairs + (int64_t)m * 2 * g.pair_c + n;
+                        *reinterpret_cast<f16x8 *>(o) = hi;
+                        *reinterpret_cast<f16x8 *>(o + g.pair_c) = lo;
+                    }
+                } else if (m < g.M && n < g.Npad) {
                     float *o = g.out32 + (int64_t)m * g.ldo + n;
                     *reinterpret_cast<float4 *>(o) = make_float4(fmaf(v[0], g.oscale, bias[0]), fmaf(v[1], g.oscale, bias[1]),
                                                                  fmaf(v[2], g.oscale, bias[2]), fmaf(v[3], g.oscale, bias[3]));
@@ -226,7 +240,8 @@ static int launch_conv_variant(const ConvArgs &a, hipStream_t stream) {
 
 int launch_conv_f16(const ConvArgs &a, hipStream_t stream) {
     if (a.split) {   // the pair form: 3x3 only, fp32 out
-        ARG_CHECK(a.act && a.wgt && a.bias && a.out32 && a.zero_page && a.taps == 9 && a.C > 0 && a.C % CBK == 0 && a.M > 0);
+        ARG_CHECK(a.act && a.wgt && a.bias && (a.out32 || a.out_pairs) && a.zero_page && a.taps == 9 && a.C > 0 && a.C % CBK == 0 && a.M > 0);
+        ARG_CHECK(!a.out_pairs || (a.pair_c % 64 == 0 && a.pair_c >= a.N));
         ARG_CHECK(a.Npad % 128 == 0 && a.N > 0 && a.Npad >= a.N && a.ldo % 4 == 0 && a.ldo >= a.Npad && a.H > 0 && a.W > 0 &&
                   a.M % (a.H * a.W) == 0);
         return a.N <= 64 ? launch_conv_variant<9, false, 64, true>(a, stream) : launch_conv_variant<9, false, 128, true>(a, stream);

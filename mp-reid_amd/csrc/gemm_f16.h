@@ -78,6 +78,8 @@ struct GemmArgs {
                           // real-time counter late, so that the CUs reach their store-heavy epilogues at different
                           // times instead of all at once (0 = off)
     int stagger_mode;     // 1: eight phases by the CU's slot inside its XCD instead ((b >> 3) mod 8) / 8
+    int relu_x;           // GE_S_BIAS_RES only: the destination holds a PRE-activation (a ResNet block input whose ReLU is pending):
+                          // x = max(x, 0) + acc * oscale + bias -- saves the producer-side pass that would write the ReLU back
     unsigned long long *stamps;   // ablation builds (DBG bit 32): [workgroup][32 tiles][8] real-time stamps, else null
 };
 

@@ -337,7 +337,13 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
                 o[2] = fmaf(a.z, g.oscale, bias4.z);
                 o[3] = fmaf(a.w, g.oscale, bias4.w);
                 if (EPI == GE_S_BIAS_RES) {
-                    const float4 x = *reinterpret_cast<const float4 *>(dst);
+                    float4 x = *reinterpret_cast<const float4 *>(dst);
+                    if (g.relu_x) {   // the destination holds a pre-activation: its ReLU is applied here (see gemm_f16.h)
+                        x.x = x.x < 0.f ? 0.f : x.x;
+                        x.y = x.y < 0.f ? 0.f : x.y;
+                        x.z = x.z < 0.f ? 0.f : x.z;
+                        x.w = x.w < 0.f ? 0.f : x.w;
+                    }
                     o[0] = x.x + o[0];
                     o[1] = x.y + o[1];
                     o[2] = x.z + o[2];
@@ -1294,6 +1300,10 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
             for (int it = 0; it < 4; ++it) {
                 f32x4_t o;
                 if constexpr (EPI == GE_S_BIAS_RES) {
+                    if (g.relu_x) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) x[it][e] = x[it][e] < 0.f ? 0.f : x[it][e];
+                    }
                     o[0] = x[it][0] + fmaf(a[it][0], g.oscale, bias4.x);
                     o[1] = x[it][1] + fmaf(a[it][1], g.oscale, bias4.y);
                     o[2] = x[it][2] + fmaf(a[it][2], g.oscale, bias4.z);
@@ -1479,6 +1489,12 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
                                                   fmaf(a.z, g.oscale, bias4.z), fmaf(a.w, g.oscale, bias4.w)));
                     } else if (EPI == GE_S_BIAS_RES) {
                         float4 x = *reinterpret_cast<const float4 *>(dst);
+                        if (g.relu_x) {
+                            x.x = x.x < 0.f ? 0.f : x.x;
+                            x.y = x.y < 0.f ? 0.f : x.y;
+                            x.z = x.z < 0.f ? 0.f : x.z;
+                            x.w = x.w < 0.f ? 0.f : x.w;
+                        }
                         x.x = x.x + fmaf(a.x, g.oscale, bias4.x);
                         x.y = x.y + fmaf(a.y, g.oscale, bias4.y);
                         x.z = x.z + fmaf(a.z, g.oscale, bias4.z);
@@ -1534,7 +1550,8 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
                     } else if (EPI == GE_S_BIAS_F32) {
                         *dst = fmaf(a, g.oscale, bias1);
                     } else if (EPI == GE_S_BIAS_RES) {
-                        *dst = *dst + fmaf(a, g.oscale, bias1);
+                        const float xv = *dst;
+                        *dst = ((g.relu_x && xv < 0.f) ? 0.f : xv) + fmaf(a, g.oscale, bias1);
                     } else if (EPI == GE_PATCH || EPI == GE_S_PATCH) {
                         if (m < g.m_valid) {
                             const int b = m / g.P, pp = m - b * g.P;

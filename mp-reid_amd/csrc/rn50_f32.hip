@@ -414,10 +414,10 @@ extern "C" int mpreid_rn50_forward_f32(const mpreid_rn50_cfg *cfg, const mpreid_
 namespace {
 
 // fp32 [rows][ld_in] (first C channels real) -> fp16 pairs [rows_pad][2 * kseg]: hi at k, lo at kseg + k, zeros for k >= C
-// and for rows >= rows.  RELU: max(x, 0) first; WB: the ReLU-ed value is also written back in place (the tensor is the
-// next block's identity).  One thread per 4 channels of kseg.
-template <bool RELU, bool WB>
-__global__ __launch_bounds__(256) void pack_pairs_kernel(float *__restrict__ in, int64_t rows, int64_t rows_pad, int C, int ld_in,
+// and for rows >= rows.  RELU: max(x, 0) first (the tensor itself keeps its pre-activation values: every reader applies the
+// ReLU on the way).  One thread per 4 channels of kseg.
+template <bool RELU>
+__global__ __launch_bounds__(256) void pack_pairs_kernel(const float *__restrict__ in, int64_t rows, int64_t rows_pad, int C, int ld_in,
                                                          int kseg, _Float16 *__restrict__ out) {
     const int k4n = kseg / 4;
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -431,7 +431,6 @@ __global__ __launch_bounds__(256) void pack_pairs_kernel(float *__restrict__ in,
         if (RELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] < 0.f ? 0.f : v[e];
-            if (WB) *reinterpret_cast<float4 *>(in + r * ld_in + k4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -474,7 +473,8 @@ __global__ __launch_bounds__(256) void relu_inplace_kernel(float *__restrict__ x
 
 struct LayoutSplit {
     LayoutF32 f;           // the fp32 part: five activation buffers (sized for padded channel strides), stem im2col, pool buffers
-    size_t pairs, total;   // one pair matrix (the GEMM A operand of the layer in flight)
+    size_t pairs, pairs2, total;   // pair matrices: the GEMM A operand of the layer in flight; the operand a 3x3 convolution
+                                   // writes for the 1x1 behind it
     size_t act_elems;
 };
 
@@ -523,6 +523,7 @@ LayoutSplit layout_split(const mpreid_rn50_cfg *cfg, int B) {
     v.f.att = take((size_t)B * E * 4);
     v.f.proj = take((size_t)B * cfg->out_dim * 4);
     v.pairs = take((size_t)pe * 2);
+    v.pairs2 = take((size_t)pe * 2);
     v.total = off;
     return v;
 }
@@ -530,8 +531,11 @@ LayoutSplit layout_split(const mpreid_rn50_cfg *cfg, int B) {
 struct ActView { float *p; int C, ld; bool dirty; };   // fp32 NHWC tensor: C real channels, row stride ld, ReLU pending?
 
 // one folded convolution of the split tower: pairs of `in` (ReLU applied on read when in.dirty) -> GEMM; res != 0: out += (GE_S_BIAS_RES)
+// pair_out (3x3 only): the result leaves as the ReLU-ed pair operand of the NEXT pair GEMM ([Mp][2 * pair_c]) instead of fp32;
+// prepacked (1x1 only): `in` has been delivered that way already -- no pack pass
 int conv_split(const mpreid_rn50_conv_split &c, ActView &in, int B, int H, int W, int res, float *out, _Float16 *pairs,
-               hipStream_t stream, bool writeback, const _Float16 *zero_page = nullptr) {
+               hipStream_t stream, const _Float16 *zero_page = nullptr, _Float16 *pair_out = nullptr,
+               int pair_c = 0, const _Float16 *prepacked = nullptr) {
     const int64_t M = (int64_t)B * H * W, Mp = pad_rows(M);
     // kseg: 1x1 -- the padded K of the pair matrix; 3x3 -- the padded channel count of ONE tap (the weights are laid out
     // for the implicit GEMM, include/mpreid.h)
@@ -544,9 +548,9 @@ int conv_split(const mpreid_rn50_conv_split &c, ActView &in, int B, int H, int W
         // views of it (conv_f16.hip, pair form) -- no im2col matrix (it cost 9x the activation bytes, written and read)
         ARG_CHECK(res == 0 && zero_page != nullptr);
         if (in.dirty)
-            hipLaunchKernelGGL((pack_pairs_kernel<true, false>), grid, dim3(256), 0, stream, in.p, M, Mp, in.C, in.ld, c.kseg, pairs);
+            hipLaunchKernelGGL((pack_pairs_kernel<true>), grid, dim3(256), 0, stream, in.p, M, Mp, in.C, in.ld, c.kseg, pairs);
         else
-            hipLaunchKernelGGL((pack_pairs_kernel<false, false>), grid, dim3(256), 0, stream, in.p, M, Mp, in.C, in.ld, c.kseg, pairs);
+            hipLaunchKernelGGL((pack_pairs_kernel<false>), grid, dim3(256), 0, stream, in.p, M, Mp, in.C, in.ld, c.kseg, pairs);
         LAUNCH_CHECK();
         ConvArgs a{};
         a.act = pairs;
@@ -561,14 +565,15 @@ int conv_split(const mpreid_rn50_conv_split &c, ActView &in, int B, int H, int W
         a.split = 1;
         a.oscale = c.oscale;
         a.out32 = out;
+        a.out_pairs = pair_out;
+        a.pair_c = pair_c;
         return launch_conv_f16(a, stream);
-    } else if (in.dirty && writeback) {
-        hipLaunchKernelGGL((pack_pairs_kernel<true, true>), grid, dim3(256), 0, stream, in.p, M, Mp, in.C, in.ld, c.kseg, pairs);
-        in.dirty = false;
+    } else if (prepacked) {
+        pairs = const_cast<_Float16 *>(prepacked);
     } else if (in.dirty) {
-        hipLaunchKernelGGL((pack_pairs_kernel<true, false>), grid, dim3(256), 0, stream, in.p, M, Mp, in.C, in.ld, c.kseg, pairs);
+        hipLaunchKernelGGL((pack_pairs_kernel<true>), grid, dim3(256), 0, stream, in.p, M, Mp, in.C, in.ld, c.kseg, pairs);
     } else {
-        hipLaunchKernelGGL((pack_pairs_kernel<false, false>), grid, dim3(256), 0, stream, in.p, M, Mp, in.C, in.ld, c.kseg, pairs);
+        hipLaunchKernelGGL((pack_pairs_kernel<false>), grid, dim3(256), 0, stream, in.p, M, Mp, in.C, in.ld, c.kseg, pairs);
     }
     LAUNCH_CHECK();
     GemmArgs g{};
@@ -582,6 +587,7 @@ int conv_split(const mpreid_rn50_conv_split &c, ActView &in, int B, int H, int W
     g.out = out;
     g.ldo = c.npad;
     g.bias = c.bias;
+    g.relu_x = res == 2;   // the destination is a block input whose ReLU is still pending (it was never written back)
     return launch_gemm_f16(g, res ? GE_S_BIAS_RES : GE_S_BIAS_F32, stream);
 }
 
@@ -609,7 +615,7 @@ extern "C" int mpreid_rn50_forward_split(const mpreid_rn50_cfg *cfg, const mprei
     for (int i = 0; i < 5; ++i) buf[i] = (float *)(base + v.f.act[i]);
     const _Float16 *zero_page = (const _Float16 *)(base + v.f.col);   // 256 bytes of zeros: the padding pixels of the 3x3 convolutions
     HIP_TRY(hipMemsetAsync(base + v.f.col, 0, 256, (hipStream_t)stream_));
-    _Float16 *pairs = (_Float16 *)(base + v.pairs);
+    _Float16 *pairs = (_Float16 *)(base + v.pairs), *pairs2 = (_Float16 *)(base + v.pairs2);
     const mpreid_rn50_weights_f32 &wf = w->f32;
 
     // ---- stem on the exact fp32 path (ReLU applied by its GEMM epilogues) ----
@@ -621,9 +627,9 @@ extern "C" int mpreid_rn50_forward_split(const mpreid_rn50_cfg *cfg, const mprei
     ARG_CHECK(w->stem2.taps == 9 && w->stem3.taps == 9);
     {
         ActView s1{buf[0], cfg->width / 2, cfg->width / 2, true};   // (stem1 applied its ReLU already: max(x, 0) again is the identity)
-        if ((rc = conv_split(w->stem2, s1, B, H, W, 0, buf[1], pairs, stream, false, zero_page))) return rc;
+        if ((rc = conv_split(w->stem2, s1, B, H, W, 0, buf[1], pairs, stream, zero_page))) return rc;
         ActView s2{buf[1], w->stem2.cout, w->stem2.npad, true};
-        if ((rc = conv_split(w->stem3, s2, B, H, W, 0, buf[2], pairs, stream, false, zero_page))) return rc;
+        if ((rc = conv_split(w->stem3, s2, B, H, W, 0, buf[2], pairs, stream, zero_page))) return rc;
         const int64_t threads = (int64_t)B * (H / 2) * (W / 2) * w->stem3.cout;
         hipLaunchKernelGGL((avgpool2_ld_kernel<true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, buf[2], B, H, W,
                            w->stem3.cout, w->stem3.npad, w->stem3.cout, buf[1]);
@@ -643,10 +649,18 @@ extern "C" int mpreid_rn50_forward_split(const mpreid_rn50_cfg *cfg, const mprei
         for (int i = 0; i < 5; ++i)
             if (i != xi) free_i[nf++] = i;
         float *t1 = buf[free_i[0]], *t2 = buf[free_i[1]], *t3 = buf[free_i[2]], *t4 = buf[free_i[3]];
-        // conv1 reads x (ReLU of the previous block's sum applied on the way AND written back: x is an identity below)
-        if ((rc = conv_split(blk.conv1, x, B, H, W, 0, t1, pairs, stream, true))) return rc;
+        // conv1 reads x with the ReLU of the previous block's sum applied on the way.  The ReLU is NOT written back (that made the
+        // pack a three-pass kernel): whoever reads x as the identity below applies it again -- the downsample branch's pack or
+        // average pool on read, conv3's residual epilogue through GemmArgs::relu_x
+        if ((rc = conv_split(blk.conv1, x, B, H, W, 0, t1, pairs, stream))) return rc;
         ActView a1{t1, blk.conv1.cout, blk.conv1.npad, true};
-        if ((rc = conv_split(blk.conv2, a1, B, H, W, 0, t2, pairs, stream, false, zero_page))) return rc;
+        // conv2 -> ReLU -> conv3 without an average pool in between (13 of the 16 blocks): conv2 writes conv3's pair operand
+        // itself (rows of the pair matrix are padded to 256: only when the pixel count is such a multiple)
+        const bool fuse23 = blk.stride == 1 && ((int64_t)B * H * W) % 256 == 0 && blk.conv3.kseg >= blk.conv2.cout &&
+                            blk.conv3.cin == blk.conv2.cout;
+        if ((rc = conv_split(blk.conv2, a1, B, H, W, 0, t2, pairs, stream, zero_page, fuse23 ? pairs2 : nullptr,
+                             blk.conv3.kseg)))
+            return rc;
         ActView a2{t2, blk.conv2.cout, blk.conv2.npad, true};
         int OH = H, OW = W;
         if (blk.stride == 2) {
@@ -660,23 +674,29 @@ extern "C" int mpreid_rn50_forward_split(const mpreid_rn50_cfg *cfg, const mprei
         }
         float *dst;
         if (blk.down.w) {
-            ActView xin = x;   // (clean: conv1's pack wrote the ReLU back)
+            ActView xin = x;   // (x.dirty: its ReLU is applied by whoever reads it)
             if (blk.stride == 2) {
                 const int64_t threads = (int64_t)B * OH * OW * x.C;
-                hipLaunchKernelGGL((avgpool2_ld_kernel<false>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, x.p, B, H,
-                                   W, x.C, x.ld, x.C, t3);
+                if (x.dirty)
+                    hipLaunchKernelGGL((avgpool2_ld_kernel<true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, x.p, B, H,
+                                       W, x.C, x.ld, x.C, t3);
+                else
+                    hipLaunchKernelGGL((avgpool2_ld_kernel<false>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, x.p, B, H,
+                                       W, x.C, x.ld, x.C, t3);
                 LAUNCH_CHECK();
                 xin = ActView{t3, x.C, x.C, false};
             }
             // conv3's operand must be packed AFTER the downsample GEMM has consumed the pair buffer: order matters (one buffer)
-            if ((rc = conv_split(blk.down, xin, B, OH, OW, 0, t4, pairs, stream, false))) return rc;
+            if ((rc = conv_split(blk.down, xin, B, OH, OW, 0, t4, pairs, stream))) return rc;
             dst = t4;
             xi = free_i[3];
         } else {
             ARG_CHECK(blk.stride == 1 && blk.conv3.cout == x.C && blk.conv3.npad == x.ld);
-            dst = x.p;      // x itself is the identity (clean) and is not needed afterwards
+            dst = x.p;      // x itself is the identity and is not needed afterwards
         }
-        if ((rc = conv_split(blk.conv3, a2, B, OH, OW, 1, dst, pairs, stream, false))) return rc;
+        const int res_mode = (dst == x.p && x.dirty) ? 2 : 1;
+        if ((rc = conv_split(blk.conv3, a2, B, OH, OW, res_mode, dst, pairs, stream, nullptr, nullptr, 0, fuse23 ? pairs2 : nullptr)))
+            return rc;
         x = ActView{dst, blk.conv3.cout, blk.conv3.npad, true};
         H = OH;
         W = OW;
@@ -700,7 +720,7 @@ extern "C" int mpreid_rn50_forward_split(const mpreid_rn50_cfg *cfg, const mprei
         ActView tk{tok, v.f.E, v.f.E, false};
         ARG_CHECK(w->k.npad == v.f.E && w->v.npad == v.f.E);
         // one pack serves both projections: conv_split packs per call, so pack once by hand and launch the two GEMMs
-        if ((rc = conv_split(w->k, tk, B * v.f.T, 1, 1, 0, k, pairs, stream, false))) return rc;
+        if ((rc = conv_split(w->k, tk, B * v.f.T, 1, 1, 0, k, pairs, stream))) return rc;
         GemmArgs g{};
         g.A = pairs; g.W = (const _Float16 *)w->v.w; g.M = (int)pad_rows((int64_t)B * v.f.T); g.N = w->v.npad; g.K = 2 * w->v.kseg;
         g.kseg = w->v.kseg; g.oscale = w->v.oscale; g.out = vv; g.ldo = w->v.npad; g.bias = w->v.bias;
