@@ -405,8 +405,10 @@ extern "C" int mpreid_rn50_forward_f32(const mpreid_rn50_cfg *cfg, const mpreid_
 //                     of zeros) -- the materialised im2col pair matrix of the first version cost 9x the activation bytes,
 //                     written and read: 21 % of the forward
 //   conv3 + identity  GE_S_BIAS_RES: the identity (block input, or the downsample branch's output) sits in the destination,
-//                     dst += acc * 2^-e + bias'; the block's closing ReLU is applied by whoever reads dst next (and written
-//                     back by the next block's first pack, because dst is that block's identity)
+//                     dst += acc * 2^-e + bias'; the block's closing ReLU is never written: every reader of dst applies it
+//                     (the next block's packs and average pools on read, its conv3 through GemmArgs::relu_x when dst is
+//                     its identity); where no average pool sits between conv2 and conv3, conv2's epilogue writes conv3's
+//                     ReLU-ed pair operand directly
 // The stem's first convolution (K = 27: direct fp32 FMAs), the one-query attention and the 1-row projections q / c stay on
 // the exact fp32 path above.  Channel counts are padded to the GEMM's granularity (kseg to 64, cout to 128: the stem's and
 // layer1's 32 / 64-channel tensors are stored with a row stride of 128).
