@@ -89,15 +89,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs g, int tiles
     auto stage = [&](int s, int kt) {
         unsigned char *abase = smem + s * C_STAGE_BYTES + wave * 4096;
         unsigned char *bbase = smem + s * C_STAGE_BYTES + C_TILE_BYTES + wave * (BROWS * 128);
-        int tap, c0;
-        if constexpr (SPLIT) {   // k step = (tap, 64-channel block, product): 0 hi.hi', 1 lo.hi', 2 hi.lo' (the weight slabs are laid out in this order)
-            const int kb = kt / 3, kind = kt - 3 * kb;
-            tap = (TAPS == 1) ? 0 : kb / cpt;
-            c0 = (kb - tap * cpt) * CBK + (kind == 1 ? C : 0);
-        } else {
-            tap = (TAPS == 1) ? 0 : kt / cpt;
-            c0 = (kt - tap * cpt) * CBK;
-        }
+        const int tap = (TAPS == 1) ? 0 : kt / cpt;
+        const int c0 = (kt - tap * cpt) * CBK;
         const int64_t shift = (TAPS == 1) ? (int64_t)c0 : (int64_t)((tap / 3 - 1) * g.W + (tap % 3 - 1)) * AS + c0;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -140,16 +133,69 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs g, int tiles
     };
 
     const int nkt = K / CBK;
-    stage(0, 0);
-    __syncthreads();
-    int cur = 0;
-    for (int kt = 0; kt < nkt - 1; ++kt) {
-        stage(cur ^ 1, kt + 1);
-        compute(cur);
+    if constexpr (SPLIT) {
+        // Pair form: ONE stage per block (tap, 64 channels) holding all four tiles -- A hi, A lo, W hi', W lo' (64 KB at
+        // BN = 128) -- single-buffered, and the three products hi.hi', lo.hi', hi.lo' run from it (96 matrix instructions per
+        // wave between two barriers; every fragment is read from LDS once).  The double-buffered two-tile steps of the fp16
+        // form staged six tiles per block and paid one DMA round trip (~1.5 us) per 32 matrix instructions (0.3 us): 1.7 us
+        // per step measured, 0.62 PF executed.  Here a workgroup still waits for its stage, but a stage carries three times
+        // the work and the CU's second workgroup computes meanwhile.
+        const int nblk = nkt / 3;
+        unsigned char *a_hi = smem, *a_lo = smem + C_TILE_BYTES, *w_hi = smem + 2 * C_TILE_BYTES, *w_lo = w_hi + BN * 128;
+        for (int kb = 0; kb < nblk; ++kb) {
+            const int tap = (TAPS == 1) ? 0 : kb / cpt;
+            const int c0 = (kb - tap * cpt) * CBK;
+            const int64_t shift = (TAPS == 1) ? (int64_t)c0 : (int64_t)((tap / 3 - 1) * g.W + (tap % 3 - 1)) * AS + c0;
+            __syncthreads();   // every wave is done with the previous block's tiles
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const bool real = (tapmask[t] >> tap) & 1u;
+                dma16(real ? a_row[t] + shift : zero, a_hi + wave * 4096 + t * 1024);
+                dma16(real ? a_row[t] + shift + C : zero, a_lo + wave * 4096 + t * 1024);
+                if (t < BROWS / 8) {
+                    dma16(b_src + (int64_t)t * 8 * K + (3 * kb) * CBK, w_hi + wave * (BROWS * 128) + t * 1024);
+                    dma16(b_src + (int64_t)t * 8 * K + (3 * kb + 2) * CBK, w_lo + wave * (BROWS * 128) + t * 1024);
+                }
+            }
+            __syncthreads();   // (waits for the DMA: vmcnt(0), then the barrier)
+            f16x8 ah[2][MI], al[2][MI], bh[2][4], bl[2][4];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    ah[ks][i] = *reinterpret_cast<const f16x8 *>(a_hi + a_row_off + i * 2048 + ksw[ks]);
+                    al[ks][i] = *reinterpret_cast<const f16x8 *>(a_lo + a_row_off + i * 2048 + ksw[ks]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bh[ks][j] = *reinterpret_cast<const f16x8 *>(w_hi + b_row_off + j * 2048 + ksw[ks]);
+                    bl[ks][j] = *reinterpret_cast<const f16x8 *>(w_lo + b_row_off + j * 2048 + ksw[ks]);
+                }
+            }
+            // (the order of the two-tile version: product by product, the two 32-wide k steps inside)
+#pragma unroll
+            for (int prod = 0; prod < 3; ++prod)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(prod == 1 ? al[ks][i] : ah[ks][i],
+                                                                               prod == 2 ? bl[ks][j] : bh[ks][j], acc[i][j], 0, 0, 0);
+        }
+    } else {
+        stage(0, 0);
         __syncthreads();
-        cur ^= 1;
+        int cur = 0;
+        for (int kt = 0; kt < nkt - 1; ++kt) {
+            stage(cur ^ 1, kt + 1);
+            compute(cur);
+            __syncthreads();
+            cur ^= 1;
+        }
+        compute(cur);
     }
-    compute(cur);
 
     // ---- epilogue: C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg ----
     __syncthreads();
