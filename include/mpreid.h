@@ -421,8 +421,7 @@ int mpreid_rn50_forward_f32(const mpreid_rn50_cfg *cfg, const mpreid_rn50_weight
  * oscale = 2^-e.  cin % 4 == 0.  Range: as for the ViT's split mode (activations below 65 504).
  * taps == 9 (the 3x3 convolutions run as IMPLICIT GEMMs over the nine shifted views of the pair activations, no im2col
  * matrix): kseg = cin rounded up to 64 (the padded channel count of ONE tap) and w = fp16 slabs
- * [npad][tap = kh*3+kw][kseg / 64][hi(64) | hi(64) | lo(64)] of W * 2^e -- one 64-half slab per k step, in the order of
- * the three products hi.hi', lo.hi', hi.lo' (channels >= cin and rows >= cout zero). */
+ * [npad][tap = kh*3+kw][kseg / 64][hi(64) | lo(64)] of W * 2^e (channels >= cin and rows >= cout zero). */
 typedef struct { const void *w; const float *bias; int32_t cin, cout, taps, kseg, npad; float oscale; } mpreid_rn50_conv_split;
 typedef struct { mpreid_rn50_conv_split conv1, conv2, conv3, down; int32_t stride; } mpreid_rn50_block_split;   /* down.w NULL: none */
 typedef struct {

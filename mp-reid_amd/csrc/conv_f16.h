@@ -16,8 +16,8 @@ struct ConvArgs {
     int taps;                  // 1 (1x1) or 9 (3x3, pad 1)
     int relu;
     // SPLIT form (the RN50 split tower's 3x3 convolutions, round 4): act = fp16 PAIRS [pixel][hi(C) | lo(C)] (row stride 2 C),
-    // wgt = [Npad][taps][C / 64][hi(64) | hi(64) | lo(64)] of W * 2^e (one 64-half slab per k step), and every (tap, 64
-    // channels) block runs the three products hi.hi' + lo.hi' + hi.lo' into the fp32 accumulators;
+    // wgt = [Npad][taps][C / 64][hi(64) | lo(64)] of W * 2^e, and every (tap, 64 channels) block runs the three products
+    // hi.hi' + lo.hi' + hi.lo' into the fp32 accumulators;
     // out32 fp32 [M][ldo] = acc * oscale + bias (no ReLU: the consumer's pack applies it)
     int split;
     float oscale;

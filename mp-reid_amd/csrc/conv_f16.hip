@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs g, int tiles
     const int C = g.C;
     const int cpt = C / CBK;                       // 64-channel blocks per tap
     const int AS = SPLIT ? 2 * C : C;              // row stride of the activations in halfs (pairs: hi | lo)
-    const int K = TAPS * C * (SPLIT ? 3 : 1);      // row length of the weights: one 64-half slab per k step
+    const int K = TAPS * C * (SPLIT ? 2 : 1);      // row length of the weights (pairs: per (tap, 64 channels) a hi' slab and a lo' slab)
 
     // ---- staging: wave w moves rows [32w, 32w+32) of both tiles, 8 rows per DMA instruction ----
     const int srow = lane >> 3;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs g, int tiles
         // form staged six tiles per block and paid one DMA round trip (~1.5 us) per 32 matrix instructions (0.3 us): 1.7 us
         // per step measured, 0.62 PF executed.  Here a workgroup still waits for its stage, but a stage carries three times
         // the work and the CU's second workgroup computes meanwhile.
-        const int nblk = nkt / 3;
+        const int nblk = nkt / 2;
         unsigned char *a_hi = smem, *a_lo = smem + C_TILE_BYTES, *w_hi = smem + 2 * C_TILE_BYTES, *w_lo = w_hi + BN * 128;
         for (int kb = 0; kb < nblk; ++kb) {
             const int tap = (TAPS == 1) ? 0 : kb / cpt;
@@ -153,8 +153,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs g, int tiles
                 dma16(real ? a_row[t] + shift : zero, a_hi + wave * 4096 + t * 1024);
                 dma16(real ? a_row[t] + shift + C : zero, a_lo + wave * 4096 + t * 1024);
                 if (t < BROWS / 8) {
-                    dma16(b_src + (int64_t)t * 8 * K + (3 * kb) * CBK, w_hi + wave * (BROWS * 128) + t * 1024);
-                    dma16(b_src + (int64_t)t * 8 * K + (3 * kb + 2) * CBK, w_lo + wave * (BROWS * 128) + t * 1024);
+                    dma16(b_src + (int64_t)t * 8 * K + (2 * kb) * CBK, w_hi + wave * (BROWS * 128) + t * 1024);
+                    dma16(b_src + (int64_t)t * 8 * K + (2 * kb + 1) * CBK, w_lo + wave * (BROWS * 128) + t * 1024);
                 }
             }
             __syncthreads();   // (waits for the DMA: vmcnt(0), then the barrier)

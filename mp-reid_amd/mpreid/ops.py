@@ -703,8 +703,7 @@ class Rn50Encoder:
 
         def pairs_of_3x3(w, bias):
             """folded [cout][cin][3][3] -> Rn50ConvSplit for the implicit GEMM (csrc/conv_f16.hip, pair form): fp16 slabs
-            [cout_pad128][tap][cin_pad64 / 64][hi(64) | hi(64) | lo(64)] of W * 2^e -- one 64-half slab per k step, in the
-            order of the three products hi.hi', lo.hi', hi.lo'; kseg = cin_pad64"""
+            [cout_pad128][tap][cin_pad64 / 64][hi(64) | lo(64)] of W * 2^e; kseg = cin_pad64"""
             cout, cin = w.shape[:2]
             cp, npad = _pad_to(cin, 64), _pad_to(cout, 128)
             wp = np.zeros((npad, 9, cp), np.float32)
@@ -717,7 +716,7 @@ class Rn50Encoder:
             hi = wt.half()
             lo = (wt - hi.float()).half()
             hi, lo = hi.view(npad, 9, cp // 64, 1, 64), lo.view(npad, 9, cp // 64, 1, 64)
-            slab = torch.cat([hi, hi, lo], dim=3).reshape(npad, 9 * (cp // 64) * 3 * 64).contiguous()
+            slab = torch.cat([hi, lo], dim=3).reshape(npad, 9 * (cp // 64) * 2 * 64).contiguous()
             self._keep.append(slab)
             return _lib.Rn50ConvSplit(_ptr(slab), _ptr(dev32(bp)), cin, cout, 9, cp, npad, float(2.0 ** -e))
 
