@@ -167,13 +167,18 @@ __global__ __launch_bounds__(256) void avgpool2_f32_kernel(const float *__restri
 
 // attention-pool tokens (model/clip/model.py:66-69): x4 [B][S][E] -> mean[b] (= avg_pool2d(x4), the prepended token),
 // tok[b][0] = mean + pos[0], tok[b][1 + t] = x4[b][t] + pos[1 + t]
+template <bool RELU>   // RELU: x4 holds pre-activations (the split tower never writes a block's closing ReLU back)
 __global__ __launch_bounds__(256) void tokens_f32_kernel(const float *__restrict__ x4, const float *__restrict__ pos, int S, int E,
                                                          float *__restrict__ mean, float *__restrict__ tok) {
+    // grid (B, ceil(E / 256)): one thread per (image, channel) -- with one workgroup per image (the first version) a
+    // 256-image batch ran on 256 workgroups of 4 waves, each thread walking 8 channels x S tokens one after the other: 0.46 ms
+    // for 0.54 GB.  Same sum order per channel: same bits.
     const int b = blockIdx.x;
-    for (int c = threadIdx.x; c < E; c += 256) {
+    for (int c = blockIdx.y * 256 + threadIdx.x; c < E; c += 256 * gridDim.y) {
         float sum = 0.0f;
         for (int t = 0; t < S; ++t) {
-            const float v = x4[((int64_t)b * S + t) * E + c];
+            float v = x4[((int64_t)b * S + t) * E + c];
+            if (RELU) v = v < 0.0f ? 0.0f : v;
             sum += v;
             tok[((int64_t)b * (S + 1) + 1 + t) * E + c] = v + pos[(int64_t)(1 + t) * E + c];
         }
@@ -376,7 +381,7 @@ extern "C" int mpreid_rn50_forward_f32(const mpreid_rn50_cfg *cfg, const mpreid_
     float *mean = (float *)(base + v.mean), *tok = (float *)(base + v.tok), *tok0 = (float *)(base + v.tok0);
     float *q = (float *)(base + v.q), *k = (float *)(base + v.k), *vv = (float *)(base + v.v);
     float *att = (float *)(base + v.att), *proj = (float *)(base + v.proj);
-    hipLaunchKernelGGL(tokens_f32_kernel, dim3(B), dim3(256), 0, stream, buf[xi], w->pos_emb, v.S, v.E, mean, tok);
+    hipLaunchKernelGGL(tokens_f32_kernel<false>, dim3(B, (v.E + 255) / 256), dim3(256), 0, stream, buf[xi], w->pos_emb, v.S, v.E, mean, tok);
     hipLaunchKernelGGL(gather_tok0_f32_kernel, dim3(B), dim3(256), 0, stream, tok, v.T, v.E, tok0);
     LAUNCH_CHECK();
     if ((rc = mpreid_gemm_f32_linear(tok0, w->q_w, B, v.E, v.E, w->q_b, q, v.E, F32_LIN, stream))) return rc;
@@ -468,10 +473,6 @@ __global__ __launch_bounds__(256) void avgpool2_ld_kernel(const float *__restric
     out[pix * ld_out + c] = (((a0 + a1) + a2) + a3) * 0.25f;
 }
 
-__global__ __launch_bounds__(256) void relu_inplace_kernel(float *__restrict__ x, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) x[i] = x[i] < 0.f ? 0.f : x[i];
-}
 
 struct LayoutSplit {
     LayoutF32 f;           // the fp32 part: five activation buffers (sized for padded channel strides), stem im2col, pool buffers
@@ -703,18 +704,13 @@ extern "C" int mpreid_rn50_forward_split(const mpreid_rn50_cfg *cfg, const mprei
         H = OH;
         W = OW;
     }
-    ARG_CHECK(H * W == v.f.S && x.C == v.f.E && x.ld == v.f.E);
-    {
-        const int64_t n = (int64_t)B * v.f.S * v.f.E;
-        hipLaunchKernelGGL(relu_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x.p, n);
-        LAUNCH_CHECK();
-    }
+    ARG_CHECK(H * W == v.f.S && x.C == v.f.E && x.ld == v.f.E && x.dirty);   // (the last block's ReLU: applied by the tokens kernel on read)
 
     // ---- attention pool: k / v projections of the B * T tokens as pair GEMMs, the rest on the fp32 path ----
     float *mean = (float *)(base + v.f.mean), *tok = (float *)(base + v.f.tok), *tok0 = (float *)(base + v.f.tok0);
     float *q = (float *)(base + v.f.q), *k = (float *)(base + v.f.k), *vv = (float *)(base + v.f.v);
     float *att = (float *)(base + v.f.att), *proj = (float *)(base + v.f.proj);
-    hipLaunchKernelGGL(tokens_f32_kernel, dim3(B), dim3(256), 0, stream, x.p, wf.pos_emb, v.f.S, v.f.E, mean, tok);
+    hipLaunchKernelGGL(tokens_f32_kernel<true>, dim3(B, (v.f.E + 255) / 256), dim3(256), 0, stream, x.p, wf.pos_emb, v.f.S, v.f.E, mean, tok);
     hipLaunchKernelGGL(gather_tok0_f32_kernel, dim3(B), dim3(256), 0, stream, tok, v.f.T, v.f.E, tok0);
     LAUNCH_CHECK();
     if ((rc = mpreid_gemm_f32_linear(tok0, wf.q_w, B, v.f.E, v.f.E, wf.q_b, q, v.f.E, F32_LIN, stream))) return rc;
