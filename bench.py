@@ -640,7 +640,7 @@ def drop_in_extras(a, cfg, model, nq, ng, pids, camids, dev):
         dt = timed_do_inference(cfg, model, ld, nq, 2, pipeline_env=f"stage={stage},streams={max(1, a.streams)}")
         out[f"do_inference_images_per_s_fp32_loader_{stage}"] = round(n / dt, 1)
     best = max(("pinned", "direct"), key=lambda k: out[f"do_inference_images_per_s_fp32_loader_{k}"])
-    out["do_inference_images_per_s_fp32_loader"] = out[f"do_inference_images_per_s_fp32_loader_pinned"]   # the default stage
+    out["do_inference_images_per_s_fp32_loader"] = out[f"do_inference_images_per_s_fp32_loader_direct"]   # the default stage
     out["do_inference_fp32_loader_best_stage"] = best
     out["do_inference_fp32_loader_h2d_gb_per_s"] = round(out["do_inference_images_per_s_fp32_loader"] * 3 * H * W * 4 / 1e9, 2)
     # the reference's own loop shape on the same loader, for scale: one 64-image batch at a time, pageable .to(device)

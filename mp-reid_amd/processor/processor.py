@@ -141,12 +141,12 @@ def do_inference(cfg, model, val_loader, num_query):
     # the reference's loop body (`img = img.to(device); feat = model(img, ...); evaluator.update(...)`, :187-198) as a
     # pipeline: a stager thread drains the loader into pinned group buffers and uploads them on a copy stream while
     # earlier groups are encoded on two alternating streams (mpreid/pipeline.py); the evaluator sees the loader's own
-    # batches, in order.  MPREID_PIPELINE="stage=direct,streams=1,slots=4" overrides the defaults (measurements).
+    # batches, in order.  MPREID_PIPELINE="stage=pinned,streams=1,slots=4" overrides the defaults (measurements).
     opts = dict(kv.split("=", 1) for kv in os.environ.get("MPREID_PIPELINE", "").split(",") if "=" in kv)
     pipe = EncodePipeline(model, group=int(opts.get("group", getattr(model, "encode_group", ENCODE_GROUP))),
                           sie_camera=bool(cfg.MODEL.SIE_CAMERA), sie_view=bool(cfg.MODEL.SIE_VIEW),
                           streams=int(opts.get("streams", 2)), slots=int(opts.get("slots", 3)),
-                          stage=opts.get("stage", "pinned"))
+                          stage=opts.get("stage", "direct"))
     for feat, (_, pid, camid, _, _, imgpath) in pipe.run(val_loader):
         evaluator.update((feat, pid, camid))
         img_path_list.extend(imgpath)

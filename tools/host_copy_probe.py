@@ -34,3 +34,25 @@ for workers in (1, 2, 4, 8):
     dt = time.perf_counter() - t
     print("%d thread(s): %.1f GB/s" % (workers, reps * n / dt / 1e9))
     pool.shutdown()
+
+# the pipeline's stager is NOT the main thread: the same single copy_ from a worker thread, main thread idle / busy in torch
+import threading
+
+def worker(out):
+    for i in range(8):
+        dst[(i % 8) * n:(i % 8 + 1) * n].copy_(srcs[i % 16])
+    t = time.perf_counter()
+    for i in range(64):
+        dst[(i % 8) * n:(i % 8 + 1) * n].copy_(srcs[i % 16])
+    out.append(64 * n / (time.perf_counter() - t) / 1e9)
+
+for busy in (False, True):
+    res = []
+    th = threading.Thread(target=worker, args=(res,))
+    th.start()
+    if busy and torch.cuda.is_available():
+        a = torch.randn(2048, 2048, device="cuda")
+        while th.is_alive():
+            (a @ a).sum().item()
+    th.join()
+    print("copy_ from a worker thread, main thread %s: %.1f GB/s" % ("launching GPU work" if busy else "idle", res[0]))
