@@ -13,8 +13,8 @@ Loader batch images, by type:
   * fp32 / uint8 tensors on the host -- the reference's loader type (datasets/make_dataloader.py:103-106, a DataLoader
     without pin_memory): ``stage='direct'`` (the default: equal or 1-3 % ahead in every measurement of round 4) hands the
     pageable memory to the HIP runtime batch by batch (the runtime pins or stages it itself; host-synchronous, which is
-    harmless in the stager thread); ``stage='pinned'`` copies each batch into a page-locked group buffer (one of ``slots``;
-    four threads per copy) and issues ONE asynchronous H2D per group.  Already-pinned batches are always copied directly.
+    harmless in the stager thread); ``stage='pinned'`` copies each batch into a page-locked group buffer (one of ``slots``)
+    and issues ONE asynchronous H2D per group.  Already-pinned batches are always copied directly.
   * tensors already on the device: read in place when a group's batches are back-to-back slices of one allocation (a
     device-resident dataset cut into batches), else gathered into the group buffer by D2D copies on the copy stream.
   * ``RawImageBatch`` (decoded uint8 RGB images of ragged sizes): packed back to back into a pinned byte buffer, one H2D
@@ -24,7 +24,6 @@ No host ``torch.cat``, no per-batch synchronisation; the host runs at most ``slo
 from __future__ import annotations
 
 import queue
-from concurrent.futures import ThreadPoolExecutor
 import threading
 from typing import Iterable, List, Optional
 
@@ -85,21 +84,6 @@ class _Group:
 _END = object()
 
 
-def _staging_copy(dst: torch.Tensor, src: torch.Tensor, pool) -> None:
-    """pageable -> page-locked bytes.  Outside the main thread torch copies on ONE core (15 GB/s on a fast host, tools/host_copy_probe.py;
-    a pipeline that feeds 17 k fp32 images/s needs 6.7): big copies are cut into four pieces, three of them on helper threads
-    (copy_ releases the GIL)."""
-    n = src.numel()
-    if n < (4 << 20):
-        dst.copy_(src)
-        return
-    step = ((n + 3) // 4 + 4095) // 4096 * 4096
-    futs = [pool.submit(dst[o:min(n, o + step)].copy_, src[o:min(n, o + step)]) for o in range(step, n, step)]
-    dst[:step].copy_(src[:step])
-    for f in futs:
-        f.result()
-
-
 def _contiguous_view(parts, count, shape, dtype):
     """the tensors of `parts` as ONE tensor [count, *shape] when they are back-to-back slices of the same allocation, else None"""
     if not parts:
@@ -137,7 +121,6 @@ class EncodePipeline:
     # ------------------------------------------------------------------------------------------------ stager thread
     def _stager(self, loader: Iterable, free_q: "queue.Queue", ready_q: "queue.Queue", meta_q: "queue.Queue",
                 stop: threading.Event, copy_s: torch.cuda.Stream):
-        pool = ThreadPoolExecutor(max_workers=3, thread_name_prefix="mpreid-stage-copy")
         try:
             torch.cuda.set_device(self.device)
             cur: Optional[_Group] = None
@@ -255,7 +238,7 @@ class EncodePipeline:
                         sb = int(np.prod(shape)) * dtype.itemsize
                         src = img[lo:lo + take].reshape(-1).view(torch.uint8)
                         if kind == "host_pinned":
-                            _staging_copy(slot.host(self.group * sb)[cur.count * sb:(cur.count + take) * sb], src, pool)
+                            slot.host(self.group * sb)[cur.count * sb:(cur.count + take) * sb].copy_(src)
                         elif kind == "device":   # decided when the group closes: read in place or gathered
                             cur.dev_parts.append(img[lo:lo + take])
                         else:   # pageable / pinned host memory straight to the device
@@ -280,8 +263,6 @@ class EncodePipeline:
             g = _Group(None)
             g.error = e
             ready_q.put(g)
-        finally:
-            pool.shutdown(wait=False)
 
     # ------------------------------------------------------------------------------------------------ consumer
     def _input_of(self, g: _Group):
