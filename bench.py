@@ -478,13 +478,13 @@ def extras(ops, dev, with_widened=True):
     ms = timed_ms(lambda: enc(img, out=fo), 3)
     out["rn50_split_mode_images_per_s_batch256"] = round(256 / ms * 1e3, 1)
     roofs.append({"stage": "rn50 tower, split precision (the default, parity-grade: 3.4e-6 vs the reference), 256 images per call",
-                  "kernel": "gemm_f16_big_kernel / gemm_f16_kernel <split_*> + im2col3x3_pairs / pack_pairs", "bound": "mfma",
+                  "kernel": "conv_gemm_kernel<9, pair form> (3x3, implicit GEMM) + gemm_f16_big_kernel / gemm_f16_kernel <split_*> (1x1) + pack_pairs", "bound": "mfma",
                   "achieved": round(256 * rn_gflop / ms, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                   "frac": round(256 * rn_gflop / ms / PEAK_F16_TFLOPS, 4), "algorithmic_flop": int(256 * rn_gflop * 1e9),
                   "avg_launch_ms": round(ms, 4), "traffic": None,
                   "note": "algorithmic 11.49 GFLOP per image (2*M*N*K of the reference's graph); the matrix cores execute 3x that on "
-                          "the pair GEMMs plus channel padding (64-channel layers in 128-wide tiles); 40 % of the time is the "
-                          "materialised pair im2col / pack passes (HBM-bound)"})
+                          "the pair GEMMs plus channel padding (64-channel layers in 128-wide tiles); the 3x3 convolutions are implicit "
+                          "GEMMs over the pair tensor (no im2col matrix), ~17 % of the time are the fp32 -> pair pack passes (HBM-bound)"})
     del enc, img, fo
     ops.release_workspaces()
     rng = np.random.default_rng(5)
