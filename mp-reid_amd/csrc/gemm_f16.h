@@ -46,9 +46,12 @@ enum GemmEpi {
     GE_S_BIAS_F32 = 10,  // out fp32 = acc * oscale + bias[n]                        (in_proj: q | k | v for the split attention)
     GE_S_BIAS_RES = 11,  // x fp32 += acc * oscale + bias[n]                         (out-proj, MLP c_proj)
     GE_S_BIAS_GELU = 12, // out fp16 pair [M][2N]: hi | lo of quickgelu(acc * oscale + bias[n])   (MLP c_fc)
-    GE_S_PATCH = 13      // x fp32[b*L + 1 + p][n] = acc * oscale + pos[1 + p][n]    (patch embed)
+    GE_S_PATCH = 13,     // x fp32[b*L + 1 + p][n] = acc * oscale + pos[1 + p][n]    (patch embed)
+    GE_S_BIAS_RELU_PAIR = 14   // out fp16 pair [M][2 * pair_c]: hi | lo of relu(acc * oscale + bias[n]) for the columns n < pair_c (the
+                               // others are padding and are not stored): the A operand of the NEXT pair convolution, written by
+                               // its producer (RN50 split tower: conv1 -> conv2); ldo = 2 * pair_c
 };
-constexpr bool gemm_epi_is_split(int epi) { return epi >= GE_S_BIAS_F32 && epi <= GE_S_PATCH; }
+constexpr bool gemm_epi_is_split(int epi) { return epi >= GE_S_BIAS_F32 && epi <= GE_S_BIAS_RELU_PAIR; }
 
 struct GemmArgs {
     const _Float16 *A;   // [M][K]
@@ -78,6 +81,7 @@ struct GemmArgs {
                           // real-time counter late, so that the CUs reach their store-heavy epilogues at different
                           // times instead of all at once (0 = off)
     int stagger_mode;     // 1: eight phases by the CU's slot inside its XCD instead ((b >> 3) mod 8) / 8
+    int pair_c;           // GE_S_BIAS_RELU_PAIR: half the row length of the pair output (hi at n, lo at pair_c + n); % 64 == 0
     int relu_x;           // GE_S_BIAS_RES only: the destination holds a PRE-activation (a ResNet block input whose ReLU is pending):
                           // x = max(x, 0) + acc * oscale + bias -- saves the producer-side pass that would write the ReLU back
     unsigned long long *stamps;   // ablation builds (DBG bit 32): [workgroup][32 tiles][8] real-time stamps, else null

@@ -234,8 +234,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
             const uint4 v = *reinterpret_cast<const uint4 *>(wreg + lr * 72 + ch * 8);
             *reinterpret_cast<uint4 *>(out + (int64_t)(m0 + wm * 64 + lr) * g.ldo + n0 + wn * 64 + ch * 8) = v;
         }
-    } else if constexpr (EPI == GE_S_BIAS_GELU) {
-        // fp16 pair out [M][2N]: the hi parts, then the lo parts, through the same patch
+    } else if constexpr (EPI == GE_S_BIAS_GELU || EPI == GE_S_BIAS_RELU_PAIR) {
+        // fp16 pair out [M][2N] (RELU_PAIR: [M][2 pair_c], columns >= pair_c dropped): the hi parts, then the lo parts, through the same patch
         _Float16 *wreg = reinterpret_cast<_Float16 *>(smem) + wave * (64 * 72);
         _Float16 *out = reinterpret_cast<_Float16 *>(g.out);
 #pragma unroll
@@ -253,9 +253,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
                         const f32x2 a = {acc[i][j][rp], acc[i][j][rp + 1]};
                         f32x2 h;
                         h = __builtin_elementwise_fma(a, f32x2{g.oscale, g.oscale}, f32x2{bias, bias});
-                        const f32x2 t = h * (-1.702f * 1.44269504088896340736f);
-                        const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + 1.0f;
-                        const f32x2 v = h * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};   // quick_gelu
+                        f32x2 v;
+                        if constexpr (EPI == GE_S_BIAS_GELU) {
+                            const f32x2 t = h * (-1.702f * 1.44269504088896340736f);
+                            const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + 1.0f;
+                            v = h * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};   // quick_gelu
+                        } else {
+                            v = f32x2{h[0] < 0.f ? 0.f : h[0], h[1] < 0.f ? 0.f : h[1]};               // relu
+                        }
                         const f16x2 hi = __builtin_convertvector(v, f16x2);
                         const f16x2 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x2), f16x2);
                         wreg[(i * 16 + fq * 4 + rp) * 72 + j * 16 + frow] = part == 0 ? hi[0] : lo[0];
@@ -267,7 +272,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
             for (int it = 0; it < 8; ++it) {
                 const int lr = it * 8 + (lane >> 3), ch = lane & 7;
                 const uint4 v = *reinterpret_cast<const uint4 *>(wreg + lr * 72 + ch * 8);
-                *reinterpret_cast<uint4 *>(out + (int64_t)(m0 + wm * 64 + lr) * g.ldo + part * g.N + n0 + wn * 64 + ch * 8) = v;
+                if constexpr (EPI == GE_S_BIAS_RELU_PAIR) {
+                    if (n0 + wn * 64 + ch * 8 < g.pair_c)
+                        *reinterpret_cast<uint4 *>(out + (int64_t)(m0 + wm * 64 + lr) * g.ldo + part * g.pair_c + n0 + wn * 64 + ch * 8) = v;
+                } else {
+                    *reinterpret_cast<uint4 *>(out + (int64_t)(m0 + wm * 64 + lr) * g.ldo + part * g.N + n0 + wn * 64 + ch * 8) = v;
+                }
             }
         }
     } else if constexpr (EPI == GE_BIAS_ADD_RELU) {
@@ -1136,8 +1146,8 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
             }
             __builtin_amdgcn_wave_barrier();
         }
-    } else if constexpr (EPI == GE_S_BIAS_GELU) {
-        // fp16 PAIR out [M][2N] (hi | lo of the fp32 value): two [16][72] patches per pass -- hi in the wave's 4 KB
+    } else if constexpr (EPI == GE_S_BIAS_GELU || EPI == GE_S_BIAS_RELU_PAIR) {
+        // fp16 PAIR out [M][2N] (hi | lo of the fp32 value; RELU_PAIR: [M][2 pair_c]): two [16][72] patches per pass -- hi in the wave's 4 KB
         // above the ring, lo in the idle k-loop ring -- so that both leave with one LDS round trip, each as whole
         // 128-byte row pieces
         _Float16 *whi = reinterpret_cast<_Float16 *>(patch + wave * 4096);
@@ -1159,9 +1169,14 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
                     typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
                     const f32x2 a = {acc[i][j][rp], acc[i][j][rp + 1]};
                     const f32x2 h = __builtin_elementwise_fma(a, f32x2{g.oscale, g.oscale}, f32x2{bias[j], bias[j]});
-                    const f32x2 t = h * (-1.702f * 1.44269504088896340736f);
-                    const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + 1.0f;
-                    const f32x2 v = h * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};   // quick_gelu
+                    f32x2 v;
+                    if constexpr (EPI == GE_S_BIAS_GELU) {
+                        const f32x2 t = h * (-1.702f * 1.44269504088896340736f);
+                        const f32x2 d = f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])} + 1.0f;
+                        v = h * f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};   // quick_gelu
+                    } else {
+                        v = f32x2{h[0] < 0.f ? 0.f : h[0], h[1] < 0.f ? 0.f : h[1]};               // relu
+                    }
                     const f16x2 hi = __builtin_convertvector(v, f16x2);
                     const f16x2 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x2), f16x2);
                     whi[(fq * 4 + rp) * 72 + j * 16 + frow] = hi[0];
@@ -1178,8 +1193,15 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
                 const uint4 vh = *reinterpret_cast<const uint4 *>(whi + lr * 72 + ch * 8);
                 const uint4 vl = *reinterpret_cast<const uint4 *>(wlo + lr * 72 + ch * 8);
                 _Float16 *dsth = out + (int64_t)(cur_m0 + wr * 128 + i * 16 + lr) * g.ldo + cur_n0 + wc * 64 + ch * 8;
-                store_nt(dsth, vh);
-                store_nt(dsth + g.N, vl);
+                if constexpr (EPI == GE_S_BIAS_RELU_PAIR) {   // (read again at once by the next convolution: plain stores)
+                    if (cur_n0 + wc * 64 + ch * 8 < g.pair_c) {
+                        *reinterpret_cast<uint4 *>(dsth) = vh;
+                        *reinterpret_cast<uint4 *>(dsth + g.pair_c) = vl;
+                    }
+                } else {
+                    store_nt(dsth, vh);
+                    store_nt(dsth + g.N, vl);
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }
@@ -2336,6 +2358,11 @@ int launch_gemm_f16(const GemmArgs &a, int epi, hipStream_t stream) {
                          GBK);
         return MPREID_ERR_ARG;
     }
+    if (epi == GE_S_BIAS_RELU_PAIR && (a.pair_c <= 0 || a.pair_c % 64 || a.ldo != 2 * (int64_t)a.pair_c)) {
+        mpreid_set_error("gemm_f16: the pair epilogue needs pair_c %% 64 == 0 and ldo == 2 * pair_c (pair_c=%d ldo=%lld)", a.pair_c,
+                         (long long)a.ldo);
+        return MPREID_ERR_ARG;
+    }
     switch (epi) {
     case GE_F32: return launch_one<GE_F32>(a, stream);
     case GE_BIAS_F16: return launch_one<GE_BIAS_F16>(a, stream);
@@ -2351,6 +2378,7 @@ int launch_gemm_f16(const GemmArgs &a, int epi, hipStream_t stream) {
     case GE_S_BIAS_RES: return launch_one<GE_S_BIAS_RES>(a, stream);
     case GE_S_BIAS_GELU: return launch_one<GE_S_BIAS_GELU>(a, stream);
     case GE_S_PATCH: return launch_one<GE_S_PATCH>(a, stream);
+    case GE_S_BIAS_RELU_PAIR: return launch_one<GE_S_BIAS_RELU_PAIR>(a, stream);
     }
     mpreid_set_error("gemm_f16: unknown epilogue %d", epi);
     return MPREID_ERR_ARG;

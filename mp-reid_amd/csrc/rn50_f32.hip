@@ -404,7 +404,8 @@ extern "C" int mpreid_rn50_forward_f32(const mpreid_rn50_cfg *cfg, const mpreid_
 // x = hi + lo on the fp16 matrix cores, three products hi.hi' + lo.hi' + hi.lo' per multiply-add with fp32 accumulation
 // (gemm_f16.hip GE_S_BIAS_F32 / GE_S_BIAS_RES: the kernels the ViT's split mode uses, unchanged):
 //   1x1 convolution   pack_pairs_kernel: fp32 [M][C] -> pairs [Mp][hi(kseg) | lo(kseg)] (ReLU of the producer applied on the
-//                     way), then out fp32 = acc * 2^-e + bias'                      (BatchNorm folded into W 2^e and bias')
+//                     way), then out fp32 = acc * 2^-e + bias'                      (BatchNorm folded into W 2^e and bias');
+//                     conv1 writes relu(.) directly as conv2's pair operand instead (GE_S_BIAS_RELU_PAIR)
 //   3x3 convolution   the same pack (channels padded to 64), then an IMPLICIT GEMM over the nine shifted views of the pair
 //                     tensor (conv_f16.hip, pair form: per (tap, 64 channels) the three products; padding pixels read a page
 //                     of zeros) -- the materialised im2col pair matrix of the first version cost 9x the activation bytes,
@@ -538,7 +539,7 @@ struct ActView { float *p; int C, ld; bool dirty; };   // fp32 NHWC tensor: C re
 // prepacked (1x1 only): `in` has been delivered that way already -- no pack pass
 int conv_split(const mpreid_rn50_conv_split &c, ActView &in, int B, int H, int W, int res, float *out, _Float16 *pairs,
                hipStream_t stream, const _Float16 *zero_page = nullptr, _Float16 *pair_out = nullptr,
-               int pair_c = 0, const _Float16 *prepacked = nullptr) {
+               int pair_c = 0, const _Float16 *prepacked = nullptr, const _Float16 *act_pairs = nullptr) {
     const int64_t M = (int64_t)B * H * W, Mp = pad_rows(M);
     // kseg: 1x1 -- the padded K of the pair matrix; 3x3 -- the padded channel count of ONE tap (the weights are laid out
     // for the implicit GEMM, include/mpreid.h)
@@ -550,7 +551,9 @@ int conv_split(const mpreid_rn50_conv_split &c, ActView &in, int B, int H, int W
         // 3x3: the input as pairs [pixel][hi(C) | lo(C)] (ReLU applied on the way), then the implicit GEMM over the nine shifted
         // views of it (conv_f16.hip, pair form) -- no im2col matrix (it cost 9x the activation bytes, written and read)
         ARG_CHECK(res == 0 && zero_page != nullptr);
-        if (in.dirty)
+        if (act_pairs)   // the producer wrote this convolution's pair operand itself (GE_S_BIAS_RELU_PAIR)
+            pairs = const_cast<_Float16 *>(act_pairs);
+        else if (in.dirty)
             hipLaunchKernelGGL((pack_pairs_kernel<true>), grid, dim3(256), 0, stream, in.p, M, Mp, in.C, in.ld, c.kseg, pairs);
         else
             hipLaunchKernelGGL((pack_pairs_kernel<false>), grid, dim3(256), 0, stream, in.p, M, Mp, in.C, in.ld, c.kseg, pairs);
@@ -591,6 +594,13 @@ int conv_split(const mpreid_rn50_conv_split &c, ActView &in, int B, int H, int W
     g.ldo = c.npad;
     g.bias = c.bias;
     g.relu_x = res == 2;   // the destination is a block input whose ReLU is still pending (it was never written back)
+    if (pair_out) {        // 1x1 whose only consumer is a pair convolution: relu(.) as that convolution's operand, no fp32 tensor
+        ARG_CHECK(res == 0 && pair_c % 64 == 0 && pair_c >= c.cout);
+        g.out = pair_out;
+        g.ldo = 2 * (int64_t)pair_c;
+        g.pair_c = pair_c;
+        return launch_gemm_f16(g, GE_S_BIAS_RELU_PAIR, stream);
+    }
     return launch_gemm_f16(g, res ? GE_S_BIAS_RES : GE_S_BIAS_F32, stream);
 }
 
@@ -654,27 +664,21 @@ extern "C" int mpreid_rn50_forward_split(const mpreid_rn50_cfg *cfg, const mprei
         float *t1 = buf[free_i[0]], *t2 = buf[free_i[1]], *t3 = buf[free_i[2]], *t4 = buf[free_i[3]];
         // conv1 reads x with the ReLU of the previous block's sum applied on the way.  The ReLU is NOT written back (that made the
         // pack a three-pass kernel): whoever reads x as the identity below applies it again -- the downsample branch's pack or
-        // average pool on read, conv3's residual epilogue through GemmArgs::relu_x
-        if ((rc = conv_split(blk.conv1, x, B, H, W, 0, t1, pairs, stream))) return rc;
+        // average pool on read, conv3's residual epilogue through GemmArgs::relu_x.
+        // Pair operands written by their producers (rows of a pair matrix are padded to 256: only when the pixel count is such
+        // a multiple): conv1 -> conv2 always (GE_S_BIAS_RELU_PAIR: no fp32 tensor, no pack pass), conv2 -> conv3 when no average
+        // pool sits between them (13 of the 16 blocks).  Two pair buffers: a convolution never writes the one it reads.
+        const bool rows_ok = ((int64_t)B * H * W) % 256 == 0;
+        const bool fuse12 = rows_ok && blk.conv2.kseg >= blk.conv1.cout && blk.conv2.cin == blk.conv1.cout;
+        const bool fuse23 = rows_ok && blk.stride == 1 && blk.conv3.kseg >= blk.conv2.cout && blk.conv3.cin == blk.conv2.cout;
+        if ((rc = conv_split(blk.conv1, x, B, H, W, 0, t1, pairs, stream, nullptr, fuse12 ? pairs2 : nullptr, blk.conv2.kseg))) return rc;
         ActView a1{t1, blk.conv1.cout, blk.conv1.npad, true};
-        // conv2 -> ReLU -> conv3 without an average pool in between (13 of the 16 blocks): conv2 writes conv3's pair operand
-        // itself (rows of the pair matrix are padded to 256: only when the pixel count is such a multiple)
-        const bool fuse23 = blk.stride == 1 && ((int64_t)B * H * W) % 256 == 0 && blk.conv3.kseg >= blk.conv2.cout &&
-                            blk.conv3.cin == blk.conv2.cout;
-        if ((rc = conv_split(blk.conv2, a1, B, H, W, 0, t2, pairs, stream, zero_page, fuse23 ? pairs2 : nullptr,
-                             blk.conv3.kseg)))
-            return rc;
-        ActView a2{t2, blk.conv2.cout, blk.conv2.npad, true};
         int OH = H, OW = W;
         if (blk.stride == 2) {
-            const int64_t threads = (int64_t)B * (H / 2) * (W / 2) * a2.C;
-            hipLaunchKernelGGL((avgpool2_ld_kernel<true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, a2.p, B, H, W,
-                               a2.C, a2.ld, a2.C, t1);
-            LAUNCH_CHECK();
-            a2 = ActView{t1, a2.C, a2.C, false};
             OH = H / 2;
             OW = W / 2;
         }
+        // the downsample branch (it only needs x) runs before conv2: `pairs` is free again afterwards
         float *dst;
         if (blk.down.w) {
             ActView xin = x;   // (x.dirty: its ReLU is applied by whoever reads it)
@@ -689,7 +693,6 @@ extern "C" int mpreid_rn50_forward_split(const mpreid_rn50_cfg *cfg, const mprei
                 LAUNCH_CHECK();
                 xin = ActView{t3, x.C, x.C, false};
             }
-            // conv3's operand must be packed AFTER the downsample GEMM has consumed the pair buffer: order matters (one buffer)
             if ((rc = conv_split(blk.down, xin, B, OH, OW, 0, t4, pairs, stream))) return rc;
             dst = t4;
             xi = free_i[3];
@@ -697,8 +700,20 @@ extern "C" int mpreid_rn50_forward_split(const mpreid_rn50_cfg *cfg, const mprei
             ARG_CHECK(blk.stride == 1 && blk.conv3.cout == x.C && blk.conv3.npad == x.ld);
             dst = x.p;      // x itself is the identity and is not needed afterwards
         }
+        _Float16 *c3_pairs = fuse12 ? pairs : pairs2;   // conv2 reads pairs2 (fuse12) or packs into pairs: it writes the other one
+        if ((rc = conv_split(blk.conv2, a1, B, H, W, 0, t2, pairs, stream, zero_page, fuse23 ? c3_pairs : nullptr, blk.conv3.kseg, nullptr,
+                             fuse12 ? pairs2 : nullptr)))
+            return rc;
+        ActView a2{t2, blk.conv2.cout, blk.conv2.npad, true};
+        if (blk.stride == 2) {
+            const int64_t threads = (int64_t)B * OH * OW * a2.C;
+            hipLaunchKernelGGL((avgpool2_ld_kernel<true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, a2.p, B, H, W,
+                               a2.C, a2.ld, a2.C, t1);
+            LAUNCH_CHECK();
+            a2 = ActView{t1, a2.C, a2.C, false};
+        }
         const int res_mode = (dst == x.p && x.dirty) ? 2 : 1;
-        if ((rc = conv_split(blk.conv3, a2, B, OH, OW, res_mode, dst, pairs, stream, nullptr, nullptr, 0, fuse23 ? pairs2 : nullptr)))
+        if ((rc = conv_split(blk.conv3, a2, B, OH, OW, res_mode, dst, pairs, stream, nullptr, nullptr, 0, fuse23 ? c3_pairs : nullptr)))
             return rc;
         x = ActView{dst, blk.conv3.cout, blk.conv3.npad, true};
         H = OH;
