@@ -50,8 +50,11 @@ enum GemmEpi {
     GE_S_BIAS_RELU_PAIR = 14   // out fp16 pair [M][2 * pair_c]: hi | lo of relu(acc * oscale + bias[n]) for the columns n < pair_c (the
                                // others are padding and are not stored): the A operand of the NEXT pair convolution, written by
                                // its producer (RN50 split tower: conv1 -> conv2); ldo = 2 * pair_c
+    , GE_S_BIAS_RES_PAIR = 15  // GE_S_BIAS_RES (x fp32 += acc * oscale + bias[n], relu_x honoured) that ALSO writes relu(x) as fp16
+                               // pairs [M][2 * pair_c] to pair_out (pair_c == N): a ResNet block output, stored once as the fp32
+                               // identity of the next block and once as the pair operand of its first convolution
 };
-constexpr bool gemm_epi_is_split(int epi) { return epi >= GE_S_BIAS_F32 && epi <= GE_S_BIAS_RELU_PAIR; }
+constexpr bool gemm_epi_is_split(int epi) { return epi >= GE_S_BIAS_F32 && epi <= GE_S_BIAS_RES_PAIR; }
 
 struct GemmArgs {
     const _Float16 *A;   // [M][K]
@@ -81,7 +84,8 @@ struct GemmArgs {
                           // real-time counter late, so that the CUs reach their store-heavy epilogues at different
                           // times instead of all at once (0 = off)
     int stagger_mode;     // 1: eight phases by the CU's slot inside its XCD instead ((b >> 3) mod 8) / 8
-    int pair_c;           // GE_S_BIAS_RELU_PAIR: half the row length of the pair output (hi at n, lo at pair_c + n); % 64 == 0
+    int pair_c;           // GE_S_BIAS_RELU_PAIR / GE_S_BIAS_RES_PAIR: half the row length of the pair output (hi at n, lo at pair_c + n); % 64 == 0
+    _Float16 *pair_out;   // GE_S_BIAS_RES_PAIR: the pair copy (out stays the fp32 tensor)
     int relu_x;           // GE_S_BIAS_RES only: the destination holds a PRE-activation (a ResNet block input whose ReLU is pending):
                           // x = max(x, 0) + acc * oscale + bias -- saves the producer-side pass that would write the ReLU back
     unsigned long long *stamps;   // ablation builds (DBG bit 32): [workgroup][32 tiles][8] real-time stamps, else null

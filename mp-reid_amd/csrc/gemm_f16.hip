@@ -38,6 +38,10 @@ __device__ __forceinline__ void dma16_sv(uint64_t sbase, unsigned voff, unsigned
 __device__ __forceinline__ void store16_sv(uint64_t sbase, unsigned voff, const f32x4 &v) {
     asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
 }
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store8_sv(uint64_t sbase, unsigned voff, const u32x2 &v) {   // 8 bytes per lane, same addressing
+    asm volatile("global_store_dwordx2 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
 __device__ __forceinline__ void store16_nt_sv(uint64_t sbase, unsigned voff, const f32x4 &v) {   // streaming variant
     asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
 }
@@ -316,8 +320,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
             }
             __syncthreads();
         }
-    } else if constexpr (EPI == GE_S_BIAS_F32 || EPI == GE_S_BIAS_RES) {
-        // split mode, fp32 outputs: out = acc * oscale + bias, or x += that; whole 256-byte row pieces, each lane four
+    } else if constexpr (EPI == GE_S_BIAS_F32 || EPI == GE_S_BIAS_RES || EPI == GE_S_BIAS_RES_PAIR) {
+        // split mode, fp32 outputs: out = acc * oscale + bias, or x += that (RES_PAIR: and relu(x) as fp16 pairs); whole 256-byte row pieces, each lane four
         // consecutive columns (the layout of the persistent kernel's epilogues)
         __syncthreads();
         float *wreg = reinterpret_cast<float *>(smem) + wave * (32 * 68);
@@ -346,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
                 o[1] = fmaf(a.y, g.oscale, bias4.y);
                 o[2] = fmaf(a.z, g.oscale, bias4.z);
                 o[3] = fmaf(a.w, g.oscale, bias4.w);
-                if (EPI == GE_S_BIAS_RES) {
+                if (EPI == GE_S_BIAS_RES || EPI == GE_S_BIAS_RES_PAIR) {
                     float4 x = *reinterpret_cast<const float4 *>(dst);
                     if (g.relu_x) {   // the destination holds a pre-activation: its ReLU is applied here (see gemm_f16.h)
                         x.x = x.x < 0.f ? 0.f : x.x;
@@ -360,6 +364,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
                     o[3] = x.w + o[3];
                 }
                 *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                if constexpr (EPI == GE_S_BIAS_RES_PAIR) {   // relu(x) as the pair operand of the next block's first convolution
+                    typedef _Float16 h4p __attribute__((ext_vector_type(4)));
+                    h4p hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float y = o[e] < 0.f ? 0.f : o[e];
+                        hi[e] = (_Float16)y;
+                        lo[e] = (_Float16)(y - (float)hi[e]);
+                    }
+                    _Float16 *po = g.pair_out + m * 2 * g.pair_c + nbase + c4;
+                    *reinterpret_cast<h4p *>(po) = hi;
+                    *reinterpret_cast<h4p *>(po + g.pair_c) = lo;
+                }
             }
             __syncthreads();
         }
@@ -1259,7 +1276,8 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
         }
         // the identity patches alias stage 0 of the ring, which the next tile's prologue fills: all waves done first
         asm volatile("s_barrier" ::: "memory");
-    } else if ((EPI == GE_BIAS_RES || EPI == GE_S_BIAS_RES) && (g.ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.out) & 15) == 0)) {
+    } else if ((EPI == GE_BIAS_RES || EPI == GE_S_BIAS_RES || EPI == GE_S_BIAS_RES_PAIR) && (g.ldo % 4 == 0) &&
+               ((reinterpret_cast<uintptr_t>(g.out) & 15) == 0)) {
         // x[m][n] += acc + bias, x fp32 (residual stream).  The x values are the expensive part: fetched pass by pass
         // into VGPRs every pass pays a full HBM round trip (8 per tile, matrix pipe idle), and there are no registers
         // to fetch them ahead.  So they are fetched ahead into LDS instead: the k-loop's ring is idle during the
@@ -1280,6 +1298,7 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
         asm volatile("" : "+v"(bias4.x), "+v"(bias4.y), "+v"(bias4.z), "+v"(bias4.w)::"memory");
         float *wreg = reinterpret_cast<float *>(patch + wave * 4096);
         const unsigned x_loff = ((unsigned)efq * (unsigned)g.ldo + (unsigned)c4) * 4u;
+        [[maybe_unused]] const unsigned p_loff = ((unsigned)efq * 2u * (unsigned)g.pair_c + (unsigned)c4) * 2u;   // RES_PAIR: lane offset in the pair tensor
         auto x_base = [&](int row16) -> uint64_t {   // row16: first row of a 4-row piece inside the wave's 128 rows
             return reinterpret_cast<uint64_t>(outp) + (uint64_t)(((int64_t)(cur_m0 + wr * 128 + row16) * g.ldo + nbase) * 4);
         };
@@ -1303,7 +1322,9 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
             __builtin_amdgcn_wave_barrier();
             // younger than pass i's block: 4 DMAs per queued pass behind it + 4 stores per finished pass since:
             // i <= 3: 12 + 4 i, i >= 4: 12 + 4 (7 - i)
-            wait_vmcnt(i < 4 ? 12 + 4 * i : 24 - 4 * (i - 4));                                      // 12 16 20 24 | 24 20 16 12
+            // (RES_PAIR: 12 stores per pass -- 4 fp32 + 4 hi + 4 lo: i <= 3: 12 + 12 i; i >= 4: 36 + 4 (7 - i))
+            if constexpr (EPI == GE_S_BIAS_RES_PAIR) wait_vmcnt(i < 4 ? 12 + 12 * i : 36 + 4 * (7 - i));   // 12 24 36 48 | 48 44 40 36
+            else wait_vmcnt(i < 4 ? 12 + 4 * i : 24 - 4 * (i - 4));                                        // 12 16 20 24 | 24 20 16 12
             f32x4_t a[4], x[4];
             asm volatile("ds_read_b128 %0, %8\n\t"
                          "ds_read_b128 %1, %8 offset:1024\n\t"
@@ -1321,7 +1342,7 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 f32x4_t o;
-                if constexpr (EPI == GE_S_BIAS_RES) {
+                if constexpr (EPI == GE_S_BIAS_RES || EPI == GE_S_BIAS_RES_PAIR) {
                     if (g.relu_x) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) x[it][e] = x[it][e] < 0.f ? 0.f : x[it][e];
@@ -1337,6 +1358,20 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
                     o[3] = x[it][3] + (a[it][3] + bias4.w);
                 }
                 store16_sv(x_base(i * 16 + it * 4), x_loff, o);
+                if constexpr (EPI == GE_S_BIAS_RES_PAIR) {   // relu(x) as fp16 pairs: 8 bytes of hi and of lo per lane
+                    typedef _Float16 h4p __attribute__((ext_vector_type(4)));
+                    h4p hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float y = o[e] < 0.f ? 0.f : o[e];
+                        hi[e] = (_Float16)y;
+                        lo[e] = (_Float16)(y - (float)hi[e]);
+                    }
+                    const uint64_t pb = reinterpret_cast<uint64_t>(g.pair_out) +
+                                        (uint64_t)(((int64_t)(cur_m0 + wr * 128 + i * 16 + it * 4) * 2 * g.pair_c + nbase) * 2);
+                    store8_sv(pb, p_loff, __builtin_bit_cast(u32x2, hi));
+                    store8_sv(pb + (uint64_t)g.pair_c * 2u, p_loff, __builtin_bit_cast(u32x2, lo));
+                }
             }
             if (i + 4 < 8) x_dma(i + 4);
             __builtin_amdgcn_wave_barrier();
@@ -1358,7 +1393,7 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
             cs1 = g.cscale[nbase + lane];
         }
         if (vec_ok) {
-            if (EPI == GE_BIAS_RES || EPI == GE_S_BIAS_RES || EPI == GE_S_BIAS_F32)
+            if (EPI == GE_BIAS_RES || EPI == GE_S_BIAS_RES || EPI == GE_S_BIAS_RES_PAIR || EPI == GE_S_BIAS_F32)
                 bias4 = *reinterpret_cast<const float4 *>(g.bias + nbase + c4);
             if (EPI == GE_EUCLID) {
                 bn4.x = (nbase + c4 + 0 < g.n_valid) ? g.aux2[nbase + c4 + 0] : 0.f;
@@ -2363,6 +2398,11 @@ int launch_gemm_f16(const GemmArgs &a, int epi, hipStream_t stream) {
                          (long long)a.ldo);
         return MPREID_ERR_ARG;
     }
+    if (epi == GE_S_BIAS_RES_PAIR && (!a.pair_out || a.pair_c != a.N || a.pair_c % 64 || a.ldo % 4 || (reinterpret_cast<uintptr_t>(a.out) & 15) ||
+                                      (reinterpret_cast<uintptr_t>(a.pair_out) & 15))) {
+        mpreid_set_error("gemm_f16: the residual + pair epilogue needs pair_out, pair_c == N, ldo %% 4 == 0, 16-byte aligned tensors");
+        return MPREID_ERR_ARG;
+    }
     switch (epi) {
     case GE_F32: return launch_one<GE_F32>(a, stream);
     case GE_BIAS_F16: return launch_one<GE_BIAS_F16>(a, stream);
@@ -2379,6 +2419,7 @@ int launch_gemm_f16(const GemmArgs &a, int epi, hipStream_t stream) {
     case GE_S_BIAS_GELU: return launch_one<GE_S_BIAS_GELU>(a, stream);
     case GE_S_PATCH: return launch_one<GE_S_PATCH>(a, stream);
     case GE_S_BIAS_RELU_PAIR: return launch_one<GE_S_BIAS_RELU_PAIR>(a, stream);
+    case GE_S_BIAS_RES_PAIR: return launch_one<GE_S_BIAS_RES_PAIR>(a, stream);
     }
     mpreid_set_error("gemm_f16: unknown epilogue %d", epi);
     return MPREID_ERR_ARG;

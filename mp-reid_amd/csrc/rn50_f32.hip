@@ -414,7 +414,8 @@ extern "C" int mpreid_rn50_forward_f32(const mpreid_rn50_cfg *cfg, const mpreid_
 //                     dst += acc * 2^-e + bias'; the block's closing ReLU is never written: every reader of dst applies it
 //                     (the next block's packs and average pools on read, its conv3 through GemmArgs::relu_x when dst is
 //                     its identity); where no average pool sits between conv2 and conv3, conv2's epilogue writes conv3's
-//                     ReLU-ed pair operand directly
+//                     ReLU-ed pair operand directly, and conv3 writes relu(dst) as the next block's conv1 operand beside the fp32
+//                     identity (GE_S_BIAS_RES_PAIR)
 // The stem's first convolution (K = 27: direct fp32 FMAs), the one-query attention and the 1-row projections q / c stay on
 // the exact fp32 path above.  Channel counts are padded to the GEMM's granularity (kseg to 64, cout to 128: the stem's and
 // layer1's 32 / 64-channel tensors are stored with a row stride of 128).
@@ -594,6 +595,12 @@ int conv_split(const mpreid_rn50_conv_split &c, ActView &in, int B, int H, int W
     g.ldo = c.npad;
     g.bias = c.bias;
     g.relu_x = res == 2;   // the destination is a block input whose ReLU is still pending (it was never written back)
+    if (pair_out && res) {   // block output: the fp32 identity AND relu(.) as the pair operand of the next block's first convolution
+        ARG_CHECK(pair_c == c.npad);
+        g.pair_out = pair_out;
+        g.pair_c = pair_c;
+        return launch_gemm_f16(g, GE_S_BIAS_RES_PAIR, stream);
+    }
     if (pair_out) {        // 1x1 whose only consumer is a pair convolution: relu(.) as that convolution's operand, no fp32 tensor
         ARG_CHECK(res == 0 && pair_c % 64 == 0 && pair_c >= c.cout);
         g.out = pair_out;
@@ -652,6 +659,8 @@ extern "C" int mpreid_rn50_forward_split(const mpreid_rn50_cfg *cfg, const mprei
     W /= 2;
     int xi = 1;
     ActView x{buf[1], w->stem3.cout, w->stem3.cout, false};
+    _Float16 *bufA = pairs, *bufB = pairs2;   // pair buffers: bufA = the current block's input pairs (see the loop)
+    bool have_xp = false;                     // bufA already holds relu(x) as pairs (written by the previous block's conv3)
 
     // ---- residual layers on the fp16 matrix cores (pairs) ----
     for (int bi = 0; bi < cfg->n_blocks; ++bi) {
@@ -663,25 +672,28 @@ extern "C" int mpreid_rn50_forward_split(const mpreid_rn50_cfg *cfg, const mprei
             if (i != xi) free_i[nf++] = i;
         float *t1 = buf[free_i[0]], *t2 = buf[free_i[1]], *t3 = buf[free_i[2]], *t4 = buf[free_i[3]];
         // conv1 reads x with the ReLU of the previous block's sum applied on the way.  The ReLU is NOT written back (that made the
-        // pack a three-pass kernel): whoever reads x as the identity below applies it again -- the downsample branch's pack or
-        // average pool on read, conv3's residual epilogue through GemmArgs::relu_x.
+        // pack a three-pass kernel): whoever reads x as the identity below applies it again -- the downsample branch's average
+        // pool on read, conv3's residual epilogue through GemmArgs::relu_x.
         // Pair operands written by their producers (rows of a pair matrix are padded to 256: only when the pixel count is such
-        // a multiple): conv1 -> conv2 always (GE_S_BIAS_RELU_PAIR: no fp32 tensor, no pack pass), conv2 -> conv3 when no average
-        // pool sits between them (13 of the 16 blocks).  Two pair buffers: a convolution never writes the one it reads.
+        // a multiple): conv1 -> conv2 (GE_S_BIAS_RELU_PAIR: no fp32 tensor, no pack pass), conv2 -> conv3 when no average pool
+        // sits between them (13 of the 16 blocks), conv3 -> the next block's conv1 (GE_S_BIAS_RES_PAIR: the block output leaves
+        // twice, as the fp32 identity and as relu(.) pairs).  Two pair buffers, bufA (this block's input pairs) and bufB: a
+        // convolution never writes the one it reads, and the roles swap from block to block.
         const bool rows_ok = ((int64_t)B * H * W) % 256 == 0;
         const bool fuse12 = rows_ok && blk.conv2.kseg >= blk.conv1.cout && blk.conv2.cin == blk.conv1.cout;
         const bool fuse23 = rows_ok && blk.stride == 1 && blk.conv3.kseg >= blk.conv2.cout && blk.conv3.cin == blk.conv2.cout;
-        if ((rc = conv_split(blk.conv1, x, B, H, W, 0, t1, pairs, stream, nullptr, fuse12 ? pairs2 : nullptr, blk.conv2.kseg))) return rc;
+        if ((rc = conv_split(blk.conv1, x, B, H, W, 0, t1, bufA, stream, nullptr, fuse12 ? bufB : nullptr, blk.conv2.kseg,
+                             have_xp ? bufA : nullptr)))
+            return rc;   // (bufA now holds relu(x) as pairs [Mp][2 * conv1.kseg], packed here or written by the previous block)
         ActView a1{t1, blk.conv1.cout, blk.conv1.npad, true};
         int OH = H, OW = W;
         if (blk.stride == 2) {
             OH = H / 2;
             OW = W / 2;
         }
-        // the downsample branch (it only needs x) runs before conv2: `pairs` is free again afterwards
+        // the downsample branch (it only needs x) runs before conv2: bufA is free again afterwards
         float *dst;
         if (blk.down.w) {
-            ActView xin = x;   // (x.dirty: its ReLU is applied by whoever reads it)
             if (blk.stride == 2) {
                 const int64_t threads = (int64_t)B * OH * OW * x.C;
                 if (x.dirty)
@@ -691,18 +703,23 @@ extern "C" int mpreid_rn50_forward_split(const mpreid_rn50_cfg *cfg, const mprei
                     hipLaunchKernelGGL((avgpool2_ld_kernel<false>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, x.p, B, H,
                                        W, x.C, x.ld, x.C, t3);
                 LAUNCH_CHECK();
-                xin = ActView{t3, x.C, x.C, false};
+                ActView xin{t3, x.C, x.C, false};
+                if ((rc = conv_split(blk.down, xin, B, OH, OW, 0, t4, bufA, stream))) return rc;
+            } else {
+                // stride 1: the operand is relu(x) as pairs with conv1's k segment -- exactly what bufA holds
+                ARG_CHECK(blk.down.kseg == blk.conv1.kseg && blk.down.cin == blk.conv1.cin);
+                ActView xin = x;
+                if ((rc = conv_split(blk.down, xin, B, OH, OW, 0, t4, bufA, stream, nullptr, nullptr, 0, bufA))) return rc;
             }
-            if ((rc = conv_split(blk.down, xin, B, OH, OW, 0, t4, pairs, stream))) return rc;
             dst = t4;
             xi = free_i[3];
         } else {
             ARG_CHECK(blk.stride == 1 && blk.conv3.cout == x.C && blk.conv3.npad == x.ld);
             dst = x.p;      // x itself is the identity and is not needed afterwards
         }
-        _Float16 *c3_pairs = fuse12 ? pairs : pairs2;   // conv2 reads pairs2 (fuse12) or packs into pairs: it writes the other one
-        if ((rc = conv_split(blk.conv2, a1, B, H, W, 0, t2, pairs, stream, zero_page, fuse23 ? c3_pairs : nullptr, blk.conv3.kseg, nullptr,
-                             fuse12 ? pairs2 : nullptr)))
+        _Float16 *c3_pairs = fuse12 ? bufA : bufB;   // conv2 reads bufB (fuse12) or packs into bufA: it writes the other one
+        if ((rc = conv_split(blk.conv2, a1, B, H, W, 0, t2, bufA, stream, zero_page, fuse23 ? c3_pairs : nullptr, blk.conv3.kseg, nullptr,
+                             fuse12 ? bufB : nullptr)))
             return rc;
         ActView a2{t2, blk.conv2.cout, blk.conv2.npad, true};
         if (blk.stride == 2) {
@@ -713,8 +730,22 @@ extern "C" int mpreid_rn50_forward_split(const mpreid_rn50_cfg *cfg, const mprei
             a2 = ActView{t1, a2.C, a2.C, false};
         }
         const int res_mode = (dst == x.p && x.dirty) ? 2 : 1;
-        if ((rc = conv_split(blk.conv3, a2, B, OH, OW, res_mode, dst, pairs, stream, nullptr, nullptr, 0, fuse23 ? c3_pairs : nullptr)))
+        // the block output as the next block's conv1 operand, when there is a next block and the layouts agree
+        _Float16 *xp_next = (c3_pairs == bufA) ? bufB : bufA;
+        bool emit = false;
+        if (bi + 1 < cfg->n_blocks) {
+            const mpreid_rn50_conv_split &n1 = w->blocks[bi + 1].conv1;
+            emit = ((int64_t)B * OH * OW) % 256 == 0 && n1.taps == 1 && n1.kseg == blk.conv3.npad && n1.cin == blk.conv3.cout &&
+                   blk.conv3.npad == blk.conv3.cout;
+        }
+        if ((rc = conv_split(blk.conv3, a2, B, OH, OW, res_mode, dst, c3_pairs, stream, nullptr, emit ? xp_next : nullptr, blk.conv3.npad,
+                             fuse23 ? c3_pairs : nullptr)))
             return rc;
+        have_xp = emit;
+        if (emit) {   // the roles of the two buffers swap when the next block's input pairs sit in the other one
+            bufB = (xp_next == bufA) ? bufB : bufA;
+            bufA = xp_next;
+        }
         x = ActView{dst, blk.conv3.cout, blk.conv3.npad, true};
         H = OH;
         W = OW;
