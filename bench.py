@@ -50,6 +50,97 @@ PEAK_HBM_GBS = 8000.0                           # HBM3E
 METRIC = "gallery images/s encode + distmat+rerank ms, 20k×20k; mAP/Rank-1 parity"
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# the ONE stdout line (<= 4 KB) and the extras file
+# ----------------------------------------------------------------------------------------------------------------
+EXTRAS_FILE = "bench_extras.json"               # written to the current directory by rank 0
+MAX_LINE_BYTES = 4096
+MAX_STR = 200
+LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+             "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "rccl_ranks", "all_gather",
+             "extras_file")
+CONFIG_KEYS = ("workload", "images_per_step", "encoder_batch", "encoder_precision", "encoder_streams", "sharding",
+               "rerank", "distance_mode")
+ROOFLINE_KEYS = ("bound", "kernel", "shape", "achieved", "peak", "unit", "frac", "achieved_executed", "frac_executed",
+                 "avg_launch_ms", "launches", "algorithmic_flop", "algorithmic_bytes", "traffic", "traffic_source", "measured")
+CPU_BASELINE_KEYS = ("value", "unit", "cores", "kind", "sample")
+ALL_GATHER_KEYS = ("calls_per_step", "bytes_per_step", "ms_per_step", "gb_per_s")
+
+
+def _clip(v):
+    """strings of the line are short by contract (<= MAX_STR characters); anything longer belongs in the extras file"""
+    if isinstance(v, str) and len(v) > MAX_STR:
+        return v[:MAX_STR - 3] + "..."
+    return v
+
+
+def _pick(d, keys):
+    return None if d is None else {k: _clip(d[k]) for k in keys if k in d}
+
+
+def format_line(res, extras_file=EXTRAS_FILE):
+    """(line, extras): `line` is the ONE JSON line of the driver contract -- the contract's keys, `roofline` of the
+    dominant kernel only, `cpu_baseline`, the RCCL figures when N > 1 -- at most MAX_LINE_BYTES bytes, every string at
+    most MAX_STR characters; `extras` is everything else (`roofline_all`, `extras`, `gemm_classes`, `drop_in`,
+    `reference_cpu`, full-length notes) for the extras file.  tests/test_bench_line.py holds the format."""
+    line = {k: _clip(res[k]) for k in LINE_KEYS if k in res and k not in ("config", "roofline", "cpu_baseline", "all_gather")}
+    line["config"] = _pick(res.get("config") or {}, CONFIG_KEYS)
+    line["roofline"] = _pick(res.get("roofline"), ROOFLINE_KEYS)
+    line["cpu_baseline"] = _pick(res.get("cpu_baseline"), CPU_BASELINE_KEYS)
+    if res.get("all_gather"):
+        line["all_gather"] = _pick(res["all_gather"], ALL_GATHER_KEYS)
+    line["extras_file"] = extras_file
+    ordered = {k: line[k] for k in LINE_KEYS if k in line}
+    text = json.dumps(ordered)
+    for drop in (("roofline", "measured"), ("roofline", "traffic_source"), ("cpu_baseline", "sample"), ("config", "sharding")):
+        if len(text.encode()) <= MAX_LINE_BYTES:
+            break
+        if ordered.get(drop[0]) and drop[1] in ordered[drop[0]]:     # never reached with the strings below; a guard, not a plan
+            del ordered[drop[0]][drop[1]]
+            text = json.dumps(ordered)
+    assert len(text.encode()) <= MAX_LINE_BYTES, len(text)
+    extras = {k: v for k, v in res.items() if k not in ("metric",)}
+    return text, extras
+
+
+def emit(res, extras_file=EXTRAS_FILE):
+    """rank 0: write the extras file (never fatal), then print the line -- the last thing on stdout"""
+    text, extras = format_line(res, extras_file)
+    try:
+        with open(extras_file, "w") as fh:
+            json.dump(extras, fh, indent=1)
+    except OSError as e:
+        print(f"bench.py: could not write {extras_file}: {e}", file=sys.stderr)
+    sys.stdout.flush()
+    print(text, flush=True)
+
+
+def visible_gpus():
+    """number of GPUs this process may use, WITHOUT initialising HIP (torch.cuda.device_count() reads the topology only
+    on this image; the parent of the self-launch must stay GPU-free)"""
+    try:
+        import torch
+        return int(torch.cuda.device_count())
+    except Exception:
+        return 0
+
+
+def check_gpu_count(n, quiet=False):
+    """--gpus N with fewer than N devices visible: exit 2 with a clear message instead of letting ranks share a device
+    silently (a 'scaling curve' on one GPU).  MPREID_DIST_BACKEND=gloo (the tests' one-GPU staging of several ranks)
+    and MPREID_ALLOW_SHARED_GPU=1 opt out."""
+    if os.environ.get("MPREID_DIST_BACKEND", "nccl") == "gloo" or os.environ.get("MPREID_ALLOW_SHARED_GPU") == "1":
+        return
+    have = visible_gpus()
+    if n > have:
+        if quiet:
+            sys.exit(2)
+        print(f"bench.py: --gpus {n} but only {have} GPU(s) are visible (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES = "
+              f"{os.environ.get('HIP_VISIBLE_DEVICES')!r} / {os.environ.get('ROCR_VISIBLE_DEVICES')!r}); refusing to run "
+              f"several RCCL ranks on one device", file=sys.stderr)
+        sys.exit(2)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -229,10 +320,12 @@ def cpu_baseline(n_img):
                        text=True)
     t_rr1 = float(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else None
     return {"value": round((NQ + NG) / total, 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"oracle ViT-B/16 fp32 (torch CPU) on {n_img} images: {t_enc:.2f} s; oracle euclid "
-                      f"{NQ}x1024x1280: {t_dist:.2f} s; extrapolated linearly to {NQ}+{NG} images; oracle re-rank "
-                      f"N=20000 (nq 4000, D 768, k1 50, k2 15) on {cores} threads: {t_rr:.2f} s; on 1 thread at "
-                      f"N=6000: {t_rr1 if t_rr1 is None else round(t_rr1, 2)} s",
+            "sample": f"oracle ViT-B/16 f32 on {n_img} images {t_enc:.1f} s + oracle euclid {NQ}x1024x1280 {t_dist:.2f} s, "
+                      f"scaled to {NQ}+{NG} images; oracle re-rank N=20000 {t_rr:.1f} s",
+            "sample_long": f"oracle ViT-B/16 fp32 (torch CPU) on {n_img} images: {t_enc:.2f} s; oracle euclid "
+                           f"{NQ}x1024x1280: {t_dist:.2f} s; extrapolated linearly to {NQ}+{NG} images; oracle re-rank "
+                           f"N=20000 (nq 4000, D 768, k1 50, k2 15) on {cores} threads: {t_rr:.2f} s; on 1 thread at "
+                           f"N=6000: {t_rr1 if t_rr1 is None else round(t_rr1, 2)} s",
             "encode_images_per_s": round(n_img / t_enc, 3), "encode_images_per_s_1thread": round(1.0 / t_enc1, 3),
             "rerank_s": round(t_rr, 3), "rerank_n": 20000, "rerank_s_1thread_n6000": t_rr1}
 
@@ -589,10 +682,11 @@ def market_cfg(a, nq, ng_total, rerank):
 
 
 def quiet_do_inference(cfg, model, loader, nq):
-    """do_inference with its prints sent to stderr (stdout carries the ONE JSON line)"""
+    """do_inference with the evaluator's progress prints dropped: stdout carries the ONE JSON line and stderr stays a
+    handful of lines (round 4's ~90 repeated evaluator lines on stderr drowned the line in the driver's capture)"""
     import contextlib
     from processor.processor import do_inference
-    with contextlib.redirect_stdout(sys.stderr):
+    with open(os.devnull, "w") as null, contextlib.redirect_stdout(null):
         return do_inference(cfg, model, loader, nq)
 
 
@@ -675,7 +769,7 @@ def drop_in_extras(a, cfg, model, nq, ng, pids, camids, dev):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     import contextlib
-    with contextlib.redirect_stdout(sys.stderr):
+    with open(os.devnull, "w") as null, contextlib.redirect_stdout(null):
         for _ in range(3):
             ev.compute()
     out["compute_ms"] = round((time.perf_counter() - t0) / 3 * 1e3, 2)   # R1_mAP_eval.compute(): normalise, distmat, ranking, D2H
@@ -693,7 +787,7 @@ def run_rank(a):
 
     rank, world, local = D.init_from_env()
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
-    local = local % max(torch.cuda.device_count(), 1)   # (debug) more ranks than GPUs share devices
+    local = local % max(torch.cuda.device_count(), 1)   # gloo staging / MPREID_ALLOW_SHARED_GPU: ranks share devices (main() checked)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     L = _lib.load()
@@ -909,18 +1003,23 @@ def run_rank(a):
             alg_tf = top["tflops"] / mult
             roof = {"bound": "mfma", "kernel": top["kernel"], "shape": [top["M"], top["N"], top["K"]],
                     "achieved": round(alg_tf, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(alg_tf / PEAK_F16_TFLOPS, 4),
+                    "avg_launch_ms": top["avg_ms"], "launches": top["launches"],
+                    "algorithmic_flop": int(round(top["gflop_per_launch"] / mult * 1e9)),
+                    "traffic": traffic,
+                    "traffic_source": f"profiles/{traffic_src} (rocprofv3 --pmc, separate FETCH/WRITE passes)" if traffic_src else None,
+                    "measured": "hipEvents per launch on the launch stream, " +
+                                ("inside the timed region" if instrument_live else
+                                 "single-stream pass of the same step right after the timed region"),
+                    # ---- below: extras file only ----
                     "algorithmic_gflop_per_launch": round(top["gflop_per_launch"] / mult, 2),
                     "flop_convention": "2*M*N*K per launch (SURVEY.md section 8d): ALGORITHMIC flops" +
                                        ("; the kernel executes three fp16 products per multiply-add (operand pairs hi + lo: "
                                         "hi.hi' + lo.hi' + hi.lo'), reported as achieved_executed / frac_executed" if sp else ""),
-                    "frac": round(alg_tf / PEAK_F16_TFLOPS, 4), "traffic": traffic,
-                    "traffic_source": (f"profiles/{traffic_src}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bytes = "
-                                       "(2*FETCH_SIZE + WRITE_SIZE)*1024, same kernel and shape at M=65536") if traffic_src else None,
-                    "avg_launch_ms": top["avg_ms"], "launches": top["launches"],
-                    "measured": "hipEvents around every launch, on the launch stream, " +
-                                ("inside the timed region" if instrument_live else
-                                 "in a single-stream pass of the same step right after the timed region "
-                                 "(the timed region alternates batches over %d streams)" % nstreams),
+                    "traffic_note": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, same kernel and shape at M=65536",
+                    "measured_note": ("inside the timed region" if instrument_live else
+                                      "in a single-stream pass of the same step right after the timed region "
+                                      "(the timed region alternates batches over %d streams)" % nstreams),
                     "all_gemm_tflops": round(sum(c["tflops"] * c["total_ms"] for c in classes) /
                                              max(sum(c["total_ms"] for c in classes), 1e-9), 1),
                     "gemm_share_of_step": round(sum(c["total_ms"] for c in classes) /
@@ -939,7 +1038,7 @@ def run_rank(a):
                     roof["mfma_busy_source"] = "profiles/r04_gemm_pmc_mfma.json"
             except Exception:
                 pass
-        desc = {
+        desc_long = {
             "market": "Market-1501 shape on MI355X (BASELINE configs[1]) through the drop-in API: one step = "
                       "processor.do_inference(cfg, make_model(cfg, ...), val_loader, num_query) -- ViT-B/16 encode of "
                       f"{nq} query + {NG // div} gallery 3x256x128 images per GPU shard (seeded random init; 64-image fp32 "
@@ -956,26 +1055,39 @@ def run_rank(a):
                  "rows sharded over the GPUs" + (" [RERANK_SPARSE_SPLIT3: blend-term distances from the fp16 matrix cores, "
                                                    "outputs within 1e-6 of the bit-parity mode]" if a.rerank_algo == "split3" else "")
                  if a.rerank else ", no re-rank")
+        desc = {   # the line's strings are <= 200 characters (format_line); the long form goes to the extras file
+            "market": f"Market-1501 shape (BASELINE configs[1]): do_inference(make_model(cfg)) = ViT-B/16 encode of {nq} query "
+                      f"+ {NG // div} gallery 3x256x128 images per GPU -> euclidean distmat -> CMC/mAP",
+            "msmt17": f"MSMT17 shape (BASELINE configs[4]): ViT-B/16 encode of {nq} query + {ng_total} gallery images over "
+                      f"{world} GPU(s) -> euclidean distmat at D=1280",
+            "synth": f"synthetic {nq} x {ng_total} x {SYN_D} features (BASELINE configs[3]), gallery rows over {world} GPU(s) "
+                     f"-> euclidean distmat",
+        }[wl] + ("; + k-reciprocal re-rank 50/15/0.3" if a.rerank else "; no re-rank")
         res = {
             "metric": METRIC,
             "value": round(images_per_step * a.steps / dt, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None,
-            "dtype": ({"split": "encoder: f16 operand PAIRS (hi+lo, 3 products per multiply-add) on the f16 MFMA, f32 "
-                                "accumulate/residual/softmax -- fp32-grade features, meets |dmAP|,|dR1| <= 1e-4 "
-                                "(tests/test_gpu_map_parity.py); ",
-                       "fp16": "encoder: single f16 MFMA operands, f32 accumulate/residual -- feature error ~4e-4, does NOT "
-                               "meet the 1e-4 mAP bound on hard data; ",
-                       "fp32": "encoder: all-f32 (exact f32 MFMA) -- meets the 1e-4 mAP bound; "}[a.encoder_precision]
+            "dtype": ({"split": "f16 pairs (hi+lo, 3 products per multiply-add) on the f16 MFMA, f32 accumulate; ",
+                       "fp16": "f16 MFMA operands, f32 accumulate; ", "fp32": "f32 (exact f32 MFMA); "}[a.encoder_precision]
                       if enc is not None else "") +
-                     {"exact": "distmat f32 (exact fp32 MFMA)", "f16": "distmat f16 operands one pass, f32 accumulate",
+                     {"exact": "distmat f32 (exact f32 MFMA chain)", "f16": "distmat f16 one pass, f32 accumulate",
                       "split3": "distmat 3-term f16 split, f32 accumulate"}[a.dist_mode],
+            "dtype_note": ({"split": "encoder: f16 operand PAIRS (hi+lo, 3 products per multiply-add) on the f16 MFMA, f32 "
+                                     "accumulate/residual/softmax -- fp32-grade features, meets |dmAP|,|dR1| <= 1e-4 "
+                                     "(tests/test_gpu_map_parity.py)",
+                            "fp16": "encoder: single f16 MFMA operands, f32 accumulate/residual -- feature error ~4e-4, does NOT "
+                                    "meet the 1e-4 mAP bound on hard data",
+                            "fp32": "encoder: all-f32 (exact f32 MFMA) -- meets the 1e-4 mAP bound"}[a.encoder_precision]
+                           if enc is not None else None),
             "data": "synthetic",
-            "config": {"workload": desc, "images_per_step": images_per_step,
+            "config": {"workload": desc, "workload_long": desc_long, "images_per_step": images_per_step,
+                       "rerank": bool(a.rerank), "distance_mode": a.dist_mode,
                        "encoder_batch": (market["model"].encode_group if market else a.batch) if enc else None,
                        "encoder_precision": a.encoder_precision if enc else None,
                        "encoder_streams": nstreams if enc else None,
-                       "sharding": (f"gallery rows over {world} GPU(s), queries 1/{world} each + all-gather")},
+                       "sharding": (f"gallery rows over {world} GPU(s), queries 1/{world} each + one all-gather of query features; "
+                                    "distance blocks concatenated on rank 0's host")},
             "host_concat": None if not host_concat else {"ms_per_step": round(host_concat_ms, 3),
                             "bytes_per_step": int(4 * nq * ng_total * (2 if a.rerank else 1)),
                             "note": "inside the timed step: per-shard distance blocks -> rank 0 (tensor gather over xGMI when "
@@ -992,6 +1104,7 @@ def run_rank(a):
             res["distmat_tflops_algorithmic"] = round(2.0 * nq * ng_total * SYN_D * a.steps / dt / 1e12, 1)
             res["unit_note"] = "images/s = (query + gallery feature rows) per second through distmat (+ re-rank)"
         if world > 1:
+            res["rccl_ranks"] = dist.get_world_size() if dist.get_backend() == "nccl" else 0   # 0: gloo staging (tests)
             res["all_gather"] = {"calls_per_step": comm_calls / max(a.steps, 1),
                                  "bytes_per_step": int(comm_bytes / max(a.steps, 1)),
                                  "ms_per_step": round(comm_ms / max(a.steps, 1), 3),
@@ -1045,7 +1158,7 @@ def run_rank(a):
                                       "algorithmic_bytes": int(o["gb_per_launch"] * 1e9), "avg_launch_ms": o["avg_ms"],
                                       "traffic": None})
             res["roofline_all"] = enc_roofs + roofs
-        print(json.dumps(res), flush=True)
+        emit(res)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -1053,7 +1166,10 @@ def run_rank(a):
 
 def main():
     a = parse()
-    if a.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+    launched = int(os.environ.get("WORLD_SIZE", "1")) > 1
+    if a.gpus > 1:                     # before anything initialises HIP or joins a rendezvous: every rank exits 2,
+        check_gpu_count(a.gpus, quiet=int(os.environ.get("LOCAL_RANK", "0")) != 0)   # local rank 0 says why
+    if a.gpus > 1 and not launched:
         launch_children(a.gpus)
         return
     run_rank(a)

@@ -44,6 +44,10 @@ extern "C" {
 typedef void *mpreid_stream_t; /* hipStream_t */
 
 int mpreid_version(void);
+/* 1 when the library was compiled with -DMPREID_ABLATION (the timing-ablation switches that skip matrix instructions or
+ * stores are honoured: wrong results by design), 0 for the product build.  The Python host refuses an ablation build unless
+ * MPREID_ALLOW_ABLATION=1 (mpreid/_lib.py). */
+int mpreid_is_ablation_build(void);
 const char *mpreid_last_error(void);
 /* number of visible HIP devices (0 when there is none); never throws, does not create a context */
 int mpreid_device_count(void);

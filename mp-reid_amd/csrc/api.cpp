@@ -53,6 +53,15 @@ int mpreid_tune(const char *key, int dflt) {
 
 extern "C" int mpreid_version(void) { return 100; } /* 0.1.0 */
 
+// 1 for a library compiled with -DMPREID_ABLATION (timing-ablation switches honoured: WRONG RESULTS by design), else 0
+extern "C" int mpreid_is_ablation_build(void) {
+#ifdef MPREID_ABLATION
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 extern "C" const char *mpreid_last_error(void) { return g_err; }
 
 extern "C" int mpreid_device_count(void) {

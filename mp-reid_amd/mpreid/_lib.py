@@ -20,7 +20,7 @@ ERR_RETRY_DENSE = -5
 
 #: every symbol include/mpreid.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "mpreid_version", "mpreid_last_error", "mpreid_device_count", "mpreid_device_info",
+    "mpreid_version", "mpreid_is_ablation_build", "mpreid_last_error", "mpreid_device_count", "mpreid_device_info",
     "mpreid_sqnorm_f32", "mpreid_l2_normalize_f32", "mpreid_distance_workspace_bytes",
     "mpreid_euclidean_distance_f32", "mpreid_cosine_similarity_f32",
     "mpreid_rerank_workspace_bytes", "mpreid_rerank_f32", "mpreid_rerank_debug_copy",
@@ -147,6 +147,14 @@ def load():
             f"{LIB_PATH} is missing: build it with `python mp-reid_amd/mpreid/build.py` "
             "(or __graft_entry__.build()).  There is no CPU fallback for the HIP path.")
     L = C.CDLL(LIB_PATH)
+    # MPREID_LIB may point at any build of the library.  One compiled with -DMPREID_ABLATION skips work on request (wrong
+    # results by design): it must say so itself, and is refused unless the caller asked for exactly that.
+    if not hasattr(L, "mpreid_is_ablation_build"):
+        raise RuntimeError(f"{LIB_PATH} does not export mpreid_is_ablation_build: a stale build; rebuild it")
+    L.mpreid_is_ablation_build.restype = C.c_int
+    if L.mpreid_is_ablation_build() and os.environ.get("MPREID_ALLOW_ABLATION") != "1":
+        raise RuntimeError(f"{LIB_PATH} is a timing-ablation build (-DMPREID_ABLATION: wrong results by design); "
+                           "set MPREID_ALLOW_ABLATION=1 to load it for a measurement")
     vp, i64, i32, f32, f64, sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_double, C.c_size_t
     L.mpreid_version.restype = i32
     L.mpreid_last_error.restype = C.c_char_p

@@ -12,11 +12,16 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(HERE), "csrc")
-# MPREID_BUILD_TAG=<tag>: a second build beside the product one (objects under csrc/_obj_<tag>/, library
-# libmpreid_hip_<tag>.so) -- e.g. the timing-ablation library for a same-device A/B through MPREID_LIB
+# MPREID_BUILD_TAG=<tag>: a second build beside the product one (objects under csrc/_obj_<tag>/) -- e.g. the
+# timing-ablation library for a same-device A/B through MPREID_LIB.  Tagged libraries are written to tools/ablation_lib/
+# (git-ignored; travels with gpurun), never next to the product library in mpreid/.
 _TAG = os.environ.get("MPREID_BUILD_TAG", "")
+if os.environ.get("MPREID_ABLATION") and not _TAG:
+    _TAG = "abl"          # an ablation build never overwrites the product library
 OBJ = os.path.join(CSRC, "_obj" + ("_" + _TAG if _TAG else ""))
-LIB = os.path.join(HERE, "libmpreid_hip" + ("_" + _TAG if _TAG else "") + ".so")
+_REPO = os.path.dirname(os.path.dirname(HERE))
+LIB = (os.path.join(_REPO, "tools", "ablation_lib", "libmpreid_hip_" + _TAG + ".so") if _TAG
+       else os.path.join(HERE, "libmpreid_hip.so"))
 SOURCES = ["api.cpp", "distance.hip", "rerank.hip", "gemm_f16.hip", "vit.hip", "evalrank.hip", "preprocess.hip", "conv_f16.hip", "rn50.hip", "rn50_f32.hip"]
 # -ffp-contract=off: the rounding sequence of the re-ranking path is part of the contract
 # (include/mpreid_numerics.h); fused multiply-adds are written as explicit fmaf().
@@ -49,6 +54,7 @@ def _stale(target, deps):
 
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # objects built with other flags (e.g. a timing-ablation build, MPREID_ABLATION=1) must not survive into this build
     stamp = os.path.join(OBJ, "flags.txt")

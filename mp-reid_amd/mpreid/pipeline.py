@@ -17,6 +17,9 @@ Loader batch images, by type:
     and issues ONE asynchronous H2D per group.  Already-pinned batches are always copied directly.
   * tensors already on the device: read in place when a group's batches are back-to-back slices of one allocation (a
     device-resident dataset cut into batches), else gathered into the group buffer by D2D copies on the copy stream.
+    CONTRACT: a device batch must be complete with respect to the device's DEFAULT stream when the loader yields it (the
+    stager thread orders its reads after that stream, the way a consumer of a DataLoader batch would); a loader that
+    fills batches on another stream synchronises that stream, or waits for its event on the default stream, first.
   * ``RawImageBatch`` (decoded uint8 RGB images of ragged sizes): packed back to back into a pinned byte buffer, one H2D
     per group, then Resize + ToTensor + Normalize inside the model call (ops.PackedRawImages).
 No host ``torch.cat``, no per-batch synchronisation; the host runs at most ``slots`` groups ahead of the device.
@@ -82,6 +85,23 @@ class _Group:
 
 
 _END = object()
+
+#: copy / encode streams per device, created once.  The encoders' workspaces are keyed by the stream they run on
+#: (ops._workspace): new streams on every run() would leave two more encoder workspaces (GBs each) in that cache per
+#: evaluation -- torch hands streams out round-robin from a pool of 32.  One run() at a time per device (one Python thread
+#: drives the evaluation: SURVEY.md section 8b).
+_STREAMS: dict = {}
+
+
+def _pipeline_streams(device, n_encode: int):
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    ent = _STREAMS.setdefault(key, {"copy": None, "enc": []})
+    if ent["copy"] is None:
+        ent["copy"] = torch.cuda.Stream(device=dev)
+    while len(ent["enc"]) < n_encode:
+        ent["enc"].append(torch.cuda.Stream(device=dev))
+    return ent["copy"], ent["enc"][:n_encode]
 
 
 def _contiguous_view(parts, count, shape, dtype):
@@ -198,7 +218,7 @@ class EncodePipeline:
                     if img.is_cuda:
                         kind = "device"
                         ev = torch.cuda.Event()
-                        ev.record(torch.cuda.current_stream())   # whatever produced the batch on this thread's stream
+                        ev.record(torch.cuda.current_stream())   # = the default stream in this thread (module docstring: CONTRACT)
                         copy_s.wait_event(ev)
                     else:
                         kind = "host_direct" if (self.stage == "direct" or img.is_pinned()) else "host_pinned"
@@ -280,8 +300,13 @@ class EncodePipeline:
     def run(self, loader: Iterable):
         dev = self.device
         main = torch.cuda.current_stream(dev)
-        copy_s = torch.cuda.Stream(device=dev)
-        enc_s = [torch.cuda.Stream(device=dev) for _ in range(self.n_streams)]
+        copy_s, enc_s = _pipeline_streams(dev, self.n_streams)
+        # a model that builds its device encoder lazily (make_model) does so HERE, on the caller's stream: the weight
+        # preparation kernels are then ordered before every encode stream by the wait_stream(main) below, not only before
+        # the stream that happens to run the first group
+        warm = getattr(self.model, "_get_encoder", None)
+        if callable(warm):
+            warm()
         free_q, ready_q, meta_q = queue.Queue(), queue.Queue(), queue.Queue()
         for _ in range(self.n_slots):
             free_q.put(_Slot(dev))
@@ -351,5 +376,9 @@ class EncodePipeline:
         finally:
             stop.set()
             th.join(timeout=30)
+            if th.is_alive():   # error path only: the stager is blocked in the loader; whatever it still copies lands in
+                import warnings   # slots nobody reads, but the copy stream must drain before their memory is reused
+                warnings.warn("mpreid encode pipeline: the stager thread is still running 30 s after shutdown was requested")
+                copy_s.synchronize()
             for s in enc_s + [copy_s]:
                 main.wait_stream(s)

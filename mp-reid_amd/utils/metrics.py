@@ -62,6 +62,9 @@ def eval_func(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50):
     return all_cmc, mAP
 
 
+_warned_host_ranking = False
+
+
 def _eval_rows_device(dist, q_pids, g_pids, max_rank):
     """Ranking statistics of the query ROWS in `dist` (device tensor [rows, ng] fp32): (cmc hit counts [max_rank] float32
     summed over the valid rows, AP of every valid row in row order (float64), number of valid rows).  Sums of 0/1 values
@@ -88,6 +91,13 @@ def _eval_rows_device(dist, q_pids, g_pids, max_rank):
     pos, cnt = pos.cpu().numpy().astype(np.int64), cnt.cpu().numpy().astype(np.int64)
     over = np.nonzero(cnt < 0)[0]          # queries with more relevant items than the kernel handles: host ranking
     if over.size:
+        global _warned_host_ranking
+        if not _warned_host_ranking:
+            _warned_host_ranking = True
+            import logging
+            logging.getLogger("transreid.test").warning(
+                "eval_func: %d of %d queries have more than %d relevant gallery items; their rows are ranked on the host "
+                "(np.argsort per row, same result)", over.size, num_q, rcap)
         pos = np.concatenate([pos, np.full((num_q, 0), -1, np.int64)], axis=1)
         rows = dist[torch.from_numpy(over).to(dev)].cpu().numpy()
         wide = max(int((g_pids[None, :] == q_pids[over, None]).sum(1).max()), pos.shape[1])
@@ -168,6 +178,9 @@ def _check_finite(feats, collective=False):
     """An encoder whose fp16 operand halves overflowed (|activation| > 65 504 in the 'split' / 'fp16' precision modes:
     include/mpreid.h, mpreid_vit_forward) hands over NaN / inf feature rows; ranking them would print a plausible-looking
     mAP.  Refuse loudly instead (one reduction over [N, D]; compute() synchronises anyway)."""
+    import os
+    if os.environ.get("MPREID_CHECK_FINITE", "1") == "0":   # opt-out: the reference's behaviour (it ranks whatever it is given)
+        return
     bad = int((~torch.isfinite(feats).all(dim=1)).sum()) if feats.numel() else 0
     if collective:   # every rank must take the same branch: a rank that raised alone would leave the others in a collective
         import torch.distributed as tdist
@@ -177,7 +190,8 @@ def _check_finite(feats, collective=False):
     if bad:
         raise RuntimeError(f"R1_mAP_eval.compute(): {bad} feature rows are non-finite -- the encoder's "
                            "fp16 operands overflowed (or the model produced NaN); use MODEL.ENCODER_PRECISION fp32 for "
-                           "this checkpoint / input range")
+                           "this checkpoint / input range (MPREID_CHECK_FINITE=0 restores the reference's behaviour: "
+                           "no check, the rows are ranked as they are)")
 
 
 _d2h_streams = {}
@@ -195,9 +209,13 @@ def _to_host_async(tensors):
         side = _d2h_streams[dev] = torch.cuda.Stream(device=dev)
     side.wait_stream(torch.cuda.current_stream(dev))
     hosts = []
+    import os
+    cap = int(os.environ.get("MPREID_PINNED_CAP_MB", "1024")) << 20
     with torch.cuda.stream(side):
         for t in tensors:
-            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            # page-locked up to the cap (Market-1501's matrix is 214 MB); a multi-GB matrix (MSMT17: 3.8 GB) is not worth
+            # that many locked pages for one copy: pageable memory, staged by the runtime
+            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=t.numel() * t.element_size() <= cap)
             h.copy_(t, non_blocking=True)
             t.record_stream(side)
             hosts.append(h)

@@ -154,3 +154,31 @@ def test_shipped_eval_configs_load():
         assert c.MODEL.NAME in ("ViT-B-16", "RN50") and c.TEST.EVAL is True, f
         assert c.MODEL.ENCODER_PRECISION in ("split", "fp16", "fp32"), f
         assert list(c.INPUT.SIZE_TEST) == [256, 128] and c.TEST.FEAT_NORM == "yes", f
+
+
+def test_ablation_build_is_refused_unless_asked_for(tmp_path):
+    """MPREID_LIB may point at any build; one that says it is a timing-ablation build (-DMPREID_ABLATION: wrong results by
+    design) is refused by mpreid._lib.load() unless MPREID_ALLOW_ABLATION=1, a stale build without the export too; the
+    product library answers 0 and lives alone in mpreid/ (ablation builds go to tools/ablation_lib/)."""
+    import subprocess
+    import sys
+    assert _lib.load().mpreid_is_ablation_build() == 0
+    pkg = os.path.join(ROOT, "mp-reid_amd", "mpreid")
+    assert [f for f in os.listdir(pkg) if f.endswith(".so")] == ["libmpreid_hip.so"]
+    src = tmp_path / "fake.c"
+    src.write_text("int mpreid_is_ablation_build(void) { return 1; }\nint mpreid_version(void) { return 100; }\n")
+    fake = tmp_path / "libfake_abl.so"
+    subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(fake), str(src)], check=True)
+    stale = tmp_path / "libfake_stale.so"
+    (tmp_path / "stale.c").write_text("int mpreid_version(void) { return 100; }\n")
+    subprocess.run(["gcc", "-shared", "-fPIC", "-o", str(stale), str(tmp_path / "stale.c")], check=True)
+    code = ("import sys; sys.path.insert(0, %r)\nfrom mpreid import _lib\ntry:\n    _lib.load()\nexcept RuntimeError as e:\n"
+            "    print('REFUSED', e)\nexcept AttributeError as e:\n    print('LOADED-PAST-GUARD')\n" % os.path.join(ROOT, "mp-reid_amd"))
+    env = {k: v for k, v in os.environ.items() if k != "MPREID_ALLOW_ABLATION"}
+    r = subprocess.run([sys.executable, "-c", code], env=dict(env, MPREID_LIB=str(fake)), capture_output=True, text=True)
+    assert "REFUSED" in r.stdout and "timing-ablation build" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([sys.executable, "-c", code], env=dict(env, MPREID_LIB=str(stale)), capture_output=True, text=True)
+    assert "REFUSED" in r.stdout and "stale build" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([sys.executable, "-c", code], env=dict(env, MPREID_LIB=str(fake), MPREID_ALLOW_ABLATION="1"),
+                       capture_output=True, text=True)
+    assert "LOADED-PAST-GUARD" in r.stdout, r.stdout + r.stderr     # (the fake exports nothing else: the prototypes fail)

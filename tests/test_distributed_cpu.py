@@ -94,7 +94,7 @@ def test_bench_parent_launches_ranks_without_touching_the_gpu():
     if torch.cuda.is_available():
         import pytest
         pytest.skip("CPU-only check of the launcher's failure path (the success path is tests/test_gpu_distributed.py)")
-    env = dict(os.environ)
+    env = dict(os.environ, MPREID_ALLOW_SHARED_GPU="1")   # (without it `--gpus 2` exits 2 up front: tests/test_bench_line.py)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--small", "--steps", "1",

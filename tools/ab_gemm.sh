@@ -5,7 +5,8 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 DBG=${1:-64}
 N=${2:-2}
-ABL=$R/mp-reid_amd/mpreid/libmpreid_hip_abl.so
+ABL=$R/tools/ablation_lib/libmpreid_hip_abl.so
+export MPREID_ALLOW_ABLATION=1   # (mpreid/_lib.py refuses an ablation build without it)
 for i in $(seq 1 $N); do
   echo "== product"; python3 $R/tools/gemm_bench.py --only split --reps 20 --rounds 3
   echo "== ablation lib, MPREID_GEMM_DBG=0"; MPREID_LIB=$ABL MPREID_GEMM_DBG=0 python3 $R/tools/gemm_bench.py --only split --reps 20 --rounds 3

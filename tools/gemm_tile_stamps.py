@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-tile phase timeline of the persistent 256 x 256 GEMM on the stored distance matrix (ablation build only:
-MPREID_ABLATION=1 python mp-reid_amd/mpreid/build.py --force).  Every workgroup stamps the 100 MHz real-time counter
+MPREID_ABLATION=1 python mp-reid_amd/mpreid/build.py -> tools/ablation_lib/libmpreid_hip_abl.so; run with
+MPREID_LIB=tools/ablation_lib/libmpreid_hip_abl.so MPREID_ALLOW_ABLATION=1).  Every workgroup stamps the 100 MHz real-time counter
 after a tile's first barrier (operands of stage 0 landed), after the k-loop and after the epilogue.
 Usage: python tools/gemm_tile_stamps.py [n d]"""
 import os

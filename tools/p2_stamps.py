@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Per-tile phase timeline of the two-workgroups-per-CU symmetric distance kernel (ablation build only:
-MPREID_ABLATION=1 MPREID_BUILD_TAG=abl python mp-reid_amd/mpreid/build.py; MPREID_LIB=.../libmpreid_hip_abl.so).
+MPREID_ABLATION=1 python mp-reid_amd/mpreid/build.py -> tools/ablation_lib/libmpreid_hip_abl.so; run with
+MPREID_LIB=tools/ablation_lib/libmpreid_hip_abl.so MPREID_ALLOW_ABLATION=1).
 Stamps of the 100 MHz counter per workgroup and tile: 0 operands of stage 0 landed, 1 k-loop done, 2 epilogue barrier passed (ring free),
 3 stores issued, 4 stores drained.  Prints the averages and the interleaving of the two workgroups of a few CUs
 (blocks b and b + 256).   Usage: python tools/p2_stamps.py [n d]"""
