@@ -1005,7 +1005,7 @@ def run_rank(a):
                     "achieved": round(alg_tf, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(alg_tf / PEAK_F16_TFLOPS, 4),
                     "avg_launch_ms": top["avg_ms"], "launches": top["launches"],
-                    "algorithmic_flop": int(round(top["gflop_per_launch"] / mult * 1e9)),
+                    "algorithmic_flop": 2 * top["M"] * top["N"] * top["K"],
                     "traffic": traffic,
                     "traffic_source": f"profiles/{traffic_src} (rocprofv3 --pmc, separate FETCH/WRITE passes)" if traffic_src else None,
                     "measured": "hipEvents per launch on the launch stream, " +

@@ -232,6 +232,27 @@ int mpreid_rr_jaccard(int64_t n, int64_t nq, int64_t q_lo, int64_t qrows, const 
                       const uint16_t *qval_all_dev, int qstride, double lambda_value, uint32_t *ccnt_dev,
                       long long *cptr_dev, int32_t *crow_dev, uint16_t *cval_dev, uint32_t *chist_dev, float *out_dev,
                       int64_t ldo, mpreid_stream_t stream);
+/* phase 4 with the inverted-index BUILD sharded by column range over the ranks (utils/reranking.py:80-82 is the build,
+ * :84-93 the Jaccard loop): mpreid_rr_jaccard builds the whole index on every rank; here rank r
+ *   1. mpreid_rr_csc_count: counts the indexed entries (rows [nq, n)) of its columns [c_lo, c_hi) -> ccnt[c_lo .. c_hi);
+ *      chist (mpreid_rr_jaccard_hist_bytes(n) bytes) keeps per-block offsets for step 2          -> ALL-GATHER ccnt [n] u32
+ *   2. mpreid_rr_csc_fill: cptr [n + 1] = exclusive scan of the gathered counts (ccnt_all is consumed), the packed entries of
+ *      its columns at their GLOBAL positions cpk[cptr[c_lo] .. cptr[c_hi]) (cpk: cptr[n] u32 words) and the rows
+ *      [c_lo, c_hi) of the chunk-boundary table hb [n][mpreid_rr_csc_chunks(n, nq) + 1] u32
+ *                                                       -> ALL-GATHER the cpk pieces (contiguous, rank order) and the hb rows
+ *   3. mpreid_rr_jaccard_indexed: Jaccard + blend of the rank's queries over the assembled index.
+ * Needs n * qstride < 2^32.  Bit-identical to mpreid_rr_jaccard for any number of column shards. */
+int mpreid_rr_csc_chunks(int64_t n, int64_t nq);
+int mpreid_rr_csc_count(int64_t n, int64_t nq, const int32_t *qcnt_all_dev, const int32_t *qidx_all_dev, int qstride,
+                        int64_t c_lo, int64_t c_hi, uint32_t *chist_dev, uint32_t *ccnt_dev, mpreid_stream_t stream);
+int mpreid_rr_csc_fill(int64_t n, int64_t nq, const int32_t *qcnt_all_dev, const int32_t *qidx_all_dev,
+                       const uint16_t *qval_all_dev, int qstride, int64_t c_lo, int64_t c_hi, uint32_t *ccnt_all_dev,
+                       uint32_t *chist_dev, long long *cptr_dev, uint32_t *cpk_dev, uint32_t *hb_dev, mpreid_stream_t stream);
+int mpreid_rr_jaccard_indexed(int64_t n, int64_t nq, int64_t q_lo, int64_t qrows, const float *d_q_dev, int64_t ld,
+                              const float *rowmax_q_dev, const int32_t *qcnt_all_dev, const int32_t *qidx_all_dev,
+                              const uint16_t *qval_all_dev, int qstride, double lambda_value, const long long *cptr_dev,
+                              const uint32_t *cpk_dev, const uint32_t *hb_dev, float *out_dev, int64_t ldo,
+                              mpreid_stream_t stream);
 
 /* ---- CLIP ViT-B/16 image encoder, model/clip/model.py:415-479 + model/make_model.py:81-115 -- */
 typedef struct {

@@ -1159,12 +1159,13 @@ constexpr int CSC_B = 256, CSC_CR = 36864;
 static_assert(CSC_B == 256, "the workspace layouts reserve 256 block histograms");
 __global__ __launch_bounds__(1024) void csc2_hist_kernel(int64_t N, const int *__restrict__ qcnt, const int *__restrict__ qidx,
                                                          int qcap, int rows_per_block, unsigned *__restrict__ H,
-                                                         int64_t row_lo) {
+                                                         int64_t row_lo, int64_t col_lo, int64_t col_hi) {
+    // columns [col_lo, col_hi) only (the whole index: 0, N; a rank's column shard of the sharded build: its range)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned *hist = (unsigned *)smem;
     const int b = blockIdx.x;
-    const int64_t c0 = (int64_t)blockIdx.y * CSC_CR;
-    const int cw = (int)((N - c0 < CSC_CR) ? N - c0 : CSC_CR);
+    const int64_t c0 = col_lo + (int64_t)blockIdx.y * CSC_CR;
+    const int cw = (int)((col_hi - c0 < CSC_CR) ? col_hi - c0 : CSC_CR);
     for (int c = threadIdx.x; c < cw; c += 1024) hist[c] = 0u;
     __syncthreads();
     const int64_t r_lo = row_lo + (int64_t)b * rows_per_block, r_hi = (r_lo + rows_per_block < N) ? r_lo + rows_per_block : N;
@@ -1180,9 +1181,10 @@ __global__ __launch_bounds__(1024) void csc2_hist_kernel(int64_t N, const int *_
     for (int c = threadIdx.x; c < cw; c += 1024) H[(int64_t)b * N + c0 + c] = hist[c];
 }
 // per column: H[b][c] <- sum of H[b'][c] over b' < b; ccnt[c] = total
-__global__ __launch_bounds__(256) void csc2_colscan_kernel(int64_t N, unsigned *__restrict__ H, unsigned *__restrict__ ccnt) {
-    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= N) return;
+__global__ __launch_bounds__(256) void csc2_colscan_kernel(int64_t N, unsigned *__restrict__ H, unsigned *__restrict__ ccnt,
+                                                           int64_t col_lo, int64_t col_hi) {
+    const int64_t c = col_lo + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= col_hi) return;
     unsigned run = 0u;
 #pragma unroll 8
     for (int b = 0; b < CSC_B; ++b) {
@@ -1275,9 +1277,10 @@ __global__ __launch_bounds__(256) void scan_apply_kernel(int64_t N, unsigned *__
 // that lies in row chunk k (= row block k * bpc), HB[c][nchunks] = end of the column.  One 8-byte read per (query,
 // chunk, column) from a table of a few MB instead of four scattered reads of cptr and the [256][N] histograms.
 __global__ __launch_bounds__(256) void csc2_bounds_kernel(int64_t N, int nchunks, int bpc, const unsigned *__restrict__ H,
-                                                          const long long *__restrict__ cptr, unsigned *__restrict__ HB) {
-    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= N) return;
+                                                          const long long *__restrict__ cptr, unsigned *__restrict__ HB,
+                                                          int64_t col_lo, int64_t col_hi) {
+    const int64_t c = col_lo + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= col_hi) return;
     const unsigned base = (unsigned)cptr[c];
     for (int k = 0; k < nchunks; ++k) HB[c * (nchunks + 1) + k] = base + H[(int64_t)k * bpc * N + c];
     HB[c * (nchunks + 1) + nchunks] = (unsigned)cptr[c + 1];
@@ -1285,15 +1288,16 @@ __global__ __launch_bounds__(256) void csc2_bounds_kernel(int64_t N, int nchunks
 __global__ __launch_bounds__(1024) void csc2_fill_kernel(int64_t N, const int *__restrict__ qcnt, const int *__restrict__ qidx,
                                                          const uint16_t *__restrict__ qval, int qcap, int rows_per_block,
                                                          const unsigned *__restrict__ H, const long long *__restrict__ cptr,
-                                                         unsigned *__restrict__ cpk, int64_t row_lo, int blocks_per_chunk) {
+                                                         unsigned *__restrict__ cpk, int64_t row_lo, int blocks_per_chunk,
+                                                         int64_t col_lo, int64_t col_hi) {
     // entries are PACKED: (row - first row of the Jaccard chunk the row block belongs to) << 16 | fp16 bits of V_qe
     // (a chunk has at most 24 K rows): 4 bytes per entry in ONE array instead of 4 + 2 in two -- a third fewer bytes
     // and, at large N, ~40 % fewer 128-byte lines per gathered sub-range
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned *cur = (unsigned *)smem;
     const int b = blockIdx.x;
-    const int64_t c0 = (int64_t)blockIdx.y * CSC_CR;
-    const int cw = (int)((N - c0 < CSC_CR) ? N - c0 : CSC_CR);
+    const int64_t c0 = col_lo + (int64_t)blockIdx.y * CSC_CR;
+    const int cw = (int)((col_hi - c0 < CSC_CR) ? col_hi - c0 : CSC_CR);
     for (int c = threadIdx.x; c < cw; c += 1024) cur[c] = (unsigned)cptr[c0 + c] + H[(int64_t)b * N + c0 + c];
     __syncthreads();
     const int64_t r_lo = row_lo + (int64_t)b * rows_per_block, r_hi = (r_lo + rows_per_block < N) ? r_lo + rows_per_block : N;
@@ -2122,8 +2126,9 @@ static int launch_csc(int64_t N, int64_t nq, const int *fcnt, const int *fidx, c
         rc = set_dyn_lds(csc2_fill_kernel, lds);
         if (rc) return rc;
         hipLaunchKernelGGL(csc2_hist_kernel, dim3(CSC_B, nranges), dim3(1024), lds, stream, N, fcnt, fidx, qcap, jp.rpb, chist,
-                           nq);
-        hipLaunchKernelGGL(csc2_colscan_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, N, chist, ccnt);
+                           nq, (int64_t)0, N);
+        hipLaunchKernelGGL(csc2_colscan_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, N, chist, ccnt,
+                           (int64_t)0, N);
         {
             const int nt = (int)((N + 1023) / 1024);
             unsigned long long *tsum = (unsigned long long *)((char *)chist + align_up((size_t)N * (CSC_B + 257) * 4, 8));   // behind the bounds table
@@ -2132,9 +2137,9 @@ static int launch_csc(int64_t N, int64_t nq, const int *fcnt, const int *fidx, c
             hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nt), dim3(256), 0, stream, N, ccnt, tsum, cptr);
         }
         hipLaunchKernelGGL(csc2_fill_kernel, dim3(CSC_B, nranges), dim3(1024), lds, stream, N, fcnt, fidx, fval, qcap, jp.rpb,
-                           chist, cptr, (unsigned *)crow, nq, jp.bpc);   // packed entries live in the crow buffer
+                           chist, cptr, (unsigned *)crow, nq, jp.bpc, (int64_t)0, N);   // packed entries live in the crow buffer
         hipLaunchKernelGGL(csc2_bounds_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, stream, N, jp.nchunks, jp.bpc,
-                           chist, cptr, chist + (size_t)N * CSC_B);
+                           chist, cptr, chist + (size_t)N * CSC_B, (int64_t)0, N);
     } else {
         HIP_TRY(hipMemsetAsync(ccnt, 0, (size_t)(N + 1) * 4, stream));
         hipLaunchKernelGGL(csc_count_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, N, fcnt, fidx, qcap, ccnt, nq);
@@ -2150,7 +2155,8 @@ static int launch_csc(int64_t N, int64_t nq, const int *fcnt, const int *fidx, c
 static int launch_jaccard(int64_t N, int64_t nq, int q0, int64_t qrows, const float *MT, int64_t ld, const float *rowmax,
                           const int *fcnt, const int *fidx, const uint16_t *fval, int qcap, const long long *cptr,
                           const int *crow, const uint16_t *cval, const unsigned *chist, bool blocked, double lambda_value,
-                          float *out, int64_t ldo, unsigned long long *pair_counter, hipStream_t stream) {
+                          float *out, int64_t ldo, unsigned long long *pair_counter, hipStream_t stream,
+                          const unsigned *bounds = nullptr) {   // bounds: the chunk-boundary table when it does not sit behind chist
     const uint16_t oml = f64_to_f16_host(1.0 - lambda_value);
     const float lam32 = (float)lambda_value;
     int rch = (int)std::min<int64_t>(N - nq, 49152);
@@ -2161,7 +2167,7 @@ static int launch_jaccard(int64_t N, int64_t nq, int q0, int64_t qrows, const fl
         const JaccardPlan jp = jaccard_plan(N - nq);
         rpb = jp.rpb; bpc = jp.bpc; nchunks = jp.nchunks; rch = jp.rch;
         threads = jp.wave_form ? 64 : JT;
-        Hp = chist + (size_t)N * CSC_B;   // the chunk-boundary table
+        Hp = bounds ? bounds : chist + (size_t)N * CSC_B;   // the chunk-boundary table
     }
     // timing ablations (wrong results): 1 nothing is accumulated, 4 no output pass, 8 no direct path for long columns.
     // (An ablation that points every gather at ONE address measures an L2 hot spot, not the loop: removed.)
@@ -3246,4 +3252,83 @@ extern "C" int mpreid_rr_jaccard(int64_t n, int64_t nq, int64_t q_lo, int64_t qr
     if (rc) return rc;
     return launch_jaccard(n, nq, (int)q_lo, qrows, d_q, ld, rowmax_q, qcnt_all, qidx_all, qval_all, qstride, cptr, crow, cval,
                           chist, blocked, lambda_value, out, ldo, nullptr, stream);
+}
+
+// ---- column-sharded build of the inverted index (phase 4 of the row-sharded re-ranking on P ranks) -------------------------
+// mpreid_rr_jaccard above builds the WHOLE index on every rank: the one part of the sharded re-ranking that does not shrink
+// as 1/P.  Here rank r builds the columns [c_lo, c_hi) of its column shard only -- the same counting sort (rows cut into the
+// same CSC_B blocks, the same packed entries and chunk-boundary table), restricted to a column window -- and the ranks
+// exchange (1) the column counts [N] u32, (2) their contiguous piece of the packed index, (3) their rows of the boundary
+// table.  Within a column the entries are grouped by row block exactly as in the single build; the order inside a block is
+// LDS-atomic arrival order in both, and the Jaccard sum does not depend on it (every row occurs once per column and owns its
+// accumulator): outputs are bit-identical (tests/test_gpu_rerank.py::test_sharded_sparse_phases_equal_single_call).
+extern "C" int mpreid_rr_csc_chunks(int64_t n, int64_t nq) { return jaccard_plan(n - nq).nchunks; }
+
+// step 1: ccnt[c] = number of indexed entries (rows [nq, n)) of every column c in [c_lo, c_hi); chist (mpreid_rr_jaccard_hist_bytes)
+// keeps the per-block offsets of those columns for step 2
+extern "C" int mpreid_rr_csc_count(int64_t n, int64_t nq, const int32_t *qcnt_all, const int32_t *qidx_all, int qstride,
+                                   int64_t c_lo, int64_t c_hi, uint32_t *chist, uint32_t *ccnt, mpreid_stream_t stream_) {
+    ARG_CHECK(qcnt_all && qidx_all && chist && ccnt && qstride > 0 && 0 <= c_lo && c_lo <= c_hi && c_hi <= n && nq >= 0 && nq <= n);
+    if ((uint64_t)n * (uint64_t)qstride >= (1ull << 32)) {
+        mpreid_set_error("mpreid_rr_csc_count: n * qstride must be below 2^32 (packed positions)");
+        return MPREID_ERR_ARG;
+    }
+    if (c_hi == c_lo) return MPREID_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    const JaccardPlan jp = jaccard_plan(n - nq);
+    const int64_t cols = c_hi - c_lo;
+    const int nranges = (int)((cols + CSC_CR - 1) / CSC_CR);
+    const size_t lds = (size_t)std::min<int64_t>(cols, CSC_CR) * 4;
+    int rc = set_dyn_lds(csc2_hist_kernel, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(csc2_hist_kernel, dim3(CSC_B, nranges), dim3(1024), lds, stream, n, qcnt_all, qidx_all, qstride, jp.rpb,
+                       chist, nq, c_lo, c_hi);
+    hipLaunchKernelGGL(csc2_colscan_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, stream, n, chist, ccnt, c_lo, c_hi);
+    LAUNCH_CHECK();
+    return MPREID_OK;
+}
+
+// step 2 (after the all-gather of the counts): cptr[0 .. n] = exclusive scan of ccnt_all (ccnt_all is zeroed: scratch), then the
+// packed entries of the columns [c_lo, c_hi) at their GLOBAL positions cpk[cptr[c_lo] .. cptr[c_hi]) and the rows [c_lo, c_hi)
+// of the boundary table hb [n][mpreid_rr_csc_chunks + 1].  chist: as left by step 1.
+extern "C" int mpreid_rr_csc_fill(int64_t n, int64_t nq, const int32_t *qcnt_all, const int32_t *qidx_all,
+                                  const uint16_t *qval_all, int qstride, int64_t c_lo, int64_t c_hi, uint32_t *ccnt_all,
+                                  uint32_t *chist, long long *cptr, uint32_t *cpk, uint32_t *hb, mpreid_stream_t stream_) {
+    ARG_CHECK(qcnt_all && qidx_all && qval_all && ccnt_all && chist && cptr && cpk && hb && qstride > 0 && 0 <= c_lo &&
+              c_lo <= c_hi && c_hi <= n);
+    hipStream_t stream = (hipStream_t)stream_;
+    const JaccardPlan jp = jaccard_plan(n - nq);
+    {
+        const int nt = (int)((n + 1023) / 1024);
+        unsigned long long *tsum = (unsigned long long *)((char *)chist + align_up((size_t)n * (CSC_B + 257) * 4, 8));
+        hipLaunchKernelGGL(scan_tile_sums_kernel, dim3((unsigned)nt), dim3(256), 0, stream, n, ccnt_all, tsum);
+        hipLaunchKernelGGL(scan_tile_bases_kernel, dim3(1), dim3(1024), 0, stream, nt, tsum, cptr + n);
+        hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nt), dim3(256), 0, stream, n, ccnt_all, tsum, cptr);
+    }
+    if (c_hi > c_lo) {
+        const int64_t cols = c_hi - c_lo;
+        const int nranges = (int)((cols + CSC_CR - 1) / CSC_CR);
+        const size_t lds = (size_t)std::min<int64_t>(cols, CSC_CR) * 4;
+        int rc = set_dyn_lds(csc2_fill_kernel, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(csc2_fill_kernel, dim3(CSC_B, nranges), dim3(1024), lds, stream, n, qcnt_all, qidx_all, qval_all, qstride,
+                           jp.rpb, chist, cptr, cpk, nq, jp.bpc, c_lo, c_hi);
+        hipLaunchKernelGGL(csc2_bounds_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, stream, n, jp.nchunks, jp.bpc,
+                           chist, cptr, hb, c_lo, c_hi);
+    }
+    LAUNCH_CHECK();
+    return MPREID_OK;
+}
+
+// step 3 (after the all-gathers of the index pieces and of the boundary rows): Jaccard + blend of this rank's queries over the
+// assembled index -- the second half of mpreid_rr_jaccard
+extern "C" int mpreid_rr_jaccard_indexed(int64_t n, int64_t nq, int64_t q_lo, int64_t qrows, const float *d_q, int64_t ld,
+                                         const float *rowmax_q, const int32_t *qcnt_all, const int32_t *qidx_all,
+                                         const uint16_t *qval_all, int qstride, double lambda_value, const long long *cptr,
+                                         const uint32_t *cpk, const uint32_t *hb, float *out, int64_t ldo,
+                                         mpreid_stream_t stream_) {
+    ARG_CHECK(d_q && rowmax_q && qcnt_all && qidx_all && qval_all && cptr && cpk && hb && out && qrows > 0 && q_lo >= 0 &&
+              q_lo + qrows <= nq && ldo >= n - nq);
+    return launch_jaccard(n, nq, (int)q_lo, qrows, d_q, ld, rowmax_q, qcnt_all, qidx_all, qval_all, qstride, cptr,
+                          (const int *)cpk, nullptr, nullptr, true, lambda_value, out, ldo, nullptr, (hipStream_t)stream_, hb);
 }

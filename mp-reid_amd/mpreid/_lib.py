@@ -28,6 +28,7 @@ SYMBOLS = [
     "mpreid_eval_rank_positions", "mpreid_rr_dist_rows", "mpreid_rr_vcap", "mpreid_rr_krecip", "mpreid_rr_krecip_scratch_bytes",
     "mpreid_rr_sparse_workspace_bytes", "mpreid_rr_neighbours_sparse", "mpreid_rr_krecip_sparse", "mpreid_rr_pack_rows", "mpreid_rr_rowptr", "mpreid_rr_ell_to_csr", "mpreid_rr_csr_to_ell", "mpreid_rr_qe_count",
     "mpreid_rr_qe_fill", "mpreid_rr_jaccard", "mpreid_rr_jaccard_hist_bytes",
+    "mpreid_rr_csc_chunks", "mpreid_rr_csc_count", "mpreid_rr_csc_fill", "mpreid_rr_jaccard_indexed",
     "mpreid_vit_workspace_bytes", "mpreid_vit_forward", "mpreid_vit_forward_u8", "mpreid_vit_forward_view",
     "mpreid_vit_workspace_bytes_f32", "mpreid_vit_forward_f32",
     "mpreid_tta_mean_f32", "mpreid_resize_workspace_bytes", "mpreid_resize_bilinear_u8", "mpreid_conv_f16_nhwc",
@@ -215,6 +216,14 @@ def load():
     L.mpreid_rr_jaccard.argtypes = [i64, i64, i64, i64, vp, i64, vp, vp, vp, vp, i32, f64, vp, vp, vp, vp, vp, vp, i64, vp]
     L.mpreid_rr_jaccard_hist_bytes.restype = sz
     L.mpreid_rr_jaccard_hist_bytes.argtypes = [i64]
+    L.mpreid_rr_csc_chunks.restype = i32
+    L.mpreid_rr_csc_chunks.argtypes = [i64, i64]
+    L.mpreid_rr_csc_count.restype = i32
+    L.mpreid_rr_csc_count.argtypes = [i64, i64, vp, vp, i32, i64, i64, vp, vp, vp]
+    L.mpreid_rr_csc_fill.restype = i32
+    L.mpreid_rr_csc_fill.argtypes = [i64, i64, vp, vp, vp, i32, i64, i64, vp, vp, vp, vp, vp, vp]
+    L.mpreid_rr_jaccard_indexed.restype = i32
+    L.mpreid_rr_jaccard_indexed.argtypes = [i64, i64, i64, i64, vp, i64, vp, vp, vp, vp, i32, f64, vp, vp, vp, vp, i64, vp]
     L.mpreid_vit_workspace_bytes.restype = sz
     L.mpreid_vit_workspace_bytes.argtypes = [C.POINTER(VitCfg), i32]
     L.mpreid_vit_forward.restype = i32

@@ -236,8 +236,10 @@ def column_to_row_blocks(block: torch.Tensor, nq: int, ng_sizes: List[int]) -> t
 #            -> ALL-GATHER V (CSR transport: row counts + the nnz entries of 6 bytes, all_gather_sparse_rows)
 #   phase 3  local query expansion of the local rows (skipped when k2 == 1)
 #            -> ALL-GATHER V_qe
-#   phase 4  queries sharded nq/P: distance rows of the local queries over the gallery columns, inverted index of V_qe
-#            (gallery rows), Jaccard + blend
+#   phase 4  queries sharded nq/P: distance rows of the local queries over the gallery columns; inverted index of V_qe
+#            (gallery rows) built BY COLUMN SHARD (round 5: rank r counts and fills the columns shard_range(N, r, P) only)
+#            -> ALL-GATHER column counts [N] u32, the packed index pieces (4 B per entry, contiguous in rank order) and the
+#               rows of the chunk-boundary table; then Jaccard + blend of the local queries over the assembled index
 #            -> each rank owns final_dist[q_lo:q_hi, nq:]; row blocks are concatenated on the host
 #
 # Phases 1-2 have a SPARSE form (default when N >= 2048 and max(k1+1, k2) <= 64): no [N/P][N] distance block per rank --
@@ -378,14 +380,14 @@ class _RerankShard:
                                                     self.lib.stream_ptr()), "mpreid_rr_qe_fill")
         return qcnt, qidx, qval
 
-    def phase4(self, qcnt_all, qidx_all, qval_all):
+    def phase4_rows(self):
+        """exact (or split3) distance rows of this rank's queries over the gallery columns + their row maxima"""
         t, dev = torch, self.dev
         qrows = self.q_hi - self.q_lo
-        ng = self.N - self.nq
-        out = t.empty((qrows, ng), dtype=t.float32, device=dev)
-        if qrows == 0:
-            return out
         self.D = None  # the row block of phase 1 (dense phases) is no longer needed
+        if qrows == 0:
+            self.dq = self.rmq = None
+            return
         dq = t.empty((qrows, self.ld), dtype=t.float32, device=dev)
         if self.rowmax_all is not None:
             # the row maxima travelled with the rank table: only the GALLERY columns of the query rows are needed (the
@@ -400,17 +402,91 @@ class _RerankShard:
             self.lib.check(self.L.mpreid_rr_dist_rows(_rr_ptr(self.feat), _rr_ptr(self.norms), self.N, self.d, self.q_lo,
                                                       qrows, _rr_ptr(dq), self.ld, _rr_ptr(rmq), None, 0,
                                                       self.lib.stream_ptr()), "mpreid_rr_dist_rows")
+        self.dq, self.rmq = dq, rmq
+
+    def phase4(self, qcnt_all, qidx_all, qval_all):
+        """phase 4 with the WHOLE inverted index built on this rank (one rank, or n * stride >= 2^32)"""
+        t, dev = torch, self.dev
+        qrows = self.q_hi - self.q_lo
+        ng = self.N - self.nq
+        out = t.empty((qrows, ng), dtype=t.float32, device=dev)
+        self.phase4_rows()
+        if qrows == 0:
+            return out
         nnz = int(qcnt_all.sum().item())
         ccnt = t.empty(self.N + 1, dtype=t.int32, device=dev)
         cptr = t.empty(self.N + 1, dtype=t.int64, device=dev)
         crow = t.empty(max(nnz, 1), dtype=t.int32, device=dev)
         cval = t.empty(max(nnz, 1), dtype=t.int16, device=dev)
         chist = t.empty(self.L.mpreid_rr_jaccard_hist_bytes(self.N), dtype=t.uint8, device=dev)
-        self.lib.check(self.L.mpreid_rr_jaccard(self.N, self.nq, self.q_lo, qrows, _rr_ptr(dq), self.ld, _rr_ptr(rmq),
+        self.lib.check(self.L.mpreid_rr_jaccard(self.N, self.nq, self.q_lo, qrows, _rr_ptr(self.dq), self.ld, _rr_ptr(self.rmq),
                                                 _rr_ptr(qcnt_all), _rr_ptr(qidx_all), _rr_ptr(qval_all),
                                                 qidx_all.shape[1], float(self.lam), _rr_ptr(ccnt), _rr_ptr(cptr),
                                                 _rr_ptr(crow), _rr_ptr(cval), _rr_ptr(chist), _rr_ptr(out), ng,
                                                 self.lib.stream_ptr()), "mpreid_rr_jaccard")
+        self.dq = self.rmq = None
+        return out
+
+    # -- phase 4 with the index build sharded by column range (include/mpreid.h: mpreid_rr_csc_*) ---------------------------
+    def index_shardable(self, qstride: int) -> bool:
+        return self.N * int(qstride) < (1 << 32)
+
+    def phase4_count(self, qcnt_all, qidx_all, world, rank):
+        """step 1: entries per column of this rank's column shard -> [cols] int32 (u32 bit patterns)"""
+        t, dev = torch, self.dev
+        self.c_lo, self.c_hi = shard_range(self.N, rank, world)
+        self.col_rank = rank
+        self.ccnt = t.zeros(self.N + 1, dtype=t.int32, device=dev)
+        self.chist = t.empty(self.L.mpreid_rr_jaccard_hist_bytes(self.N), dtype=t.uint8, device=dev)
+        self.lib.check(self.L.mpreid_rr_csc_count(self.N, self.nq, _rr_ptr(qcnt_all), _rr_ptr(qidx_all), qidx_all.shape[1],
+                                                  self.c_lo, self.c_hi, _rr_ptr(self.chist), _rr_ptr(self.ccnt),
+                                                  self.lib.stream_ptr()), "mpreid_rr_csc_count")
+        return self.ccnt[self.c_lo:self.c_hi]
+
+    def phase4_fill(self, ccnt_all, qcnt_all, qidx_all, qval_all, world):
+        """step 2: global column pointers, this rank's piece of the packed index (at its global position in a buffer of the
+        whole index's size) and its rows of the boundary table.  Returns (piece [entries] int32, hb rows [cols][nchunks + 1]
+        int32, piece boundaries of all ranks: python list of world + 1 offsets)."""
+        t, dev = torch, self.dev
+        total = int(qcnt_all[self.nq:].sum().item())     # indexed entries = entries of the gallery rows
+        nb1 = self.L.mpreid_rr_csc_chunks(self.N, self.nq) + 1
+        self.cptr = t.empty(self.N + 1, dtype=t.int64, device=dev)
+        self.cpk = t.empty(max(total, 1), dtype=t.int32, device=dev)
+        self.hb = t.empty((self.N, nb1), dtype=t.int32, device=dev)
+        scratch = t.zeros(self.N + 1, dtype=t.int32, device=dev)
+        scratch[:self.N] = ccnt_all                  # (consumed by the scan)
+        self.lib.check(self.L.mpreid_rr_csc_fill(self.N, self.nq, _rr_ptr(qcnt_all), _rr_ptr(qidx_all), _rr_ptr(qval_all),
+                                                 qidx_all.shape[1], self.c_lo, self.c_hi, _rr_ptr(scratch),
+                                                 _rr_ptr(self.chist), _rr_ptr(self.cptr), _rr_ptr(self.cpk), _rr_ptr(self.hb),
+                                                 self.lib.stream_ptr()), "mpreid_rr_csc_fill")
+        self.chist = self.ccnt = None
+        edges = [shard_range(self.N, r, world)[0] for r in range(world)] + [self.N]
+        self.bounds = self.cptr[t.tensor(edges, dtype=t.int64, device=dev)].cpu().tolist()   # the collective's sizes: one sync
+        assert self.bounds[-1] == total, (self.bounds[-1], total)
+        return self.cpk[self.bounds[self.col_rank]:self.bounds[self.col_rank + 1]], self.hb[self.c_lo:self.c_hi]
+
+    def phase4_assemble(self, pieces, hb_all, world):
+        """the gathered pieces (rank order; this rank's own may be None) into the index buffer, the gathered boundary table"""
+        me = self.col_rank
+        for r, piece in enumerate(pieces):
+            if r != me and self.bounds[r + 1] > self.bounds[r]:
+                self.cpk[self.bounds[r]:self.bounds[r + 1]] = piece[:self.bounds[r + 1] - self.bounds[r]]
+        self.hb = hb_all
+
+    def phase4_jaccard(self, qcnt_all, qidx_all, qval_all):
+        """step 3: Jaccard + blend of this rank's queries over the assembled index"""
+        t = torch
+        qrows = self.q_hi - self.q_lo
+        ng = self.N - self.nq
+        out = t.empty((qrows, ng), dtype=t.float32, device=self.dev)
+        if qrows:
+            self.lib.check(self.L.mpreid_rr_jaccard_indexed(self.N, self.nq, self.q_lo, qrows, _rr_ptr(self.dq), self.ld,
+                                                            _rr_ptr(self.rmq), _rr_ptr(qcnt_all), _rr_ptr(qidx_all),
+                                                            _rr_ptr(qval_all), qidx_all.shape[1], float(self.lam),
+                                                            _rr_ptr(self.cptr), _rr_ptr(self.cpk), _rr_ptr(self.hb),
+                                                            _rr_ptr(out), ng, self.lib.stream_ptr()),
+                           "mpreid_rr_jaccard_indexed")
+        self.dq = self.rmq = self.cpk = self.hb = self.cptr = None
         return out
 
 
@@ -493,6 +569,46 @@ def all_gather_sparse_rows(cnt, idx, val, n_total):
     return cnt_all, idx_all, val_all, 4 * n_total + 6 * world * mx
 
 
+def all_gather_ragged(x: torch.Tensor, sizes: List[int]) -> List[torch.Tensor]:
+    """All-gather of 1-D pieces whose lengths `sizes` every rank already knows (the index pieces of phase 4: contiguous
+    column ranges of the packed inverted index).  Padded to the largest piece for the collective; returns per-rank views
+    (rank order) of the gathered buffer."""
+    rank, world = rank_world()
+    assert x.dim() == 1 and len(sizes) == world and x.shape[0] == sizes[rank], (x.shape, sizes, rank)
+    mx = max(max(sizes), 1)
+    timed = comm_stats["timing"] and x.is_cuda
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    pad = torch.zeros(mx, dtype=x.dtype, device=x.device)
+    pad[: x.shape[0]] = x
+    if dist.get_backend() == "gloo" and x.is_cuda:
+        host = [torch.empty(mx, dtype=x.dtype) for _ in range(world)]
+        dist.all_gather(host, pad.cpu())
+        out = torch.cat(host).to(x.device)
+    else:
+        out = torch.empty(world * mx, dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, pad)
+    if timed:
+        e1.record()
+        comm_stats["events"].append((e0, e1))
+    comm_stats["bytes"] += sum(sizes) * x.element_size()
+    comm_stats["calls"] += 1
+    return [out[r * mx: r * mx + sizes[r]] for r in range(world)]
+
+
+_side_streams: dict = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    """one side stream per device, created once (workspaces are keyed by stream: ops._workspace)"""
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=dev)
+    return _side_streams[key]
+
+
 def _rr_prepare(qf, gf):
     from . import ops
     dev = ops._lib.require_gpu()
@@ -529,7 +645,26 @@ def re_ranking_sharded(qf_all, gf_all, k1, k2, lambda_value, algo=0):
         qcap = max(gmax(sh.phase3_count(vc, vi, vv)), 1)
         qc, qi, qv = sh.phase3_fill(qcap)
         vc, vi, vv, _ = all_gather_sparse_rows(qc, qi, qv, N)
-    return sh.phase4(vc, vi, vv)
+    if not sh.index_shardable(vi.shape[1]):
+        return sh.phase4(vc, vi, vv)                  # (n * row stride >= 2^32: every rank builds the whole index)
+    # phase 4: the index build sharded by column range; three all-gathers (counts, packed pieces, boundary rows)
+    # The exact distance rows of the local queries (matrix cores, ~3 ms at N = 100 000 / P = 8) run on a side stream beside
+    # the index build and its three all-gathers (HBM / LDS / xGMI): the Jaccard stage is the first to need both.
+    main = torch.cuda.current_stream(feat.device)
+    side = _side_stream(feat.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        sh.phase4_rows()
+        for t_ in (sh.dq, sh.rmq):
+            if t_ is not None:
+                t_.record_stream(main)     # allocated under the side stream, read (and released) on the main one
+    ccnt_all = all_gather_rows(sh.phase4_count(vc, vi, world, rank).contiguous(), N)
+    piece, hb_rows = sh.phase4_fill(ccnt_all, vc, vi, vv, world)
+    sizes = [sh.bounds[r + 1] - sh.bounds[r] for r in range(world)]
+    pieces = all_gather_ragged(piece.contiguous(), sizes)
+    sh.phase4_assemble(pieces, all_gather_rows(hb_rows.contiguous(), N), world)
+    main.wait_stream(side)
+    return sh.phase4_jaccard(vc, vi, vv)
 
 
 def re_ranking_virtual(qf_all, gf_all, k1, k2, lambda_value, world, algo=0, timings=None):
@@ -579,7 +714,26 @@ def re_ranking_virtual(qf_all, gf_all, k1, k2, lambda_value, world, algo=0, timi
         vc, vi, vv, bq = virtual_gather(fills)
         gathers["V_qe"] = bq
         gathers["V_qe_ell_round2"] = vc.numel() * 4 + vi.numel() * 6
-    out = torch.cat([timed("phase4_jaccard", lambda s=s: s.phase4(vc, vi, vv)) for s in shards], dim=0)
+    if world > 1 and shards[0].index_shardable(vi.shape[1]) and os.environ.get("MPREID_RR_FULL_INDEX") != "1":
+        # column-sharded index build: per virtual rank count -> (gather) -> fill -> (gather) -> Jaccard; the per-rank phase 4
+        # time is the sum of its three steps
+        def step(s, name, fn):
+            return timed(f"phase4_{name}", fn)
+        for s in shards:
+            step(s, "rows", s.phase4_rows)
+        cc = torch.cat([step(s, "index_count", lambda s=s, r=r: s.phase4_count(vc, vi, world, r)) for r, s in enumerate(shards)])
+        filled = [step(s, "index_fill", lambda s=s: s.phase4_fill(cc, vc, vi, vv, world)) for s in shards]
+        hb_all = torch.cat([f[1] for f in filled], dim=0)
+        pieces = [f[0] for f in filled]
+        for s in shards:
+            s.phase4_assemble(pieces, hb_all, world)      # (on the wire: the ragged all-gather of the pieces)
+        out = torch.cat([step(s, "jaccard", lambda s=s: s.phase4_jaccard(vc, vi, vv)) for s in shards], dim=0)
+        gathers["index"] = cc.numel() * 4 + sum(p.numel() for p in pieces) * 4 + hb_all.numel() * 4
+        if timings is not None:   # slowest rank of phase 4 = max over ranks of the sum of its steps
+            keys = ("phase4_rows", "phase4_index_count", "phase4_index_fill", "phase4_jaccard")
+            timings["phase4_jaccard_total"] = [sum(timings[k][r] for k in keys) for r in range(world)]
+    else:
+        out = torch.cat([timed("phase4_jaccard", lambda s=s: s.phase4(vc, vi, vv)) for s in shards], dim=0)
     if timings is not None:
         timings["all_gather_bytes"] = gathers
         timings["sparse_ranks"] = sum(1 for s in shards if s.sparse)

@@ -267,6 +267,33 @@ def test_sharded_sparse_phases_equal_single_call(ops, n, nq, d, k1, k2, world):
     assert torch.equal(sparse, dense)
 
 
+@pytest.mark.parametrize("n,nq,d,k1,k2,world", [(4100, 800, 256, 50, 15, 3), (2500, 300, 100, 20, 6, 8), (1500, 300, 256, 50, 15, 7),
+                                                 (700, 100, 128, 10, 1, 5), (3000, 2999, 64, 30, 40, 5), (2600, 0, 64, 20, 6, 4)])
+def test_column_sharded_index_build_equals_full_build(ops, monkeypatch, n, nq, d, k1, k2, world):
+    """phase 4 of the sharded re-ranking (utils/reranking.py:80-93): the inverted index built by column shard (rank r counts
+    and fills columns shard_range(N, r, P) only: mpreid_rr_csc_count / _fill / mpreid_rr_jaccard_indexed; counts, packed
+    pieces and boundary rows exchanged) == every rank building the whole index (mpreid_rr_jaccard, MPREID_RR_FULL_INDEX=1)
+    == the single call == the oracle, bit for bit; also the assembled index itself: column pointers identical, every column
+    the same multiset of packed entries"""
+    from mpreid import distributed as D, synth
+    if nq == 0:
+        pytest.skip("no queries: nothing to re-rank") if False else None
+    f, _ = synth.clustered_features(n, d, 2.5, seed=n + world, per_id=20)
+    nq_ = max(nq, 1)
+    q, g = torch.from_numpy(f[:nq_]).cuda(), torch.from_numpy(f[nq_:]).cuda()
+    tm = {}
+    sharded = D.re_ranking_virtual(q, g, k1, k2, 0.3, world, timings=tm)
+    assert "phase4_index_fill" in tm and tm["all_gather_bytes"]["index"] > 0          # the sharded build ran
+    monkeypatch.setenv("MPREID_RR_FULL_INDEX", "1")
+    tm2 = {}
+    full = D.re_ranking_virtual(q, g, k1, k2, 0.3, world, timings=tm2)
+    assert "phase4_index_fill" not in tm2
+    assert torch.equal(sharded, full)
+    single, _ = ops.re_ranking(q, g, k1, k2, 0.3)
+    assert torch.equal(sharded, single)
+    assert np.array_equal(sharded.cpu().numpy(), orc.re_ranking(f[:nq_], f[nq_:], k1, k2, 0.3))
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_rerank_small_n_clamped_like_reference(ops, golden, tag):
     """N < k1+1 / N < k2 (the reference's slices clamp): HIP == oracle bit for bit, both within tolerance of the

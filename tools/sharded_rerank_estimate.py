@@ -30,6 +30,15 @@ for algo, name in ((ops.RERANK_SPARSE, "sparse"), (ops.RERANK_SPARSE_SPLIT3, "sp
         out = D.re_ranking_virtual(q, ga, 50, 15, 0.3, w, algo=algo, timings=tm)
         assert torch.equal(out, ref) if algo != ops.RERANK_SPARSE_SPLIT3 else float((out - ref).abs().max()) <= 1e-6
         phases = {k: round(max(v), 2) for k, v in tm.items() if isinstance(v, list)}
+        if "phase4_jaccard_total" in phases:   # column-sharded index build: phase 4 = slowest rank's rows + count + fill + Jaccard
+            sub = {k: phases.pop(k) for k in ("phase4_rows", "phase4_index_count", "phase4_index_fill", "phase4_jaccard")}
+            phases["phase4 (rows + index count + index fill + jaccard)"] = phases.pop("phase4_jaccard_total")
+            phases["phase4_steps_slowest"] = sub
+            total = sum(v for k, v in phases.items() if not isinstance(v, dict))
+            print(f"{name:6s} P={w}: per-phase slowest rank {phases} -> {total:.2f} ms compute; all-gather bytes {tm['all_gather_bytes']}",
+                  flush=True)
+            del out
+            continue
         total = sum(phases.values())
         print(f"{name:6s} P={w}: per-phase slowest rank {phases} -> {total:.2f} ms compute; all-gather bytes {tm['all_gather_bytes']}",
               flush=True)
