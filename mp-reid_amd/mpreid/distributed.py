@@ -10,11 +10,37 @@ result does not depend on the number of ranks.
 """
 from __future__ import annotations
 
+import contextlib
 import os
+import threading
 from typing import List, Tuple
 
 import torch
 import torch.distributed as dist
+
+
+# The collectives go through _pg(): torch.distributed's default process group -- or, in the tests only, an object with the
+# same functions installed for the calling thread by use_group() (tests/emulated_group.py runs P virtual ranks as threads
+# of ONE process on ONE GPU and delivers the collectives by device copies, so that the branches only a multi-rank RCCL run
+# reaches -- ragged all_to_all_single splits, padded gathers, device-tensor all-gathers -- execute with P > 1).
+_tls = threading.local()
+
+
+def _pg():
+    return getattr(_tls, "group", None) or dist
+
+
+@contextlib.contextmanager
+def use_group(group):
+    """route this thread's collectives through `group` (same functions as torch.distributed: get_rank, get_world_size,
+    get_backend, is_initialized, all_gather, all_gather_into_tensor, all_to_all_single, gather, all_reduce,
+    all_gather_object, barrier)"""
+    old = getattr(_tls, "group", None)
+    _tls.group = group
+    try:
+        yield group
+    finally:
+        _tls.group = old
 
 
 def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
@@ -76,19 +102,19 @@ def all_gather_rows(x: torch.Tensor, n_total: int) -> torch.Tensor:
 
 
 def _all_gather_rows(x: torch.Tensor, n_total: int) -> torch.Tensor:
-    world = dist.get_world_size()
+    world = _pg().get_world_size()
     sizes = shard_sizes(n_total, world)
     mx = max(sizes)
-    assert x.shape[0] == sizes[dist.get_rank()], (x.shape, sizes)
+    assert x.shape[0] == sizes[_pg().get_rank()], (x.shape, sizes)
     pad = torch.zeros((mx,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
     pad[: x.shape[0]] = x
-    if dist.get_backend() == "gloo" and x.is_cuda:   # debug backend: stage through the host
+    if _pg().get_backend() == "gloo" and x.is_cuda:   # debug backend: stage through the host
         host = [torch.empty(pad.shape, dtype=pad.dtype) for _ in range(world)]
-        dist.all_gather(host, pad.cpu())
+        _pg().all_gather(host, pad.cpu())
         out = torch.cat(host, dim=0).to(x.device)
     else:
         out = torch.empty((world * mx,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(out, pad)
+        _pg().all_gather_into_tensor(out, pad)
     if all(s == mx for s in sizes):
         return out
     return torch.cat([out[r * mx: r * mx + sizes[r]] for r in range(world)], dim=0)
@@ -96,8 +122,8 @@ def _all_gather_rows(x: torch.Tensor, n_total: int) -> torch.Tensor:
 
 def rank_world() -> Tuple[int, int]:
     """(rank, world) of the default process group; (0, 1) without one"""
-    if dist.is_available() and dist.is_initialized():
-        return dist.get_rank(), dist.get_world_size()
+    if _pg().is_initialized():
+        return _pg().get_rank(), _pg().get_world_size()
     return 0, 1
 
 
@@ -105,9 +131,9 @@ def _single() -> bool:
     """True when the single-process shortcuts apply.  MPREID_DIST_FORCE_COLLECTIVES=1 (tests) sends a ONE-rank process group
     through every collective instead, so that the RCCL branches (device tensors, all_to_all_single, gather, byte views) run
     on one GPU -- RCCL refuses two ranks per device, so this is the only way to execute them without a second GPU."""
-    if not (dist.is_available() and dist.is_initialized()):
+    if not _pg().is_initialized():
         return True
-    return dist.get_world_size() == 1 and os.environ.get("MPREID_DIST_FORCE_COLLECTIVES") != "1"
+    return _pg().get_world_size() == 1 and os.environ.get("MPREID_DIST_FORCE_COLLECTIVES") != "1"
 
 
 def sharded_active() -> bool:
@@ -144,18 +170,18 @@ def _gather_blocks_to_host(block: torch.Tensor, dim: int, dst: int, reuse_buffer
             torch.cuda.current_stream().synchronize()
         return host.numpy() if reuse_buffer else host.numpy().copy()
     other = 1 - dim
-    sz = torch.tensor([block.shape[dim]], dtype=torch.int64, device=block.device if dist.get_backend() != "gloo" else "cpu")
+    sz = torch.tensor([block.shape[dim]], dtype=torch.int64, device=block.device if _pg().get_backend() != "gloo" else "cpu")
     sizes = [torch.empty_like(sz) for _ in range(world)]
-    dist.all_gather(sizes, sz)
+    _pg().all_gather(sizes, sz)
     sizes = [int(t.item()) for t in sizes]
     mx = max(max(sizes), 1)
     shape = list(block.shape)
     shape[dim] = mx
-    staged = dist.get_backend() == "gloo"
+    staged = _pg().get_backend() == "gloo"
     pad = torch.zeros(shape, dtype=block.dtype, device="cpu" if staged else block.device)
     pad.narrow(dim, 0, block.shape[dim]).copy_(block)
     parts = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
-    dist.gather(pad, parts, dst=dst)
+    _pg().gather(pad, parts, dst=dst)
     if rank != dst:
         return None
     return _concat_parts_to_host(parts, sizes, dim, block.shape[other], reuse_buffer)
@@ -203,12 +229,12 @@ def column_to_row_blocks(block: torch.Tensor, nq: int, ng_sizes: List[int]) -> t
     nql = q_sizes[rank]
     ng = sum(ng_sizes)
     out = torch.empty((nql, ng), dtype=block.dtype, device=block.device)
-    if dist.get_backend() == "gloo":   # debug backend (CPU tests, several ranks on one GPU): all-gather, keep own rows
+    if _pg().get_backend() == "gloo":   # debug backend (CPU tests, several ranks on one GPU): all-gather, keep own rows
         mx = max(max(ng_sizes), 1)
         pad = torch.zeros((nq, mx), dtype=block.dtype)
         pad[:, :block.shape[1]] = block.cpu()
         parts = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(parts, pad)
+        _pg().all_gather(parts, pad)
         q_lo, q_hi = shard_range(nq, rank, world)
         lo = 0
         for p, n in zip(parts, ng_sizes):
@@ -217,7 +243,7 @@ def column_to_row_blocks(block: torch.Tensor, nq: int, ng_sizes: List[int]) -> t
         return out
     send = block.contiguous().view(-1)
     recv = torch.empty(nql * ng, dtype=block.dtype, device=block.device)
-    dist.all_to_all_single(recv, send, output_split_sizes=[nql * n for n in ng_sizes],
+    _pg().all_to_all_single(recv, send, output_split_sizes=[nql * n for n in ng_sizes],
                            input_split_sizes=[q * ng_sizes[rank] for q in q_sizes])
     lo = off = 0
     for n in ng_sizes:
@@ -546,10 +572,10 @@ def all_gather_sparse_rows(cnt, idx, val, n_total):
     ranges = [shard_range(n_total, r, world) for r in range(world)]
     if _single():
         return (cnt_all,) + _csr_unpack(lib, L, cnt_all, [(ci, cv)], ranges) + (0,)
-    staged = dist.get_backend() == "gloo"
+    staged = _pg().get_backend() == "gloo"
     sz = torch.tensor([nnz], dtype=torch.int64, device="cpu" if staged else cnt.device)
     sizes = [torch.empty_like(sz) for _ in range(world)]
-    dist.all_gather(sizes, sz)
+    _pg().all_gather(sizes, sz)
     mx = max(max(int(x.item()) for x in sizes), 1)
     payloads = []
     for buf in (ci, cv.view(torch.uint8)):        # (int16 has no collective type: bytes)
@@ -558,11 +584,11 @@ def all_gather_sparse_rows(cnt, idx, val, n_total):
         pad[: nnz * per] = buf[: nnz * per]
         if staged and pad.is_cuda:
             host = [torch.empty(pad.shape, dtype=pad.dtype) for _ in range(world)]
-            dist.all_gather(host, pad.cpu())
+            _pg().all_gather(host, pad.cpu())
             out = torch.cat(host).to(buf.device)
         else:
             out = torch.empty(world * mx * per, dtype=buf.dtype, device=buf.device)
-            dist.all_gather_into_tensor(out, pad)
+            _pg().all_gather_into_tensor(out, pad)
         payloads.append([out[r * mx * per: (r + 1) * mx * per] for r in range(world)])
     pl = [(payloads[0][r], payloads[1][r].view(torch.int16)) for r in range(world)]
     idx_all, val_all = _csr_unpack(lib, L, cnt_all, pl, ranges)
@@ -582,13 +608,13 @@ def all_gather_ragged(x: torch.Tensor, sizes: List[int]) -> List[torch.Tensor]:
         e0.record()
     pad = torch.zeros(mx, dtype=x.dtype, device=x.device)
     pad[: x.shape[0]] = x
-    if dist.get_backend() == "gloo" and x.is_cuda:
+    if _pg().get_backend() == "gloo" and x.is_cuda:
         host = [torch.empty(mx, dtype=x.dtype) for _ in range(world)]
-        dist.all_gather(host, pad.cpu())
+        _pg().all_gather(host, pad.cpu())
         out = torch.cat(host).to(x.device)
     else:
         out = torch.empty(world * mx, dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(out, pad)
+        _pg().all_gather_into_tensor(out, pad)
     if timed:
         e1.record()
         comm_stats["events"].append((e0, e1))
@@ -620,8 +646,8 @@ def re_ranking_sharded(qf_all, gf_all, k1, k2, lambda_value, algo=0):
     """Re-ranking with the rows of the N x N problem sharded over the ranks of the default process group
     (every rank passes the full, all-gathered query and gallery features).  Returns this rank's
     final_dist[q_lo:q_hi, nq:] block on the GPU; use gather_row_blocks_to_host() for the full matrix."""
-    world = dist.get_world_size() if dist.is_initialized() else 1
-    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = _pg().get_world_size() if _pg().is_initialized() else 1
+    rank = _pg().get_rank() if _pg().is_initialized() else 0
     if _single():
         # one GPU: the single call (symmetric distance GEMM: half the tiles) gives the same bits as the phases below
         # (tests/test_gpu_rerank.py::test_sharded_rerank_is_rank_count_independent)
@@ -635,7 +661,7 @@ def re_ranking_sharded(qf_all, gf_all, k1, k2, lambda_value, algo=0):
         if _single():
             return v
         tt = torch.tensor([v], dtype=torch.int64, device=feat.device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        _pg().all_reduce(tt, op=dist.ReduceOp.MAX)
         return int(tt.item())
 
     rank_all, sh.rowmax_all = sh.split_ext(all_gather_rows(sh.phase1_ext(), N), sh.KR)

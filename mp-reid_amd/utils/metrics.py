@@ -144,7 +144,7 @@ def eval_func_sharded(dist_rows, q_pids_local, g_pids, max_rank=50):
     `eval_func`): every rank ranks its own rows [q_lo, q_hi) on its GPU; the hit counts (exact small integers) are
     summed and the per-query AP lists are concatenated in rank = query order, so every rank ends up with the cmc / mAP
     of the unsharded call BIT FOR BIT (integer sums; np.mean over the same float64 list in the same order)."""
-    import torch.distributed as tdist
+    import torch.distributed  # noqa: F401  (ReduceOp)
     from mpreid import distributed as D
     rank, world = D.rank_world()
     num_g = dist_rows.shape[1]
@@ -154,18 +154,18 @@ def eval_func_sharded(dist_rows, q_pids_local, g_pids, max_rank=50):
             print("Note: number of gallery samples is quite small, got {}".format(num_g))
     hits, ap, num_valid = _eval_rows_device(dist_rows, q_pids_local, g_pids, max_rank)
     if D.sharded_active():
-        staged = tdist.get_backend() == "gloo"
+        staged = D._pg().get_backend() == "gloo"
         dev = "cpu" if staged else dist_rows.device
         # one small all-gather: [hit counts (max_rank) | number of valid rows | AP of the valid rows, NaN padded]
         cap = torch.tensor([ap.size], dtype=torch.int64, device=dev)
-        tdist.all_reduce(cap, op=tdist.ReduceOp.MAX)
+        D._pg().all_reduce(cap, op=torch.distributed.ReduceOp.MAX)
         cap = int(cap.item())
         msg = np.full(max_rank + 1 + cap, np.nan, np.float64)
         msg[:max_rank] = hits
         msg[max_rank] = num_valid
         msg[max_rank + 1: max_rank + 1 + ap.size] = ap
         parts = [torch.empty(msg.size, dtype=torch.float64, device=dev) for _ in range(world)]
-        tdist.all_gather(parts, torch.from_numpy(msg).to(dev))
+        D._pg().all_gather(parts, torch.from_numpy(msg).to(dev))
         parts = [p.cpu().numpy() for p in parts]
         hits = np.sum([p[:max_rank] for p in parts], axis=0).astype(np.float32)   # exact: integers < 2^24
         num_valid = int(sum(p[max_rank] for p in parts))
@@ -183,9 +183,9 @@ def _check_finite(feats, collective=False):
         return
     bad = int((~torch.isfinite(feats).all(dim=1)).sum()) if feats.numel() else 0
     if collective:   # every rank must take the same branch: a rank that raised alone would leave the others in a collective
-        import torch.distributed as tdist
-        t = torch.tensor([bad], dtype=torch.int64, device="cpu" if tdist.get_backend() == "gloo" else feats.device)
-        tdist.all_reduce(t)
+        from mpreid import distributed as D
+        t = torch.tensor([bad], dtype=torch.int64, device="cpu" if D._pg().get_backend() == "gloo" else feats.device)
+        D._pg().all_reduce(t)
         bad = int(t.item())
     if bad:
         raise RuntimeError(f"R1_mAP_eval.compute(): {bad} feature rows are non-finite -- the encoder's "
@@ -292,7 +292,7 @@ class R1_mAP_eval():
         own query rows (eval_func_sharded); the blocks concatenated on the host of rank 0.  No floating-point reduction
         crosses ranks: rank 0 returns the 7-tuple of the single-process compute() byte for byte; the other ranks get the
         same cmc / mAP / pids / camids / qf, None for distmat and their own gallery shard for gf."""
-        import torch.distributed as tdist
+        import torch.distributed  # noqa: F401  (ReduceOp)
         from mpreid import distributed as D
         rank, world = D.rank_world()
         dev = _ops._lib.require_gpu()
@@ -302,8 +302,8 @@ class R1_mAP_eval():
         n_local = sum(f.shape[0] for f in self.feats)
         assert n_local >= nql, f"rank {rank}: {n_local} samples but {nql} of them must be its query shard"
         dim = torch.tensor([self.feats[0].shape[1] if self.feats else 0], dtype=torch.int64,
-                           device="cpu" if tdist.get_backend() == "gloo" else dev)
-        tdist.all_reduce(dim, op=tdist.ReduceOp.MAX)
+                           device="cpu" if D._pg().get_backend() == "gloo" else dev)
+        D._pg().all_reduce(dim, op=torch.distributed.ReduceOp.MAX)
         feats = torch.cat(self.feats, dim=0) if self.feats else torch.empty((0, int(dim.item())), device=dev)
         _check_finite(feats, collective=True)
         if self.feat_norm:
@@ -311,7 +311,7 @@ class R1_mAP_eval():
                 print("The test feature is normalized")
             feats = _ops.l2_normalize(feats)
         meta = [None] * world     # labels (python ints): metadata, not the data path
-        tdist.all_gather_object(meta, ([int(p) for p in self.pids], [int(c) for c in self.camids], n_local - nql))
+        D._pg().all_gather_object(meta, ([int(p) for p in self.pids], [int(c) for c in self.camids], n_local - nql))
         ng_sizes = [m[2] for m in meta]
         ng = sum(ng_sizes)
         assert ng_sizes == D.shard_sizes(ng, world), (
