@@ -72,6 +72,35 @@ __device__ __forceinline__ void tile_coords(unsigned id, int tiles_m, int tiles_
     tn = (int)(in_group / (unsigned)gsize);
 }
 
+// fp16 PAIR split of the `split` precision modes, x = hi + lo with hi = fp16(x), lo = fp16(x - float(hi)), two values at a
+// time in THREE instructions: v_cvt_pk_f16_f32 (both hi), then v_fma_mixlo_f16 / v_fma_mixhi_f16 computing fma(hi, -1, x)
+// from the packed hi halves and rounding it once into the low / high half of the packed lo.  x - hi is exact in fp32, so the
+// single rounding gives the bits of the plain form (tools/probes/mix_probe.hip: 2^25 pairs incl. 14 M subnormal lo, 0
+// mismatches); hipcc compiles the plain form to 6.5 instructions per two values (separate conversions back to fp32, subtract,
+// convert, pack) and folds fma(hi, -1, x) back into a subtraction, hence the inline assembly.
+typedef _Float16 mp_h2_t __attribute__((ext_vector_type(2)));
+typedef float mp_f2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair2(float x0, float x1, mp_h2_t &hi, mp_h2_t &lo) {
+    hi = __builtin_convertvector(mp_f2_t{x0, x1}, mp_h2_t);
+    const unsigned hb = __builtin_bit_cast(unsigned, hi);
+    unsigned d;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hb), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(hb), "v"(x1));
+    lo = __builtin_bit_cast(mp_h2_t, d);
+}
+// N values (N even) -> vectors of N halves (any ext_vector_type of _Float16 with N elements)
+template <int N, typename HV>
+__device__ __forceinline__ void split_pairs(const float (&x)[N], HV &hi, HV &lo) {
+    static_assert(N % 2 == 0, "pairs");
+#pragma unroll
+    for (int j = 0; j < N; j += 2) {
+        mp_h2_t h, l;
+        split_pair2(x[j], x[j + 1], h, l);
+        hi[j] = h[0]; hi[j + 1] = h[1];
+        lo[j] = l[0]; lo[j + 1] = l[1];
+    }
+}
+
 __device__ __forceinline__ float wave_bfly_add(float s) {
     // fixed butterfly 32,16,8,4,2,1 — the order the oracle mirrors (oracle/mpreid_oracle.c sqnorm_row)
 #pragma unroll

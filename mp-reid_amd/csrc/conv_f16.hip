@@ -228,13 +228,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs g, int tiles
                 if (g.out_pairs) {   // the consumer is a pair GEMM: its operand directly (ReLU applied), no fp32 round trip
                     if (m < g.M && n < g.pair_c) {
                         f16x8 hi, lo;
+                        float yv[8];
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            float y = fmaf(v[e], g.oscale, bias[e]);
-                            y = (n + e < g.N && y > 0.f) ? y : 0.f;
-                            hi[e] = (_Float16)y;
-                            lo[e] = (_Float16)(y - (float)hi[e]);
+                            const float y = fmaf(v[e], g.oscale, bias[e]);
+                            yv[e] = (n + e < g.N && y > 0.f) ? y : 0.f;
                         }
+                        split_pairs<8>(yv, hi, lo);
                         _Float16 *o = g.out_pairs + (int64_t)m * 2 * g.pair_c + n;
                         *reinterpret_cast<f16x8 *>(o) = hi;
                         *reinterpret_cast<f16x8 *>(o + g.pair_c) = lo;

@@ -265,8 +265,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
                         } else {
                             v = f32x2{h[0] < 0.f ? 0.f : h[0], h[1] < 0.f ? 0.f : h[1]};               // relu
                         }
-                        const f16x2 hi = __builtin_convertvector(v, f16x2);
-                        const f16x2 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x2), f16x2);
+                        f16x2 hi, lo;
+                        split_pair2(v[0], v[1], hi, lo);
                         wreg[(i * 16 + fq * 4 + rp) * 72 + j * 16 + frow] = part == 0 ? hi[0] : lo[0];
                         wreg[(i * 16 + fq * 4 + rp + 1) * 72 + j * 16 + frow] = part == 0 ? hi[1] : lo[1];
                     }
@@ -367,11 +367,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs g, int tiles_
                 if constexpr (EPI == GE_S_BIAS_RES_PAIR) {   // relu(x) as the pair operand of the next block's first convolution
                     typedef _Float16 h4p __attribute__((ext_vector_type(4)));
                     h4p hi, lo;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float y = o[e] < 0.f ? 0.f : o[e];
-                        hi[e] = (_Float16)y;
-                        lo[e] = (_Float16)(y - (float)hi[e]);
+                    {
+                        const float y[4] = {o[0] < 0.f ? 0.f : o[0], o[1] < 0.f ? 0.f : o[1], o[2] < 0.f ? 0.f : o[2],
+                                            o[3] < 0.f ? 0.f : o[3]};
+                        split_pairs<4>(y, hi, lo);
                     }
                     _Float16 *po = g.pair_out + m * 2 * g.pair_c + nbase + c4;
                     *reinterpret_cast<h4p *>(po) = hi;
@@ -1194,8 +1193,8 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
                     } else {
                         v = f32x2{h[0] < 0.f ? 0.f : h[0], h[1] < 0.f ? 0.f : h[1]};               // relu
                     }
-                    const f16x2 hi = __builtin_convertvector(v, f16x2);
-                    const f16x2 lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x2), f16x2);
+                    f16x2 hi, lo;
+                    split_pair2(v[0], v[1], hi, lo);   // (common.h: v_cvt_pk_f16_f32 + two v_fma_mix*_f16, same bits)
                     whi[(fq * 4 + rp) * 72 + j * 16 + frow] = hi[0];
                     whi[(fq * 4 + rp + 1) * 72 + j * 16 + frow] = hi[1];
                     wlo[(fq * 4 + rp) * 72 + j * 16 + frow] = lo[0];
@@ -1361,11 +1360,10 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
                 if constexpr (EPI == GE_S_BIAS_RES_PAIR) {   // relu(x) as fp16 pairs: 8 bytes of hi and of lo per lane
                     typedef _Float16 h4p __attribute__((ext_vector_type(4)));
                     h4p hi, lo;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float y = o[e] < 0.f ? 0.f : o[e];
-                        hi[e] = (_Float16)y;
-                        lo[e] = (_Float16)(y - (float)hi[e]);
+                    {
+                        const float y[4] = {o[0] < 0.f ? 0.f : o[0], o[1] < 0.f ? 0.f : o[1], o[2] < 0.f ? 0.f : o[2],
+                                            o[3] < 0.f ? 0.f : o[3]};
+                        split_pairs<4>(y, hi, lo);
                     }
                     const uint64_t pb = reinterpret_cast<uint64_t>(g.pair_out) +
                                         (uint64_t)(((int64_t)(cur_m0 + wr * 128 + i * 16 + it * 4) * 2 * g.pair_c + nbase) * 2);

@@ -444,11 +444,7 @@ __global__ __launch_bounds__(256) void pack_pairs_kernel(const float *__restrict
     }
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     h4 hi, lo;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        hi[e] = (_Float16)v[e];
-        lo[e] = (_Float16)(v[e] - (float)hi[e]);
-    }
+    split_pairs<4>(v, hi, lo);
     _Float16 *o = out + r * 2 * kseg + k4 * 4;
     *reinterpret_cast<h4 *>(o) = hi;
     *reinterpret_cast<h4 *>(o + kseg) = lo;

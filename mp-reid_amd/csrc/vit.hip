@@ -33,11 +33,7 @@ typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
 template <bool SPLIT>
 __device__ __forceinline__ void store_patch_row(_Float16 *__restrict__ out, int64_t m, int Kp, int ch, const float (&v)[8]) {
     h8_t hi, lo;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        hi[j] = (_Float16)v[j];
-        lo[j] = (_Float16)(v[j] - (float)hi[j]);
-    }
+    split_pairs<8>(v, hi, lo);
     if constexpr (SPLIT) {
         *reinterpret_cast<h8_t *>(out + m * 2 * Kp + ch * 8) = hi;
         *reinterpret_cast<h8_t *>(out + m * 2 * Kp + Kp + ch * 8) = lo;
@@ -189,9 +185,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
             *reinterpret_cast<h4 *>(reinterpret_cast<_Float16 *>(out) + row * (int64_t)W + k) = o;
         } else if (MODE == 2) {
             typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-            const h4 hi = {(_Float16)y.x, (_Float16)y.y, (_Float16)y.z, (_Float16)y.w};
-            const h4 lo = {(_Float16)(y.x - (float)hi[0]), (_Float16)(y.y - (float)hi[1]), (_Float16)(y.z - (float)hi[2]),
-                           (_Float16)(y.w - (float)hi[3])};
+            h4 hi, lo;
+            {
+                const float yv[4] = {y.x, y.y, y.z, y.w};
+                split_pairs<4>(yv, hi, lo);
+            }
             _Float16 *orow = reinterpret_cast<_Float16 *>(out) + row * 2 * (int64_t)W;
             *reinterpret_cast<h4 *>(orow + k) = hi;
             *reinterpret_cast<h4 *>(orow + W + k) = lo;
@@ -282,7 +280,13 @@ typedef __attribute__((address_space(3))) att_s4 att_lds_s4;
 template <int KTP, int NW, bool EXACT>
 __global__ __launch_bounds__(64 * NW, (NW == 8 && KTP <= 10) ? 4 : 2) void attention_kernel(const _Float16 *__restrict__ qkv, int L, int W, int heads,
                                                                _Float16 *__restrict__ out, int q_tiles,
-                                                               int total_pairs, int dbg) {
+                                                               int total_pairs, int dbg_) {
+#ifdef MPREID_ABLATION
+    const int dbg = dbg_;
+#else
+    constexpr int dbg = 0;   // (see attention_split_kernel)
+    (void)dbg_;
+#endif
     constexpr int KEYS = KTP * 16;
     constexpr int NT = 64 * NW;
     constexpr int K_ITERS = (KEYS * 8 + NT - 1) / NT;
@@ -453,21 +457,35 @@ __device__ __forceinline__ float4 load_nt_f4(const float *p) {
     const att_f4 v = __builtin_nontemporal_load(reinterpret_cast<const att_f4 *>(p));
     return make_float4(v[0], v[1], v[2], v[3]);
 }
+typedef unsigned att_u4 __attribute__((ext_vector_type(4)));
+// 16 bytes through a buffer descriptor: base in scalar registers, 32-bit lane offset, scalar offset (both in bytes); nt
+template <typename RS>
+__device__ __forceinline__ float4 buffer_load_nt_f4(const RS &rs, unsigned voff, int soff) {
+    const att_f4 v = __builtin_bit_cast(att_f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, soff, 2));
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
 __device__ __forceinline__ void split4(const float4 &v, h4_t &hi, h4_t &lo) {
-    hi = h4_t{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-    lo = h4_t{(_Float16)(v.x - (float)hi[0]), (_Float16)(v.y - (float)hi[1]), (_Float16)(v.z - (float)hi[2]),
-              (_Float16)(v.w - (float)hi[3])};
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    split_pairs<4>(x, hi, lo);   // (common.h: three instructions per two values)
 }
 #define ATS_FOR_EACH_ITER(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
-#define ATS_DECL(i) float4 k##i = make_float4(0.f, 0.f, 0.f, 0.f), v##i = k##i;
-// thread -> (row, 16-byte chunk of 4 floats), 16 lanes per 256-byte row; rows past L clamped (see the fp16 kernel)
-#define ATS_LOAD(i)                                                                                  \
+#define ATS_DECL(i) float4 k##i = make_float4(0.f, 0.f, 0.f, 0.f), v##i = k##i; unsigned koff##i = 0u;
+// thread -> (row, 16-byte chunk of 4 floats), 16 lanes per 256-byte row; rows past L clamped (see the fp16 kernel).
+// The byte offset of a thread's chunk inside an (image, head) slab does not depend on the pair: computed ONCE (ATS_OFFS, a
+// 32-bit register per iteration) and every load is a BUFFER load: descriptor of the image's q | k | v slab (scalar registers,
+// rebuilt per pair from uniform values), 32-bit lane offset, scalar offset of the head's K / V columns -- no vector ALU work per
+// load (the 64-bit per-lane address arithmetic of plain global loads cost three v_lshl_add_u64 each).
+#define ATS_OFFS(i)                                                                                  \
     if constexpr (K_ITERS > i) {                                                                     \
         const int idx_ = tid + i * NT;                                                               \
         const int row_ = idx_ >> 4, c_ = idx_ & 15;                                                  \
         const int rc_ = row_ < L ? row_ : L - 1;                                                     \
-        k##i = load_nt_f4(pbase_ + (int64_t)rc_ * ld + W + c_ * 4);                                  \
-        v##i = load_nt_f4(pbase_ + (int64_t)rc_ * ld + 2 * W + c_ * 4);                              \
+        koff##i = (unsigned)(rc_ * (int)ld + c_ * 4) * 4u;                                           \
+    }
+#define ATS_LOAD(i)                                                                                  \
+    if constexpr (K_ITERS > i) {                                                                     \
+        k##i = buffer_load_nt_f4(prs_, koff##i, pso_);                                               \
+        v##i = buffer_load_nt_f4(prs_, koff##i, pso_ + W * 4);                                       \
     }
 #define ATS_STORE(i)                                                                                 \
     if constexpr (K_ITERS > i) {                                                                     \
@@ -488,7 +506,9 @@ __device__ __forceinline__ void split4(const float4 &v, h4_t &hi, h4_t &lo) {
 #define ATS_PREFETCH(pr)                                                                             \
     {                                                                                                \
         const int pb_ = (pr) / heads, ph_ = (pr) - pb_ * heads;                                      \
-        const float *pbase_ = qkv + (int64_t)pb_ * L * ld + ph_ * 64;                                \
+        const auto prs_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(qkv + (int64_t)pb_ * L * ld), 0,   \
+                                                             (int)(L * (int)ld * 4), 0x00020000);   \
+        const int pso_ = (ph_ * 64 + W) * 4;                                                         \
         ATS_FOR_EACH_ITER(ATS_LOAD)                                                                  \
     }
 
@@ -501,7 +521,17 @@ __device__ __forceinline__ void split4(const float4 &v, h4_t &hi, h4_t &lo) {
 template <int KTP, int NW, bool XKEY>
 __global__ __launch_bounds__(64 * NW, (NW >= 8 || XKEY) ? 2 : 1) void attention_split_kernel(const float *__restrict__ qkv, int L, int W,
                                                                                    int heads, _Float16 *__restrict__ out,
-                                                                                   int q_tiles, int total_pairs, int dbg) {
+                                                                                   int q_tiles, int total_pairs, int dbg_) {
+    // The timing-ablation switches are compile-time zero in the product build: as a run-time argument `dbg & 32` kept
+    // every key tile's score chain behind its own branch (eight basic blocks, each one strictly serial chain of six
+    // dependent matrix instructions with the full issue-to-result latency between them) -- with the flag gone the eight
+    // independent chains are one block and interleave.
+#ifdef MPREID_ABLATION
+    const int dbg = dbg_;
+#else
+    constexpr int dbg = 0;
+    (void)dbg_;
+#endif
     constexpr int KEYS = KTP * 16;
     constexpr int NT = 64 * NW;
     constexpr int K_ITERS = (KEYS * 16 + NT - 1) / NT;
@@ -518,6 +548,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8 || XKEY) ? 2 : 1) void attention_
     const float scale_log2e = 0.125f * 1.44269504088896340736f;
 
     ATS_FOR_EACH_ITER(ATS_DECL)
+    ATS_FOR_EACH_ITER(ATS_OFFS)
 
     float4 xrow = make_float4(0.f, 0.f, 0.f, 0.f);   // XKEY: lanes 0-15 of wave 0 hold the K row of token L-1, lanes 16-31 its V row
     auto x_request = [&](int pr) {
@@ -584,11 +615,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8 || XKEY) ? 2 : 1) void attention_
             for (int ks = 0; ks < 2; ++ks) {
                 const float4 a0 = qraw[2 * ks], a1 = qraw[2 * ks + 1];
                 const float qv[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    qh[ks][e] = (_Float16)qv[e];
-                    ql[ks][e] = (_Float16)(qv[e] - (float)qh[ks][e]);
-                }
+                split_pairs<8>(qv, qh[ks], ql[ks]);
             }
             float sx = 0.f;   // XKEY: q . k of the extra key (token L-1), fp32, for this lane's query column
             if constexpr (XKEY) {
@@ -657,12 +684,10 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8 || XKEY) ? 2 : 1) void attention_
 #pragma unroll
             for (int s2 = 0; s2 < ((dbg & 8) ? 0 : KTP / 2); ++s2) {
                 f16x8 ph, pl;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    ph[j] = (_Float16)s[2 * s2][j];
-                    pl[j] = (_Float16)(s[2 * s2][j] - (float)ph[j]);
-                    ph[4 + j] = (_Float16)s[2 * s2 + 1][j];
-                    pl[4 + j] = (_Float16)(s[2 * s2 + 1][j] - (float)ph[4 + j]);
+                {
+                    const float pv[8] = {s[2 * s2][0], s[2 * s2][1], s[2 * s2][2], s[2 * s2][3],
+                                         s[2 * s2 + 1][0], s[2 * s2 + 1][1], s[2 * s2 + 1][2], s[2 * s2 + 1][3]};
+                    split_pairs<8>(pv, ph, pl);
                 }
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
@@ -698,19 +723,17 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8 || XKEY) ? 2 : 1) void attention_
             if (!(dbg & 16)) {   // O^T -> fp16 pair, through the wave's LDS patch as whole 128-byte rows: hi part, then lo part
                 const float inv = 1.0f / sum;
                 _Float16 *ot = Ot + wave * (16 * OS);
+                h4_t ohi[4], olo[4];   // both halves once (split_pairs: three instructions per two values)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const float ovf[4] = {o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv};
+                    split_pairs<4>(ovf, ohi[dt], olo[dt]);
+                }
 #pragma unroll
                 for (int part = 0; part < 2; ++part) {
 #pragma unroll
-                    for (int dt = 0; dt < 4; ++dt) {
-                        h4_t ov;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float v = o[dt][r] * inv;
-                            const _Float16 hi = (_Float16)v;
-                            ov[r] = part == 0 ? hi : (_Float16)(v - (float)hi);
-                        }
-                        *reinterpret_cast<h4_t *>(ot + fr * OS + dt * 16 + fq * 4) = ov;
-                    }
+                    for (int dt = 0; dt < 4; ++dt)
+                        *reinterpret_cast<h4_t *>(ot + fr * OS + dt * 16 + fq * 4) = part == 0 ? ohi[dt] : olo[dt];
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -733,11 +756,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8 || XKEY) ? 2 : 1) void attention_
                 for (int ks = 0; ks < 2; ++ks) {
                     const float4 a0 = qraw[2 * ks], a1 = qraw[2 * ks + 1];
                     const float qv[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        qh[ks][e] = (_Float16)qv[e];
-                        ql[ks][e] = (_Float16)(qv[e] - (float)qh[ks][e]);
-                    }
+                    split_pairs<8>(qv, qh[ks], ql[ks]);
                 }
                 f32x4 s2t[2];
 #pragma unroll
@@ -791,12 +810,9 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8 || XKEY) ? 2 : 1) void attention_
                 for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
                 {
                     f16x8 ph, pl;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        ph[j] = (_Float16)s2t[0][j];
-                        pl[j] = (_Float16)(s2t[0][j] - (float)ph[j]);
-                        ph[4 + j] = (_Float16)s2t[1][j];
-                        pl[4 + j] = (_Float16)(s2t[1][j] - (float)ph[4 + j]);
+                    {
+                        const float pv[8] = {s2t[0][0], s2t[0][1], s2t[0][2], s2t[0][3], s2t[1][0], s2t[1][1], s2t[1][2], s2t[1][3]};
+                        split_pairs<8>(pv, ph, pl);
                     }
 #pragma unroll
                     for (int dt = 0; dt < 4; ++dt) {
