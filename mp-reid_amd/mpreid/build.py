@@ -11,14 +11,17 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-CSRC = os.path.join(os.path.dirname(HERE), "csrc")
+# MPREID_CSRC=<dir>: build another source tree (e.g. the previous round's kernels checked out to a scratch directory, for a
+# same-device A/B through MPREID_LIB); needs MPREID_BUILD_TAG so that the product library is never overwritten
+CSRC = os.environ.get("MPREID_CSRC") or os.path.join(os.path.dirname(HERE), "csrc")
+assert not os.environ.get("MPREID_CSRC") or os.environ.get("MPREID_BUILD_TAG"), "MPREID_CSRC needs MPREID_BUILD_TAG"
 # MPREID_BUILD_TAG=<tag>: a second build beside the product one (objects under csrc/_obj_<tag>/) -- e.g. the
 # timing-ablation library for a same-device A/B through MPREID_LIB.  Tagged libraries are written to tools/ablation_lib/
 # (git-ignored; travels with gpurun), never next to the product library in mpreid/.
 _TAG = os.environ.get("MPREID_BUILD_TAG", "")
 if os.environ.get("MPREID_ABLATION") and not _TAG:
     _TAG = "abl"          # an ablation build never overwrites the product library
-OBJ = os.path.join(CSRC, "_obj" + ("_" + _TAG if _TAG else ""))
+OBJ = os.path.join(os.path.join(os.path.dirname(HERE), "csrc"), "_obj" + ("_" + _TAG if _TAG else ""))
 _REPO = os.path.dirname(os.path.dirname(HERE))
 LIB = (os.path.join(_REPO, "tools", "ablation_lib", "libmpreid_hip_" + _TAG + ".so") if _TAG
        else os.path.join(HERE, "libmpreid_hip.so"))

@@ -129,12 +129,20 @@ def synthetic_images(n: int, h: int, w: int, seed: int = 1234):
     return np.clip(x, -1.0, 1.0)
 
 
-def identity_images(n_ids: int, per_id: int, beta: float, h: int = 256, w: int = 128, seed: int = 5):
+def identity_images(n_ids: int, per_id: int, beta: float, h: int = 256, w: int = 128, seed: int = 5, grid=None):
     """Synthetic re-id images with identity structure: one random template per identity, every image is
     ``clip((1 - beta) * template + beta * noise, -1, 1)``, shuffled.  Returns (fp32 NCHW images, pid int64).
-    With the seeded random-init ViT-B/16, beta ~ 0.55-0.6 gives a Euclidean mAP well inside (0.3, 0.9)."""
+    With the seeded random-init ViT-B/16, beta ~ 0.55-0.6 gives a Euclidean mAP well inside (0.3, 0.9).
+    grid=(gh, gw): LOW-FREQUENCY templates -- a gh x gw grid of uniform random colours, each cell h/gh x w/gw pixels -- for a
+    convolutional tower, whose pooled features cannot tell two white-noise templates apart (default: white-noise templates)."""
     rng = np.random.default_rng(seed)
-    tmpl = np.clip(rng.standard_normal((n_ids, 3, h, w)).astype(np.float32), -1.0, 1.0)
+    if grid is None:
+        tmpl = np.clip(rng.standard_normal((n_ids, 3, h, w)).astype(np.float32), -1.0, 1.0)
+    else:
+        gh, gw = grid
+        assert h % gh == 0 and w % gw == 0, (h, w, grid)
+        cells = rng.uniform(-1.0, 1.0, (n_ids, 3, gh, gw)).astype(np.float32)
+        tmpl = np.repeat(np.repeat(cells, h // gh, axis=2), w // gw, axis=3)
     pid = np.repeat(np.arange(n_ids, dtype=np.int64), per_id)
     x = np.empty((n_ids * per_id, 3, h, w), np.float32)
     for i, p in enumerate(pid):   # one image at a time: the noise tensor of 2048 images would be 800 MB

@@ -157,6 +157,38 @@ def gen_rerank():
     save("r1_map_eval.npz", **e2e)
 
 
+def gen_r1_map_eval_edge():
+    """R1_mAP_eval's quirks as the reference itself behaves (utils/metrics.py:91-134): `feat_norm` is used as a TRUTH VALUE
+    (:112) -- the shipped config passes the string 'yes' (config/defaults_base.py:178), so 'no' normalises too and only a
+    falsy value ('' / 0 / False) does not; `max_rank` is stored (:95) but never forwarded to eval_func (:132), so
+    max_rank=10 still returns 50 ranks."""
+    seed = int(np.load(os.path.join(HERE, "rerank.npz"))["seed"])
+    N, nq, D = 480, 96, 256
+    raw, pid = synth.clustered_features(N, D, sigma=2.2, seed=seed, per_id=8, normalize=False)
+    cam = synth.labels_for(N)
+    out = {"seed": seed, "nq": nq}
+    cases = {"fn_empty": dict(feat_norm='', reranking=False), "fn_no": dict(feat_norm='no', reranking=False),
+             "fn_zero_rr": dict(feat_norm=0, reranking=True), "max_rank_10": dict(max_rank=10, feat_norm='yes', reranking=False),
+             "max_rank_10_rr": dict(max_rank=10, feat_norm='yes', reranking=True)}
+    for tag, kw in cases.items():
+        ev = ref_metrics.R1_mAP_eval(nq, **kw)
+        ev.reset()
+        for s in range(0, N, 64):
+            ev.update((torch.from_numpy(raw[s:s + 64]), tuple(int(x) for x in pid[s:s + 64]), tuple(int(x) for x in cam[s:s + 64])))
+        cmc, mAP, distmat, pids, camids, qf, gf = quiet(ev.compute)
+        out[f"cmc_{tag}"] = cmc
+        out[f"mAP_{tag}"] = np.float64(mAP)
+        # the matrices equal those of the four plain cases already committed (r1_map_eval.npz), bit for bit: store which
+        twin = {"fn_empty": "rr0_fn0", "fn_no": "rr0_fn1", "fn_zero_rr": "rr1_fn0", "max_rank_10": "rr0_fn1", "max_rank_10_rr": "rr1_fn1"}[tag]
+        base = np.load(os.path.join(HERE, "r1_map_eval.npz"))
+        assert np.array_equal(distmat.astype(np.float32), base[f"distmat_{twin}"]), tag
+        assert np.array_equal(cmc, base[f"cmc_{twin}"]) and float(mAP) == float(base[f"mAP_{twin}"]), tag
+        out[f"twin_{tag}"] = np.array(twin)
+        out[f"qf_rownorm_{tag}"] = np.linalg.norm(np.asarray(qf), axis=1).astype(np.float32)   # 1.0 iff the features were normalised
+        print(tag, "cmc len", len(cmc), "mAP", float(mAP), "|qf| in", float(out[f"qf_rownorm_{tag}"].min()), float(out[f"qf_rownorm_{tag}"].max()))
+    save("r1_map_eval_edge.npz", **out)
+
+
 def gen_rerank_small():
     """N smaller than k1+1 / k2: numpy slicing clamps the neighbour lists and np.mean divides by the clamped
     row count (utils/reranking.py:53-54,60-62,76) - behaviour the build has to follow, pinned here."""
@@ -439,6 +471,8 @@ if __name__ == "__main__":
         gen_distance()
     if "rerank" in which:
         gen_rerank()
+    if "r1_edge" in which:
+        gen_r1_map_eval_edge()
     if "rerank_small" in which:
         gen_rerank_small()
     if "rerank_seeds" in which:

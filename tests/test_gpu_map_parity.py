@@ -113,6 +113,42 @@ def test_image_to_map_parity(data, name, rerank):
         assert rel <= 1e-3 and dmap <= 1e-3 and dr1 <= 2.0 / nq + 1e-9, res["fp16"]
 
 
+def test_image_to_map_parity_4096_images():
+    """the spread geometry at four times the size (512 ids x 8 = 4096 images, 819 queries; round 4 ran this once as
+    tools/map_parity_large.py, round 5 asserts it): split (the default, measured mode) and fp32 within north_star's 1e-4 on
+    mAP and Rank-1 -- not one of 819 queries -- with and without re-ranking (k1 50, k2 15, lambda 0.3), features within 2e-5.
+    The oracle encode of 4096 images takes ~3 minutes on the GPU box's host cores: the suite's longest test."""
+    from mpreid import ops, synth
+    n_ids, per_id, beta, std = 512, 8, 0.4, 0.05
+    torch.set_num_threads(min(torch.get_num_threads(), 32))
+    x, pid = synth.identity_images(n_ids, per_id, beta)
+    sd = synth.vit_state_dict(synth.VIT_B16, seed=7, std=std)
+    n = len(pid)
+    nq = n // 5
+    f_or = np.concatenate([orc.vit_features(sd, synth.VIT_B16, x[s:s + 64]) for s in range(0, n, 64)])
+    fo = orc.l2_normalize(f_or)
+    ref = {}
+    for rr in (False, True):
+        d = orc.re_ranking(fo[:nq], fo[nq:], 50, 15, 0.3) if rr else orc.euclidean_distance(fo[:nq], fo[nq:])
+        ref[rr] = orc.eval_func(d, pid[:nq], pid[nq:])
+        assert 0.1 < ref[rr][1] < 0.9
+    out = []
+    for prec in ("split", "fp32", "fp16"):
+        enc = ops.VitEncoder(synth.VIT_B16, sd, (256, 128), precision=prec)
+        f = torch.empty((n, enc.feat_dim), device="cuda")
+        for s in range(0, n, 508):
+            enc(torch.from_numpy(x[s:s + 508]), out=f[s:s + 508])
+        rel = float(np.linalg.norm(f.cpu().numpy() - f_or) / np.linalg.norm(f_or))
+        for rr in (False, True):
+            cmc, mAP = _evaluate(ops, f, pid, nq, rr)
+            dmap, dr1 = abs(mAP - ref[rr][1]), abs(float(cmc[0]) - float(ref[rr][0][0]))
+            out.append(f"{prec} rerank={rr}: rel-L2 {rel:.2e} |dmAP| {dmap:.2e} |dR1| {dr1:.2e} ({round(dr1 * nq)} of {nq})")
+            if prec != "fp16":
+                assert rel <= 2e-5 and dmap <= 1e-4 and dr1 <= 1e-4, (prec, rr, rel, dmap, dr1)
+        del enc
+    print("image->mAP parity, 4096 images: oracle mAP %.4f / re-ranked %.4f | " % (ref[False][1], ref[True][1]) + " | ".join(out))
+
+
 def test_fp32_encoder_small_config_and_options(golden):
     """the fp32 mode against the reference's own outputs (tests/golden/vit.npz): reduced config, camera embedding,
     stride 12 (L = 211), at fp32 accuracy"""

@@ -208,6 +208,36 @@ def test_r1_map_eval_vs_reference(golden):
                 assert dd.max() < 1e-5, (tag, dd.max())
 
 
+def test_r1_map_eval_quirks_vs_reference(golden):
+    """the reference's R1_mAP_eval quirks, pinned by a run of the reference itself (tests/golden/r1_map_eval_edge.npz,
+    make_goldens.py:gen_r1_map_eval_edge): `feat_norm` is a truth value (utils/metrics.py:112: '' does not normalise, 'no'
+    does), `max_rank` is stored but not forwarded (:95, :132: max_rank=10 still returns 50 ranks)"""
+    from utils.metrics import R1_mAP_eval
+    g, base = golden("r1_map_eval_edge.npz"), golden("r1_map_eval.npz")
+    nq = int(g["nq"])
+    raw, pid, cam = base["raw"], base["pid"], base["cam"]
+    cases = {"fn_empty": dict(feat_norm='', reranking=False), "fn_no": dict(feat_norm='no', reranking=False),
+             "fn_zero_rr": dict(feat_norm=0, reranking=True), "max_rank_10": dict(max_rank=10, feat_norm='yes', reranking=False),
+             "max_rank_10_rr": dict(max_rank=10, feat_norm='yes', reranking=True)}
+    for tag, kw in cases.items():
+        ev = R1_mAP_eval(nq, **kw)
+        ev.reset()
+        for s in range(0, raw.shape[0], 64):
+            ev.update((torch.from_numpy(raw[s:s + 64]).cuda(), tuple(int(x) for x in pid[s:s + 64]),
+                       tuple(int(x) for x in cam[s:s + 64])))
+        cmc, mAP, distmat, pids, camids, qf, gf = ev.compute()
+        assert len(cmc) == 50 and cmc.dtype == np.float32, tag                       # never `max_rank` ranks
+        assert abs(mAP - float(g[f"mAP_{tag}"])) < 1e-4 and np.abs(cmc - g[f"cmc_{tag}"]).max() < 1e-4, tag
+        rn = np.linalg.norm(qf.numpy(), axis=1)
+        assert np.abs(rn - g[f"qf_rownorm_{tag}"]).max() <= 1e-4 * float(g[f"qf_rownorm_{tag}"].max()), tag   # normalised iff truthy
+        want = base[f"distmat_{str(g[f'twin_{tag}'])}"]
+        dd = np.abs(distmat - want) / max(1.0, float(np.abs(want).max()))
+        if kw["reranking"]:
+            assert (dd > 1e-5).mean() <= RR_FRAC and dd.max() <= (7.5e-4 if tag == "fn_zero_rr" else RR_MAX), (tag, dd.max())
+        else:
+            assert dd.max() < 1e-5, (tag, dd.max())
+
+
 def test_rerank_market_scale_properties(ops):
     """N = 19 281 (Market-1501 shape): size-independent properties instead of the oracle.
     lambda = 1 reduces the result to the normalised original distance; results do not depend on

@@ -246,3 +246,21 @@ def test_rerank_unselected_seeds_vs_reference(golden, row):
     got2 = orc.re_ranking(feat[:nq], feat[nq:], k1, k2, lam, local_distmat=d_or, only_local=True)
     assert np.array_equal(got2.reshape(-1)[idx], g[f"{tag}_sameD_val"]), tag
     assert hashlib.sha256(np.ascontiguousarray(got2).tobytes()).hexdigest() == str(g[f"{tag}_sameD_sha"]), tag
+
+
+def test_r1_map_eval_quirks_fixture(golden):
+    """tests/golden/r1_map_eval_edge.npz (the reference run with a falsy / 'no' feat_norm and with max_rank=10,
+    utils/metrics.py:95,112,132): the oracle pipeline follows the same rules -- normalise iff feat_norm is truthy, always
+    50 ranks"""
+    g, base = golden("r1_map_eval_edge.npz"), golden("r1_map_eval.npz")
+    nq = int(g["nq"])
+    raw, pid = base["raw"], base["pid"]
+    for tag, (truthy, rr) in {"fn_empty": (False, 0), "fn_no": (True, 0), "fn_zero_rr": (False, 1), "max_rank_10": (True, 0),
+                              "max_rank_10_rr": (True, 1)}.items():
+        assert str(g[f"twin_{tag}"]) == f"rr{rr}_fn{int(truthy)}"
+        assert len(g[f"cmc_{tag}"]) == 50
+        assert (abs(float(g[f"qf_rownorm_{tag}"].max()) - 1.0) < 1e-5) == truthy
+        f = orc.l2_normalize(raw) if truthy else raw
+        d = orc.re_ranking(f[:nq], f[nq:], 50, 15, 0.3) if rr else orc.euclidean_distance(f[:nq], f[nq:])
+        cmc, mAP = orc.eval_func(d, pid[:nq], pid[nq:])
+        assert abs(mAP - float(g[f"mAP_{tag}"])) < 1e-4 and np.abs(cmc - g[f"cmc_{tag}"]).max() < 1e-4, tag
