@@ -271,41 +271,59 @@ def test_rn50_image_to_map_parity_spread_set():
     trained network's BatchNorm layers hold); (2) all 2048 pooled post-ReLU channels are positive for every image -- the last
     block's channels are made selective (its bn3 bias lowered so that a channel's pre-activation sits one standard deviation
     below zero on average) and the projected part is centred.  Low-frequency identity templates (8 x 4 colour grids: pooled
-    convolutional features cannot tell white-noise templates apart).  Result: normalised distances 0.1 ... 1.2, median ~0.3,
-    the spread of a trained re-id model.  Asserted for the split (default) and the fp32 tower, with and without re-ranking:
-    features <= 2e-5 relative L2, |dmAP| <= 1e-4, |dRank-1| <= 1e-4 (not one query).  Reference: model/clip/model.py:10-148,
-    model/make_model.py:82-86, utils/metrics.py:28-88."""
+    convolutional features cannot tell white-noise templates apart).  Result: 1024 images, normalised distances 0.1 ... 1.2,
+    median ~0.3 -- the spread of a trained re-id model -- Euclidean mAP 0.60, re-ranked 0.69.
+
+    Asserted for the split (default) and the fp32 tower: features <= 2e-5 relative L2; WITHOUT re-ranking |dmAP| <= 1e-4 and
+    |dRank-1| <= 1e-4 against the fp32 oracle (measured <= 6e-7, no query).  WITH re-ranking (k1 20, k2 6) the fp32 ORACLE is
+    its own noise source on this set: the same graph evaluated in float64 (features 4.3e-6 away, oracle.rn50_features(dtype=
+    'float64')) moves the re-ranked mAP by 3.5e-4 -- one k-reciprocal membership flipping -- so the 1e-4 is asserted against
+    that exact-arithmetic answer (measured: split 3.8e-5, fp32 tower 8.4e-5, no query's Rank-1; reproducible, the float64 graph
+    does not depend on the host's BLAS path) and the distance to the fp32 oracle is held to the noise envelope of a random
+    feature error of the modes' size, capped at 5e-4 as in tests/test_gpu_map_parity.py (measured 3.9e-4 / 2.6e-4 against an
+    envelope of 2.8e-4).  Reference: model/clip/model.py:10-148, model/make_model.py:82-86, utils/metrics.py:28-88."""
+    from conftest import map_noise_envelope
     from mpreid import ops, synth
-    n_ids, per_id = 128, 4
+    n_ids, per_id = 128, 8
     x, pid = synth.identity_images(n_ids, per_id, 0.5, grid=(8, 4))
     torch.set_num_threads(min(torch.get_num_threads(), 32))
     sd = orc.rn50_calibrate_bn(synth.rn50_state_dict(synth.RN50, seed=11), synth.RN50, x[:64], selective=1.0)
-    f_or = np.concatenate([orc.rn50_features(sd, synth.RN50, x[s:s + 32]) for s in range(0, len(pid), 32)])
     n = len(pid)
     nq = n // 4
-    fo = orc.l2_normalize(f_or)
+    f_or = np.concatenate([orc.rn50_features(sd, synth.RN50, x[s:s + 32]) for s in range(0, n, 32)])
+    f_64 = np.concatenate([orc.rn50_features(sd, synth.RN50, x[s:s + 32], dtype="float64") for s in range(0, n, 32)])
+    fo, fo64 = orc.l2_normalize(f_or), orc.l2_normalize(f_64.astype(np.float32))
     d_plain = orc.euclidean_distance(fo[:nq], fo[nq:])
     med = float(np.median(d_plain))
     assert 0.1 < med < 1.0, med          # the spread geometry (the degenerate set: 0.007)
+    ref = {False: orc.eval_func(d_plain, pid[:nq], pid[nq:]),
+           True: orc.eval_func(orc.re_ranking(fo[:nq], fo[nq:], 20, 6, 0.3), pid[:nq], pid[nq:]),
+           "rr64": orc.eval_func(orc.re_ranking(fo64[:nq], fo64[nq:], 20, 6, 0.3), pid[:nq], pid[nq:])}
+    assert 0.15 < ref[False][1] < 0.97 and 0.15 < ref[True][1] < 0.97
     res = {}
     for prec in ("split", "fp32", "fp16"):
         enc = ops.Rn50Encoder(synth.RN50, sd, (256, 128), precision=prec)
         f = torch.cat([enc(torch.from_numpy(x[s:s + 256])) for s in range(0, n, 256)])
-        res[prec] = [float(np.linalg.norm(f.cpu().numpy() - f_or) / np.linalg.norm(f_or))]
+        rel = float(np.linalg.norm(f.cpu().numpy() - f_or) / np.linalg.norm(f_or))
         fn = ops.l2_normalize(f)
-        for rerank in (False, True):
-            d_or = orc.re_ranking(fo[:nq], fo[nq:], 20, 6, 0.3) if rerank else d_plain
-            cmc_o, map_o = orc.eval_func(d_or, pid[:nq], pid[nq:])
-            assert 0.15 < map_o < 0.97, map_o
-            d = ops.re_ranking(fn[:nq], fn[nq:], 20, 6, 0.3)[0] if rerank else ops.euclidean_distance(fn[:nq], fn[nq:])
-            cmc, mAP = orc.eval_func(d.cpu().numpy(), pid[:nq], pid[nq:])
-            res[prec] += [map_o, abs(mAP - map_o), abs(float(cmc[0]) - float(cmc_o[0]))]
+        cmc_e, map_e = orc.eval_func(ops.euclidean_distance(fn[:nq], fn[nq:]).cpu().numpy(), pid[:nq], pid[nq:])
+        cmc_r, map_r = orc.eval_func(ops.re_ranking(fn[:nq], fn[nq:], 20, 6, 0.3)[0].cpu().numpy(), pid[:nq], pid[nq:])
+        res[prec] = dict(rel=rel, e_dmap=abs(map_e - ref[False][1]), e_dr1=abs(float(cmc_e[0]) - float(ref[False][0][0])),
+                         r_dmap=abs(map_r - ref[True][1]), r_dr1=abs(float(cmc_r[0]) - float(ref[True][0][0])),
+                         r64_dmap=abs(map_r - ref["rr64"][1]), r64_dr1=abs(float(cmc_r[0]) - float(ref["rr64"][0][0])))
         del enc
-    print("rn50 image->mAP [spread]: median distance %.4f | " % med +
-          " | ".join(f"{k}: feat rel-L2 {v[0]:.2e}; euclid mAP {v[1]:.4f} dmAP {v[2]:.2e} dR1 {v[3]:.2e}; "
-                     f"rerank mAP {v[4]:.4f} dmAP {v[5]:.2e} dR1 {v[6]:.2e}" for k, v in res.items()))
+    rel_max = max(res["split"]["rel"], res["fp32"]["rel"])
+    env = map_noise_envelope(orc, f_or, rel_max, pid, nq, True, 20, 6, seeds=4)
+    bound_rr = min(5e-4, 1e-4 + 2.0 * env[0])
+    print("rn50 image->mAP [spread, %d images]: median distance %.4f, oracle mAP %.4f / re-ranked %.4f (float64 graph %.4f: %.1e away), "
+          "re-ranked noise envelope %.2e -> bound %.2e | " % (n, med, ref[False][1], ref[True][1], ref["rr64"][1],
+                                                             abs(ref[True][1] - ref["rr64"][1]), env[0], bound_rr) +
+          " | ".join(f"{k}: " + " ".join(f"{a} {b:.2e}" for a, b in v.items()) for k, v in res.items()))
     for prec in ("split", "fp32"):
         r = res[prec]
-        assert r[0] <= 2e-5 and r[2] <= 1e-4 and r[5] <= 1e-4 and r[3] <= 1e-4 and r[6] <= 1e-4, (prec, r)
+        assert r["rel"] <= 2e-5, (prec, r)
+        assert r["e_dmap"] <= 1e-4 and r["e_dr1"] <= 1e-4, (prec, r)                  # north_star, plain
+        assert r["r64_dmap"] <= 1e-4 and r["r64_dr1"] <= 1e-4, (prec, r)             # re-ranked: against exact arithmetic
+        assert r["r_dmap"] <= bound_rr and r["r_dr1"] <= 1.0 / nq + 2.0 * env[1] + 1e-9, (prec, r, env)
     r = res["fp16"]
-    assert r[0] <= 1e-2 and max(r[2], r[5]) <= 5e-2, r     # (reported: what fp16 activations support)
+    assert r["rel"] <= 1e-2 and max(r["e_dmap"], r["r_dmap"]) <= 5e-2, r     # (reported: what fp16 activations support)
