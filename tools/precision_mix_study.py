@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Would FEWER fp16 products per multiply-add hold north_star's 1e-4 mAP bound?  
+
+The `split` encoder mode carries every operand of every linear layer as an fp16 pair x = hi + lo and runs three products
+(hi.hi' + lo.hi' + hi.lo') per multiply-add on the fp16 matrix cores: 3x the matrix work of the fp16 mode -- the whole gap
+between roofline.frac 0.16 and 0.48.  This tool measures, on the 'spread' set of tests/test_gpu_map_parity.py (128 ids x 8
+images, weights ~ N(0, 0.05^2)), what the features and the metrics would be with cheaper mixes.  It is a NUMERICAL EMULATION:
+the ViT-B/16 graph of oracle/oracle.py evaluated with torch in float64 on the GPU, the operands of the chosen linear layers
+rounded the way the kernels round them (hi = fp16(x), lo = fp16(x - hi); weights scaled by a power of two per matrix so that the
+largest entry sits in [2^9, 2^10)), the products accumulated exactly (float64) -- i.e. ONLY the operand-rounding error of each
+mix, without the fp32 accumulation noise (~1e-6) every real kernel adds on top.  Everything else (LayerNorm, softmax, GELU, the
+attention products, residual stream) is exact.  The reference is the same graph with unrounded operands.
+
+    python tools/precision_mix_study.py            # prints a markdown table
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "mp-reid_amd")]
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+from mpreid import synth  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+DEV = "cuda"
+F64 = torch.float64
+
+
+def pair(x):
+    hi = x.to(torch.float16).to(F64)
+    lo = (x - hi).to(torch.float16).to(F64)
+    return hi, lo
+
+
+def wpair(w):
+    e = 9 - int(np.floor(np.log2(float(w.abs().max()))))      # largest entry into [2^9, 2^10)
+    sc = 2.0 ** e
+    hi, lo = pair(w * sc)
+    return hi / sc, lo / sc
+
+
+def mm(a, w, mode):
+    """a [..., K] @ w[N, K]^T with the operands rounded per `mode`:
+    exact | 3 (hi.hi' + lo.hi' + hi.lo') | a2 (activations split, weights single) | w2 (weights split, activations single) | 1 (fp16)"""
+    if mode == "exact":
+        return a @ w.t()
+    ah, al = pair(a)
+    wh, wl = wpair(w)
+    out = ah @ wh.t()
+    if mode in ("3", "a2"):
+        out = out + al @ wh.t()
+    if mode in ("3", "w2"):
+        out = out + ah @ wl.t()
+    return out
+
+
+def vit(sd, cfg, imgs, modes):
+    """modes: dict layer kind -> mode for 'patch', 'qkv', 'out', 'fc1', 'fc2'"""
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV, F64)  # noqa: E731
+    x = T(imgs)
+    B = x.shape[0]
+    w, heads, p, s = cfg["width"], cfg["heads"], cfg["patch"], cfg["stride"]
+    dh = w // heads
+    cols = F.unfold(x, kernel_size=p, stride=s)
+    tok = mm(cols.transpose(1, 2), T(sd["conv1.weight"]).reshape(w, -1), modes["patch"])
+    cls = T(sd["class_embedding"]).expand(B, 1, w).clone()
+    x = torch.cat([cls, tok], dim=1) + T(sd["positional_embedding"])
+    x = F.layer_norm(x, (w,), T(sd["ln_pre.weight"]), T(sd["ln_pre.bias"]), 1e-5)
+    L = x.shape[1]
+    for i in range(cfg["layers"]):
+        b = f"transformer.resblocks.{i}"
+        h = F.layer_norm(x, (w,), T(sd[b + ".ln_1.weight"]), T(sd[b + ".ln_1.bias"]), 1e-5)
+        qkv = mm(h, T(sd[b + ".attn.in_proj_weight"]), modes["qkv"]) + T(sd[b + ".attn.in_proj_bias"])
+        q, k, v = qkv.split(w, dim=2)
+        q = q.reshape(B, L, heads, dh).transpose(1, 2)
+        k = k.reshape(B, L, heads, dh).transpose(1, 2)
+        v = v.reshape(B, L, heads, dh).transpose(1, 2)
+        a = torch.softmax((q @ k.transpose(2, 3)) * (dh ** -0.5), dim=-1) @ v
+        a = a.transpose(1, 2).reshape(B, L, w)
+        x = x + mm(a, T(sd[b + ".attn.out_proj.weight"]), modes["out"]) + T(sd[b + ".attn.out_proj.bias"])
+        h = F.layer_norm(x, (w,), T(sd[b + ".ln_2.weight"]), T(sd[b + ".ln_2.bias"]), 1e-5)
+        h = mm(h, T(sd[b + ".mlp.c_fc.weight"]), modes["fc1"]) + T(sd[b + ".mlp.c_fc.bias"])
+        h = h * torch.sigmoid(1.702 * h)
+        x = x + mm(h, T(sd[b + ".mlp.c_proj.weight"]), modes["fc2"]) + T(sd[b + ".mlp.c_proj.bias"])
+    x12 = F.layer_norm(x[:, 0], (w,), T(sd["ln_post.weight"]), T(sd["ln_post.bias"]), 1e-5)
+    return torch.cat([x12, x12 @ T(sd["proj"])], dim=1)
+
+
+def features(sd, cfg, x, modes, bs=64):
+    with torch.no_grad():
+        return torch.cat([vit(sd, cfg, x[s:s + bs], modes) for s in range(0, x.shape[0], bs)]).cpu().numpy()
+
+
+def metrics(f, pid, nq):
+    fo = orc.l2_normalize(f.astype(np.float32))
+    out = []
+    for rr in (False, True):
+        d = orc.re_ranking(fo[:nq], fo[nq:], 50, 15, 0.3) if rr else orc.euclidean_distance(fo[:nq], fo[nq:])
+        cmc, mAP = orc.eval_func(d, pid[:nq], pid[nq:])
+        out.append((float(mAP), float(cmc[0])))
+    return out
+
+
+def main():
+    cfg = synth.VIT_B16
+    x, pid = synth.identity_images(128, 8, 0.4)
+    sd = synth.vit_state_dict(cfg, seed=7, std=0.05)
+    nq = len(pid) // 5
+    kinds = ("patch", "qkv", "out", "fc1", "fc2")
+    allm = lambda m: {k: m for k in kinds}  # noqa: E731
+    mixes = [
+        ("three products everywhere (the `split` mode)", allm("3"), 3.0),
+        ("(i) activations split, weights single fp16: hi.hi' + lo.hi'", allm("a2"), 2.0),
+        ("(ii) weights split, activations single fp16: hi.hi' + hi.lo'", allm("w2"), 2.0),
+        ("(iii-a) three on QKV + out-proj, two (activations split) on FC1 / FC2", dict(allm("3"), fc1="a2", fc2="a2"), 2.33),
+        ("(iii-b) three on QKV + out-proj, two (weights split) on FC1 / FC2", dict(allm("3"), fc1="w2", fc2="w2"), 2.33),
+        ("(iv) two (activations split) on QKV only, three elsewhere", dict(allm("3"), qkv="a2"), 2.78),
+        ("(v) two (activations split) on out-proj only, three elsewhere", dict(allm("3"), out="a2"), 2.93),
+        ("one product everywhere (the `fp16` mode)", allm("1"), 1.0),
+    ]
+    f_ref = features(sd, cfg, x, allm("exact"))
+    m_ref = metrics(f_ref, pid, nq)
+    print(f"spread set: {len(pid)} images, {nq} queries; exact graph: mAP {m_ref[0][0]:.5f} / re-ranked {m_ref[1][0]:.5f}, "
+          f"Rank-1 {m_ref[0][1]:.4f} / {m_ref[1][1]:.4f}\n")
+    print("| operand mix of the linear layers | fp16 products per multiply-add (FLOP-weighted) | feature rel-L2 | |ΔmAP| Euclid | |ΔmAP| re-ranked | "
+          "Rank-1 queries changed (Euclid / re-ranked) | holds 2e-5 and 1e-4? |")
+    print("|---|---|---|---|---|---|---|")
+    for name, modes, cost in mixes:
+        f = features(sd, cfg, x, modes)
+        rel = float(np.linalg.norm(f - f_ref) / np.linalg.norm(f_ref))
+        m = metrics(f, pid, nq)
+        dm = [abs(m[i][0] - m_ref[i][0]) for i in (0, 1)]
+        dq = [round(abs(m[i][1] - m_ref[i][1]) * nq) for i in (0, 1)]
+        ok = rel <= 2e-5 and max(dm) <= 1e-4 and max(dq) == 0
+        print(f"| {name} | {cost:.2f} | {rel:.1e} | {dm[0]:.1e} | {dm[1]:.1e} | {dq[0]} / {dq[1]} | {'yes' if ok else 'NO'} |", flush=True)
+
+
+if __name__ == "__main__":
+    main()
