@@ -545,7 +545,7 @@ def extras(ops, dev, with_widened=True):
     del img508
     torch.cuda.empty_cache()
     # widened rows: the RN50 tower, the Pillow-exact Resize, the PCIe-inclusive encoder
-    enc = ops.Rn50Encoder(synth.RN50, synth.rn50_state_dict(synth.RN50, seed=11), (256, 128))
+    enc = ops.Rn50Encoder(synth.RN50, synth.rn50_state_dict(synth.RN50, seed=11), (256, 128), precision="fp16")
     img = torch.from_numpy(synth.synthetic_images(64, 256, 128, seed=1)).to(dev).repeat(4, 1, 1, 1).contiguous()
     fo = torch.empty((256, enc.feat_dim), device=dev)
     ms = timed_ms(lambda: enc(img, out=fo), 3)

@@ -434,6 +434,12 @@ typedef struct {
 size_t mpreid_rn50_workspace_bytes_f32(const mpreid_rn50_cfg *cfg, int batch);
 int mpreid_rn50_forward_f32(const mpreid_rn50_cfg *cfg, const mpreid_rn50_weights_f32 *w, const float *img_f32_dev, int batch,
                             float *out_dev, void *ws_dev, size_t ws_bytes, mpreid_stream_t stream);
+/* the same tower fed with uint8 [batch][H][W][3] images (after Resize): ToTensor + Normalize of
+ * datasets/make_dataloader.py:57-61, (x / 255 - mean[c]) / std[c] with correctly rounded divisions, inside the stem's first
+ * convolution -- same bits as the host-transformed fp32 tensor, a quarter of the input bytes, no intermediate tensor */
+int mpreid_rn50_forward_f32_u8(const mpreid_rn50_cfg *cfg, const mpreid_rn50_weights_f32 *w, const uint8_t *img_u8_hwc_dev,
+                               const float *mean3, const float *std3, int batch, float *out_dev, void *ws_dev, size_t ws_bytes,
+                               mpreid_stream_t stream);
 
 /* SPLIT-precision mode of the RN50 tower (MODEL.NAME 'RN50' + MODEL.ENCODER_PRECISION 'split', the default): fp32 NHWC
  * activations; the convolutions of layer1-4 and the attention pool's k / v projections run on the fp16 matrix cores over
@@ -458,6 +464,9 @@ typedef struct {
 size_t mpreid_rn50_workspace_bytes_split(const mpreid_rn50_cfg *cfg, int batch);
 int mpreid_rn50_forward_split(const mpreid_rn50_cfg *cfg, const mpreid_rn50_weights_split *w, const float *img_f32_dev, int batch,
                               float *out_dev, void *ws_dev, size_t ws_bytes, mpreid_stream_t stream);
+int mpreid_rn50_forward_split_u8(const mpreid_rn50_cfg *cfg, const mpreid_rn50_weights_split *w, const uint8_t *img_u8_hwc_dev,
+                                 const float *mean3, const float *std3, int batch, float *out_dev, void *ws_dev, size_t ws_bytes,
+                                 mpreid_stream_t stream);   /* uint8 input, as mpreid_rn50_forward_f32_u8 */
 
 /* One convolution layer of the RN50 tower as the encoder runs it (unit tests, micro-benchmarks):
  * NHWC fp16 in [batch][h][w][cin] (cin % 64 == 0), stride 1, taps = 1 (1x1) or 9 (3x3, pad 1); weights fp16

@@ -22,8 +22,21 @@ enum { F32_LIN = 2, F32_LIN_RES = 4, F32_LIN_RELU = 5, F32_LIN_RES_RELU = 6 };  
 
 namespace {
 
+// The stem's input: fp32 [B][3][H][W] (val_transforms applied), or -- img8 != NULL -- uint8 [B][H][W][3] (what the loader has
+// after Resize) with ToTensor + Normalize of datasets/make_dataloader.py:57-61 applied on the fly, in the reference's order and
+// rounding: (x / 255 - mean) / std with two correctly rounded divisions (same bits as the host-transformed fp32 tensor).
+struct StemIn {
+    const float *img;
+    const uint8_t *img8;
+    float mean[3], sd[3];
+};
+__device__ __forceinline__ float stem_px(const StemIn &in, int b, int c, int iy, int ix, int H, int W) {
+    if (in.img8) return __fdiv_rn(__fdiv_rn((float)in.img8[(((int64_t)b * H + iy) * W + ix) * 3 + c], 255.0f) - in.mean[c], in.sd[c]);
+    return in.img[(((int64_t)b * 3 + c) * H + iy) * W + ix];
+}
+
 // stem conv1 + bn1 + relu: [B][3][H][W] fp32 -> [B][H/2][W/2][cout] fp32 (stride 2, pad 1); w [cout][c][kh][kw] folded
-__global__ __launch_bounds__(256) void stem1_f32_kernel(const float *__restrict__ img, const float *__restrict__ w,
+__global__ __launch_bounds__(256) void stem1_f32_kernel(const StemIn img, const float *__restrict__ w,
                                                         const float *__restrict__ bias, int cout, int B, int H, int W,
                                                         float *__restrict__ out) {
     const int OH = H / 2, OW = W / 2;
@@ -37,7 +50,7 @@ __global__ __launch_bounds__(256) void stem1_f32_kernel(const float *__restrict_
         for (int kh = 0; kh < 3; ++kh)
             for (int kw = 0; kw < 3; ++kw) {
                 const int iy = oy * 2 + kh - 1, ix = ox * 2 + kw - 1;
-                const float x = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? img[(((int64_t)b * 3 + c) * H + iy) * W + ix] : 0.0f;
+                const float x = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? stem_px(img, b, c, iy, ix, H, W) : 0.0f;
                 acc = fmaf(x, w[n * 27 + c * 9 + kh * 3 + kw], acc);
             }
     const float v = acc + bias[n];
@@ -49,7 +62,7 @@ __global__ __launch_bounds__(256) void stem1_f32_kernel(const float *__restrict_
 // contiguous run.  Same arithmetic per output (fmaf chain over (c, kh, kw) ascending, + bias, ReLU): same bits as
 // stem1_f32_kernel, which stays for channel counts other than 32 / 16 / 8.
 template <int COUT>
-__global__ __launch_bounds__(256) void stem1_px_kernel(const float *__restrict__ img, const float *__restrict__ w,
+__global__ __launch_bounds__(256) void stem1_px_kernel(const StemIn img, const float *__restrict__ w,
                                                        const float *__restrict__ bias, int B, int H, int W,
                                                        float *__restrict__ out) {
     __shared__ float ws[27 * COUT + COUT];
@@ -75,8 +88,7 @@ __global__ __launch_bounds__(256) void stem1_px_kernel(const float *__restrict__
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const int iy = oy * 2 + kh - 1, ix = ox * 2 + kw - 1;
-                xin[c * 9 + kh * 3 + kw] =
-                    (iy >= 0 && iy < H && ix >= 0 && ix < W) ? img[(((int64_t)b * 3 + c) * H + iy) * W + ix] : 0.0f;
+                xin[c * 9 + kh * 3 + kw] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? stem_px(img, b, c, iy, ix, H, W) : 0.0f;
             }
 #pragma unroll
     for (int t = 0; t < 27; ++t) {   // t = c * 9 + kh * 3 + kw: the accumulation order of the reference chain
@@ -119,7 +131,7 @@ __global__ __launch_bounds__(256) void stem1_px_kernel(const float *__restrict__
     }
 }
 
-static int launch_stem1(const float *img, const float *w, const float *bias, int c1, int B, int H, int W, float *out,
+static int launch_stem1(const StemIn &img, const float *w, const float *bias, int c1, int B, int H, int W, float *out,
                         hipStream_t stream) {
     const int64_t px = (int64_t)B * (H / 2) * (W / 2);
     const dim3 gp((unsigned)((px + 255) / 256));
@@ -310,11 +322,21 @@ extern "C" size_t mpreid_rn50_workspace_bytes_f32(const mpreid_rn50_cfg *cfg, in
     return layout_f32(cfg, batch).total;
 }
 
-extern "C" int mpreid_rn50_forward_f32(const mpreid_rn50_cfg *cfg, const mpreid_rn50_weights_f32 *w, const float *img, int B,
-                                       float *out, void *ws, size_t ws_bytes, mpreid_stream_t stream_) {
+static StemIn stem_in(const float *img, const uint8_t *img8, const float *mean, const float *sd) {
+    StemIn s{img, img8, {0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}};
+    if (img8)
+        for (int c = 0; c < 3; ++c) {
+            s.mean[c] = mean[c];
+            s.sd[c] = sd[c];
+        }
+    return s;
+}
+
+static int rn50_forward_f32_impl(const mpreid_rn50_cfg *cfg, const mpreid_rn50_weights_f32 *w, const StemIn &img, int B,
+                                 float *out, void *ws, size_t ws_bytes, mpreid_stream_t stream_) {
     int rc = check_cfg_f32(cfg);
     if (rc) return rc;
-    ARG_CHECK(w && img && out && B > 0 && w->blocks && w->stem1_w && w->stem1_b && w->q_w && w->k_w && w->v_w && w->c_w);
+    ARG_CHECK(w && (img.img || img.img8) && out && B > 0 && w->blocks && w->stem1_w && w->stem1_b && w->q_w && w->k_w && w->v_w && w->c_w);
     const LayoutF32 v = layout_f32(cfg, B);
     if (!ws || ws_bytes < v.total) {
         mpreid_set_error("rn50 fp32 workspace too small: %zu < %zu", ws_bytes, v.total);
@@ -394,6 +416,19 @@ extern "C" int mpreid_rn50_forward_f32(const mpreid_rn50_cfg *cfg, const mpreid_
     hipLaunchKernelGGL(head_f32_kernel, dim3(B), dim3(256), 0, stream, mean, proj, v.E, cfg->out_dim, w->bn_scale, w->bn_shift, out);
     LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int mpreid_rn50_forward_f32(const mpreid_rn50_cfg *cfg, const mpreid_rn50_weights_f32 *w, const float *img, int B,
+                                       float *out, void *ws, size_t ws_bytes, mpreid_stream_t stream_) {
+    ARG_CHECK(img);
+    return rn50_forward_f32_impl(cfg, w, stem_in(img, nullptr, nullptr, nullptr), B, out, ws, ws_bytes, stream_);
+}
+
+extern "C" int mpreid_rn50_forward_f32_u8(const mpreid_rn50_cfg *cfg, const mpreid_rn50_weights_f32 *w, const uint8_t *img_hwc,
+                                          const float *mean, const float *stdv, int B, float *out, void *ws, size_t ws_bytes,
+                                          mpreid_stream_t stream_) {
+    ARG_CHECK(img_hwc && mean && stdv);
+    return rn50_forward_f32_impl(cfg, w, stem_in(nullptr, img_hwc, mean, stdv), B, out, ws, ws_bytes, stream_);
 }
 
 
@@ -614,11 +649,11 @@ extern "C" size_t mpreid_rn50_workspace_bytes_split(const mpreid_rn50_cfg *cfg, 
     return layout_split(cfg, batch).total;
 }
 
-extern "C" int mpreid_rn50_forward_split(const mpreid_rn50_cfg *cfg, const mpreid_rn50_weights_split *w, const float *img, int B,
-                                         float *out, void *ws, size_t ws_bytes, mpreid_stream_t stream_) {
+static int rn50_forward_split_impl(const mpreid_rn50_cfg *cfg, const mpreid_rn50_weights_split *w, const StemIn &img, int B,
+                                   float *out, void *ws, size_t ws_bytes, mpreid_stream_t stream_) {
     int rc = check_cfg_f32(cfg);
     if (rc) return rc;
-    ARG_CHECK(w && img && out && B > 0 && w->blocks && w->f32.stem1_w && w->f32.stem1_b && w->f32.q_w && w->f32.c_w && w->k.w && w->v.w &&
+    ARG_CHECK(w && (img.img || img.img8) && out && B > 0 && w->blocks && w->f32.stem1_w && w->f32.stem1_b && w->f32.q_w && w->f32.c_w && w->k.w && w->v.w &&
               w->stem2.w && w->stem3.w);
     const LayoutSplit v = layout_split(cfg, B);
     if (!ws || ws_bytes < v.total) {
@@ -774,4 +809,17 @@ extern "C" int mpreid_rn50_forward_split(const mpreid_rn50_cfg *cfg, const mprei
     hipLaunchKernelGGL(head_f32_kernel, dim3(B), dim3(256), 0, stream, mean, proj, v.f.E, cfg->out_dim, wf.bn_scale, wf.bn_shift, out);
     LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int mpreid_rn50_forward_split(const mpreid_rn50_cfg *cfg, const mpreid_rn50_weights_split *w, const float *img, int B,
+                                         float *out, void *ws, size_t ws_bytes, mpreid_stream_t stream_) {
+    ARG_CHECK(img);
+    return rn50_forward_split_impl(cfg, w, stem_in(img, nullptr, nullptr, nullptr), B, out, ws, ws_bytes, stream_);
+}
+
+extern "C" int mpreid_rn50_forward_split_u8(const mpreid_rn50_cfg *cfg, const mpreid_rn50_weights_split *w, const uint8_t *img_hwc,
+                                            const float *mean, const float *stdv, int B, float *out, void *ws, size_t ws_bytes,
+                                            mpreid_stream_t stream_) {
+    ARG_CHECK(img_hwc && mean && stdv);
+    return rn50_forward_split_impl(cfg, w, stem_in(nullptr, img_hwc, mean, stdv), B, out, ws, ws_bytes, stream_);
 }

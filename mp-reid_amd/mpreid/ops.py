@@ -545,7 +545,7 @@ class Rn50Encoder:
     multiples of 64 are stored zero-padded to 64 (the 32-channel stem; reduced test configurations)."""
 
     def __init__(self, cfg: dict, state_dict: dict, img_hw, neck_after: bool = False, bn: Optional[dict] = None,
-                 device=None, ws_tag: str = "rn50", precision: str = "fp16"):
+                 device=None, ws_tag: str = "rn50", precision: str = "split"):
         """precision: 'fp16' = fp16 NHWC activations, implicit-GEMM convolutions on the fp16 matrix cores (the throughput
         path, relative feature error 2.6e-3); 'fp32' = everything fp32 on the exact fp32 matrix instruction
         (mpreid_rn50_forward_f32: ~1e-6); 'split' = fp32 activations, the convolutions of layer1-4 and the attention pool's
@@ -793,13 +793,15 @@ class Rn50Encoder:
         L = _lib.load()
         if self.precision in ("fp32", "split"):
             split = self.precision == "split"
-            if img.dtype == torch.uint8:   # ToTensor + Normalize of val_transforms with tensor ops, then the fp32 tower
-                t = img.detach().to(self.device).permute(0, 3, 1, 2).to(torch.float32).div(255)
-                mean = torch.tensor(pixel_mean, dtype=torch.float32, device=self.device)[None, :, None, None]
-                std = torch.tensor(pixel_std, dtype=torch.float32, device=self.device)[None, :, None, None]
-                img = ((t - mean) / std).contiguous()
-            img = _dev_f32(img, self.device)
-            assert tuple(img.shape[1:]) == (3,) + self.img_hw, img.shape
+            u8 = img.dtype == torch.uint8    # ToTensor + Normalize inside the stem's first convolution (mpreid_rn50_forward_*_u8)
+            if u8:
+                img = img.detach().to(device=self.device).contiguous()
+                assert tuple(img.shape[1:]) == self.img_hw + (3,), img.shape
+                mean = (C.c_float * 3)(*[float(x) for x in pixel_mean])
+                std = (C.c_float * 3)(*[float(x) for x in pixel_std])
+            else:
+                img = _dev_f32(img, self.device)
+                assert tuple(img.shape[1:]) == (3,) + self.img_hw, img.shape
             B = img.shape[0]
             if out is None:
                 out = torch.empty((B, self.feat_dim), dtype=torch.float32, device=self.device)
@@ -808,14 +810,24 @@ class Rn50Encoder:
                 e0 = min(B, s0 + step)
                 if split:
                     ws = _workspace(self.ws_tag + "_split", L.mpreid_rn50_workspace_bytes_split(C.byref(self.c_cfg), e0 - s0), self.device)
-                    _lib.check(L.mpreid_rn50_forward_split(C.byref(self.c_cfg), C.byref(self.c_ws), _ptr(img[s0:e0]), e0 - s0,
-                                                           _ptr(out[s0:e0]), _ptr(ws), ws.numel(), _lib.stream_ptr()),
-                               "mpreid_rn50_forward_split")
+                    if u8:
+                        _lib.check(L.mpreid_rn50_forward_split_u8(C.byref(self.c_cfg), C.byref(self.c_ws), _ptr(img[s0:e0]), mean, std,
+                                                                  e0 - s0, _ptr(out[s0:e0]), _ptr(ws), ws.numel(), _lib.stream_ptr()),
+                                   "mpreid_rn50_forward_split_u8")
+                    else:
+                        _lib.check(L.mpreid_rn50_forward_split(C.byref(self.c_cfg), C.byref(self.c_ws), _ptr(img[s0:e0]), e0 - s0,
+                                                               _ptr(out[s0:e0]), _ptr(ws), ws.numel(), _lib.stream_ptr()),
+                                   "mpreid_rn50_forward_split")
                     continue
                 ws = _workspace(self.ws_tag + "_f32", L.mpreid_rn50_workspace_bytes_f32(C.byref(self.c_cfg), e0 - s0), self.device)
-                _lib.check(L.mpreid_rn50_forward_f32(C.byref(self.c_cfg), C.byref(self.c_w), _ptr(img[s0:e0]), e0 - s0,
-                                                     _ptr(out[s0:e0]), _ptr(ws), ws.numel(), _lib.stream_ptr()),
-                           "mpreid_rn50_forward_f32")
+                if u8:
+                    _lib.check(L.mpreid_rn50_forward_f32_u8(C.byref(self.c_cfg), C.byref(self.c_w), _ptr(img[s0:e0]), mean, std,
+                                                            e0 - s0, _ptr(out[s0:e0]), _ptr(ws), ws.numel(), _lib.stream_ptr()),
+                               "mpreid_rn50_forward_f32_u8")
+                else:
+                    _lib.check(L.mpreid_rn50_forward_f32(C.byref(self.c_cfg), C.byref(self.c_w), _ptr(img[s0:e0]), e0 - s0,
+                                                         _ptr(out[s0:e0]), _ptr(ws), ws.numel(), _lib.stream_ptr()),
+                               "mpreid_rn50_forward_f32")
             return out
         u8 = img.dtype == torch.uint8
         if u8:

@@ -64,7 +64,7 @@ def test_rn50_small_vs_reference(golden):
     fp16 activations + fp16 MFMA operands through ~20 layers: relative L2 <= 5e-3"""
     from mpreid import ops, synth
     g = golden("rn50.npz")
-    enc = ops.Rn50Encoder(SMALL, synth.rn50_state_dict(SMALL, seed=11), (64, 32))
+    enc = ops.Rn50Encoder(SMALL, synth.rn50_state_dict(SMALL, seed=11), (64, 32), precision="fp16")
     f = enc(torch.from_numpy(synth.synthetic_images(3, 64, 32, seed=31))).cpu().numpy()
     assert f.shape == (3, 576)
     print("rn50 small rel-L2:", _check(f, g["small_feat"], 5e-3))
@@ -74,7 +74,7 @@ def test_rn50_full_vs_reference(golden):
     from mpreid import ops, synth
     g = golden("rn50.npz")
     sd = synth.rn50_state_dict(synth.RN50, seed=11)
-    enc = ops.Rn50Encoder(synth.RN50, sd, (256, 128))
+    enc = ops.Rn50Encoder(synth.RN50, sd, (256, 128), precision="fp16")
     imgs = synth.synthetic_images(3, 256, 128, seed=32)
     f = enc(torch.from_numpy(imgs)).cpu().numpy()
     assert f.shape == (3, 3072)
@@ -93,7 +93,7 @@ def test_rn50_u8_and_bn_neck_vs_oracle():
     bn = {n: (1 + 0.1 * rng.standard_normal(d).astype(np.float32), 0.1 * rng.standard_normal(d).astype(np.float32),
               0.1 * rng.standard_normal(d).astype(np.float32), (0.5 + rng.random(d)).astype(np.float32))
           for n, d in (("bottleneck", 512), ("bottleneck_proj", 64))}
-    enc = ops.Rn50Encoder(SMALL, sd, (64, 32), neck_after=True, bn=bn)
+    enc = ops.Rn50Encoder(SMALL, sd, (64, 32), neck_after=True, bn=bn, precision="fp16")
     u8 = rng.integers(0, 256, (5, 64, 32, 3), dtype=np.uint8)
     mean, std = (0.5, 0.4, 0.45), (0.5, 0.25, 0.3)
     t = torch.from_numpy(u8).permute(0, 3, 1, 2).float().div(255)
@@ -111,7 +111,7 @@ def test_rn50_other_resolution_vs_oracle():
     from mpreid import ops, synth
     cfg = dict(layers=(1, 1, 2, 1), width=16, heads=8, out_dim=64, h_res=6, w_res=4)
     sd = synth.rn50_state_dict(cfg, seed=21)
-    enc = ops.Rn50Encoder(cfg, sd, (96, 64))
+    enc = ops.Rn50Encoder(cfg, sd, (96, 64), precision="fp16")
     imgs = synth.synthetic_images(5, 96, 64, seed=41)
     got = enc(torch.from_numpy(imgs)).cpu().numpy()
     want = orc.rn50_features(sd, cfg, imgs)
@@ -153,8 +153,11 @@ def test_rn50_fp32_mode_options_vs_oracle():
     t = torch.from_numpy(u8).permute(0, 3, 1, 2).float().div(255)
     t = (t - torch.tensor(mean)[None, :, None, None]) / torch.tensor(std)[None, :, None, None]
     want = orc.rn50_features(sd, SMALL, t.numpy(), bn=bn, neck_feat="after")
-    _check(enc.forward_u8(torch.from_numpy(u8), mean, std).cpu().numpy(), want, 2e-5)
-    _check(enc(t.contiguous()).cpu().numpy(), want, 2e-5)
+    got_u8 = enc.forward_u8(torch.from_numpy(u8), mean, std).cpu().numpy()
+    _check(got_u8, want, 2e-5)
+    got_f = enc(t.contiguous()).cpu().numpy()
+    _check(got_f, want, 2e-5)
+    assert np.array_equal(got_u8, got_f)   # ToTensor + Normalize inside the stem's first convolution (round 5): same bits
     cfg = dict(layers=(1, 1, 2, 1), width=16, heads=8, out_dim=64, h_res=6, w_res=4)
     sd = synth.rn50_state_dict(cfg, seed=21)
     imgs = synth.synthetic_images(5, 96, 64, seed=41)
@@ -199,8 +202,11 @@ def test_rn50_split_mode_options_vs_oracle():
     t = torch.from_numpy(u8).permute(0, 3, 1, 2).float().div(255)
     t = (t - torch.tensor(mean)[None, :, None, None]) / torch.tensor(std)[None, :, None, None]
     want = orc.rn50_features(sd, SMALL, t.numpy(), bn=bn, neck_feat="after")
-    _check(enc.forward_u8(torch.from_numpy(u8), mean, std).cpu().numpy(), want, 2e-5)
-    _check(enc(t.contiguous()).cpu().numpy(), want, 2e-5)
+    got_u8 = enc.forward_u8(torch.from_numpy(u8), mean, std).cpu().numpy()
+    _check(got_u8, want, 2e-5)
+    got_f = enc(t.contiguous()).cpu().numpy()
+    _check(got_f, want, 2e-5)
+    assert np.array_equal(got_u8, got_f)   # ToTensor + Normalize inside the stem's first convolution (round 5): same bits
     cfg = dict(layers=(1, 1, 2, 1), width=16, heads=8, out_dim=64, h_res=6, w_res=4)
     sd = synth.rn50_state_dict(cfg, seed=21)
     imgs = synth.synthetic_images(5, 96, 64, seed=41)

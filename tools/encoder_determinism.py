@@ -43,7 +43,7 @@ def main():
     bad += check("ViT-B/16 split mode (default), batch 508",
                  lambda t: ops.VitEncoder(synth.VIT_B16, sd, (256, 128), ws_tag="dets_" + t, precision="split"), img, a.reps)
     sdr = synth.rn50_state_dict(synth.RN50, seed=11)
-    bad += check("RN50 batch 256", lambda t: ops.Rn50Encoder(synth.RN50, sdr, (256, 128), ws_tag="detr_" + t),
+    bad += check("RN50 batch 256", lambda t: ops.Rn50Encoder(synth.RN50, sdr, (256, 128), ws_tag="detr_" + t, precision="fp16"),
                  img[:256].contiguous(), a.reps)
     sys.exit(1 if bad else 0)
 
