@@ -1796,7 +1796,10 @@ __device__ __forceinline__ void p2_tile_at(int k, int tiles_m, int tiles_n, int 
     tn = 2 * SH * br + j;
 }
 
-template <int abl>   // ablation variants (MPREID_ABLATION builds): bit 0 no stores, 1 no k-loop, 2 no mirrored stores, 3 operands aliased
+// FULL (round 5): the same two-workgroups-per-CU schedule for TWO tensors (q != g, the evaluator's real shape,
+// utils/metrics.py:7-13): every tile of the tiles_m x tiles_n grid is computed, nothing is mirrored.  Walk: strips of SH tile
+// rows, column-major inside a strip, cut into eight equal contiguous ranges (one per XCD) like the symmetric walk.
+template <int abl, bool FULL = false>   // ablation variants (MPREID_ABLATION builds): bit 0 no stores, 1 no k-loop, 2 no mirrored stores, 3 operands aliased
                      // onto two L2-resident panels, 4 stores straight from the accumulators (wrong data)
 __global__ __launch_bounds__(256, 2) void dist_sym_p2_kernel(GemmArgs g, int tiles_m, int tiles_n, int naps, int SH) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1807,7 +1810,7 @@ __global__ __launch_bounds__(256, 2) void dist_sym_p2_kernel(GemmArgs g, int til
     const int nst = (abl & 2) ? 1 : K / PBK;
     const int per_xcd = (int)gridDim.x >> 3;                      // the grid is a multiple of 8
     const int xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3);
-    const int total = p2_total_tiles(tiles_m, tiles_n, SH);
+    const int total = FULL ? tiles_m * tiles_n : p2_total_tiles(tiles_m, tiles_n, SH);
     const int lo = (int)((int64_t)xcd * total / 8), hi = (int)((int64_t)(xcd + 1) * total / 8);
 
     // (experiments) the second workgroup of every CU -- blocks b and b + gridDim/2 share a CU, tools/probes/hwid_probe.hip --
@@ -1841,7 +1844,15 @@ __global__ __launch_bounds__(256, 2) void dist_sym_p2_kernel(GemmArgs g, int til
     };
     for (int it = lo + slot; it < hi; it += per_xcd) {
         int tm, tn;
-        p2_tile_at(it, tiles_m, tiles_n, SH, tm, tn);
+        if constexpr (FULL) {   // strip br = SH tile rows x all tile columns, column-major inside the strip
+            const int per_strip = SH * tiles_n;
+            const int br = it / per_strip, kk = it - br * per_strip;
+            const int R = min(SH, tiles_m - SH * br);
+            tn = kk / R;
+            tm = SH * br + (kk - tn * R);
+        } else {
+            p2_tile_at(it, tiles_m, tiles_n, SH, tm, tn);
+        }
         const int m0 = tm * PBM, n0 = tn * PBN;
         const int ma = (abl & 8) ? (tm & 1) * PBM : m0, na = (abl & 8) ? (tn & 1) * PBN : n0;   // (experiment) L2-resident operands
         const _Float16 *a_src = g.A + (int64_t)(ma + wave * 64 + drow) * K + dchunk * 8;
@@ -2006,7 +2017,7 @@ __global__ __launch_bounds__(256, 2) void dist_sym_p2_kernel(GemmArgs g, int til
         // (2) its transpose, when the tile lies entirely above the diagonal: 64 rows x 128 columns in two halves, each
         // through a [64 n][64 m] patch whose 16-byte chunks are XOR-swizzled by n & 15 (b128 writes of a 16-lane group
         // and b128 reads of a row both touch 16 different chunk banks)
-        if (tn >= 2 * tm + 2 && !(abl & (4 | 16))) {
+        if (!FULL && tn >= 2 * tm + 2 && !(abl & (4 | 16))) {
             float *Trow = T + frow * 64;                      // + j * 1024: row n = j * 16 + frow
             const int cx = fq ^ frow;                         // chunk (ii * 4 + fq) ^ frow = (ii * 4) ^ cx
             const unsigned ldo_bT = (unsigned)g.ldo * 4u;
@@ -2231,11 +2242,18 @@ static int launch_one(const GemmArgs &a_in, hipStream_t stream) {
     }
     // MPREID_TUNE dist_sym_p2: 0 = never, 1 = symmetric stored distance problems of at least 16 tile rows (default),
     // 2 = every symmetric problem whose padded size allows it (tests)
-    bool use_p2 = false;
+    bool use_p2 = false, p2_full = false;
     if constexpr (EPI == GE_EUCLID) {
         static const int p2_mode = mpreid_tune("dist_sym_p2", 1);
         use_p2 = a.sym && p2_mode > 0 && a.M == a.N && (a.A == a.W || p2_mode >= 3) && (a.M % PBM == 0) && (a.K % PBK == 0) &&
                  (p2_mode >= 2 || a.M / PBM >= 16);   // (3: also the 3-term split operands, A != W: measured slower, see DESIGN)
+        // MPREID_TUNE dist_p2_full: the two-workgroups-per-CU kernel for TWO tensors (stored distances, one-pass fp16 and
+        // 3-term split operands): 0 never (default: measured), 1 problems of at least 16 x 32 tiles, 2 whenever
+        // the padded sizes allow (tests)
+        static const int full_mode = mpreid_tune("dist_p2_full", 0);
+        if (!use_p2 && !a.sym && full_mode > 0 && a.out && (a.M % PBM == 0) && (a.N % PBN == 0) && (a.K % PBK == 0) &&
+            (full_mode >= 2 || (a.M / PBM >= 16 && a.N / PBN >= 32)))
+            use_p2 = p2_full = true;
     }
     if (use_p2) {
         if constexpr (EPI == GE_EUCLID) {
@@ -2264,6 +2282,11 @@ static int launch_one(const GemmArgs &a_in, hipStream_t stream) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES));                 \
         hipLaunchKernelGGL(dist_sym_p2_kernel<V>, gdim, dim3(256), P_LDS_BYTES, stream, a, a.M / PBM, a.N / PBN, naps, strip); \
         break;
+            if (p2_full) {
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(dist_sym_p2_kernel<0, true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES));
+                hipLaunchKernelGGL((dist_sym_p2_kernel<0, true>), gdim, dim3(256), P_LDS_BYTES, stream, a, a.M / PBM, a.N / PBN, naps, strip);
+            } else
             switch (abl) {
                 MPREID_P2_CASE(1) MPREID_P2_CASE(2) MPREID_P2_CASE(3) MPREID_P2_CASE(4) MPREID_P2_CASE(8) MPREID_P2_CASE(9)
                 MPREID_P2_CASE(16) MPREID_P2_CASE(24) MPREID_P2_CASE(32) MPREID_P2_CASE(33)
@@ -2272,7 +2295,18 @@ static int launch_one(const GemmArgs &a_in, hipStream_t stream) {
             }
 #undef MPREID_P2_CASE
 #else
-            hipLaunchKernelGGL(dist_sym_p2_kernel<0>, gdim, dim3(256), P_LDS_BYTES, stream, a, a.M / PBM, a.N / PBN, naps, strip);
+            if (p2_full) {
+                static PerDeviceOnce p2f_once;
+                const int rcf = p2f_once.run([]() -> int {
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(dist_sym_p2_kernel<0, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES));
+                    return MPREID_OK;
+                });
+                if (rcf) return rcf;
+                hipLaunchKernelGGL((dist_sym_p2_kernel<0, true>), gdim, dim3(256), P_LDS_BYTES, stream, a, a.M / PBM, a.N / PBN, naps, strip);
+            } else {
+                hipLaunchKernelGGL(dist_sym_p2_kernel<0>, gdim, dim3(256), P_LDS_BYTES, stream, a, a.M / PBM, a.N / PBN, naps, strip);
+            }
 #endif
         }
     } else if (use_big) {

@@ -271,12 +271,15 @@ def test_stored_distance_kernels_bit_identical():
         print("HASHES " + " ".join(res))
     """)
     outs = []
-    for big in ("0", "2"):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MPREID_TUNE="gemm_big=" + big), capture_output=True,
+    # ... and (round 5) the two-workgroups-per-CU 256 x 128 kernel in its two-tensor form (dist_p2_full=2: whenever the padded
+    # sizes allow -- every shape here: rows are padded to 256, columns to 256)
+    for tune in ("gemm_big=0", "gemm_big=2", "gemm_big=2,dist_p2_full=2"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MPREID_TUNE=tune), capture_output=True,
                            text=True, timeout=900)
         assert r.returncode == 0, r.stdout + r.stderr
         outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("HASHES ")][0].split()[1:])
     assert outs[0] == outs[1], list(zip(outs[0], outs[1]))
+    assert outs[0] == outs[2], list(zip(outs[0], outs[2]))
 
 
 # ---- all-pairs distances of ONE set: euclidean_distance(f, f) computes the upper-triangular tiles and mirrors them ----
