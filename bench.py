@@ -347,7 +347,7 @@ RERANK_STAGE_KERNELS = {
 def _pmc_stage_bytes():
     """HBM bytes per launch of every re-rank stage at N = 20 000 from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE in separate runs, gfx950 corrections applied by tools/pmc_summary.py): {stage: (bytes, source file)}"""
-    for fn in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json"):
+    for fn in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json"):
         try:
             per = json.load(open(os.path.join(ROOT, "profiles", fn)))["rerank_N20000_hbm_bytes_per_launch"]
         except Exception:
@@ -434,6 +434,26 @@ def rerank_roofline(st):
     return rows
 
 
+def sym_tiles_executed(n, tile_m, tile_n):
+    """tiles a symmetric all-pairs kernel computes: those that reach the upper triangle (tn * tile_n + tile_n > tm * tile_m)"""
+    tm_n, tn_n = -(-n // tile_m), -(-n // tile_n)
+    return sum(1 for tm in range(tm_n) for tn in range(tn_n) if (tn + 1) * tile_n > tm * tile_m)
+
+
+def sym_entry(stage, kernel, n, d, ms, peak, tile_m, tile_n, products=1, **more):
+    """roofline entry of a SYMMETRIC all-pairs kernel: `achieved` / `frac` count the matrix work the kernel EXECUTES (the tiles on
+    or above the diagonal, x `products` fp16 products per multiply-add) -- never above 1 --; the 2*N*N*D of SURVEY.md section 8d
+    (what a caller gets: the whole matrix) is reported beside it as algorithmic_*, without being called a fraction of a roofline"""
+    ex = 2.0 * sym_tiles_executed(n, tile_m, tile_n) * tile_m * tile_n * d * products
+    alg = 2.0 * n * n * d
+    e = {"stage": stage, "kernel": kernel, "bound": "mfma", "achieved": round(ex / ms / 1e9, 1), "peak": peak, "unit": "TFLOP/s",
+         "frac": round(ex / ms / 1e9 / peak, 4), "executed_flop": int(ex), "avg_launch_ms": round(ms, 4),
+         "algorithmic_flop": int(alg), "algorithmic_tflops": round(alg / ms / 1e9, 1),
+         "algorithmic_2NND_over_peak": round(alg / ms / 1e9 / peak, 4), "traffic": None}
+    e.update(more)
+    return e
+
+
 def extras(ops, dev, with_widened=True):
     """secondary figures named by BASELINE.json's metric: 20k x 20k feat-GEMM and re-rank; returns (extras dict,
     roofline entries)"""
@@ -458,7 +478,7 @@ def extras(ops, dev, with_widened=True):
     out["feat_gemm_20kx20k_d768_fp16_two_tensors_ms"] = round(ms_full, 4)
     out["feat_gemm_20kx20k_d768_fp16_two_tensors_frac_of_peak"] = round(flop / ms_full / 1e9 / PEAK_F16_TFLOPS, 4)
     fg_traffic = fg_src = None
-    for fn in ("r04_pmc_summary.json",):
+    for fn in ("r05_pmc_summary.json", "r04_pmc_summary.json"):
         try:
             per = json.load(open(os.path.join(ROOT, "profiles", fn)))["featgemm_20kx20kx768_fp16_hbm_bytes_per_launch"]
             fg_traffic = int(sum(v for k, v in per.items() if k.startswith(("void gemm_f16_big_kernel<5, 0", "void dist_sym_p2_kernel", "void gemm_f16_store"))))
@@ -470,33 +490,25 @@ def extras(ops, dev, with_widened=True):
                   "kernel": "gemm_f16_big_kernel<euclid>", "bound": "mfma", "achieved": round(flop / ms_full / 1e9, 1),
                   "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(flop / ms_full / 1e9 / PEAK_F16_TFLOPS, 4),
                   "algorithmic_flop": int(flop), "avg_launch_ms": round(ms_full, 4), "traffic": None})
-    roofs.append({"stage": "feat_gemm_20kx20k_d768 (fp16 one pass, fp32 N x N stored; all pairs of one tensor: symmetric form)",
-                  "kernel": "dist_sym_p2_kernel (two workgroups per CU, 256 x 128 tiles; MPREID_TUNE dist_sym_p2=0: gemm_f16_big_kernel<euclid, sym>)",
-                  "bound": "mfma", "achieved": round(flop / ms / 1e9, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                  "frac": round(flop / ms / 1e9 / PEAK_F16_TFLOPS, 4), "frac_of_sustainable_1250TF": round(flop / ms / 1e9 / 1250.0, 4),
-                  "algorithmic_flop": int(flop),
-                  "avg_launch_ms": round(ms, 4), "traffic": fg_traffic,
-                  "traffic_source": f"profiles/{fg_src}" if fg_src else None,
-                  "hbm": {"achieved": round(byts / ms / 1e6, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                          "frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 4), "algorithmic_bytes": int(byts)}})
+    roofs.append(sym_entry("feat_gemm_20kx20k_d768 (fp16 one pass, fp32 N x N stored; all pairs of one tensor: symmetric form)",
+                           "dist_sym_p2_kernel (two workgroups per CU, 256 x 128 tiles; MPREID_TUNE dist_sym_p2=0: gemm_f16_big_kernel<euclid, sym>)",
+                           20000, 768, ms, PEAK_F16_TFLOPS, 256, 128, traffic=fg_traffic,
+                           traffic_source=f"profiles/{fg_src}" if fg_src else None,
+                           hbm={"achieved": round(byts / ms / 1e6, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                "frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 4), "algorithmic_bytes": int(byts)}))
     del ft_copy
     if hasattr(ops, "GEMM_F16_SPLIT3"):
         ms = timed_ms(lambda: ops.euclidean_distance(ft, ft, mode=ops.GEMM_F16_SPLIT3, out=buf), 10, warm=3)
         out["feat_gemm_20kx20k_d768_split3_ms"] = round(ms, 4)
         out["feat_gemm_20kx20k_d768_split3_executed_tflops"] = round(3 * flop / ms / 1e9, 1)
-        roofs.append({"stage": "feat_gemm_20kx20k_d768 (3-term fp16 split, |err| <= 1e-6; all pairs of one tensor: symmetric form)", "kernel": "dist_sym_p2_kernel (split3 operands)",
-                      "bound": "mfma", "achieved": round(flop / ms / 1e9, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                      "frac": round(flop / ms / 1e9 / PEAK_F16_TFLOPS, 4), "algorithmic_flop": int(flop),
-                      "achieved_executed": round(3 * flop / ms / 1e9, 1), "frac_executed": round(3 * flop / ms / 1e9 / PEAK_F16_TFLOPS, 4),
-                      "avg_launch_ms": round(ms, 4), "traffic": None})
+        roofs.append(sym_entry("feat_gemm_20kx20k_d768 (3-term fp16 split, |err| <= 1e-6; all pairs of one tensor: symmetric form)",
+                               "gemm_f16_big_kernel<euclid, sym> (split3 operands, 256 x 256 tiles)", 20000, 768, ms, PEAK_F16_TFLOPS, 256, 256,
+                               products=3))
     ms = timed_ms(lambda: ops.euclidean_distance(ft, ft, mode=ops.GEMM_F32_EXACT, out=buf), 3)
     out["feat_gemm_20kx20k_d768_fp32exact_ms"] = round(ms, 4)
     out["feat_gemm_20kx20k_d768_fp32exact_tflops"] = round(flop / ms / 1e9, 1)
-    roofs.append({"stage": "feat_gemm_20kx20k_d768 (exact fp32 MFMA, bit-parity mode; all pairs of one tensor: symmetric kernel, half the tiles "
-                           "executed -- `achieved` counts 2*N*N*D as SURVEY 8d does, so it can exceed the fp32 MFMA peak)", "kernel": "gemm_f32_exact_kernel<SYM>",
-                  "bound": "mfma", "achieved": round(flop / ms / 1e9, 1), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                  "frac": round(flop / ms / 1e9 / PEAK_F32_TFLOPS, 4), "algorithmic_flop": int(flop),
-                  "avg_launch_ms": round(ms, 4), "traffic": None})
+    roofs.append(sym_entry("feat_gemm_20kx20k_d768 (exact fp32 MFMA, bit-parity mode; all pairs of one tensor: symmetric kernel)",
+                           "gemm_f32_exact_kernel<SYM> (128 x 128 tiles)", 20000, 768, ms, PEAK_F32_TFLOPS, 128, 128))
     del buf
     ops.re_ranking(ft[:4000], ft[4000:], 50, 15, 0.3)
     _, st = ops.re_ranking(ft[:4000], ft[4000:], 50, 15, 0.3, timing=True)
@@ -986,7 +998,7 @@ def run_rank(a):
         traffic = None
         traffic_src = None
         if top:
-            for fn in ("r04_gemm_pmc_traffic.json", "r03_gemm_pmc_traffic.json", "r02_gemm_pmc_traffic.json"):
+            for fn in ("r05_gemm_pmc_traffic.json", "r04_gemm_pmc_traffic.json", "r03_gemm_pmc_traffic.json"):
                 try:  # HBM bytes per launch of the dominant kernel: committed rocprofv3 PMC passes (profiles/)
                     tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
                     key = f"{_lib.GEMM_EPILOGUE_NAMES.get(top['epilogue_id'])}:{top['N']}:{top['K']}"
@@ -1031,11 +1043,12 @@ def run_rank(a):
                 roof["frac_executed"] = round(top["tflops"] / PEAK_F16_TFLOPS, 4)
                 roof["frac_of_sustainable_1250TF"] = round(top["tflops"] / 1250.0, 4)
             try:   # matrix-pipe counters of the same kernel class (committed rocprofv3 --pmc pass, tools/collect_profiles.sh)
-                mj = json.load(open(os.path.join(ROOT, "profiles", "r04_gemm_pmc_mfma.json")))
+                mfn = next(f for f in ("r05_gemm_pmc_mfma.json", "r04_gemm_pmc_mfma.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+                mj = json.load(open(os.path.join(ROOT, "profiles", mfn)))
                 key = f"{_lib.GEMM_EPILOGUE_NAMES.get(top['epilogue_id'])}:{top['N']}:{top['K']}"
                 if key in mj.get("classes", {}):
                     roof["mfma_busy"] = mj["classes"][key]
-                    roof["mfma_busy_source"] = "profiles/r04_gemm_pmc_mfma.json"
+                    roof["mfma_busy_source"] = "profiles/" + mfn
             except Exception:
                 pass
         desc_long = {

@@ -1,25 +1,31 @@
 #!/bin/bash
 # Collect the round's evidence on the GPU box (run through gpurun from the repo root):
-#   bash tools/collect_profiles.sh r04
+#   bash tools/collect_profiles.sh r05
 # Writes everything under gpurun_out/profiles_<tag>/; the summaries are then copied into profiles/ (tracked).
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# 1. the default bench line (N = 1), and the other workloads
-python3 $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
+# every bench.py run leaves bench_extras.json in the current directory (/tmp here): keep the ones that are cited
+keep_extras() { cp /tmp/bench_extras.json $OUT/$1 2>/dev/null; }
+# 1. the bench line EXACTLY as the driver runs it (N = 1: --gpus 1 --steps 20 --warmup 5), and the other workloads
+python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/${TAG}_bench.json 2> $OUT/bench.err
+keep_extras ${TAG}_bench_extras.json
 python3 $R/bench.py --encoder-precision fp16 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_fp16_encoder.json 2>> $OUT/bench.err
 python3 $R/bench.py --workload synth --rerank --steps 2 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_synth_rerank.json 2>> $OUT/bench.err
 python3 $R/bench.py --workload synth --dist-mode split3 --steps 3 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_synth_split3.json 2>> $OUT/bench.err
 python3 $R/bench.py --workload synth --rerank --rerank-algo split3 --dist-mode split3 --steps 2 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_synth_rerank_split3.json 2>> $OUT/bench.err
 python3 $R/bench.py --workload msmt17 --rerank --steps 1 --warmup 1 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_msmt17_rerank.json 2>> $OUT/bench.err
 python3 $R/bench.py --rerank --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_market_rerank.json 2>> $OUT/bench.err
+keep_extras ${TAG}_bench_market_rerank_extras.json
 # 2. kernel trace + stats of the same bench command (--streams 1 is honoured by every leg, also the host-loader ones of
 #    `extras`: no two kernels of the process overlap, so a kernel's average duration here is its launch duration)
 #    --no-extras: only the headline step's launches are in the trace (the extras run the same kernels at other shapes -- the
 #    reference-loop leg encodes 64 images per call -- and rocprofv3 --stats averages per kernel NAME)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_bench -o b -- python3 $R/bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_under_rocprof.json 2>/dev/null
+#    Same --steps / --warmup as the driver's run, so that `Calls` are the driver run's launch counts.
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_bench -o b -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --streams 1 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_under_rocprof.json 2>/dev/null
+keep_extras ${TAG}_bench_under_rocprof_extras.json
 cp $OUT/kt_bench/b_kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv
 # 3. re-ranking alone (N = 20 000): kernel stats and the FETCH / WRITE passes (separate runs)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_rr -o rr -- python3 $R/tools/rerank_bench.py 20000 4000 768 > $OUT/rr.log 2>&1
