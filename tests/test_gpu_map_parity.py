@@ -40,7 +40,7 @@ SETS = {
     # name: (identities, images per identity, beta, weight std)
     "big": (512, 8, 0.4, 0.05),          # 4096 images, the spread geometry (test_image_to_map_parity_4096_images)
     "spread": (128, 8, 0.4, 0.05),       # = the 1024 images of identities 0 .. 127 of "big" (ONE oracle encode serves both)
-    "degenerate": (128, 8, 0.55, 0.02),  # (round 5: 1024 images instead of 2048 -- the suite's time went to the 4096-image set)
+    "degenerate": (128, 16, 0.55, 0.02),
 }
 
 
