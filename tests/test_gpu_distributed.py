@@ -92,8 +92,12 @@ def test_bench_self_launches_two_ranks(args):
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
+    assert len(lines[0].encode()) <= 4096                      # the N-rank line obeys the same size contract
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["all_gather"]["bytes_per_step"] > 0
+    assert set(j["all_gather"]) == {"calls_per_step", "bytes_per_step", "ms_per_step", "gb_per_s"}
+    assert j["rccl_ranks"] == 0                                # gloo staging: NOT an RCCL run, and the line says so
+    assert j["cpu_baseline"] is None and "roofline" in j and j["extras_file"] == "bench_extras.json"
     assert j["scaling"] == ("weak" if args[1] == "market" else "strong")
 
 
