@@ -1441,7 +1441,7 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
         // order: same bits.  MPREID_FAST_NBLK 16-row blocks are laid into the idle ring per LDS round trip; measured on
         // one device in one run (20k x 20k x 768 stored distances): 1 block 0.803 ms, 2 blocks 0.813, 4 blocks 0.844 --
         // batching the round trips only adds live registers (per-tile stamps: epilogue 8.5 -> 10.2 us), the time goes to
-        // the stores themselves.
+        // the stores themselves (docs/HISTORY_r01-r03.md).
         bool fast_done = false;
         if constexpr (EPI == GE_EUCLID || EPI == GE_S_BIAS_F32) {
             if (fast_path) {
@@ -1744,7 +1744,7 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
 // Symmetric stored distance matrix (all-pairs distances of ONE set: A == W), "p2" schedule: PERSISTENT, TWO independent
 // 4-wave workgroups per CU walking tiles out of phase.
 //   Why: in the one-workgroup-per-CU kernel above ~45 % of a tile of this problem is its epilogue -- 2 x 256 KB of fp32
-//   leaving through the CU's ~16 B/clk store path with the matrix pipe idle.  That kernel owns the
+//   leaving through the CU's ~16 B/clk store path with the matrix pipe idle (docs/HISTORY_r04.md).  That kernel owns the
 //   CU's whole LDS and half of its registers, so nothing else can run beside its stores.  Here a workgroup is half the
 //   size (tile 256 x 128, waves 2 x 2 of 128 x 64 -- the same fragment code -- and a 3-slot ring of 24 KB stages = 72 KB),
 //   two of them share a CU, and while one drains its stores the other runs its k-loop.
@@ -1891,7 +1891,7 @@ __global__ __launch_bounds__(256, 2) void dist_sym_p2_kernel(GemmArgs g, int til
         // workgroup of the CU fills the gaps.  (A software-pipelined version -- fragments of stage t+1 and the DMA of stage
         // t+3 spread between the matrix instructions of stage t, as in the 256 x 256 kernel -- runs the k-loop ALONE 7 %
         // faster and the whole kernel slower, 0.62 against 0.54-0.59 ms at N = 20 000 on one device: this kernel's
-        // k-loop is bound by the CU's vector-memory path, which its stores share)
+        // k-loop is bound by the CU's vector-memory path, which its stores share; docs/HISTORY_r04.md.)
         for (int t = 0; t < nst; ++t) {
             if (t + 1 < nst) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -2248,7 +2248,7 @@ static int launch_one(const GemmArgs &a_in, hipStream_t stream) {
         use_p2 = a.sym && p2_mode > 0 && a.M == a.N && (a.A == a.W || p2_mode >= 3) && (a.M % PBM == 0) && (a.K % PBK == 0) &&
                  (p2_mode >= 2 || a.M / PBM >= 16);   // (3: also the 3-term split operands, A != W: measured slower, see DESIGN)
         // MPREID_TUNE dist_p2_full: the two-workgroups-per-CU kernel for TWO tensors (stored distances, one-pass fp16 and
-        // 3-term split operands): 0 never (default: measured), 1 problems of at least 16 x 32 tiles, 2 whenever
+        // 3-term split operands): 0 never (default: measured slower), 1 problems of at least 16 x 32 tiles, 2 whenever
         // the padded sizes allow (tests)
         static const int full_mode = mpreid_tune("dist_p2_full", 0);
         if (!use_p2 && !a.sym && full_mode > 0 && a.out && (a.M % PBM == 0) && (a.N % PBN == 0) && (a.K % PBK == 0) &&
