@@ -334,6 +334,13 @@ size_t mpreid_vit_workspace_bytes_f32(const mpreid_vit_cfg *cfg, int batch);
 int mpreid_vit_forward_f32(const mpreid_vit_cfg *cfg, const mpreid_vit_weights *w_f32, const float *img_dev, int batch,
                            const float *cv_emb_dev, float *out_dev, void *ws_dev, size_t ws_bytes,
                            mpreid_stream_t stream);
+/* the all-fp32 mode on uint8 input and / or one test-time-augmentation view (MPREID_VIEW_* below): exactly one of
+ * img_f32_dev ([B][3][H][W], already normalised) and img_hwc_u8_dev ([B][H][W][3] + pixel_mean3 / pixel_std3 host arrays) is
+ * non-NULL; ToTensor + Normalize and the view transform happen inside the patch gather, in the reference's arithmetic */
+int mpreid_vit_forward_f32_view(const mpreid_vit_cfg *cfg, const mpreid_vit_weights *w_f32, const float *img_f32_dev,
+                                const uint8_t *img_hwc_u8_dev, const float *pixel_mean3, const float *pixel_std3, int view,
+                                int batch, const float *cv_emb_dev, float *out_dev, void *ws_dev, size_t ws_bytes,
+                                mpreid_stream_t stream);
 
 /* same, from uint8 images [B][img_h][img_w][3] (HWC, after Resize): ToTensor (x/255) and Normalize
  * ((x - pixel_mean)/pixel_std, host arrays of 3 floats: INPUT.PIXEL_MEAN / PIXEL_STD) of the reference's

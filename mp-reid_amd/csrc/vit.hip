@@ -1301,8 +1301,20 @@ int mpreid_gemm_f32_linear(const float *A, const float *Wt, int64_t M, int64_t N
                            int64_t ldc, int epi, hipStream_t stream);
 enum { F32_LIN = 2, F32_LIN_GELU = 3, F32_LIN_RES = 4 };   // distance.hip: EPI_LIN*
 
-// img [B][3][H][W] fp32 -> patches [B*P][3*p*p] fp32, inner order (c, kh, kw)
-__global__ __launch_bounds__(256) void im2col_f32_kernel(const float *__restrict__ img, int B, int H, int Wd, int p, int stride,
+// img [B][3][H][W] fp32 (or img8 [B][H][W][3] uint8 with ToTensor + Normalize applied on the fly, as in im2col_u8_kernel)
+// -> patches [B*P][3*p*p] fp32, inner order (c, kh, kw); view = the test-time-augmentation views of im2col_kernel (run-time
+// here: the all-fp32 mode is the parity / debugging mode, not a throughput path)
+struct F32In {
+    const float *img;
+    const unsigned char *img8;
+    float mean[3], sd[3];
+    int view;
+};
+__device__ __forceinline__ float f32in_px(const F32In &in, int b, int c, int y, int x, int H, int Wd) {
+    if (in.img8) return __fdiv_rn(__fdiv_rn((float)in.img8[(((int64_t)b * H + y) * Wd + x) * 3 + c], 255.0f) - in.mean[c], in.sd[c]);
+    return in.img[(((int64_t)b * 3 + c) * H + y) * Wd + x];
+}
+__global__ __launch_bounds__(256) void im2col_f32_kernel(const F32In in, int B, int H, int Wd, int p, int stride,
                                                          int h_res, int w_res, float *__restrict__ out) {
     const int Kp = 3 * p * p, P = h_res * w_res;
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1310,7 +1322,14 @@ __global__ __launch_bounds__(256) void im2col_f32_kernel(const float *__restrict
     const int m = (int)(gid / Kp), k = (int)(gid % Kp);
     const int b = m / P, pi = m % P, ph = pi / w_res, pw = pi % w_res;
     const int c = k / (p * p), kh = (k % (p * p)) / p, kw = k % p;
-    out[gid] = img[(((int64_t)b * 3 + c) * H + (ph * stride + kh)) * Wd + pw * stride + kw];
+    const int y = ph * stride + kh, x0 = pw * stride + kw;
+    const int x = in.view == 1 ? Wd - 1 - x0 : x0;                       // torch.flip(img, [3])
+    float v;
+    if (in.view == 2)                                                     // img.mean(dim=1): ((c0 + c1) + c2) / 3
+        v = __fdiv_rn((f32in_px(in, b, 0, y, x, H, Wd) + f32in_px(in, b, 1, y, x, H, Wd)) + f32in_px(in, b, 2, y, x, H, Wd), 3.0f);
+    else
+        v = f32in_px(in, b, in.view == 3 ? 0 : c, y, x, H, Wd);           // 3: img[:, 0:1] in all three channels
+    out[gid] = v;
 }
 
 // x[b*L + 1 + p][:] = tok[b*P + p][:] + pos[1 + p][:]
@@ -1395,11 +1414,11 @@ extern "C" size_t mpreid_vit_workspace_bytes_f32(const mpreid_vit_cfg *cfg, int 
     return vit_layout_f32(cfg, batch).total;
 }
 
-extern "C" int mpreid_vit_forward_f32(const mpreid_vit_cfg *cfg, const mpreid_vit_weights *w, const float *img, int B,
-                                      const float *cv_emb, float *out, void *ws, size_t ws_bytes, mpreid_stream_t stream_) {
+static int vit_forward_f32_impl(const mpreid_vit_cfg *cfg, const mpreid_vit_weights *w, const F32In &img, int B,
+                                const float *cv_emb, float *out, void *ws, size_t ws_bytes, mpreid_stream_t stream_) {
     int rc = vit_check_cfg(cfg);
     if (rc) return rc;
-    ARG_CHECK(w && img && out && B > 0 && w->layers);
+    ARG_CHECK(w && (img.img || img.img8) && img.view >= 0 && img.view <= 3 && out && B > 0 && w->layers);
     if (cfg->width / cfg->heads != 64) {
         mpreid_set_error("fp32 attention: head dimension %d != 64", cfg->width / cfg->heads);
         return MPREID_ERR_UNSUPPORTED;
@@ -1463,6 +1482,26 @@ extern "C" int mpreid_vit_forward_f32(const mpreid_vit_cfg *cfg, const mpreid_vi
                        neck ? w->bn_proj_scale : nullptr, neck ? w->bn_proj_shift : nullptr, out);
     LAUNCH_CHECK();
     return MPREID_OK;
+}
+
+extern "C" int mpreid_vit_forward_f32(const mpreid_vit_cfg *cfg, const mpreid_vit_weights *w, const float *img, int B,
+                                      const float *cv_emb, float *out, void *ws, size_t ws_bytes, mpreid_stream_t stream_) {
+    ARG_CHECK(img);
+    const F32In in{img, nullptr, {0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}, 0};
+    return vit_forward_f32_impl(cfg, w, in, B, cv_emb, out, ws, ws_bytes, stream_);
+}
+
+extern "C" int mpreid_vit_forward_f32_view(const mpreid_vit_cfg *cfg, const mpreid_vit_weights *w, const float *img_f32,
+                                           const uint8_t *img_u8, const float *mean, const float *stdv, int view, int B,
+                                           const float *cv_emb, float *out, void *ws, size_t ws_bytes, mpreid_stream_t stream_) {
+    ARG_CHECK((img_f32 != nullptr) != (img_u8 != nullptr) && (!img_u8 || (mean && stdv)));
+    F32In in{img_f32, img_u8, {0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}, view};
+    if (img_u8)
+        for (int c = 0; c < 3; ++c) {
+            in.mean[c] = mean[c];
+            in.sd[c] = stdv[c];
+        }
+    return vit_forward_f32_impl(cfg, w, in, B, cv_emb, out, ws, ws_bytes, stream_);
 }
 
 extern "C" int mpreid_vit_forward(const mpreid_vit_cfg *cfg, const mpreid_vit_weights *w, const float *img, int B,

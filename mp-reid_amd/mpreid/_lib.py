@@ -30,7 +30,7 @@ SYMBOLS = [
     "mpreid_rr_qe_fill", "mpreid_rr_jaccard", "mpreid_rr_jaccard_hist_bytes",
     "mpreid_rr_csc_chunks", "mpreid_rr_csc_count", "mpreid_rr_csc_fill", "mpreid_rr_jaccard_indexed",
     "mpreid_vit_workspace_bytes", "mpreid_vit_forward", "mpreid_vit_forward_u8", "mpreid_vit_forward_view",
-    "mpreid_vit_workspace_bytes_f32", "mpreid_vit_forward_f32",
+    "mpreid_vit_workspace_bytes_f32", "mpreid_vit_forward_f32", "mpreid_vit_forward_f32_view",
     "mpreid_tta_mean_f32", "mpreid_resize_workspace_bytes", "mpreid_resize_bilinear_u8", "mpreid_conv_f16_nhwc",
     "mpreid_rn50_workspace_bytes", "mpreid_rn50_forward", "mpreid_rn50_workspace_bytes_f32", "mpreid_rn50_forward_f32",
     "mpreid_rn50_workspace_bytes_split", "mpreid_rn50_forward_split", "mpreid_rn50_forward_f32_u8", "mpreid_rn50_forward_split_u8",
@@ -232,6 +232,9 @@ def load():
     L.mpreid_vit_workspace_bytes_f32.argtypes = [C.POINTER(VitCfg), i32]
     L.mpreid_vit_forward_f32.restype = i32
     L.mpreid_vit_forward_f32.argtypes = [C.POINTER(VitCfg), C.POINTER(VitWeights), vp, i32, vp, vp, vp, sz, vp]
+    L.mpreid_vit_forward_f32_view.restype = i32
+    L.mpreid_vit_forward_f32_view.argtypes = [C.POINTER(VitCfg), C.POINTER(VitWeights), vp, vp, C.POINTER(C.c_float),
+                                              C.POINTER(C.c_float), i32, i32, vp, vp, vp, sz, vp]
     L.mpreid_vit_forward_u8.restype = i32
     L.mpreid_vit_forward_u8.argtypes = [C.POINTER(VitCfg), C.POINTER(VitWeights), vp, C.POINTER(C.c_float),
                                         C.POINTER(C.c_float), i32, vp, vp, vp, sz, vp]

@@ -393,19 +393,43 @@ class VitEncoder:
 
     __call__ = forward
 
-    def _to_f32_images(self, img_hwc, pixel_mean, pixel_std):
-        """ToTensor + Normalize of val_transforms (datasets/make_dataloader.py:59-60) with torch ops: fp32 mode only"""
-        t = img_hwc.detach().to(device=self.device).permute(0, 3, 1, 2).to(torch.float32).div(255)
-        mean = torch.tensor(pixel_mean, dtype=torch.float32, device=self.device)[None, :, None, None]
-        std = torch.tensor(pixel_std, dtype=torch.float32, device=self.device)[None, :, None, None]
-        return ((t - mean) / std).contiguous()
+    def _forward_f32_view(self, img, view, cv_emb, pixel_mean, pixel_std, out):
+        """the all-fp32 mode on fp32 [B,3,H,W] or uint8 [B,H,W,3] input, one view: ToTensor + Normalize and the view transform
+        inside the patch gather (mpreid_vit_forward_f32_view)"""
+        L = _lib.load()
+        u8 = img.dtype == torch.uint8
+        if u8:
+            img = img.detach().to(device=self.device).contiguous()
+            assert tuple(img.shape[1:]) == self.img_hw + (3,), img.shape
+        else:
+            img = _dev_f32(img, self.device)
+            assert tuple(img.shape[1:]) == (3,) + self.img_hw, img.shape
+        B = img.shape[0]
+        cv = None
+        if cv_emb is not None:
+            cv = _dev_f32(cv_emb, self.device)
+            assert tuple(cv.shape) == (B, self.cfg["width"])
+        if out is None:
+            out = torch.empty((B, self.feat_dim), dtype=torch.float32, device=self.device)
+        assert out.is_contiguous() and out.dtype == torch.float32 and tuple(out.shape) == (B, self.feat_dim)
+        mean = (C.c_float * 3)(*[float(x) for x in pixel_mean])
+        std = (C.c_float * 3)(*[float(x) for x in pixel_std])
+        step = 64   # fp32 activations: 4x the bytes per token
+        for s in range(0, B, step):
+            e = min(B, s + step)
+            ws = _workspace(self.ws_tag + "_f32", L.mpreid_vit_workspace_bytes_f32(C.byref(self.c_cfg), e - s), self.device)
+            _lib.check(L.mpreid_vit_forward_f32_view(C.byref(self.c_cfg), C.byref(self.c_w), None if u8 else _ptr(img[s:e]),
+                                                     _ptr(img[s:e]) if u8 else None, mean, std, int(view), e - s,
+                                                     _ptr(None if cv is None else cv[s:e].contiguous()), _ptr(out[s:e]), _ptr(ws),
+                                                     ws.numel(), _lib.stream_ptr()), "mpreid_vit_forward_f32_view")
+        return out
 
     @torch.no_grad()
     def forward_u8(self, img_hwc: torch.Tensor, pixel_mean=(0.5, 0.5, 0.5), pixel_std=(0.5, 0.5, 0.5),
                    cv_emb: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """uint8 images [B, H, W, 3] (after Resize); ToTensor + Normalize run inside the patch-gather kernel."""
         if self.precision == "fp32":
-            return self.forward(self._to_f32_images(img_hwc, pixel_mean, pixel_std), cv_emb, out)
+            return self._forward_f32_view(img_hwc.to(torch.uint8), VIEW_ORIGINAL, cv_emb, pixel_mean, pixel_std, out)
         L = _lib.load()
         img = img_hwc.detach().to(device=self.device, dtype=torch.uint8).contiguous()
         B = img.shape[0]
@@ -429,15 +453,8 @@ class VitEncoder:
         img is either fp32 [B,3,H,W] (already normalised) or uint8 [B,H,W,3].  The view transform of
         processor/processor_uniprompt_stage2.py:605-633 happens inside the patch gather."""
         L = _lib.load()
-        if self.precision == "fp32":   # the views as the reference materialises them (tensor ops), then the fp32 encoder
-            t = self._to_f32_images(img, pixel_mean, pixel_std) if img.dtype == torch.uint8 else _dev_f32(img, self.device)
-            if view == VIEW_FLIP:
-                t = torch.flip(t, [3])
-            elif view == VIEW_PSEUDO_IR:
-                t = t.mean(dim=1, keepdim=True).repeat(1, 3, 1, 1)
-            elif view == VIEW_PSEUDO_RGB:
-                t = t[:, 0:1].repeat(1, 3, 1, 1)
-            return self.forward(t.contiguous(), cv_emb, out)
+        if self.precision == "fp32":   # (round 5: inside the fp32 patch gather too, no materialised view tensor)
+            return self._forward_f32_view(img, view, cv_emb, pixel_mean, pixel_std, out)
         u8 = img.dtype == torch.uint8
         if u8:
             img = img.detach().to(device=self.device).contiguous()

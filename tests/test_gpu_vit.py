@@ -262,6 +262,29 @@ def test_split_vit_uint8_and_views_match_float_path():
                           enc(x[:, 0:1].repeat(1, 3, 1, 1).contiguous()).cpu().numpy())
 
 
+def test_fp32_vit_uint8_and_views_match_materialised_tensors():
+    """the all-fp32 mode (round 5: mpreid_vit_forward_f32_view): uint8 input and all three test-time-augmentation views inside
+    the fp32 patch gather == the tensors the reference materialises (torch ops: ToTensor + Normalize,
+    processor/processor_uniprompt_stage2.py:605-633) through the plain fp32 entry point, bit for bit; 70 images = two
+    workspace chunks of 64"""
+    from mpreid import ops, synth
+    rng = np.random.default_rng(1)
+    sd = synth.vit_state_dict(SMALL, seed=7, std=0.05, ln_jitter=0.1)
+    enc = _encoder(SMALL, sd, (64, 32), precision="fp32")
+    u8 = rng.integers(0, 256, size=(70, 64, 32, 3), dtype=np.uint8)
+    mean, std = (0.5, 0.4, 0.45), (0.5, 0.25, 0.3)
+    x = torch.from_numpy(u8).permute(0, 3, 1, 2).float().div(255.0)
+    x = ((x - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)).contiguous()
+    views = {ops.VIEW_ORIGINAL: x, ops.VIEW_FLIP: torch.flip(x, [3]).contiguous(),
+             ops.VIEW_PSEUDO_IR: x.mean(dim=1, keepdim=True).repeat(1, 3, 1, 1).contiguous(),
+             ops.VIEW_PSEUDO_RGB: x[:, 0:1].repeat(1, 3, 1, 1).contiguous()}
+    assert np.array_equal(enc.forward_u8(torch.from_numpy(u8), mean, std).cpu().numpy(), enc(x).cpu().numpy())
+    for v, t in views.items():
+        want = enc(t).cpu().numpy()
+        assert np.array_equal(enc.forward_view(x, v).cpu().numpy(), want), v                         # fp32 input, fused view
+        assert np.array_equal(enc.forward_view(torch.from_numpy(u8), v, None, mean, std).cpu().numpy(), want), v   # uint8 input
+
+
 def test_split_vit_bn_neck_vs_oracle():
     from mpreid import synth
     rng = np.random.default_rng(0)
