@@ -474,6 +474,15 @@ int mpreid_rn50_forward_split(const mpreid_rn50_cfg *cfg, const mpreid_rn50_weig
 int mpreid_rn50_forward_split_u8(const mpreid_rn50_cfg *cfg, const mpreid_rn50_weights_split *w, const uint8_t *img_u8_hwc_dev,
                                  const float *mean3, const float *std3, int batch, float *out_dev, void *ws_dev, size_t ws_bytes,
                                  mpreid_stream_t stream);   /* uint8 input, as mpreid_rn50_forward_f32_u8 */
+/* one test-time-augmentation view (MPREID_VIEW_*) of fp32 [B][3][H][W] or uint8 [B][H][W][3] input (exactly one pointer
+ * non-NULL), the view transform applied to the normalised pixels inside the stem's first convolution: the same bits as the
+ * materialised view tensor of processor/processor_uniprompt_stage2.py:605-633 */
+int mpreid_rn50_forward_split_view(const mpreid_rn50_cfg *cfg, const mpreid_rn50_weights_split *w, const float *img_f32_dev,
+                                   const uint8_t *img_u8_hwc_dev, const float *mean3, const float *std3, int view, int batch,
+                                   float *out_dev, void *ws_dev, size_t ws_bytes, mpreid_stream_t stream);
+int mpreid_rn50_forward_f32_view(const mpreid_rn50_cfg *cfg, const mpreid_rn50_weights_f32 *w, const float *img_f32_dev,
+                                 const uint8_t *img_u8_hwc_dev, const float *mean3, const float *std3, int view, int batch,
+                                 float *out_dev, void *ws_dev, size_t ws_bytes, mpreid_stream_t stream);
 
 /* One convolution layer of the RN50 tower as the encoder runs it (unit tests, micro-benchmarks):
  * NHWC fp16 in [batch][h][w][cin] (cin % 64 == 0), stride 1, taps = 1 (1x1) or 9 (3x3, pad 1); weights fp16

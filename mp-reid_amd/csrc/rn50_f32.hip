@@ -25,14 +25,25 @@ namespace {
 // The stem's input: fp32 [B][3][H][W] (val_transforms applied), or -- img8 != NULL -- uint8 [B][H][W][3] (what the loader has
 // after Resize) with ToTensor + Normalize of datasets/make_dataloader.py:57-61 applied on the fly, in the reference's order and
 // rounding: (x / 255 - mean) / std with two correctly rounded divisions (same bits as the host-transformed fp32 tensor).
+// view: the test-time-augmentation views of processor/processor_uniprompt_stage2.py:605-633 applied to the NORMALISED image while
+// it is read (0 original, 1 torch.flip(img, [3]), 2 pseudo-IR img.mean(dim=1) in all channels = ((c0 + c1) + c2) / 3, 3 pseudo-RGB
+// channel 0 in all channels) -- what include/mpreid.h calls MPREID_VIEW_*; same bits as the materialised view tensor.
 struct StemIn {
     const float *img;
     const uint8_t *img8;
     float mean[3], sd[3];
+    int view;
 };
-__device__ __forceinline__ float stem_px(const StemIn &in, int b, int c, int iy, int ix, int H, int W) {
+__device__ __forceinline__ float stem_px_raw(const StemIn &in, int b, int c, int iy, int ix, int H, int W) {
     if (in.img8) return __fdiv_rn(__fdiv_rn((float)in.img8[(((int64_t)b * H + iy) * W + ix) * 3 + c], 255.0f) - in.mean[c], in.sd[c]);
     return in.img[(((int64_t)b * 3 + c) * H + iy) * W + ix];
+}
+__device__ __forceinline__ float stem_px(const StemIn &in, int b, int c, int iy, int ix, int H, int W) {
+    if (in.view == 0) return stem_px_raw(in, b, c, iy, ix, H, W);
+    const int x = in.view == 1 ? W - 1 - ix : ix;
+    if (in.view == 2)
+        return __fdiv_rn((stem_px_raw(in, b, 0, iy, x, H, W) + stem_px_raw(in, b, 1, iy, x, H, W)) + stem_px_raw(in, b, 2, iy, x, H, W), 3.0f);
+    return stem_px_raw(in, b, in.view == 3 ? 0 : c, iy, x, H, W);
 }
 
 // stem conv1 + bn1 + relu: [B][3][H][W] fp32 -> [B][H/2][W/2][cout] fp32 (stride 2, pad 1); w [cout][c][kh][kw] folded
@@ -322,8 +333,8 @@ extern "C" size_t mpreid_rn50_workspace_bytes_f32(const mpreid_rn50_cfg *cfg, in
     return layout_f32(cfg, batch).total;
 }
 
-static StemIn stem_in(const float *img, const uint8_t *img8, const float *mean, const float *sd) {
-    StemIn s{img, img8, {0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}};
+static StemIn stem_in(const float *img, const uint8_t *img8, const float *mean, const float *sd, int view = 0) {
+    StemIn s{img, img8, {0.f, 0.f, 0.f}, {1.f, 1.f, 1.f}, view};
     if (img8)
         for (int c = 0; c < 3; ++c) {
             s.mean[c] = mean[c];
@@ -429,6 +440,13 @@ extern "C" int mpreid_rn50_forward_f32_u8(const mpreid_rn50_cfg *cfg, const mpre
                                           mpreid_stream_t stream_) {
     ARG_CHECK(img_hwc && mean && stdv);
     return rn50_forward_f32_impl(cfg, w, stem_in(nullptr, img_hwc, mean, stdv), B, out, ws, ws_bytes, stream_);
+}
+
+extern "C" int mpreid_rn50_forward_f32_view(const mpreid_rn50_cfg *cfg, const mpreid_rn50_weights_f32 *w, const float *img_f32,
+                                            const uint8_t *img_hwc, const float *mean, const float *stdv, int view, int B,
+                                            float *out, void *ws, size_t ws_bytes, mpreid_stream_t stream_) {
+    ARG_CHECK((img_f32 != nullptr) != (img_hwc != nullptr) && (!img_hwc || (mean && stdv)) && view >= 0 && view <= 3);
+    return rn50_forward_f32_impl(cfg, w, stem_in(img_f32, img_hwc, mean, stdv, view), B, out, ws, ws_bytes, stream_);
 }
 
 
@@ -822,4 +840,11 @@ extern "C" int mpreid_rn50_forward_split_u8(const mpreid_rn50_cfg *cfg, const mp
                                             mpreid_stream_t stream_) {
     ARG_CHECK(img_hwc && mean && stdv);
     return rn50_forward_split_impl(cfg, w, stem_in(nullptr, img_hwc, mean, stdv), B, out, ws, ws_bytes, stream_);
+}
+
+extern "C" int mpreid_rn50_forward_split_view(const mpreid_rn50_cfg *cfg, const mpreid_rn50_weights_split *w, const float *img_f32,
+                                              const uint8_t *img_hwc, const float *mean, const float *stdv, int view, int B,
+                                              float *out, void *ws, size_t ws_bytes, mpreid_stream_t stream_) {
+    ARG_CHECK((img_f32 != nullptr) != (img_hwc != nullptr) && (!img_hwc || (mean && stdv)) && view >= 0 && view <= 3);
+    return rn50_forward_split_impl(cfg, w, stem_in(img_f32, img_hwc, mean, stdv, view), B, out, ws, ws_bytes, stream_);
 }

@@ -152,9 +152,12 @@ class build_transformer(nn.Module):
         if isinstance(x, (list, tuple, _ops.PackedRawImages)):
             x = _ops.resize_bilinear_u8(x, self.img_hw)
         if self.model_name == 'RN50':
+            if view != 0 and self.precision in ("split", "fp32"):
+                # (round 5) the view transform happens inside the stem's first convolution (mpreid_rn50_forward_*_view)
+                return enc.forward_view(x, view, None, self.pixel_mean, self.pixel_std)
             if view != 0:
-                # the view gather is fused into the ViT patch kernel only; for RN50 the view tensor is materialised
-                # on the device the way the reference does it (processor/processor_uniprompt_stage2.py:605-633)
+                # the fp16 throughput tower: the view tensor is materialised on the device the way the reference does it
+                # (processor/processor_uniprompt_stage2.py:605-633)
                 if x.dtype == torch.uint8:
                     mean = torch.tensor(self.pixel_mean, device=x.device)[None, :, None, None]
                     std = torch.tensor(self.pixel_std, device=x.device)[None, :, None, None]

@@ -34,6 +34,7 @@ SYMBOLS = [
     "mpreid_tta_mean_f32", "mpreid_resize_workspace_bytes", "mpreid_resize_bilinear_u8", "mpreid_conv_f16_nhwc",
     "mpreid_rn50_workspace_bytes", "mpreid_rn50_forward", "mpreid_rn50_workspace_bytes_f32", "mpreid_rn50_forward_f32",
     "mpreid_rn50_workspace_bytes_split", "mpreid_rn50_forward_split", "mpreid_rn50_forward_f32_u8", "mpreid_rn50_forward_split_u8",
+    "mpreid_rn50_forward_f32_view", "mpreid_rn50_forward_split_view",
     "mpreid_gemm_f16_nt", "mpreid_gemm_f16_nt_ex", "mpreid_gemm_f16_split_nt", "mpreid_split_pack_f32",
     "mpreid_cast_f32_to_f16", "mpreid_profile_enable", "mpreid_profile_reset", "mpreid_profile_query",
 ]
@@ -266,6 +267,12 @@ def load():
     L.mpreid_rn50_forward_split_u8.restype = i32
     L.mpreid_rn50_forward_split_u8.argtypes = [C.POINTER(Rn50Cfg), C.POINTER(Rn50WeightsSplit), vp, C.POINTER(C.c_float),
                                                C.POINTER(C.c_float), i32, vp, vp, sz, vp]
+    L.mpreid_rn50_forward_f32_view.restype = i32
+    L.mpreid_rn50_forward_f32_view.argtypes = [C.POINTER(Rn50Cfg), C.POINTER(Rn50WeightsF32), vp, vp, C.POINTER(C.c_float),
+                                               C.POINTER(C.c_float), i32, i32, vp, vp, sz, vp]
+    L.mpreid_rn50_forward_split_view.restype = i32
+    L.mpreid_rn50_forward_split_view.argtypes = [C.POINTER(Rn50Cfg), C.POINTER(Rn50WeightsSplit), vp, vp, C.POINTER(C.c_float),
+                                                 C.POINTER(C.c_float), i32, i32, vp, vp, sz, vp]
     L.mpreid_conv_f16_nhwc.restype = i32
     L.mpreid_conv_f16_nhwc.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, i32, i32, vp, i32, vp, vp, vp]
     L.mpreid_gemm_f16_nt.restype = i32

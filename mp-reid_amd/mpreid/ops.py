@@ -804,10 +804,12 @@ class Rn50Encoder:
 
     @torch.no_grad()
     def forward(self, img: torch.Tensor, cv_emb=None, pixel_mean=(0.5, 0.5, 0.5), pixel_std=(0.5, 0.5, 0.5),
-                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                out: Optional[torch.Tensor] = None, view: int = 0) -> torch.Tensor:
         """img: fp32 [B,3,H,W] (val_transforms applied) or uint8 [B,H,W,3] (after Resize).  cv_emb is ignored: the
-        reference's RN50 branch has no SIE embedding (model/make_model.py:82-86)."""
+        reference's RN50 branch has no SIE embedding (model/make_model.py:82-86).  view (split / fp32 towers): a
+        test-time-augmentation view applied inside the stem's first convolution (mpreid_rn50_forward_*_view)."""
         L = _lib.load()
+        assert view == 0 or self.precision in ("fp32", "split"), "the fp16 tower takes materialised view tensors"
         if self.precision in ("fp32", "split"):
             split = self.precision == "split"
             u8 = img.dtype == torch.uint8    # ToTensor + Normalize inside the stem's first convolution (mpreid_rn50_forward_*_u8)
@@ -827,7 +829,12 @@ class Rn50Encoder:
                 e0 = min(B, s0 + step)
                 if split:
                     ws = _workspace(self.ws_tag + "_split", L.mpreid_rn50_workspace_bytes_split(C.byref(self.c_cfg), e0 - s0), self.device)
-                    if u8:
+                    if view:
+                        _lib.check(L.mpreid_rn50_forward_split_view(C.byref(self.c_cfg), C.byref(self.c_ws), None if u8 else _ptr(img[s0:e0]),
+                                                                    _ptr(img[s0:e0]) if u8 else None, mean if u8 else None,
+                                                                    std if u8 else None, int(view), e0 - s0, _ptr(out[s0:e0]), _ptr(ws),
+                                                                    ws.numel(), _lib.stream_ptr()), "mpreid_rn50_forward_split_view")
+                    elif u8:
                         _lib.check(L.mpreid_rn50_forward_split_u8(C.byref(self.c_cfg), C.byref(self.c_ws), _ptr(img[s0:e0]), mean, std,
                                                                   e0 - s0, _ptr(out[s0:e0]), _ptr(ws), ws.numel(), _lib.stream_ptr()),
                                    "mpreid_rn50_forward_split_u8")
@@ -837,7 +844,12 @@ class Rn50Encoder:
                                    "mpreid_rn50_forward_split")
                     continue
                 ws = _workspace(self.ws_tag + "_f32", L.mpreid_rn50_workspace_bytes_f32(C.byref(self.c_cfg), e0 - s0), self.device)
-                if u8:
+                if view:
+                    _lib.check(L.mpreid_rn50_forward_f32_view(C.byref(self.c_cfg), C.byref(self.c_w), None if u8 else _ptr(img[s0:e0]),
+                                                              _ptr(img[s0:e0]) if u8 else None, mean if u8 else None, std if u8 else None,
+                                                              int(view), e0 - s0, _ptr(out[s0:e0]), _ptr(ws), ws.numel(),
+                                                              _lib.stream_ptr()), "mpreid_rn50_forward_f32_view")
+                elif u8:
                     _lib.check(L.mpreid_rn50_forward_f32_u8(C.byref(self.c_cfg), C.byref(self.c_w), _ptr(img[s0:e0]), mean, std,
                                                             e0 - s0, _ptr(out[s0:e0]), _ptr(ws), ws.numel(), _lib.stream_ptr()),
                                "mpreid_rn50_forward_f32_u8")
@@ -868,3 +880,7 @@ class Rn50Encoder:
 
     def forward_u8(self, img_hwc, pixel_mean=(0.5, 0.5, 0.5), pixel_std=(0.5, 0.5, 0.5), cv_emb=None, out=None):
         return self.forward(img_hwc, None, pixel_mean, pixel_std, out)
+
+    def forward_view(self, img, view, cv_emb=None, pixel_mean=(0.5, 0.5, 0.5), pixel_std=(0.5, 0.5, 0.5), out=None):
+        """one test-time-augmentation view (VIEW_*) of fp32 [B,3,H,W] or uint8 [B,H,W,3] input, inside the stem (split / fp32)"""
+        return self.forward(img, None, pixel_mean, pixel_std, out, view=int(view))

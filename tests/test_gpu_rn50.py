@@ -269,6 +269,28 @@ def test_rn50_image_to_map_parity():
     assert r[0] <= 5e-3 and max(r[2], r[5]) <= 2e-2, r
 
 
+@pytest.mark.parametrize("precision", ["split", "fp32"])
+def test_rn50_views_inside_the_stem_match_materialised_tensors(precision):
+    """the test-time-augmentation views (processor/processor_uniprompt_stage2.py:605-633) inside the stem's first convolution
+    (mpreid_rn50_forward_split_view / _f32_view, round 5) == the view tensors the reference materialises (torch ops) through the
+    plain entry point, bit for bit -- fp32 and uint8 input, all three views; and through make_model's _encode"""
+    from mpreid import ops, synth
+    rng = np.random.default_rng(3)
+    sd = synth.rn50_state_dict(SMALL, seed=12)
+    enc = ops.Rn50Encoder(SMALL, sd, (64, 32), precision=precision)
+    u8 = rng.integers(0, 256, (5, 64, 32, 3), dtype=np.uint8)
+    mean, std = (0.5, 0.4, 0.45), (0.5, 0.25, 0.3)
+    x = torch.from_numpy(u8).permute(0, 3, 1, 2).float().div(255)
+    x = ((x - torch.tensor(mean)[None, :, None, None]) / torch.tensor(std)[None, :, None, None]).contiguous()
+    views = {ops.VIEW_FLIP: torch.flip(x, [3]).contiguous(),
+             ops.VIEW_PSEUDO_IR: x.mean(dim=1, keepdim=True).repeat(1, 3, 1, 1).contiguous(),
+             ops.VIEW_PSEUDO_RGB: x[:, 0:1].repeat(1, 3, 1, 1).contiguous()}
+    for v, t in views.items():
+        want = enc(t).cpu().numpy()
+        assert np.array_equal(enc.forward_view(x, v).cpu().numpy(), want), v
+        assert np.array_equal(enc.forward_view(torch.from_numpy(u8), v, None, mean, std).cpu().numpy(), want), v
+
+
 def test_rn50_image_to_map_parity_spread_set():
     """north_star's plain 1e-4 on mAP / Rank-1 for MODEL.NAME RN50, on a set where it MEANS something (round-4 advisor: the
     degenerate set above lets a systematic bias of 2e-3 pass).  The degenerate geometry of a random-init ResNet has two
