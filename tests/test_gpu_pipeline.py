@@ -327,16 +327,20 @@ def test_do_inference_rn50_matches_oracle_pipeline(tmp_path):
 
 
 def test_rn50_tta_views_and_uniprompt_branches():
-    """RN50 under the Uni-Prompt evaluation: the TTA views are materialised tensors (as in the reference) and
-    get_image returns the attention-pool output"""
+    """RN50 under the Uni-Prompt evaluation: the TTA views (round 5: applied inside the stem's first convolution in the default
+    split precision) equal the materialised view tensors of the reference loop -- built here with torch on the HOST, the
+    arithmetic the fused gathers follow (mean over the channels = ((c0 + c1) + c2) / 3 with a true division; torch's device
+    kernel multiplies by a rounded 1/3 instead: one ulp apart on a third of the pixels) -- and get_image returns the
+    attention-pool output"""
     from mpreid import synth
     from model.make_model_uniprompt import make_model
     cfg = _raw_cfg(4, 4, 4, **{"MODEL.NAME": "RN50", "TEST.NECK_FEAT": "after"})
     m = make_model(cfg, num_class=7, camera_num=6, view_num=1)
-    x = torch.from_numpy(synth.synthetic_images(3, 256, 128, seed=6)).cuda()
-    assert torch.equal(m(x=x, tta_view=1), m(x=torch.flip(x, [3]).contiguous()))
-    assert torch.equal(m(x=x, tta_view=2), m(x=x.mean(dim=1, keepdim=True).repeat(1, 3, 1, 1)))
-    assert torch.equal(m(x=x, tta_view=3), m(x=x[:, 0:1].repeat(1, 3, 1, 1)))
+    xh = torch.from_numpy(synth.synthetic_images(3, 256, 128, seed=6))
+    x = xh.cuda()
+    assert torch.equal(m(x=x, tta_view=1), m(x=torch.flip(xh, [3]).contiguous().cuda()))
+    assert torch.equal(m(x=x, tta_view=2), m(x=xh.mean(dim=1, keepdim=True).repeat(1, 3, 1, 1).contiguous().cuda()))
+    assert torch.equal(m(x=x, tta_view=3), m(x=xh[:, 0:1].repeat(1, 3, 1, 1).contiguous().cuda()))
     proj = m(x=x, get_image=True)
     assert proj.shape == (3, 1024)
     full = m(x=x)
