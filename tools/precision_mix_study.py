@@ -49,12 +49,17 @@ def mm(a, w, mode):
     ah, al = pair(a)
     wh, wl = wpair(w)
     out = ah @ wh.t()
-    if mode == "f8c":   # both cross terms with fp8 (OCP e4m3) operands: lo scaled by a power of two into e4m3's range, hi rounded to 4 bits
+    if mode in ("f8c", "f8a", "f8w"):   # cross terms with fp8 (OCP e4m3) operands: lo scaled by a power of two into e4m3's range, hi rounded to 4 bits
         def f8(x, per_row=True):
             amax = x.abs().amax(dim=-1, keepdim=True).clamp_min(1e-300) if per_row else x.abs().max()
             sc = torch.exp2(torch.floor(torch.log2(256.0 / amax)))          # largest entry into [128, 256) <= 448
             return (x * sc).to(torch.float32).to(torch.float8_e4m3fn).to(F64) / sc
-        return out + f8(al) @ f8(wh).t() + f8(ah) @ f8(wl).t()
+        if mode == "f8c":
+            return out + f8(al) @ f8(wh).t() + f8(ah) @ f8(wl).t()
+    if mode == "f8a":   # lo.hi' on fp8, hi.lo' on fp16
+        return out + f8(al) @ f8(wh).t() + ah @ wl.t()
+    if mode == "f8w":   # hi.lo' on fp8, lo.hi' on fp16
+        return out + al @ wh.t() + f8(ah) @ f8(wl).t()
     if mode in ("3", "a2"):
         out = out + al @ wh.t()
     if mode in ("3", "w2"):
@@ -125,6 +130,8 @@ def main():
         ("(iv) two (activations split) on QKV only, three elsewhere", dict(allm("3"), qkv="a2"), 2.78),
         ("(v) two (activations split) on out-proj only, three elsewhere", dict(allm("3"), out="a2"), 2.93),
         ("(vi) hi.hi' on fp16, BOTH cross terms on the fp8 matrix cores (e4m3 operands, per-row power-of-two scales; fp8 = 2x the fp16 rate)", allm("f8c"), 2.0),
+        ("(vii) as (vi) but only lo.hi' (activations' lo) on fp8, hi.lo' on fp16", allm("f8a"), 2.5),
+        ("(viii) as (vi) but only hi.lo' (weights' lo) on fp8, lo.hi' on fp16", allm("f8w"), 2.5),
         ("one product everywhere (the `fp16` mode)", allm("1"), 1.0),
     ]
     f_ref = features(sd, cfg, x, allm("exact"))
