@@ -307,9 +307,9 @@ def test_rn50_image_to_map_parity_spread_set():
     its own noise source on this set: the same graph evaluated in float64 (features 4.3e-6 away, oracle.rn50_features(dtype=
     'float64')) moves the re-ranked mAP by 3.5e-4 -- one k-reciprocal membership flipping -- so the 1e-4 is asserted against
     that exact-arithmetic answer (measured: split 3.8e-5, fp32 tower 8.4e-5, no query's Rank-1; reproducible, the float64 graph
-    does not depend on the host's BLAS path) and the distance to the fp32 oracle is held to the noise envelope of a random
-    feature error of the modes' size, capped at 5e-4 as in tests/test_gpu_map_parity.py (measured 3.9e-4 / 2.6e-4 against an
-    envelope of 2.8e-4).  Reference: model/clip/model.py:10-148, model/make_model.py:82-86, utils/metrics.py:28-88."""
+    does not depend on the host's BLAS path) and the distance to the fp32 oracle is held to 1e-4 + the oracle's OWN measured
+    distance from the float64 answer (triangle inequality; measured 3.9e-4 / 2.6e-4 against 1e-4 + 3.5e-4; the noise envelope of
+    a random feature error of the modes' size, 2.8e-4, is printed beside it).  Reference: model/clip/model.py:10-148, model/make_model.py:82-86, utils/metrics.py:28-88."""
     from conftest import map_noise_envelope
     from mpreid import ops, synth
     n_ids, per_id = 128, 8
@@ -352,6 +352,9 @@ def test_rn50_image_to_map_parity_spread_set():
         assert r["rel"] <= 2e-5, (prec, r)
         assert r["e_dmap"] <= 1e-4 and r["e_dr1"] <= 1e-4, (prec, r)                  # north_star, plain
         assert r["r64_dmap"] <= 1e-4 and r["r64_dr1"] <= 1e-4, (prec, r)             # re-ranked: against exact arithmetic
-        assert r["r_dmap"] <= bound_rr and r["r_dr1"] <= 1.0 / nq + 2.0 * env[1] + 1e-9, (prec, r, env)
+        # vs the fp32 oracle: by the triangle inequality no further than the oracle's own distance from exact arithmetic (host
+        # dependent: its BLAS path) + the 1e-4 asserted above; the capped envelope bound of round 5's first version is printed
+        oracle_noise = abs(ref[True][1] - ref["rr64"][1])
+        assert r["r_dmap"] <= 1e-4 + oracle_noise + 1e-12 and r["r_dr1"] <= 1.0 / nq + 2.0 * env[1] + 1e-9, (prec, r, env, oracle_noise)
     r = res["fp16"]
     assert r["rel"] <= 1e-2 and max(r["e_dmap"], r["r_dmap"]) <= 5e-2, r     # (reported: what fp16 activations support)
