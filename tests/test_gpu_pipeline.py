@@ -604,3 +604,26 @@ def test_do_inference_host_and_raw_loaders_match_direct_calls():
                 del os.environ["MPREID_PIPELINE"]
             assert (float(r1), float(r5)) == (float(cmc[0]), float(cmc[4])), (raw, stage)
             assert do_inference.last_pipeline_stats["images"] == 70
+
+
+def test_repeated_do_inference_keeps_its_streams_and_workspaces():
+    """round-4 advisor: the pipeline created new copy / encode streams on every run() and the encoders' workspaces are keyed
+    by stream (ops._workspace), so every evaluation left two more encoder workspaces (GBs each at full size) in the cache.  The
+    streams are now created once per device (pipeline._STREAMS): five evaluations in a row -- a periodic eval, bench.py's
+    timed loop -- end with the SAME set of cached workspaces as the first, and the same results."""
+    from datasets.make_dataloader import make_dataloader
+    from model.make_model import make_model
+    from mpreid import ops, pipeline
+    from processor.processor import do_inference
+    cfg = _cfg(neck="before", rerank=False)
+    _, _, val_loader, num_query, num_classes, cam_num, view_num = make_dataloader(cfg)
+    model = make_model(cfg, num_class=num_classes, camera_num=cam_num, view_num=view_num)
+    first = do_inference(cfg, model, val_loader, num_query)
+    keys = set(ops._ws_cache)
+    streams = {k: (v["copy"].cuda_stream, tuple(s.cuda_stream for s in v["enc"])) for k, v in pipeline._STREAMS.items()}
+    nbytes = sum(t.numel() for t in ops._ws_cache.values())
+    for _ in range(4):
+        assert do_inference(cfg, model, val_loader, num_query) == first
+    assert set(ops._ws_cache) == keys, (sorted(ops._ws_cache), sorted(keys))
+    assert sum(t.numel() for t in ops._ws_cache.values()) == nbytes
+    assert {k: (v["copy"].cuda_stream, tuple(s.cuda_stream for s in v["enc"])) for k, v in pipeline._STREAMS.items()} == streams
