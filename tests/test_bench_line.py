@@ -88,3 +88,22 @@ def test_gpus_beyond_visible_devices_exit_2_with_a_message():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--small"], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 2 and r.stdout.strip() == "" and r.stderr.strip() == ""   # only local rank 0 speaks
+
+
+@pytest.mark.gpu
+def test_bench_on_the_gpu_prints_one_small_line_and_a_quiet_stderr(tmp_path):
+    """the driver's view of `python bench.py --gpus 1 ...` (a 1/16 workload): stdout is ONE line that parses and obeys the size
+    contract, stderr is a handful of lines (round 4: ~90 evaluator lines), the extras file lands in the current directory"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--small", "--steps", "2", "--warmup", "1",
+                        "--cpu-images", "8"], cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0].encode()) <= bench.MAX_LINE_BYTES
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["value"] > 0 and j["unit"] == "images/s"
+    assert j["roofline"]["bound"] == "mfma" and 0 < j["roofline"]["frac"] <= 1 and j["roofline"]["avg_launch_ms"] > 0
+    assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["cores"] >= 1
+    assert j["config"]["encoder_precision"] == "split" and "Market-1501" in j["config"]["workload"]
+    assert len([ln for ln in r.stderr.splitlines() if ln.strip()]) <= 12, r.stderr[-1500:]
+    extras = json.load(open(tmp_path / "bench_extras.json"))
+    assert "gemm_classes" in extras and "drop_in" in extras
