@@ -55,14 +55,20 @@ METRIC = "gallery images/s encode + distmat+rerank ms, 20k×20k; mAP/Rank-1 pari
 # ----------------------------------------------------------------------------------------------------------------
 EXTRAS_FILE = "bench_extras.json"               # written to the current directory by rank 0
 MAX_LINE_BYTES = 4096
-MAX_STR = 200
+MAX_STR = 110                                   # (round 5's driver record clipped strings near 120 characters)
 LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-             "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "rccl_ranks", "all_gather",
+             "vs_baseline", "dtype", "data", "config", "metric_20k", "roofline", "cpu_baseline", "rccl_ranks", "all_gather",
              "extras_file")
+# the other two thirds of BASELINE.json's metric ("distmat + rerank ms, 20k x 20k; mAP / Rank-1 parity"): bare numbers
+METRIC_20K_KEYS = ("distmat_exact_ms", "distmat_split3_ms", "distmat_split3_frac_exec", "distmat_f16_ms", "distmat_f16_frac",
+                   "distmat_f16_2t_ms", "distmat_f16_2t_frac", "rerank_ms", "rerank_cpu_port_ms", "rerank_vs_cpu_x",
+                   "rerank_vs_ref265s_x", "dist_err_exact", "dist_err_split3", "dist_err_f16", "feat_rel_l2_split",
+                   "dmap_split", "dr1_split", "dmap_rr_split", "dr1_rr_split", "parity_images")
 CONFIG_KEYS = ("workload", "images_per_step", "encoder_batch", "encoder_precision", "encoder_streams", "sharding",
                "rerank", "distance_mode")
 ROOFLINE_KEYS = ("bound", "kernel", "shape", "achieved", "peak", "unit", "frac", "achieved_executed", "frac_executed",
-                 "avg_launch_ms", "launches", "algorithmic_flop", "algorithmic_bytes", "traffic", "traffic_source", "measured")
+                 "avg_launch_ms", "launches", "algorithmic_flop", "algorithmic_bytes", "traffic", "traffic_replayed",
+                 "traffic_source", "measured")
 CPU_BASELINE_KEYS = ("value", "unit", "cores", "kind", "sample")
 ALL_GATHER_KEYS = ("calls_per_step", "bytes_per_step", "ms_per_step", "gb_per_s")
 
@@ -83,9 +89,11 @@ def format_line(res, extras_file=EXTRAS_FILE):
     dominant kernel only, `cpu_baseline`, the RCCL figures when N > 1 -- at most MAX_LINE_BYTES bytes, every string at
     most MAX_STR characters; `extras` is everything else (`roofline_all`, `extras`, `gemm_classes`, `drop_in`,
     `reference_cpu`, full-length notes) for the extras file.  tests/test_bench_line.py holds the format."""
-    line = {k: _clip(res[k]) for k in LINE_KEYS if k in res and k not in ("config", "roofline", "cpu_baseline", "all_gather")}
+    line = {k: _clip(res[k]) for k in LINE_KEYS if k in res and k not in ("config", "roofline", "cpu_baseline", "all_gather", "metric_20k")}
     line["config"] = _pick(res.get("config") or {}, CONFIG_KEYS)
     line["roofline"] = _pick(res.get("roofline"), ROOFLINE_KEYS)
+    if res.get("metric_20k"):
+        line["metric_20k"] = _pick(res["metric_20k"], METRIC_20K_KEYS)
     line["cpu_baseline"] = _pick(res.get("cpu_baseline"), CPU_BASELINE_KEYS)
     if res.get("all_gather"):
         line["all_gather"] = _pick(res["all_gather"], ALL_GATHER_KEYS)
@@ -152,6 +160,9 @@ def parse():
                          "tiles on 256 CUs (reference yml: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic in this run (two rocprofv3 --pmc child runs of the dominant GEMM class, "
+                         "~40 s): replay the committed figure of profiles/ instead, labelled traffic_replayed")
     ap.add_argument("--cpu-images", type=int, default=192,
                     help="images of the cpu_baseline's oracle encode (~25 images/s on 32 host threads: ~8 s; round 4 extrapolated from 24)")
     ap.add_argument("--small", action="store_true", help="debug: 1/16 of the workload")
@@ -283,20 +294,27 @@ def timed_ms(fn, reps, warm=1):
 
 
 def cpu_baseline(n_img):
-    """CPU oracle (kind 'port') on a bounded sample of the same workload: all host cores, and one thread."""
-    import numpy as np
+    """CPU oracle (kind 'port') on a bounded sample of the same workload: all host cores, and one thread.  Returns
+    (cpu_baseline dict, parity sample): the encode leg's images are synthetic identity images under the `spread` weights of
+    tests/test_gpu_map_parity.py, so the oracle features it has just timed also serve as the checker of parity_deltas()."""
+    import numpy as np  # noqa: F401
     import torch
     from mpreid import synth
     from oracle import oracle as orc
     cores = min(os.cpu_count() or 1, 32)   # more threads than this only add contention for these sizes
     torch.set_num_threads(cores)
-    sd = synth.vit_state_dict(synth.VIT_B16, seed=7)
-    imgs = synth.synthetic_images(n_img, H, W, seed=1)
+    per_id = 8 if n_img >= 64 else 4
+    n_ids = max(2, n_img // per_id)
+    n_img = n_ids * per_id
+    sd = synth.vit_state_dict(synth.VIT_B16, seed=7, std=0.05)
+    imgs, pid = synth.identity_images(n_ids, per_id, 0.4)
     orc.vit_features(sd, synth.VIT_B16, imgs[:2])  # warm
     t0 = time.perf_counter()
+    f_or = []
     for s0 in range(0, n_img, 64):      # (the reference's batch size: TEST.IMS_PER_BATCH 64)
-        orc.vit_features(sd, synth.VIT_B16, imgs[s0:s0 + 64])
+        f_or.append(orc.vit_features(sd, synth.VIT_B16, imgs[s0:s0 + 64]))
     t_enc = time.perf_counter() - t0
+    f_or = np.concatenate(f_or)
     torch.set_num_threads(1)
     t0 = time.perf_counter()
     orc.vit_features(sd, synth.VIT_B16, imgs[:3])
@@ -321,15 +339,104 @@ def cpu_baseline(n_img):
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True,
                        text=True)
     t_rr1 = float(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else None
-    return {"value": round((NQ + NG) / total, 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"oracle ViT-B/16 f32 on {n_img} images {t_enc:.1f} s + oracle euclid {NQ}x1024x1280 {t_dist:.2f} s, "
-                      f"scaled to {NQ}+{NG} images; oracle re-rank N=20000 {t_rr:.1f} s",
+    base = {"value": round((NQ + NG) / total, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"oracle ViT f32 {n_img} img {t_enc:.1f}s + euclid {NQ}x1024x1280 {t_dist:.2f}s, scaled to {NQ + NG} img; "
+                      f"re-rank N=20000 {t_rr:.1f}s",
             "sample_long": f"oracle ViT-B/16 fp32 (torch CPU) on {n_img} images: {t_enc:.2f} s; oracle euclid "
                            f"{NQ}x1024x1280: {t_dist:.2f} s; extrapolated linearly to {NQ}+{NG} images; oracle re-rank "
                            f"N=20000 (nq 4000, D 768, k1 50, k2 15) on {cores} threads: {t_rr:.2f} s; on 1 thread at "
                            f"N=6000: {t_rr1 if t_rr1 is None else round(t_rr1, 2)} s",
             "encode_images_per_s": round(n_img / t_enc, 3), "encode_images_per_s_1thread": round(1.0 / t_enc1, 3),
             "rerank_s": round(t_rr, 3), "rerank_n": 20000, "rerank_s_1thread_n6000": t_rr1}
+    return base, {"imgs": imgs, "pid": pid, "sd": sd, "f_or": f_or}
+
+
+def parity_deltas(ops, sample, precision="split"):
+    """north_star's parity clause, measured live on the cpu_baseline leg's sample (the oracle here is the CHECKER): the HIP
+    encoder's features against the oracle's (relative L2), |dmAP| / |dRank-1| of the two pipelines with and without
+    re-ranking (k1 20, k2 6: the sample is a few hundred images), and the largest distance-entry error of the three
+    distance modes against the oracle's exact chain.  The asserted versions: tests/test_gpu_map_parity.py (1024 / 4096
+    images), tests/test_gpu_distance.py."""
+    import numpy as np
+    import torch
+    from mpreid import synth
+    from oracle import oracle as orc
+    imgs, pid, f_or = sample["imgs"], sample["pid"], sample["f_or"]
+    n = len(pid)
+    nq = max(1, n // 5)
+    enc = ops.VitEncoder(synth.VIT_B16, sample["sd"], (H, W), precision=precision)
+    f = enc(torch.from_numpy(imgs))
+    del enc
+    out = {"parity_images": n,
+           "feat_rel_l2_split": float(np.linalg.norm(f.cpu().numpy() - f_or) / np.linalg.norm(f_or))}
+    fo = orc.l2_normalize(f_or)
+    fn = ops.l2_normalize(f)
+    k1, k2 = (20, 6) if n >= 64 else (4, 2)
+    for key, rr in (("", False), ("_rr", True)):
+        d_o = orc.re_ranking(fo[:nq], fo[nq:], k1, k2, 0.3) if rr else orc.euclidean_distance(fo[:nq], fo[nq:])
+        d_h = ops.re_ranking(fn[:nq], fn[nq:], k1, k2, 0.3)[0] if rr else ops.euclidean_distance(fn[:nq], fn[nq:])
+        cmc_o, map_o = orc.eval_func(d_o, pid[:nq], pid[nq:])
+        cmc_h, map_h = orc.eval_func(d_h.cpu().numpy(), pid[:nq], pid[nq:])
+        out[f"dmap{key}_split"] = float(abs(map_h - map_o))
+        out[f"dr1{key}_split"] = float(abs(float(cmc_h[0]) - float(cmc_o[0])))
+    # distance entries (north_star: within 1e-5 fp32): the three modes on the oracle's own normalised features
+    fot = torch.from_numpy(fo).to(f.device)
+    want = orc.euclidean_distance(fo[:nq], fo[nq:])
+    for key, mode in (("exact", ops.GEMM_F32_EXACT), ("split3", getattr(ops, "GEMM_F16_SPLIT3", None)), ("f16", ops.GEMM_F16_FAST)):
+        if mode is not None:
+            got = ops.euclidean_distance(fot[:nq], fot[nq:], mode=mode).cpu().numpy()
+            out[f"dist_err_{key}"] = float(np.abs(got - want).max())
+    return out
+
+
+def live_gemm_traffic(epi_id, n, k, timeout_s=240):
+    """HBM bytes per launch of ONE encoder GEMM class, measured in THIS run: two child processes (never an exec of this
+    one) run tools/gemm_bench.py -- the same kernel at the same shape, M = 65 536, random data -- under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, counters only: MI355X_MICROARCH.md's HBM
+    section), bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (FETCH_SIZE reads 1/2 on gfx950).  Returns (bytes or None, note).
+    Skipped when this process itself runs under rocprofv3, when MPREID_BENCH_LIVE_TRAFFIC=0, or when the tool is missing:
+    the caller then REPLAYS the committed figure and says so (`traffic_replayed`)."""
+    import shutil
+    import tempfile
+    if os.environ.get("MPREID_BENCH_LIVE_TRAFFIC", "1") == "0":
+        return None, "MPREID_BENCH_LIVE_TRAFFIC=0"
+    if any(key.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for key in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this run is itself under rocprofv3"
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    shapes = {"qkv": (2304, 768, 1), "out": (768, 768, 2), "fc1": (3072, 768, 3), "fc2": (768, 3072, 2),
+              "sqkv": (2304, 768, 10), "sout": (768, 768, 11), "sfc1": (3072, 768, 12), "sfc2": (768, 3072, 11)}   # = tools/gemm_bench.py SHAPES
+    name = next((nm for nm, v in shapes.items() if v == (n, k, epi_id)), None)
+    if name is None:
+        return None, f"no micro-benchmark shape for class ({epi_id}, {n}, {k})"
+    import pmc_traffic
+    tmp = tempfile.mkdtemp(prefix="mpreid_pmc_", dir="/tmp")
+    vals = {}
+    t0 = time.perf_counter()
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "g", "--", sys.executable,
+                   os.path.join(ROOT, "tools", "gemm_bench.py"), "--reps", "2", "--rounds", "1", "--only", name]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True,
+                               timeout=max(30.0, timeout_s - (time.perf_counter() - t0)))
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} exited {r.returncode}"
+            per = pmc_traffic.collect(d, counter)
+            got = [v for kn, lst in per.items() if f"gemm_f16_big_kernel<{epi_id}," in kn for _, v in lst]
+            if not got:
+                return None, f"no {counter} rows for gemm_f16_big_kernel<{epi_id}>"
+            got.sort()
+            vals[counter] = got[len(got) // 2]
+    except (subprocess.TimeoutExpired, OSError) as e:
+        return None, f"{type(e).__name__}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), (
+        f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of tools/gemm_bench.py --only {name} "
+        f"({time.perf_counter() - t0:.0f} s)")
 
 
 #: kernels of each re-rank stage as rocprofv3 names them (prefix match) -> used to sum the committed PMC bytes per stage
@@ -349,7 +456,7 @@ RERANK_STAGE_KERNELS = {
 def _pmc_stage_bytes():
     """HBM bytes per launch of every re-rank stage at N = 20 000 from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE in separate runs, gfx950 corrections applied by tools/pmc_summary.py): {stage: (bytes, source file)}"""
-    for fn in ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json"):
+    for fn in ("r06_pmc_summary.json", "r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json"):
         try:
             per = json.load(open(os.path.join(ROOT, "profiles", fn)))["rerank_N20000_hbm_bytes_per_launch"]
         except Exception:
@@ -480,7 +587,7 @@ def extras(ops, dev, with_widened=True):
     out["feat_gemm_20kx20k_d768_fp16_two_tensors_ms"] = round(ms_full, 4)
     out["feat_gemm_20kx20k_d768_fp16_two_tensors_frac_of_peak"] = round(flop / ms_full / 1e9 / PEAK_F16_TFLOPS, 4)
     fg_traffic = fg_src = None
-    for fn in ("r05_pmc_summary.json", "r04_pmc_summary.json"):
+    for fn in ("r06_pmc_summary.json", "r05_pmc_summary.json", "r04_pmc_summary.json"):
         try:
             per = json.load(open(os.path.join(ROOT, "profiles", fn)))["featgemm_20kx20kx768_fp16_hbm_bytes_per_launch"]
             fg_traffic = int(sum(v for k, v in per.items() if k.startswith(("void gemm_f16_big_kernel<5, 0", "void dist_sym_p2_kernel", "void gemm_f16_store"))))
@@ -979,7 +1086,8 @@ def run_rank(a):
             e = ents[i]
             avg_ms = e.total_ms / max(e.launches, 1)
             if e.epilogue >= 100:   # HBM-bound encoder kernels: flops_total holds algorithmic bytes
-                other.append({"kernel": {100: "layernorm_kernel", 101: "attention_kernel / attention_split_kernel"}.get(e.epilogue),
+                other.append({"kernel": {100: "layernorm_kernel", 101: "attention_kernel / attention_split_kernel",
+                                         102: "eval_rank_kernel"}.get(e.epilogue),
                               "rows": e.m, "launches": e.launches, "avg_ms": round(avg_ms, 4), "total_ms": round(e.total_ms, 2),
                               "cls_tail": bool(e.n == 1) if e.epilogue == 101 else None,
                               "gb_per_launch": round(e.flops_total / max(e.launches, 1) / 1e9, 4),
@@ -999,14 +1107,22 @@ def run_rank(a):
         roof = None
         traffic = None
         traffic_src = None
-        if top:
-            for fn in ("r05_gemm_pmc_traffic.json", "r04_gemm_pmc_traffic.json", "r03_gemm_pmc_traffic.json"):
+        traffic_replayed = None
+        if top and world == 1 and not a.small and not a.no_live_traffic:
+            traffic, traffic_src = live_gemm_traffic(top["epilogue_id"], top["N"], top["K"])
+            traffic_replayed = False if traffic is not None else None
+            live_note = traffic_src
+        else:
+            live_note = "not attempted (N > 1, --small or --no-live-traffic)"
+        if top and traffic is None:
+            for fn in ("r06_gemm_pmc_traffic.json", "r05_gemm_pmc_traffic.json", "r04_gemm_pmc_traffic.json"):
                 try:  # HBM bytes per launch of the dominant kernel: committed rocprofv3 PMC passes (profiles/)
                     tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
                     key = f"{_lib.GEMM_EPILOGUE_NAMES.get(top['epilogue_id'])}:{top['N']}:{top['K']}"
                     traffic = tj["classes"].get(key, {}).get("hbm_bytes_per_launch")
                     if traffic is not None:
-                        traffic_src = fn
+                        traffic_src = f"replayed: profiles/{fn} (rocprofv3 --pmc, separate FETCH / WRITE passes)"
+                        traffic_replayed = True
                         break
                 except Exception:
                     traffic = None
@@ -1020,11 +1136,12 @@ def run_rank(a):
                     "frac": round(alg_tf / PEAK_F16_TFLOPS, 4),
                     "avg_launch_ms": top["avg_ms"], "launches": top["launches"],
                     "algorithmic_flop": 2 * top["M"] * top["N"] * top["K"],
-                    "traffic": traffic,
-                    "traffic_source": f"profiles/{traffic_src} (rocprofv3 --pmc, separate FETCH/WRITE passes)" if traffic_src else None,
-                    "measured": "hipEvents per launch on the launch stream, " +
+                    "traffic": traffic, "traffic_replayed": traffic_replayed,
+                    "traffic_source": traffic_src if traffic is not None else None,
+                    "traffic_live_note": live_note,
+                    "measured": "hipEvents per launch on its stream, " +
                                 ("inside the timed region" if instrument_live else
-                                 "single-stream pass of the same step right after the timed region"),
+                                 "1-stream pass of the same step right after the timed region"),
                     # ---- below: extras file only ----
                     "algorithmic_gflop_per_launch": round(top["gflop_per_launch"] / mult, 2),
                     "flop_convention": "2*M*N*K per launch (SURVEY.md section 8d): ALGORITHMIC flops" +
@@ -1045,7 +1162,7 @@ def run_rank(a):
                 roof["frac_executed"] = round(top["tflops"] / PEAK_F16_TFLOPS, 4)
                 roof["frac_of_sustainable_1250TF"] = round(top["tflops"] / 1250.0, 4)
             try:   # matrix-pipe counters of the same kernel class (committed rocprofv3 --pmc pass, tools/collect_profiles.sh)
-                mfn = next(f for f in ("r05_gemm_pmc_mfma.json", "r04_gemm_pmc_mfma.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+                mfn = next(f for f in ("r06_gemm_pmc_mfma.json", "r05_gemm_pmc_mfma.json", "r04_gemm_pmc_mfma.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
                 mj = json.load(open(os.path.join(ROOT, "profiles", mfn)))
                 key = f"{_lib.GEMM_EPILOGUE_NAMES.get(top['epilogue_id'])}:{top['N']}:{top['K']}"
                 if key in mj.get("classes", {}):
@@ -1070,24 +1187,20 @@ def run_rank(a):
                  "rows sharded over the GPUs" + (" [RERANK_SPARSE_SPLIT3: blend-term distances from the fp16 matrix cores, "
                                                    "outputs within 1e-6 of the bit-parity mode]" if a.rerank_algo == "split3" else "")
                  if a.rerank else ", no re-rank")
-        desc = {   # the line's strings are <= 200 characters (format_line); the long form goes to the extras file
-            "market": f"Market-1501 shape (BASELINE configs[1]): do_inference(make_model(cfg)) = ViT-B/16 encode of {nq} query "
-                      f"+ {NG // div} gallery 3x256x128 images per GPU -> euclidean distmat -> CMC/mAP",
-            "msmt17": f"MSMT17 shape (BASELINE configs[4]): ViT-B/16 encode of {nq} query + {ng_total} gallery images over "
-                      f"{world} GPU(s) -> euclidean distmat at D=1280",
-            "synth": f"synthetic {nq} x {ng_total} x {SYN_D} features (BASELINE configs[3]), gallery rows over {world} GPU(s) "
-                     f"-> euclidean distmat",
-        }[wl] + ("; + k-reciprocal re-rank 50/15/0.3" if a.rerank else "; no re-rank")
+        desc = {   # the line's strings are <= MAX_STR characters (format_line); the long form goes to the extras file
+            "market": f"Market-1501 configs[{2 if a.rerank else 1}]: do_inference ViT-B/16 {nq}q+{NG // div}g/GPU",
+            "msmt17": f"MSMT17 shape (configs[4]): ViT-B/16 {nq}q+{ng_total}g over {world} GPU(s), euclid D=1280",
+            "synth": f"synthetic {nq}x{ng_total}x{SYN_D} feats (configs[3]), gallery rows over {world} GPU(s), euclid",
+        }[wl] + (", rerank" if a.rerank else ", no rerank") + ("; HBM-resident loader" if wl == "market" else "")
         res = {
             "metric": METRIC,
             "value": round(images_per_step * a.steps / dt, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None,
-            "dtype": ({"split": "f16 pairs (hi+lo, 3 products per multiply-add) on the f16 MFMA, f32 accumulate; ",
-                       "fp16": "f16 MFMA operands, f32 accumulate; ", "fp32": "f32 (exact f32 MFMA); "}[a.encoder_precision]
+            "dtype": ({"split": "f16 pairs hi+lo (3 MFMA products per multiply-add, f32-grade), f32 acc; ",
+                       "fp16": "f16 MFMA operands, f32 acc; ", "fp32": "f32 (exact f32 MFMA); "}[a.encoder_precision]
                       if enc is not None else "") +
-                     {"exact": "distmat f32 (exact f32 MFMA chain)", "f16": "distmat f16 one pass, f32 accumulate",
-                      "split3": "distmat 3-term f16 split, f32 accumulate"}[a.dist_mode],
+                     {"exact": "distmat f32 exact", "f16": "distmat f16 one pass", "split3": "distmat 3-term f16 split"}[a.dist_mode],
             "dtype_note": ({"split": "encoder: f16 operand PAIRS (hi+lo, 3 products per multiply-add) on the f16 MFMA, f32 "
                                      "accumulate/residual/softmax -- fp32-grade features, meets |dmAP|,|dR1| <= 1e-4 "
                                      "(tests/test_gpu_map_parity.py)",
@@ -1101,8 +1214,7 @@ def run_rank(a):
                        "encoder_batch": (market["model"].encode_group if market else a.batch) if enc else None,
                        "encoder_precision": a.encoder_precision if enc else None,
                        "encoder_streams": nstreams if enc else None,
-                       "sharding": (f"gallery rows over {world} GPU(s), queries 1/{world} each + one all-gather of query features; "
-                                    "distance blocks concatenated on rank 0's host")},
+                       "sharding": f"gallery rows over {world} GPU(s); 1 all-gather of query feats; blocks concatenated on rank 0's host"},
             "host_concat": None if not host_concat else {"ms_per_step": round(host_concat_ms, 3),
                             "bytes_per_step": int(4 * nq * ng_total * (2 if a.rerank else 1)),
                             "note": "inside the timed step: per-shard distance blocks -> rank 0 (tensor gather over xGMI when "
@@ -1137,8 +1249,14 @@ def run_rank(a):
                 s3 = ops.euclidean_distance(qf_s, gf_s, mode=ops.GEMM_F16_SPLIT3)
                 chk["fp16_split3_max_abs_err"] = float((ex - s3).abs().max())
             res["tolerance_check_vs_exact_fp32"] = chk
+        parity = {}
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(a.cpu_images)
+            res["cpu_baseline"], sample = cpu_baseline(a.cpu_images)
+            parity = parity_deltas(ops, sample, a.encoder_precision if enc is not None else "split")
+            res["parity_sample"] = dict(parity, note="oracle (CPU checker) vs HIP on the cpu_baseline leg's identity images, "
+                                                     "spread weights (std 0.05), nq = n/5, re-rank k1 20 k2 6; "
+                                                     "asserted at 1024 / 4096 images in tests/test_gpu_map_parity.py")
+            del sample
         if market is not None:
             from processor.processor import do_inference as _di
             res["drop_in"] = {"call": "processor.do_inference(cfg, model.make_model.make_model(cfg, ...), val_loader, num_query)",
@@ -1163,16 +1281,42 @@ def run_rank(a):
             if drop:
                 res["extras"]["do_inference_fp32_loader_over_headline"] = round(drop["do_inference_images_per_s_fp32_loader"] / res["value"], 4)
                 res["extras"]["do_inference_raw_loader_over_headline"] = round(drop["do_inference_images_per_s_raw_loader"] / res["value"], 4)
+                res["config"]["workload"] += "; host-fed x%.2f" % res["extras"]["do_inference_fp32_loader_over_headline"]
+            ex = res["extras"]
+            rr_ms = ex["rerank_N20000_nq4000_d768_k50_15_ms"]
+            m20 = {"distmat_exact_ms": ex["feat_gemm_20kx20k_d768_fp32exact_ms"],
+                   "distmat_split3_ms": ex.get("feat_gemm_20kx20k_d768_split3_ms"),
+                   "distmat_split3_frac_exec": (round(ex["feat_gemm_20kx20k_d768_split3_executed_tflops"] / PEAK_F16_TFLOPS, 4)
+                                                if "feat_gemm_20kx20k_d768_split3_executed_tflops" in ex else None),
+                   "distmat_f16_ms": ex["feat_gemm_20kx20k_d768_fp16_ms"],
+                   "distmat_f16_frac": ex["feat_gemm_20kx20k_d768_fp16_frac_of_peak"],
+                   "distmat_f16_2t_ms": ex["feat_gemm_20kx20k_d768_fp16_two_tensors_ms"],
+                   "distmat_f16_2t_frac": ex["feat_gemm_20kx20k_d768_fp16_two_tensors_frac_of_peak"],
+                   "rerank_ms": rr_ms, "rerank_vs_ref265s_x": round(265e3 / rr_ms, 0)}
+            if res.get("cpu_baseline"):
+                m20["rerank_cpu_port_ms"] = round(res["cpu_baseline"]["rerank_s"] * 1e3, 0)
+                m20["rerank_vs_cpu_x"] = round(res["cpu_baseline"]["rerank_s"] * 1e3 / rr_ms, 0)
+            res["metric_20k"] = m20
+            res["metric_20k_note"] = (
+                "the rest of BASELINE.json's metric, N = 20 000 clustered features, D = 768: all-pairs stored distance matrix in the "
+                "exact fp32 chain (bit-parity mode), the 3-term fp16 split (<= 1e-6) and one-pass fp16 (~1e-4; `frac` = 2*N*N*D "
+                "over the 2.5 PF fp16 peak; `_2t` = two separate tensors, every tile computed), re-ranking nq 4000 / k1 50 / k2 15 "
+                "(bit-identical to the oracle) against the oracle port on this box's host cores and the reference's 265 s "
+                "(BASELINE.md: its own Python, 8 threads, N = 19 281); parity deltas: parity_sample")
             enc_roofs = [dict(roof, stage="encoder dominant GEMM class")] if roof else []
             for o in other:   # the HBM-bound encoder kernels of the timed (or single-stream) pass
                 if o["gbps"]:
-                    enc_roofs.append({"stage": "encoder." + ("layernorm" if o["class_id"] == 100 else
-                                                             ("attention (CLS tile only, last block)" if o["cls_tail"] else "attention")),
+                    enc_roofs.append({"stage": "eval_func ranking (R1_mAP_eval.compute(), matrix resident)" if o["class_id"] == 102 else
+                                      "encoder." + ("layernorm" if o["class_id"] == 100 else
+                                                    ("attention (CLS tile only, last block)" if o["cls_tail"] else "attention")),
                                       "kernel": o["kernel"], "bound": "hbm", "achieved": o["gbps"], "peak": PEAK_HBM_GBS,
                                       "unit": "GB/s", "frac": round(o["gbps"] / PEAK_HBM_GBS, 4),
                                       "algorithmic_bytes": int(o["gb_per_launch"] * 1e9), "avg_launch_ms": o["avg_ms"],
                                       "traffic": None})
             res["roofline_all"] = enc_roofs + roofs
+        if parity:
+            res["metric_20k"] = dict(res.get("metric_20k") or {}, **{k: (float("%.3g" % v) if isinstance(v, float) else v)
+                                                                      for k, v in parity.items()})
         emit(res)
     if world > 1:
         dist.barrier()

@@ -165,9 +165,10 @@ int mpreid_rerank_debug_copy_ex(const void *ws_dev, int64_t nq, int64_t ng, int 
  * For every query: the 0-based positions, in the ascending (distance, gallery index) order of its row, of the
  * gallery items whose pid equals the query's pid (what the reference reads off np.argsort + matches).
  * pos_out [nq][rcap] int32 ascending, padded with -1; cnt_out [nq] = number of relevant items, or -1 when a
- * query has more than min(rcap, 2048) of them (LIMIT: the sorted relevant keys of a query live in LDS, 2048 entries;
- * the caller ranks such a row on the host -- utils/metrics.py:eval_func_device does -- Market-1501 / MSMT17 queries
- * have at most a few hundred relevant gallery images).  CMC / AP are finished
+ * query has more than min(rcap, 8192) of them (LIMIT: the sorted relevant keys of a query live in LDS -- the launch sizes
+ * its dynamic LDS for rcap rounded up to a power of two, 64 ... 8192 entries; the caller ranks such a row on the host --
+ * utils/metrics.py:eval_func_device does -- Market-1501 / MSMT17 queries have at most a few hundred relevant gallery
+ * images).  CMC / AP are finished
  * on the host from the positions (float64, numpy's summation order): mp-reid_amd/utils/metrics.py. */
 int mpreid_eval_rank_positions(const float *dist_dev, int64_t ld, int nq, int ng, const int64_t *q_pids_dev,
                                const int64_t *g_pids_dev, int rcap, int32_t *pos_out_dev, int32_t *cnt_out_dev,
@@ -241,7 +242,9 @@ int mpreid_rr_jaccard(int64_t n, int64_t nq, int64_t q_lo, int64_t qrows, const 
  *      [c_lo, c_hi) of the chunk-boundary table hb [n][mpreid_rr_csc_chunks(n, nq) + 1] u32
  *                                                       -> ALL-GATHER the cpk pieces (contiguous, rank order) and the hb rows
  *   3. mpreid_rr_jaccard_indexed: Jaccard + blend of the rank's queries over the assembled index.
- * Needs n * qstride < 2^32.  Bit-identical to mpreid_rr_jaccard for any number of column shards. */
+ * Needs n * qstride < 2^32 and at least one indexed row (0 <= nq < n): all three entry points check both and return
+ * MPREID_ERR_ARG otherwise (mpreid_rr_csc_chunks returns the chunk count, > 0, or that negative code).
+ * Bit-identical to mpreid_rr_jaccard for any number of column shards. */
 int mpreid_rr_csc_chunks(int64_t n, int64_t nq);
 int mpreid_rr_csc_count(int64_t n, int64_t nq, const int32_t *qcnt_all_dev, const int32_t *qidx_all_dev, int qstride,
                         int64_t c_lo, int64_t c_hi, uint32_t *chist_dev, uint32_t *ccnt_dev, mpreid_stream_t stream);
@@ -520,6 +523,7 @@ int mpreid_cast_f32_to_f16(const float *x_dev, void *y_dev, int64_t n, mpreid_st
  * output written) */
 #define MPREID_PROF_LAYERNORM 100
 #define MPREID_PROF_ATTENTION 101
+#define MPREID_PROF_EVALRANK 102   /* eval_rank_kernel: m = nq, n = ng; work = 4*nq*ng bytes (the matrix read once) */
 typedef struct {
     int32_t epilogue;        /* GemmEpi id of the fp16 GEMM class, or MPREID_PROF_* */
     int32_t n, k;            /* GEMM N and K (split epilogues: K = 2 * kseg halfs per operand row; 3 * kseg is executed) */

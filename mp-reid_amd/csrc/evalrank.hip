@@ -12,7 +12,8 @@
 // The host finishes CMC / AP from the positions (float64, numpy's pairwise order) — utils/metrics.py.
 #include "common.h"
 
-constexpr int EV_CAP = 2048; // max relevant gallery items per query handled on the GPU
+constexpr int EV_CAP_MAX = 8192; // max relevant gallery items per query handled on the GPU (64 KB of keys + 32 KB of counters)
+constexpr int EV_HIST_MIN = 2112; // counter words of the smallest instance: room for privatised copies of a short bucket list
 
 __device__ __forceinline__ unsigned long long ev_key(float f, unsigned idx) {
     f = f + 0.0f; // -0 -> +0
@@ -22,13 +23,19 @@ __device__ __forceinline__ unsigned long long ev_key(float f, unsigned idx) {
 }
 
 // pos_out [nq][rcap] int32 ascending positions (padded with -1), cnt_out [nq] (= -1 when the query has more
-// than EV_CAP relevant items: the caller falls back to the host for that row)
+// than min(rcap, cap) relevant items: the caller falls back to the host for that row)
+// Dynamic LDS: rel [cap] u64 | hist [hw] u32, cap a power of two >= 64, hw = max(cap + 1, EV_HIST_MIN).
+// Step 2's counters are PRIVATISED: with R relevant items there are R + 1 buckets and C = the largest power of two with
+// C * (R + 1) <= hw (at most 64) copies of them, copy = lane & (C - 1).  Round 5's single copy took one LDS atomic per
+// gallery item into ~22 addresses (Market-1501: ~21 relevant items per query): up to 64 lanes of an instruction on one
+// address, serialised by the LDS atomic unit; with R < 32 every lane owns its copy and no two lanes ever collide.
 __global__ __launch_bounds__(256) void eval_rank_kernel(const float *__restrict__ dist, int64_t ld, int nq, int ng,
                                                         const long long *__restrict__ q_pids,
-                                                        const long long *__restrict__ g_pids, int rcap,
+                                                        const long long *__restrict__ g_pids, int rcap, int cap, int hw,
                                                         int *__restrict__ pos_out, int *__restrict__ cnt_out) {
-    __shared__ unsigned long long rel[EV_CAP];
-    __shared__ unsigned hist[EV_CAP + 1];
+    extern __shared__ unsigned long long ev_lds[];
+    unsigned long long *rel = ev_lds;
+    unsigned *hist = reinterpret_cast<unsigned *>(ev_lds + cap);
     __shared__ unsigned s_cnt;
     __shared__ int s_wave[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -36,26 +43,41 @@ __global__ __launch_bounds__(256) void eval_rank_kernel(const float *__restrict_
     const float *row = dist + (int64_t)q * ld;
     const long long pid = q_pids[q];
     if (tid == 0) s_cnt = 0;
-    for (int t = tid; t < EV_CAP; t += 256) rel[t] = ~0ull;
-    for (int t = tid; t <= EV_CAP; t += 256) hist[t] = 0;
     __syncthreads();
-    // 1. relevant items
-    for (int j = tid; j < ng; j += 256) {
-        if (g_pids[j] == pid) {
-            const unsigned p = atomicAdd(&s_cnt, 1u);
-            if (p < (unsigned)EV_CAP) rel[p] = ev_key(row[j], (unsigned)j);
+    // 1. relevant items (wave-aggregated reservation: one LDS atomic per wave and 64 items)
+    for (int j0 = 0; j0 < ng; j0 += 256) {
+        const int j = j0 + tid;
+        const bool hit = j < ng && g_pids[j] == pid;
+        const unsigned long long m = __ballot(hit);
+        if (m) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(&s_cnt, (unsigned)__popcll(m));
+            base = __shfl(base, 0, 64);
+            if (hit) {
+                const unsigned p = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+                if (p < (unsigned)cap) rel[p] = ev_key(row[j], (unsigned)j);
+            }
         }
     }
     __syncthreads();
     const int R = (int)s_cnt;
-    if (R > EV_CAP || R > rcap) {
+    if (R > cap || R > rcap) {
         if (tid == 0) cnt_out[q] = -1;
         return;
     }
     if (tid == 0) cnt_out[q] = R;
-    if (R == 0) return;
+    if (R == 0) {
+        for (int t = tid; t < rcap; t += 256) pos_out[(int64_t)q * rcap + t] = -1;
+        return;
+    }
     int npow = 1;
     while (npow < R) npow <<= 1;
+    for (int t = R + tid; t < npow; t += 256) rel[t] = ~0ull; // padding sorts last
+    const int nb = R + 1;
+    int C = 1;
+    while (C < 64 && 2 * C * nb <= hw) C <<= 1;
+    for (int t = tid; t < C * nb; t += 256) hist[t] = 0;
+    __syncthreads();
     for (int size = 2; size <= npow; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             for (int t = tid; t < npow; t += 256) {
@@ -71,7 +93,8 @@ __global__ __launch_bounds__(256) void eval_rank_kernel(const float *__restrict_
             }
             __syncthreads();
         }
-    // 2. bucket every gallery item: b = number of relevant keys <= key_j (relevant items land in their own bucket+1)
+    // 2. bucket every gallery item: b = number of relevant keys < key_j (a relevant item t lands in bucket t)
+    unsigned *mine = hist + (lane & (C - 1)) * nb;
     for (int j = tid; j < ng; j += 256) {
         const unsigned long long k = ev_key(row[j], (unsigned)j);
         int lo = 0, hi = R; // first t with rel[t] >= k
@@ -79,9 +102,17 @@ __global__ __launch_bounds__(256) void eval_rank_kernel(const float *__restrict_
             const int mid = (lo + hi) >> 1;
             if (rel[mid] < k) lo = mid + 1; else hi = mid;
         }
-        atomicAdd(&hist[lo], 1u); // items with key in (rel[lo-1], rel[lo]] ; the relevant item t itself falls in bucket t
+        atomicAdd(&mine[lo], 1u); // items with key in (rel[lo-1], rel[lo]]
     }
     __syncthreads();
+    if (C > 1) { // fold the copies into copy 0 (thread t touches column t of every copy and nothing else)
+        for (int t = tid; t < nb; t += 256) {
+            unsigned s = 0;
+            for (int c = 0; c < C; ++c) s += hist[c * nb + t];
+            hist[t] = s;
+        }
+        __syncthreads();
+    }
     // 3. position of relevant item t = number of items with a smaller key = sum_{b<=t} hist[b] - 1 (itself)
     unsigned run = 0;
     for (int t0 = 0; t0 < R; t0 += 256) {
@@ -115,8 +146,25 @@ extern "C" int mpreid_eval_rank_positions(const float *dist_dev, int64_t ld, int
                                           int32_t *cnt_out_dev, mpreid_stream_t stream) {
     ARG_CHECK(dist_dev && q_pids_dev && g_pids_dev && pos_out_dev && cnt_out_dev && nq > 0 && ng > 0 && ld >= ng &&
               rcap > 0);
-    hipLaunchKernelGGL(eval_rank_kernel, dim3((unsigned)nq), dim3(256), 0, (hipStream_t)stream, dist_dev, ld, nq, ng,
-                       (const long long *)q_pids_dev, (const long long *)g_pids_dev, rcap, pos_out_dev, cnt_out_dev);
+    int cap = 64;
+    while (cap < rcap && cap < EV_CAP_MAX) cap <<= 1;
+    const int hw = cap + 1 > EV_HIST_MIN ? cap + 1 : EV_HIST_MIN;
+    const size_t lds = (size_t)cap * 8 + (size_t)hw * 4;
+    static PerDeviceOnce attr_once;
+    {
+        const int rc = attr_once.run([]() -> int {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(eval_rank_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        EV_CAP_MAX * 8 + (EV_CAP_MAX + 1) * 4));
+            return MPREID_OK;
+        });
+        if (rc != MPREID_OK) return rc;
+    }
+    void *ptok = mpreid_prof_begin((hipStream_t)stream);
+    hipLaunchKernelGGL(eval_rank_kernel, dim3((unsigned)nq), dim3(256), lds, (hipStream_t)stream, dist_dev, ld, nq, ng,
+                       (const long long *)q_pids_dev, (const long long *)g_pids_dev, rcap, cap, hw, pos_out_dev,
+                       cnt_out_dev);
+    mpreid_prof_end(ptok, (hipStream_t)stream, MPREID_PROF_EVALRANK, nq, ng, 0, 4.0 * (double)nq * (double)ng);
     LAUNCH_CHECK();
     return MPREID_OK;
 }

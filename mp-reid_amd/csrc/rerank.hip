@@ -3262,13 +3262,19 @@ extern "C" int mpreid_rr_jaccard(int64_t n, int64_t nq, int64_t q_lo, int64_t qr
 // table.  Within a column the entries are grouped by row block exactly as in the single build; the order inside a block is
 // LDS-atomic arrival order in both, and the Jaccard sum does not depend on it (every row occurs once per column and owns its
 // accumulator): outputs are bit-identical (tests/test_gpu_rerank.py::test_sharded_sparse_phases_equal_single_call).
-extern "C" int mpreid_rr_csc_chunks(int64_t n, int64_t nq) { return jaccard_plan(n - nq).nchunks; }
+// (n, nq) of the three csc entry points: at least one INDEXED row (nq < n: jaccard_plan divides by the rows per block) and
+// packed positions that fit 32 bits
+static bool csc_shape_ok(int64_t n, int64_t nq) { return n > 0 && nq >= 0 && nq < n; }
+extern "C" int mpreid_rr_csc_chunks(int64_t n, int64_t nq) {
+    ARG_CHECK(csc_shape_ok(n, nq));
+    return jaccard_plan(n - nq).nchunks;
+}
 
 // step 1: ccnt[c] = number of indexed entries (rows [nq, n)) of every column c in [c_lo, c_hi); chist (mpreid_rr_jaccard_hist_bytes)
 // keeps the per-block offsets of those columns for step 2
 extern "C" int mpreid_rr_csc_count(int64_t n, int64_t nq, const int32_t *qcnt_all, const int32_t *qidx_all, int qstride,
                                    int64_t c_lo, int64_t c_hi, uint32_t *chist, uint32_t *ccnt, mpreid_stream_t stream_) {
-    ARG_CHECK(qcnt_all && qidx_all && chist && ccnt && qstride > 0 && 0 <= c_lo && c_lo <= c_hi && c_hi <= n && nq >= 0 && nq <= n);
+    ARG_CHECK(qcnt_all && qidx_all && chist && ccnt && qstride > 0 && 0 <= c_lo && c_lo <= c_hi && c_hi <= n && csc_shape_ok(n, nq));
     if ((uint64_t)n * (uint64_t)qstride >= (1ull << 32)) {
         mpreid_set_error("mpreid_rr_csc_count: n * qstride must be below 2^32 (packed positions)");
         return MPREID_ERR_ARG;
@@ -3295,7 +3301,11 @@ extern "C" int mpreid_rr_csc_fill(int64_t n, int64_t nq, const int32_t *qcnt_all
                                   const uint16_t *qval_all, int qstride, int64_t c_lo, int64_t c_hi, uint32_t *ccnt_all,
                                   uint32_t *chist, long long *cptr, uint32_t *cpk, uint32_t *hb, mpreid_stream_t stream_) {
     ARG_CHECK(qcnt_all && qidx_all && qval_all && ccnt_all && chist && cptr && cpk && hb && qstride > 0 && 0 <= c_lo &&
-              c_lo <= c_hi && c_hi <= n);
+              c_lo <= c_hi && c_hi <= n && csc_shape_ok(n, nq));
+    if ((uint64_t)n * (uint64_t)qstride >= (1ull << 32)) {   // (cptr is consumed as u32 positions by the fill and the Jaccard stage)
+        mpreid_set_error("mpreid_rr_csc_fill: n * qstride must be below 2^32 (packed positions)");
+        return MPREID_ERR_ARG;
+    }
     hipStream_t stream = (hipStream_t)stream_;
     const JaccardPlan jp = jaccard_plan(n - nq);
     {

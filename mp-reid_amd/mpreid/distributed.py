@@ -60,6 +60,39 @@ def init_from_env(backend: str | None = None) -> Tuple[int, int, int]:
     return rank, world, local
 
 
+def ensure_group_from_env(logger=None) -> Tuple[int, int]:
+    """(rank, world).  Called by the drop-in ``do_inference``: the REFERENCE's test.py (test.py:39,65) never initialises a
+    process group -- it goes multi-device inside do_inference (nn.DataParallel, processor/processor.py:178-182).  Started
+    unchanged under ``python -m torch.distributed.run --nproc-per-node P test.py ...`` every rank arrives here with
+    WORLD_SIZE / RANK / LOCAL_RANK set and no group: initialise it (RCCL; MPREID_DIST_BACKEND=gloo for staging) and bind the
+    rank to cuda:LOCAL_RANK, instead of silently evaluating everything P times on one device.  A rank that cannot see one
+    device per local rank raises -- the reference sets CUDA_VISIBLE_DEVICES = cfg.MODEL.DEVICE_ID (test.py:39; '0' in the
+    shipped YAMLs): pass MODEL.DEVICE_ID "('0,1,2,3,4,5,6,7')" (INTEGRATION.md section C)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 or dist.is_initialized():
+        return rank_world()
+    backend = os.environ.get("MPREID_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    ndev = torch.cuda.device_count()
+    if backend == "nccl":
+        if ndev < local_world or local >= ndev:
+            raise RuntimeError(
+                f"WORLD_SIZE={world} (LOCAL_RANK={local} of {local_world} on this node) but this process sees {ndev} HIP "
+                f"device(s) (CUDA_VISIBLE_DEVICES={os.environ.get('CUDA_VISIBLE_DEVICES')!r}, HIP_VISIBLE_DEVICES="
+                f"{os.environ.get('HIP_VISIBLE_DEVICES')!r}): one process per GPU needs one visible device per local rank and "
+                "RCCL cannot run several ranks on one device.  The reference's test.py sets CUDA_VISIBLE_DEVICES = "
+                "cfg.MODEL.DEVICE_ID: pass MODEL.DEVICE_ID \"('0,1,...')\" listing every GPU of the node")
+        torch.cuda.set_device(local)
+    elif ndev:
+        torch.cuda.set_device(local % ndev)    # gloo staging: ranks may share a device
+    rank, world, _ = init_from_env(backend)
+    if logger is not None:
+        logger.info("process group initialised by do_inference: rank {} of {} on cuda:{} ({})".format(
+            rank, world, torch.cuda.current_device() if ndev else "-", backend))
+    return rank, world
+
+
 def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     """contiguous [lo, hi) slice of range(n) owned by `rank`; sizes differ by at most one"""
     base, rem = divmod(n, world)
@@ -475,7 +508,10 @@ class _RerankShard:
         int32, piece boundaries of all ranks: python list of world + 1 offsets)."""
         t, dev = torch, self.dev
         total = int(qcnt_all[self.nq:].sum().item())     # indexed entries = entries of the gallery rows
-        nb1 = self.L.mpreid_rr_csc_chunks(self.N, self.nq) + 1
+        nch = self.L.mpreid_rr_csc_chunks(self.N, self.nq)
+        if nch <= 0:      # (negative: the library's argument error -- no indexed row, nq >= n)
+            self.lib.check(nch, "mpreid_rr_csc_chunks")
+        nb1 = nch + 1
         self.cptr = t.empty(self.N + 1, dtype=t.int64, device=dev)
         self.cpk = t.empty(max(total, 1), dtype=t.int32, device=dev)
         self.hb = t.empty((self.N, nb1), dtype=t.int32, device=dev)
@@ -671,8 +707,10 @@ def re_ranking_sharded(qf_all, gf_all, k1, k2, lambda_value, algo=0):
         qcap = max(gmax(sh.phase3_count(vc, vi, vv)), 1)
         qc, qi, qv = sh.phase3_fill(qcap)
         vc, vi, vv, _ = all_gather_sparse_rows(qc, qi, qv, N)
-    if not sh.index_shardable(vi.shape[1]):
-        return sh.phase4(vc, vi, vv)                  # (n * row stride >= 2^32: every rank builds the whole index)
+    if os.environ.get("MPREID_RR_FULL_INDEX") == "1" or not sh.index_shardable(vi.shape[1]):
+        # n * row stride >= 2^32, or the documented switch back to round 4's form (set it IDENTICALLY ON EVERY RANK: the
+        # column-sharded build below adds three collectives): every rank builds the whole index, no further exchange
+        return sh.phase4(vc, vi, vv)
     # phase 4: the index build sharded by column range; three all-gathers (counts, packed pieces, boundary rows)
     # The exact distance rows of the local queries (matrix cores, ~3 ms at N = 100 000 / P = 8) run on a side stream beside
     # the index build and its three all-gathers (HBM / LDS / xGMI): the Jaccard stage is the first to need both.

@@ -131,10 +131,13 @@ def do_inference(cfg, model, val_loader, num_query):
         str(getattr(cfg.TEST, "RERANK_ALGO", "exact"))]
     evaluator.reset()
 
+    # the reference's test.py never initialises a process group (test.py:39,65): under a launcher (WORLD_SIZE > 1) this
+    # call does, and binds the rank to cuda:LOCAL_RANK, before anything touches a device (raises when the ranks of the
+    # node cannot each see their own device -- MODEL.DEVICE_ID must list them: INTEGRATION.md section C)
+    rank, world = _D.ensure_group_from_env(logger)
     model.to(device)
     model.eval()
     img_path_list = []
-    rank, world = _D.rank_world()
     if world > 1:
         logger.info("rank {} of {}: encoding 1/{} of the queries and its gallery shard".format(rank, world, world))
         val_loader = shard_val_loader(val_loader, num_query)

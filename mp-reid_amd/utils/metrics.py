@@ -65,10 +65,12 @@ def eval_func(distmat, q_pids, g_pids, q_camids, g_camids, max_rank=50):
 _warned_host_ranking = False
 
 
-def _eval_rows_device(dist, q_pids, g_pids, max_rank):
+def _eval_rows_device(dist, q_pids, g_pids, max_rank, after_launch=None):
     """Ranking statistics of the query ROWS in `dist` (device tensor [rows, ng] fp32): (cmc hit counts [max_rank] float32
     summed over the valid rows, AP of every valid row in row order (float64), number of valid rows).  Sums of 0/1 values
-    are exact in float32, so hit counts of row shards add up to the unsharded counts bit for bit."""
+    are exact in float32, so hit counts of row shards add up to the unsharded counts bit for bit.
+    `after_launch()` is called once the ranking kernel is queued and before the host waits for it (compute() starts the
+    matrix's D2H copy there, ordered BEHIND the kernel)."""
     import ctypes as C
     from mpreid import _lib
     dev = _lib.require_gpu()
@@ -79,8 +81,10 @@ def _eval_rows_device(dist, q_pids, g_pids, max_rank):
     q_pids = np.ascontiguousarray(q_pids, dtype=np.int64)
     g_pids = np.ascontiguousarray(g_pids, dtype=np.int64)
     if num_q == 0:
+        if after_launch is not None:
+            after_launch()
         return np.zeros(max_rank, np.float32), np.zeros(0, np.float64), 0
-    rcap = int(min(max(np.unique(g_pids, return_counts=True)[1].max(), 1), 2048))
+    rcap = int(min(max(np.unique(g_pids, return_counts=True)[1].max(), 1), 8192))   # (the kernel's LDS limit, include/mpreid.h)
     qp, gp = torch.from_numpy(q_pids).to(dev), torch.from_numpy(g_pids).to(dev)
     pos = torch.empty((num_q, rcap), dtype=torch.int32, device=dev)
     cnt = torch.empty(num_q, dtype=torch.int32, device=dev)
@@ -88,6 +92,8 @@ def _eval_rows_device(dist, q_pids, g_pids, max_rank):
                                             C.c_void_p(qp.data_ptr()), C.c_void_p(gp.data_ptr()), rcap,
                                             C.c_void_p(pos.data_ptr()), C.c_void_p(cnt.data_ptr()), _lib.stream_ptr()),
                "mpreid_eval_rank_positions")
+    if after_launch is not None:
+        after_launch()
     pos, cnt = pos.cpu().numpy().astype(np.int64), cnt.cpu().numpy().astype(np.int64)
     over = np.nonzero(cnt < 0)[0]          # queries with more relevant items than the kernel handles: host ranking
     if over.size:
@@ -120,7 +126,7 @@ def _eval_rows_device(dist, q_pids, g_pids, max_rank):
     return cmc_rows.sum(0), terms.sum(axis=1) / cnt, num_valid
 
 
-def eval_func_device(dist, q_pids, g_pids, q_camids=None, g_camids=None, max_rank=50):
+def eval_func_device(dist, q_pids, g_pids, q_camids=None, g_camids=None, max_rank=50, after_launch=None):
     """eval_func with the ranking done on the GPU (dist: device tensor [nq, ng] fp32, left on the device).
 
     Per query the kernel returns the positions of the relevant gallery items in the ascending (distance, index)
@@ -134,7 +140,7 @@ def eval_func_device(dist, q_pids, g_pids, q_camids=None, g_camids=None, max_ran
     if num_g < max_rank:
         max_rank = num_g
         print("Note: number of gallery samples is quite small, got {}".format(num_g))
-    hits, ap, num_valid = _eval_rows_device(dist, q_pids, g_pids, max_rank)
+    hits, ap, num_valid = _eval_rows_device(dist, q_pids, g_pids, max_rank, after_launch)
     assert num_valid > 0, "Error: all query identities do not appear in gallery"
     return hits / float(num_valid), np.mean(ap)
 
@@ -257,6 +263,9 @@ class R1_mAP_eval():
         if self.feat_norm:
             print("The test feature is normalized")
             feats = _ops.l2_normalize(feats)
+        # the features go to the host only because compute() returns them: their D2H copy (98 MB at Market-1501 scale) starts
+        # NOW, on a side stream, and runs beside the distance GEMM / the re-ranking (round 6; it used to queue behind them)
+        (h_feats,), feats_copied = _to_host_async([feats])
         qf = feats[:self.num_query]
         gf = feats[self.num_query:]
         q_pids = np.asarray(self.pids[:self.num_query])
@@ -273,10 +282,23 @@ class R1_mAP_eval():
         else:
             print('=> Computing DistMat with euclidean_distance')
             dist = _ops.euclidean_distance(qf, gf, mode=self.distance_mode)
-        # ranking statistics on the GPU while the matrix is still resident; the matrix and the features go to the host
-        # only because compute() returns them: their D2H copies run on a side stream beside the ranking kernel
-        (h_dist, h_feats), copied = _to_host_async([dist, feats])
-        cmc, mAP = eval_func_device(dist, q_pids, g_pids, q_camids, g_camids)
+        # ranking statistics on the GPU while the matrix is still resident; the matrix's own D2H copy runs on the side stream
+        # BESIDE the ranking kernel.  (Measured, tools/evalrank_bench.py at Market-1501 shape: the kernel takes 0.15 ms alone
+        # and 0.20 ms beside the copy; queueing the copy BEHIND it makes compute() 0.8 ms slower.  The 5.4 ms average of
+        # round 5's rocprofv3 trace was the profiler serialising the two queues -- the kernel's interval there includes the
+        # blit kernels it waited for.  MPREID_EVAL_D2H=behind orders the copy after the kernel: used for kernel traces only.)
+        import os
+        box = {}
+
+        def start_copy():
+            box["h"], box["ev"] = _to_host_async([dist])
+        if os.environ.get("MPREID_EVAL_D2H") == "behind":
+            cmc, mAP = eval_func_device(dist, q_pids, g_pids, q_camids, g_camids, after_launch=start_copy)
+        else:
+            start_copy()
+            cmc, mAP = eval_func_device(dist, q_pids, g_pids, q_camids, g_camids)
+        (h_dist,), copied = box["h"], box["ev"]
+        feats_copied.synchronize()
         copied.synchronize()
         return cmc, mAP, h_dist.numpy(), self.pids, self.camids, h_feats[:self.num_query], h_feats[self.num_query:]
 

@@ -23,6 +23,9 @@ def _canned():
     res["rccl_ranks"] = 8
     res["all_gather"] = {"calls_per_step": 1.0, "bytes_per_step": 17244160, "ms_per_step": 0.2, "gb_per_s": 86.2,
                          "note": "n" * 500}
+    res["metric_20k"] = {"distmat_exact_ms": 3.1, "distmat_split3_ms": 1.15, "distmat_f16_ms": 0.54, "distmat_f16_frac": 0.45,
+                         "rerank_ms": 4.12, "rerank_vs_cpu_x": 1100.0, "dmap_split": 2.7e-8, "dr1_split": 0.0,
+                         "not_a_line_key": "x" * 300}
     return res
 
 
@@ -45,6 +48,11 @@ def test_line_is_small_parses_and_carries_the_contract(tmp_path):
     c = j["cpu_baseline"]
     assert set(c) == {"value", "unit", "cores", "kind", "sample"} and c["kind"] in ("port", "reference")
     assert j["rccl_ranks"] == 8 and set(j["all_gather"]) == set(bench.ALL_GATHER_KEYS)
+    # the rest of BASELINE.json's metric (20k x 20k distmat + re-rank ms, parity deltas): bare numbers under one key
+    m = j["metric_20k"]
+    assert set(m) <= set(bench.METRIC_20K_KEYS) and m["rerank_ms"] == 4.12 and m["distmat_exact_ms"] == 3.1
+    assert all(isinstance(v, (int, float)) or v is None for v in m.values())
+    assert bench.MAX_STR <= 110   # the driver's record clipped strings near 120 characters in round 5
 
     def strings(o):
         if isinstance(o, dict):
@@ -104,6 +112,19 @@ def test_bench_on_the_gpu_prints_one_small_line_and_a_quiet_stderr(tmp_path):
     assert j["roofline"]["bound"] == "mfma" and 0 < j["roofline"]["frac"] <= 1 and j["roofline"]["avg_launch_ms"] > 0
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["cores"] >= 1
     assert j["config"]["encoder_precision"] == "split" and "Market-1501" in j["config"]["workload"]
+    assert "HBM-resident loader" in j["config"]["workload"]
+
+    def strings(o):
+        if isinstance(o, dict):
+            for v in o.values():
+                yield from strings(v)
+        elif isinstance(o, str):
+            yield o
+    assert not [s_ for s_ in strings(j) if s_.endswith("...") or len(s_) > bench.MAX_STR], "a string of the line was clipped"
+    # the parity clause of the metric, measured live against the CPU checker on the cpu_baseline leg's sample
+    m = j["metric_20k"]
+    assert m["parity_images"] >= 8 and m["feat_rel_l2_split"] <= 2e-5 and m["dist_err_exact"] == 0.0 and m["dist_err_split3"] <= 1e-5
+    assert j["roofline"]["traffic_replayed"] in (True, False, None)
     assert len([ln for ln in r.stderr.splitlines() if ln.strip()]) <= 12, r.stderr[-1500:]
     extras = json.load(open(tmp_path / "bench_extras.json"))
     assert "gemm_classes" in extras and "drop_in" in extras

@@ -189,3 +189,49 @@ def test_concat_parts_to_host_ragged_cpu(dim):
     parts, sizes, other, want = _ragged_parts(dim, "cpu")
     got = D._concat_parts_to_host(parts, sizes, dim, other)
     assert got.shape == want.shape and np.array_equal(got, want)
+
+
+ENSURE_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path[:0] = [{root!r}, os.path.join({root!r}, "mp-reid_amd")]
+    import torch.distributed as dist
+    from mpreid import distributed as D
+    # the REFERENCE-shaped caller: nothing here initialises a process group (reference test.py:39,65 never does)
+    assert not dist.is_initialized()
+    rank, world = D.ensure_group_from_env()
+    assert dist.is_initialized() and dist.get_backend() == "gloo"
+    assert (rank, world) == (int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])) == D.rank_world()
+    assert D.ensure_group_from_env() == (rank, world)          # idempotent: a second do_inference call re-uses the group
+    import torch
+    t = torch.tensor([rank + 1])
+    dist.all_reduce(t)
+    assert int(t) == world * (world + 1) // 2
+    dist.barrier(); dist.destroy_process_group()
+""")
+
+
+def test_do_inference_initialises_the_group_itself_under_a_launcher(tmp_path):
+    """The reference's test.py never calls init_process_group; started unchanged under torch.distributed.run its ranks reach
+    do_inference with WORLD_SIZE / RANK / LOCAL_RANK set and no group.  processor.do_inference's first step
+    (mpreid.distributed.ensure_group_from_env) initialises it: two gloo ranks here, no explicit init in the caller."""
+    script = tmp_path / "ensure_worker.py"
+    script.write_text(ENSURE_WORKER.format(root=ROOT))
+    from conftest import run_ranks
+    run_ranks([sys.executable, str(script)], 2, 300, dict(OMP_NUM_THREADS="2", MPREID_DIST_BACKEND="gloo"))
+
+
+def test_ranks_that_share_one_visible_device_are_refused(monkeypatch):
+    """WORLD_SIZE = 8 with MODEL.DEVICE_ID '0' (the shipped YAMLs; the reference's test.py turns it into
+    CUDA_VISIBLE_DEVICES): every rank would see ONE device.  RCCL cannot run them and a silent fallback would evaluate
+    everything eight times on one GPU: a RuntimeError that names the fix instead.  Without WORLD_SIZE nothing happens."""
+    import torch
+    from mpreid import distributed as D
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    assert D.ensure_group_from_env() == (0, 1)
+    monkeypatch.setenv("WORLD_SIZE", "8"), monkeypatch.setenv("RANK", "3"), monkeypatch.setenv("LOCAL_RANK", "3")
+    monkeypatch.setenv("MPREID_DIST_BACKEND", "nccl")
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(RuntimeError, match=r"sees 1 HIP device.*MODEL\.DEVICE_ID"):
+        D.ensure_group_from_env()
+    assert not torch.distributed.is_initialized()

@@ -62,22 +62,33 @@ def test_evaluator_through_the_rccl_branches_with_virtual_ranks(world, case):
 
 @pytest.mark.parametrize("world,n,nq,d,k1,k2", [(8, 6000, 1200, 256, 50, 15), (3, 4100, 800, 128, 20, 6), (5, 3000, 2999, 64, 30, 40),
                                                  (4, 900, 7, 64, 20, 6), (2, 700, 100, 128, 10, 1)])
-def test_sharded_rerank_through_the_rccl_branches_with_virtual_ranks(world, n, nq, d, k1, k2):
+def test_sharded_rerank_through_the_rccl_branches_with_virtual_ranks(world, n, nq, d, k1, k2, monkeypatch):
     """mpreid.distributed.re_ranking_sharded itself (not the virtual-rank loop of re_ranking_virtual): rank table, CSR
-    all-gathers of V / V_qe, the column-sharded index exchange of phase 4, row blocks to the host -- P ranks, ragged shards"""
+    all-gathers of V / V_qe, the column-sharded index exchange of phase 4, row blocks to the host -- P ranks, ragged shards.
+    Both branches of phase 4 of the REAL function: the column-sharded index build (default) and MPREID_RR_FULL_INDEX=1, the
+    documented switch back to round 4's form (every rank builds the whole index, no index exchange; advisor r5: the switch
+    was only read by re_ranking_virtual) -- same bits, and the switch really removes the three index collectives."""
     from mpreid import distributed as D, ops, synth
     f, _ = synth.clustered_features(n, d, 2.5, seed=n + world, per_id=20)
     q, g = torch.from_numpy(f[:nq]).cuda(), torch.from_numpy(f[nq:]).cuda()
     single, _ = ops.re_ranking(q, g, k1, k2, 0.3)
-    W = EmulatedWorld(world)
+    calls = {}
+    for full_index in (False, True):
+        if full_index:
+            monkeypatch.setenv("MPREID_RR_FULL_INDEX", "1")
+        else:
+            monkeypatch.delenv("MPREID_RR_FULL_INDEX", raising=False)
+        W = EmulatedWorld(world)
 
-    def rank_fn(r):
-        rows = D.re_ranking_sharded(q, g, k1, k2, 0.3)
-        q_lo, q_hi = D.shard_range(nq, r, world)
-        assert rows.shape == (q_hi - q_lo, n - nq)
-        assert torch.equal(rows, single[q_lo:q_hi]), r
-        return D.gather_row_blocks_to_host(rows, dst=0)
+        def rank_fn(r):
+            rows = D.re_ranking_sharded(q, g, k1, k2, 0.3)
+            q_lo, q_hi = D.shard_range(nq, r, world)
+            assert rows.shape == (q_hi - q_lo, n - nq)
+            assert torch.equal(rows, single[q_lo:q_hi]), (r, full_index)
+            return D.gather_row_blocks_to_host(rows, dst=0)
 
-    res = W.run(rank_fn)
-    assert np.array_equal(res[0], single.cpu().numpy())
-    assert W.log.count("all_gather_into_tensor") >= 5
+        res = W.run(rank_fn)
+        assert np.array_equal(res[0], single.cpu().numpy()), full_index
+        assert W.log.count("all_gather_into_tensor") >= (3 if full_index else 5)
+        calls[full_index] = len(W.log)
+    assert calls[False] > calls[True], calls   # counts, packed pieces, boundary rows: exchanged only by the sharded build
