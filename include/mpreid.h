@@ -357,7 +357,11 @@ int mpreid_vit_forward_u8(const mpreid_vit_cfg *cfg, const mpreid_vit_weights *w
  * materialising a transformed [B,3,H,W] tensor per view. */
 #define MPREID_VIEW_ORIGINAL 0
 #define MPREID_VIEW_FLIP 1        /* torch.flip(img, [3]) */
-#define MPREID_VIEW_PSEUDO_IR 2   /* img.mean(dim=1, keepdim=True).repeat(1, 3, 1, 1) */
+#define MPREID_VIEW_PSEUDO_IR 2   /* img.mean(dim=1, keepdim=True).repeat(1, 3, 1, 1) -- in the HOST arithmetic of torch.mean,
+                                   * ((c0 + c1) + c2) / 3 with a correctly rounded division: the reference's CPU path, bit for
+                                   * bit.  torch's device kernel multiplies the sum by a rounded 1/3 (<= 1 ulp apart per pixel):
+                                   * features of a device-materialised view agree to ~1e-6, not to the bit
+                                   * (tests/test_gpu_preprocess.py::test_pseudo_ir_view_against_a_device_materialised_view) */
 #define MPREID_VIEW_PSEUDO_RGB 3  /* img[:, 0:1].repeat(1, 3, 1, 1) */
 /* mpreid_vit_forward / mpreid_vit_forward_u8 on one view: exactly one of img_f32_dev ([B][3][H][W], already
  * normalised) and img_hwc_u8_dev ([B][H][W][3] + pixel_mean3 / pixel_std3 host arrays) is non-NULL. */

@@ -2090,6 +2090,19 @@ static int set_dyn_lds(F kernel, size_t bytes) {
     return MPREID_OK;
 }
 
+// the k-reciprocal kernel's LDS request, with an error that names the limit in the caller's terms (include/mpreid.h "Limits")
+template <typename F>
+static int set_krecip_lds(F kernel, size_t bytes, int K, int64_t N) {
+    if (bytes > 160 * 1024) {
+        mpreid_set_error("re_ranking: k1 = %d at N = %lld needs %zu bytes of LDS for the expansion lists of one row; the limit is "
+                         "160 KiB per workgroup (k1 <= ~190 at N >= 20000, k1 <= 255 for N <= 18000; include/mpreid.h). The "
+                         "reference (utils/reranking.py:29) takes any k1 and is called with k1 = 50",
+                         K - 1, (long long)N, bytes);
+        return MPREID_ERR_UNSUPPORTED;
+    }
+    return set_dyn_lds(kernel, bytes);
+}
+
 // max of x[0..n) -> out[0] (one workgroup)
 __global__ __launch_bounds__(1024) void max_i32_kernel(const int *__restrict__ x, int64_t n, int *__restrict__ out) {
     __shared__ int part[16];
@@ -2368,7 +2381,9 @@ static int rerank_dense(const float *q, const float *g, int64_t nq, int64_t ng, 
     const int64_t N = L.N;
     ARG_CHECK(L.KR <= N);
     if (L.KR > 256) {
-        mpreid_set_error("max(k1+1, k2) = %d > 256 is not supported", L.KR);
+        mpreid_set_error("re_ranking: max(k1 + 1, k2) = %d exceeds this build's limit of 256 (the neighbour selection sorts its "
+                         "winners in one 256-entry LDS network and the reciprocity masks hold 256 bits per row; include/mpreid.h). "
+                         "The reference (utils/reranking.py:29) takes any k and is called with k1 = 50, k2 = 15", L.KR);
         return MPREID_ERR_UNSUPPORTED;
     }
     if (N >= (1ll << 31) - 64) {
@@ -2422,7 +2437,7 @@ static int rerank_dense(const float *q, const float *g, int64_t nq, int64_t ng, 
     // (4)-(6) V rows
     {
         const size_t lds = krecip_lds_bytes(false, nw, L.K, L.vcap, 0);
-        int rc = set_dyn_lds(krecip_kernel<false>, lds);
+        int rc = set_krecip_lds(krecip_kernel<false>, lds, L.K, N);
         if (rc) return rc;
         unsigned *rk = (unsigned *)(base + L.rbits);
         hipLaunchKernelGGL(recip_bits_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, rank, N, L.K, L.KR, L.h, rk,
@@ -2736,7 +2751,7 @@ static int rerank_sparse(const float *q, const float *g, int64_t nq, int64_t ng,
     tm.mark(); // 2
     {   // V rows, distances on the fly
         const size_t lds = krecip_lds_bytes(true, nw, L.K, L.vcap, d);
-        rc = set_dyn_lds(krecip_kernel<true>, lds);
+        rc = set_krecip_lds(krecip_kernel<true>, lds, L.K, N);
         if (rc) return rc;
         unsigned *rk = (unsigned *)(base + L.rbits);
         hipLaunchKernelGGL(recip_bits_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, stream, rank, N, L.K, L.KR, L.h, rk,
@@ -2935,7 +2950,7 @@ extern "C" int mpreid_rr_krecip(const float *d_local, int64_t ld, int64_t n, con
     ARG_CHECK(d_local && rowmax_local && rank_all && vcnt && vidx && vval && scratch && rows > 0 && kr >= K);
     const int nw = (int)((n + 31) >> 5);
     const size_t lds = krecip_lds_bytes(false, nw, K, vcap, 0);
-    int rc = set_dyn_lds(krecip_kernel<false>, lds);
+    int rc = set_krecip_lds(krecip_kernel<false>, lds, K, n);
     if (rc) return rc;
     // reciprocity bits of ALL rows (candidates of a local row live anywhere): recomputed by every rank from the
     // all-gathered table -- N x K membership tests, cheaper than another exchange
@@ -3105,7 +3120,7 @@ extern "C" int mpreid_rr_krecip_sparse(const float *feat_all, const float *norms
               kr >= K);
     const int nw = (int)((n + 31) >> 5);
     const size_t lds = krecip_lds_bytes(true, nw, K, vcap, d);
-    int rc = set_dyn_lds(krecip_kernel<true>, lds);
+    int rc = set_krecip_lds(krecip_kernel<true>, lds, K, n);
     if (rc) return rc;
     unsigned *rk = (unsigned *)scratch;
     hipLaunchKernelGGL(recip_bits_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, rank_all, n, K, kr,

@@ -27,7 +27,9 @@ namespace {
 // rounding: (x / 255 - mean) / std with two correctly rounded divisions (same bits as the host-transformed fp32 tensor).
 // view: the test-time-augmentation views of processor/processor_uniprompt_stage2.py:605-633 applied to the NORMALISED image while
 // it is read (0 original, 1 torch.flip(img, [3]), 2 pseudo-IR img.mean(dim=1) in all channels = ((c0 + c1) + c2) / 3, 3 pseudo-RGB
-// channel 0 in all channels) -- what include/mpreid.h calls MPREID_VIEW_*; same bits as the materialised view tensor.
+// channel 0 in all channels) -- what include/mpreid.h calls MPREID_VIEW_*; same bits as the view tensor materialised on the
+// HOST (torch CPU: sum, then a true division -- the reference's CPU path); torch's DEVICE mean multiplies by a rounded 1/3 and
+// is up to one ulp apart per pseudo-IR pixel (include/mpreid.h, MPREID_VIEW_PSEUDO_IR).
 struct StemIn {
     const float *img;
     const uint8_t *img8;

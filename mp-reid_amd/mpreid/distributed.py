@@ -87,6 +87,15 @@ def ensure_group_from_env(logger=None) -> Tuple[int, int]:
     elif ndev:
         torch.cuda.set_device(local % ndev)    # gloo staging: ranks may share a device
     rank, world, _ = init_from_env(backend)
+    import atexit
+
+    def _teardown():   # the caller (the reference's test.py) knows nothing about the group: leave no RCCL communicator behind
+        try:
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        except Exception:
+            pass
+    atexit.register(_teardown)
     if logger is not None:
         logger.info("process group initialised by do_inference: rank {} of {} on cuda:{} ({})".format(
             rank, world, torch.cuda.current_device() if ndev else "-", backend))

@@ -113,7 +113,7 @@ EVAL_WORKER = textwrap.dedent("""
     from utils.metrics import R1_mAP_eval
     import torch.distributed as dist
     rank, world, local = D.init_from_env()
-    torch.cuda.set_device(0)
+    torch.cuda.set_device({device})
     res = {{}}
     for ci, (n, nq, d, rerank) in enumerate({cases!r}):
         f, pid = synth.clustered_features(n, d, 2.5, seed=77 + n, per_id=6, normalize=False)
@@ -148,9 +148,16 @@ def test_r1_map_eval_sharded_equals_single_process(tmp_path, world):
     from mpreid import synth
     from utils.metrics import R1_mAP_eval
     script = tmp_path / "eval_worker.py"
-    script.write_text(EVAL_WORKER.format(root=ROOT, cases=EVAL_CASES))
+    script.write_text(EVAL_WORKER.format(root=ROOT, cases=EVAL_CASES, device="0"))
     _spawn(script, [str(tmp_path)], world, tmp_path)
-    got = np.load(tmp_path / "eval.npz")
+    _check_eval_npz(tmp_path / "eval.npz")
+
+
+def _check_eval_npz(path):
+    import torch
+    from mpreid import synth
+    from utils.metrics import R1_mAP_eval
+    got = np.load(path)
     for ci, (n, nq, d, rerank) in enumerate(EVAL_CASES):
         f, pid = synth.clustered_features(n, d, 2.5, seed=77 + n, per_id=6, normalize=False)
         cam = synth.labels_for(n)
@@ -263,3 +270,121 @@ def test_concat_parts_to_host_ragged_device_pieces(dim):
     assert got.shape == want.shape and np.array_equal(got, want)
     view = D._concat_parts_to_host(parts, sizes, dim, other, reuse_buffer=True)
     assert np.array_equal(view, want)
+
+
+# ---- the reference's OWN test.py shape under a launcher: no process group is initialised by the caller ------------------------
+# reference test.py:10-65 parses the config, sets CUDA_VISIBLE_DEVICES = cfg.MODEL.DEVICE_ID (:39), builds loader and model,
+# load_param(TEST.WEIGHT) and calls do_inference -- it never touches torch.distributed.  This script is that flow, written
+# against the drop-in modules; processor.do_inference must bring the ranks up by itself (mpreid.distributed.ensure_group_from_env).
+REF_SHAPED_TEST_PY = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, {pkg!r}); os.chdir({pkg!r})
+    from config import cfg_base as cfg
+    from datasets.make_dataloader import make_dataloader
+    from model.make_model import make_model
+    from processor.processor import do_inference
+    from utils.logger import setup_logger
+    cfg.merge_from_list(sys.argv[1:])
+    cfg.freeze()
+    logger = setup_logger("transreid", cfg.OUTPUT_DIR, if_train=False)
+    os.environ['CUDA_VISIBLE_DEVICES'] = cfg.MODEL.DEVICE_ID
+    train_loader, train_loader_normal, val_loader, num_query, num_classes, camera_num, view_num = make_dataloader(cfg)
+    model = make_model(cfg, num_class=num_classes, camera_num=camera_num, view_num=view_num)
+    model.load_param(cfg.TEST.WEIGHT)
+    r = do_inference(cfg, model, val_loader, num_query)
+    print('RESULT', float(r[0]), float(r[1]))
+""")
+REF_OPTS = ['DATASETS.SYNTH_QUERY', '24', 'DATASETS.SYNTH_GALLERY', '131', 'DATASETS.SYNTH_IDS', '6', 'TEST.IMS_PER_BATCH', '16',
+            'MODEL.SIE_CAMERA', 'True']
+
+
+def _ref_shaped_setup(tmp_path):
+    """(script path, weight path): the harness above and a checkpoint in the reference's layout (a state dict)"""
+    import torch
+    from config import cfg_base
+    from model.make_model import make_model
+    cfg = cfg_base.clone()
+    cfg.defrost()
+    cfg.merge_from_list(REF_OPTS + ['MODEL.INIT_SEED', '11'])
+    cfg.freeze()
+    w = tmp_path / "weights.pth"
+    torch.save(make_model(cfg, num_class=6, camera_num=6, view_num=1).state_dict(), w)
+    script = tmp_path / "ref_shaped_test.py"
+    script.write_text(REF_SHAPED_TEST_PY.format(pkg=os.path.join(ROOT, "mp-reid_amd")))
+    return script, w
+
+
+def _result_lines(text):
+    return [ln for ln in text.splitlines() if ln.startswith("RESULT")]
+
+
+def _metric_lines(text):
+    return [ln.split("transreid.test INFO: ")[1] for ln in text.splitlines() if "mAP:" in ln or "CMC curve" in ln]
+
+
+@pytest.mark.parametrize("rerank", ["False", "True"])
+def test_reference_shaped_test_py_needs_no_explicit_init(tmp_path, rerank):
+    """two gloo-staged ranks (one GPU) through the reference-shaped harness: do_inference initialises the group itself, shards
+    the loader and every rank prints the single-process (Rank-1, Rank-5); rank 0 alone logs the metric lines"""
+    from conftest import run_ranks
+    script, w = _ref_shaped_setup(tmp_path)
+    cmd = [sys.executable, str(script)] + REF_OPTS + ['TEST.WEIGHT', str(w), 'TEST.RE_RANKING', rerank, 'MODEL.DEVICE_ID', "('0')"]
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MPREID_DIST_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:]
+    single = r.stdout
+    multi = run_ranks(cmd, 2, 900, dict(MPREID_DIST_BACKEND="gloo", OMP_NUM_THREADS="4"), local_rank=lambda r_: 0,
+                      capture_dir=tmp_path)
+    assert len(_result_lines(single)) == 1
+    for o in multi:
+        assert _result_lines(o) == _result_lines(single)
+
+
+def _visible_gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif(_visible_gpus() < 2, reason="needs >= 2 visible GPUs: real RCCL ranks (one per device) cannot share a device")
+def test_real_rccl_ranks_end_to_end(tmp_path):
+    """Switches itself on the day >= 2 devices are visible (every other multi-rank test of this suite is gloo-staged, one-rank
+    nccl or emulated: RCCL with P > 1 has never run in the builder's environment).  P = min(8, devices) FRESH ranks per leg,
+    started by a launcher that has not touched a GPU; a failing rank exits non-zero and takes the leg down; nothing re-execs.
+      1. the reference-shaped test.py under `python -m torch.distributed.run` (MODEL.DEVICE_ID lists the devices): every
+         rank prints the single-process result;
+      2. R1_mAP_eval sharded over real RCCL ranks: rank 0's 7-tuple == the single-process compute() byte for byte
+         (ragged shards, with and without re-ranking);
+      3. bench.py --gpus P --workload synth --rerank (1/16 size): one line, rccl_ranks == P, all-gather figures present."""
+    from conftest import free_port, run_ranks
+    P = min(8, _visible_gpus())
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MPREID_DIST_BACKEND")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # 1. reference-shaped harness
+    script, w = _ref_shaped_setup(tmp_path)
+    opts = REF_OPTS + ['TEST.WEIGHT', str(w), 'TEST.RE_RANKING', 'True',
+                       'MODEL.DEVICE_ID', "('%s')" % ",".join(str(i) for i in range(P))]
+    r1 = subprocess.run([sys.executable, str(script)] + opts, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                        timeout=900)
+    assert r1.returncode == 0, r1.stdout[-2000:]
+    rP = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={P}",
+                         "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(script)] + opts,
+                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1800)
+    assert rP.returncode == 0, rP.stdout[-3000:]
+    assert len(_result_lines(r1.stdout)) == 1 and _result_lines(rP.stdout) == _result_lines(r1.stdout) * P
+    assert _metric_lines(rP.stdout) == _metric_lines(r1.stdout)          # rank 0 alone logs, and logs the same lines
+    # 2. the evaluator's 7-tuple over real RCCL ranks
+    worker = tmp_path / "eval_worker.py"
+    worker.write_text(EVAL_WORKER.format(root=ROOT, cases=EVAL_CASES, device="local"))
+    run_ranks([sys.executable, str(worker), str(tmp_path)], P, 1800, dict(OMP_NUM_THREADS="4"))
+    _check_eval_npz(tmp_path / "eval.npz")
+    # 3. the bench's own launcher
+    rb = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(P), "--workload", "synth", "--rerank",
+                         "--small", "--steps", "1", "--warmup", "1", "--no-extras", "--no-cpu-baseline"], env=env,
+                        cwd=str(tmp_path), capture_output=True, text=True, timeout=1800)
+    assert rb.returncode == 0, rb.stderr[-3000:]
+    lines = [ln for ln in rb.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == P and j["rccl_ranks"] == P and j["value"] > 0 and j["all_gather"]["bytes_per_step"] > 0
