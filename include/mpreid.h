@@ -30,6 +30,11 @@ extern "C" {
  * between BIT-IDENTICAL forms of a stage; no other variable changes which kernel runs.  Keys (default):
  *   gemm_big (1)            0 = never the 256x256 persistent GEMM, 1 = when its grid fills the chip, 2 = whenever divisible
  *   gemm_stagger, gemm_stagger_all (0)   start delay (ticks) of the persistent workgroups
+ *   gemm_walk (-1 auto)     tile order inside an XCD's group of 8 tile rows: 0 row-fastest, 1 column-fastest when the output
+ *                           has <= 4 tile columns (N = 768: out-proj, FC2), 2 column-fastest always, 3 / 4 groups of 4 / 16 tile
+ *                           rows; auto = column-fastest for <= 4 tile columns with operand rows >= 8 KB (the split FC2: -2.4 %);
+ *                           groups of 4 rows whenever groups of 8 do not divide among the XCDs but groups of 4 do
+ *   gemm_grid (0 = all CUs) persistent GEMM workgroups on fewer CUs (experiments: profiles/r06_cu_partition_experiment.log)
  *   dist_sym_p2 (1)         all-pairs distances of ONE tensor (q == g), fp16 modes: 0 = the 256x256 kernel's symmetric form,
  *                           1 = the two-workgroups-per-CU kernel from 16 tile rows on (N >= 3841; one-pass fp16 mode only: the 3-term
  *                           split operands stay on the first), 2 = whenever the padded size allows, 3 = also the 3-term split;

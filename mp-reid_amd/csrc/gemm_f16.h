@@ -84,6 +84,7 @@ struct GemmArgs {
                           // real-time counter late, so that the CUs reach their store-heavy epilogues at different
                           // times instead of all at once (0 = off)
     int stagger_mode;     // 1: eight phases by the CU's slot inside its XCD instead ((b >> 3) mod 8) / 8
+    int walk;             // persistent kernel, XCD-owned row groups: 1 = column-fastest tile order inside a group (set by the launcher)
     int pair_c;           // GE_S_BIAS_RELU_PAIR / GE_S_BIAS_RES_PAIR: half the row length of the pair output (hi at n, lo at pair_c + n); % 64 == 0
     _Float16 *pair_out;   // GE_S_BIAS_RES_PAIR: the pair copy (out stays the fp32 tensor)
     int relu_x;           // GE_S_BIAS_RES only: the destination holds a PRE-activation (a ResNet block input whose ReLU is pending):

@@ -563,7 +563,11 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
     const int nb = (int)gridDim.x;
     // (only when the groups divide evenly among the eight XCDs: with tiles_m = 16 -- the 4000 x 16 000 distance rows of
     // the re-ranking -- two XCDs owned everything and the other six idled: 1.12 ms instead of 0.4)
-    const bool owned = (tiles_m % 64 == 0) && (nb % 8 == 0);
+    // g.walk: 0 = groups of 8 tile rows, row-fastest inside a group; 1 = column-fastest inside a group; 3 / 4 = groups of
+    // 4 / 16 tile rows, row-fastest (32 CUs then cover 4 x 8 or 16 x 2 tiles at a time); | 8 = groups of 4 rows
+    const int GR = (g.walk == 3 || (g.walk & 8)) ? 4 : (g.walk == 4 ? 16 : 8);
+    const bool colfast = (g.walk & 7) == 1;
+    const bool owned = (tiles_m % (8 * GR) == 0) && (nb % 8 == 0);
     // Any other shape on a full grid (the distance GEMMs: 79 x 79 tiles at N = 20 000): "blocked" walk.  In round r
     // XCD x works on block r*8 + x of the tile grid cut into blocks of 8 tile rows x (CUs per XCD / 8) tile columns
     // (8 x 4 on 256 CUs), one tile per CU: 12 operand panels feed 32 tiles.  (The plain grouped walk gave an XCD ONE
@@ -571,7 +575,7 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
     // 2.66 GB of fabric reads against 62 MB of operands on the 20k x 20k x 768 distance GEMM.)  Edge blocks have
     // unused slots, which are skipped.
     const bool blocked = !owned && (nb % 64 == 0) && ntiles >= nb;
-    const int xcd = (int)(blockIdx.x & 7), per_xcd = nb >> 3, per_group = 8 * tiles_n, ngroups = tiles_m >> 3;
+    const int xcd = (int)(blockIdx.x & 7), per_xcd = nb >> 3, per_group = GR * tiles_n, ngroups = tiles_m / GR;
     const int bc_w = per_xcd >> 3;                                   // tile columns per block (blocked mode)
     const int nbc = blocked ? (tiles_n + bc_w - 1) / bc_w : 1, nbr = (tiles_m + 7) >> 3;
     // SYM_STORE on the blocked walk: COMPACTED.  The blocks that straddle the diagonal (and the edge blocks) have unused
@@ -656,8 +660,13 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
         const int grp = xcd + 8 * (p / per_group);
         if (grp >= ngroups) return -1;
         const int within = p % per_group;
-        if (SYM_EPI && g.sym && (within >> 3) < grp * 8 + (within & 7)) return -2;
-        return (grp * 8 + (within & 7)) * tiles_n + (within >> 3); // row-major tile id
+        // order inside a group of 8 tile rows: row fastest (32 CUs = 8 rows x 4 columns at a time), or -- g.walk, narrow
+        // outputs -- column fastest: with tiles_n = 3 (N = 768: out-proj, FC2) 32 slots then cover ~11 whole tile rows, each A
+        // panel read by its three CUs at the same time, instead of 8 rows x 3 columns plus one column of the next group
+        // whose A panels come back a round later
+        const int wrow = colfast ? within / tiles_n : within % GR, wcol = colfast ? within % tiles_n : within / GR;
+        if (SYM_EPI && g.sym && wcol < grp * GR + wrow) return -2;
+        return (grp * GR + wrow) * tiles_n + wcol; // row-major tile id
     };
     auto tile_at = [&](int &p) -> int {    // advances p past unused slots
         if constexpr (SYM_EPI) {
@@ -2316,15 +2325,28 @@ static int launch_one(const GemmArgs &a_in, hipStream_t stream) {
             int big_cus = 0;
             if (const int rcc = current_device_cus(&big_cus)) return rcc;
             static const int stag_all = mpreid_tune("gemm_stagger_all", 0);
+            // tile order inside an XCD's row group (bit-identical results; tools/walk_ab.sh on one device, M = 65 536, split
+            // operands): column-fastest takes FC2 (N = 768, 12 KB operand rows) from 711 / 709 to 693 / 693 us and leaves
+            // out-proj (3 KB rows) 0.5-1 % SLOWER (219.6 / 217.7 -> 221.5 / 220.7); groups of 4 tile rows (an A panel that fits
+            // the 4 MB L2) change nothing (QKV 552.6 / 554.0, FC1 755 / 756), groups of 16 lose 1-3 %.  auto (-1) = column-fastest
+            // for narrow outputs with operand rows of >= 8 KB, i.e. the split FC2.
+            static const int walk_tune = mpreid_tune("gemm_walk", -1);   // 0 row-fastest; 1 column-fastest when tiles_n <= 4; 2 always; 3 / 4: groups of 4 / 16 rows
             GemmArgs a = a_in;
             if (stag_all > 0) {
                 a.stagger = stag_all;
                 a.stagger_mode = 1;
             }
+            a.walk = walk_tune >= 3 ? walk_tune
+                   : (walk_tune == 2 || (walk_tune == 1 && tiles_n <= 4) || (walk_tune < 0 && tiles_n <= 4 && (int64_t)a.K * 2 >= 8192)) ? 1 : 0;
+            // row groups of 4 tile rows when groups of 8 do not divide among the XCDs but groups of 4 do (e.g. tiles_m = 224):
+            // bit 3 of walk
+            if (walk_tune < 3 && tiles_m % 64 != 0 && tiles_m % 32 == 0) a.walk |= 8;
             const unsigned total_tiles = (unsigned)tiles_m * (unsigned)tiles_n;
 #ifdef MPREID_ABLATION
             if (const char *gg = getenv("MPREID_GEMM_GRID")) big_cus = atoi(gg);   // (ablation) fewer workgroups than CUs
 #endif
+            static const int grid_tune = mpreid_tune("gemm_grid", 0);   // experiment: persistent workgroups on fewer CUs (same bits)
+            if (grid_tune > 0 && grid_tune < big_cus) big_cus = grid_tune;
             const dim3 grid(total_tiles < (unsigned)big_cus ? total_tiles : (unsigned)big_cus);
 #ifdef MPREID_ABLATION
             if (dbg == 64 && gemm_epi_is_split(EPI)) {   // operand panels aliased onto two (L2-resident): see set_tile
