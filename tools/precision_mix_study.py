@@ -56,6 +56,41 @@ def mm(a, w, mode):
             return (x * sc).to(torch.float32).to(torch.float8_e4m3fn).to(F64) / sc
         if mode == "f8c":
             return out + f8(al) @ f8(wh).t() + f8(ah) @ f8(wl).t()
+    if mode in ("m6w", "m6c", "m6s", "m8c"):
+        # round 6: the cross terms on the BLOCK-SCALED matrix instruction (v_mfma_scale_f32_16x16x128_f8f6f4):
+        # MX operands = 32 consecutive k share one power-of-two scale (E8M0), elements fp6 e2m3 (4 significant bits, 4x the fp16
+        # rate on the data sheet) or fp8 e4m3 (2x).  Two SLICES per operand (x ~ s1 + s2, s2 = MX(x - s1) with its own block
+        # scales: ~8 significant bits relative to the block maximum) and the three products s1.t1 + s2.t1 + s1.t2 per cross term.
+        def mx(x, fmt):
+            K = x.shape[-1]
+            xb = x.reshape(*x.shape[:-1], K // 32, 32)
+            amax = xb.abs().amax(dim=-1, keepdim=True).clamp_min(1e-300)
+            emax = 2 if fmt == "fp6" else 7
+            sc = torch.exp2(torch.floor(torch.log2(amax)) - emax)
+            y = xb / sc
+            if fmt == "fp6":    # e2m3: steps 1/8 below 2, 1/4 in [2, 4), 1/2 in [4, 7.5]; saturates at 7.5
+                mag = y.abs().clamp_max(7.5)
+                step = torch.where(mag < 2, 0.125, torch.where(mag < 4, 0.25, 0.5)).to(F64)
+                q = torch.sign(y) * torch.round(mag / step) * step
+            else:
+                q = y.to(torch.float32).to(torch.float8_e4m3fn).to(F64)
+            return (q * sc).reshape(x.shape)
+
+        def two(x, fmt):
+            s1 = mx(x, fmt)
+            return s1, mx(x - s1, fmt)
+
+        def cross2(u, v, fmt):      # u . v^T with both operands as two MX slices, the s2.t2 product dropped
+            u1, u2 = two(u, fmt)
+            v1, v2 = two(v, fmt)
+            return u1 @ v1.t() + u2 @ v1.t() + u1 @ v2.t()
+        if mode == "m6w":    # hi.lo' on two fp6 slices, lo.hi' on fp16
+            return out + al @ wh.t() + cross2(ah, wl, "fp6")
+        if mode == "m6c":    # both cross terms on two fp6 slices
+            return out + cross2(al, wh, "fp6") + cross2(ah, wl, "fp6")
+        if mode == "m6s":    # both cross terms on ONE fp6 slice per operand
+            return out + mx(al, "fp6") @ mx(wh, "fp6").t() + mx(ah, "fp6") @ mx(wl, "fp6").t()
+        return out + mx(al, "fp8") @ mx(wh, "fp8").t() + mx(ah, "fp8") @ mx(wl, "fp8").t()   # m8c: one MX fp8 slice
     if mode == "f8a":   # lo.hi' on fp8, hi.lo' on fp16
         return out + f8(al) @ f8(wh).t() + ah @ wl.t()
     if mode == "f8w":   # hi.lo' on fp8, lo.hi' on fp16
@@ -121,6 +156,7 @@ def main():
     nq = len(pid) // 5
     kinds = ("patch", "qkv", "out", "fc1", "fc2")
     allm = lambda m: {k: m for k in kinds}  # noqa: E731
+    only = os.environ.get("MIX_ONLY")   # e.g. MIX_ONLY="(ix),(x),(xi),(xii)": just those rows (+ the first)
     mixes = [
         ("three products everywhere (the `split` mode)", allm("3"), 3.0),
         ("(i) activations split, weights single fp16: hi.hi' + lo.hi'", allm("a2"), 2.0),
@@ -132,8 +168,15 @@ def main():
         ("(vi) hi.hi' on fp16, BOTH cross terms on the fp8 matrix cores (e4m3 operands, per-row power-of-two scales; fp8 = 2x the fp16 rate)", allm("f8c"), 2.0),
         ("(vii) as (vi) but only lo.hi' (activations' lo) on fp8, hi.lo' on fp16", allm("f8a"), 2.5),
         ("(viii) as (vi) but only hi.lo' (weights' lo) on fp8, lo.hi' on fp16", allm("f8w"), 2.5),
+        ("(ix) both cross terms on ONE block-scaled (MX, 32 k per scale) fp8 e4m3 slice per operand", allm("m8c"), 2.0),
+        ("(x) both cross terms on ONE MX fp6 e2m3 slice per operand (fp6 = 4x the fp16 rate on the data sheet)", allm("m6s"), 1.5),
+        ("(xi) hi.lo' on TWO MX fp6 slices per operand (3 fp6 products), lo.hi' on fp16", allm("m6w"), 2.75),
+        ("(xii) both cross terms on TWO MX fp6 slices per operand (3 + 3 fp6 products)", allm("m6c"), 2.5),
+        ("(xii-b) as (xii) on FC1 / FC2 only, three fp16 products elsewhere", dict(allm("3"), fc1="m6c", fc2="m6c"), 2.67),
         ("one product everywhere (the `fp16` mode)", allm("1"), 1.0),
     ]
+    if only:
+        mixes = [m for i, m in enumerate(mixes) if i == 0 or any(m[0].startswith(t + " ") for t in only.split(","))]
     f_ref = features(sd, cfg, x, allm("exact"))
     m_ref = metrics(f_ref, pid, nq)
     print(f"spread set: {len(pid)} images, {nq} queries; exact graph: mAP {m_ref[0][0]:.5f} / re-ranked {m_ref[1][0]:.5f}, "
