@@ -1,8 +1,8 @@
 #!/bin/bash
 # Collect the round's evidence on the GPU box (run through gpurun from the repo root):
-#   bash tools/collect_profiles.sh r05
+#   bash tools/collect_profiles.sh r06
 # Writes everything under gpurun_out/profiles_<tag>/; the summaries are then copied into profiles/ (tracked).
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_$TAG
 mkdir -p $OUT
@@ -24,7 +24,12 @@ keep_extras ${TAG}_bench_market_rerank_extras.json
 #    --no-extras: only the headline step's launches are in the trace (the extras run the same kernels at other shapes -- the
 #    reference-loop leg encodes 64 images per call -- and rocprofv3 --stats averages per kernel NAME)
 #    Same --steps / --warmup as the driver's run, so that `Calls` are the driver run's launch counts.
+#    MPREID_EVAL_D2H=behind: the matrix's D2H copy is queued BEHIND eval_rank_kernel in this trace only.  The product overlaps them
+#    (faster: tools/evalrank_bench.py), but rocprofv3 serialises the two queues and then books the blit kernels the ranking
+#    kernel waited for into ITS interval (round 5's 5.4 ms average); ordered this way the trace shows the kernel's own time.
+export MPREID_EVAL_D2H=behind
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_bench -o b -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --streams 1 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_under_rocprof.json 2>/dev/null
+unset MPREID_EVAL_D2H
 keep_extras ${TAG}_bench_under_rocprof_extras.json
 cp $OUT/kt_bench/b_kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv
 # 3. re-ranking alone (N = 20 000): kernel stats and the FETCH / WRITE passes (separate runs)
@@ -38,6 +43,14 @@ cp $OUT/kt_euclid/e_kernel_stats.csv $OUT/${TAG}_featgemm_kernel_stats.csv
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_e_sq -o e -- python3 $R/tools/distgemm_bench.py 20000 20000 768 f16 > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_e_fetch -o e -- python3 $R/tools/distgemm_bench.py 20000 20000 768 f16 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_e_write -o e -- python3 $R/tools/distgemm_bench.py 20000 20000 768 f16 > /dev/null 2>&1
+# 4b. the same matrix from TWO tensors (the evaluator's shape: every tile computed, 256 x 256 one-workgroup-per-CU kernel)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_euclid2 -o e -- python3 $R/tools/distgemm_bench.py 20000 20000 768 f16 full > $OUT/distgemm_two_tensors.log 2>&1
+cp $OUT/kt_euclid2/e_kernel_stats.csv $OUT/${TAG}_featgemm_two_tensors_kernel_stats.csv
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_e2_sq -o e -- python3 $R/tools/distgemm_bench.py 20000 20000 768 f16 full > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_e2_fetch -o e -- python3 $R/tools/distgemm_bench.py 20000 20000 768 f16 full > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_e2_write -o e -- python3 $R/tools/distgemm_bench.py 20000 20000 768 f16 full > /dev/null 2>&1
+# 4c. eval_rank_kernel alone / beside the D2H copy, compute() in both orders
+python3 $R/tools/evalrank_bench.py > $OUT/${TAG}_evalrank.log 2>&1
 # 5. encoder GEMM classes (fp16 and split-precision): FETCH / WRITE passes over the micro-benchmark (tools/pmc_traffic.py reduces them)
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_g_fetch -o g -- python3 $R/tools/gemm_bench.py --reps 3 --rounds 2 --only qkv,out,fc1,fc2,sqkv,sout,sfc1,sfc2 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_g_write -o g -- python3 $R/tools/gemm_bench.py --reps 3 --rounds 2 --only qkv,out,fc1,fc2,sqkv,sout,sfc1,sfc2 > /dev/null 2>&1

@@ -26,12 +26,13 @@ def med(v):
 def main():
     root, tag = sys.argv[1], sys.argv[2]
     out = {"note": __doc__.split("Usage")[0].strip(), "runs": {}}
-    for name in ("pmc_rr_fetch", "pmc_rr_write", "pmc_e_fetch", "pmc_e_write", "pmc_e_sq"):
+    for name in ("pmc_rr_fetch", "pmc_rr_write", "pmc_e_fetch", "pmc_e_write", "pmc_e_sq", "pmc_e2_fetch", "pmc_e2_write", "pmc_e2_sq"):
         per = collect(f"{root}/{name}")
         out["runs"][name] = {k[:110]: {c: med(list(v.values())) for c, v in cs.items()} for k, cs in per.items()
                              if not k.startswith("__amd") and "at::" not in k}
     # HBM bytes per launch where both passes exist
-    for pre, label in (("pmc_rr", "rerank_N20000"), ("pmc_e", "featgemm_20kx20kx768_fp16")):
+    for pre, label in (("pmc_rr", "rerank_N20000"), ("pmc_e", "featgemm_20kx20kx768_fp16"),
+                       ("pmc_e2", "featgemm_two_tensors_20kx20kx768_fp16")):
         f, w = out["runs"].get(pre + "_fetch", {}), out["runs"].get(pre + "_write", {})
         out[label + "_hbm_bytes_per_launch"] = {
             k: int((2 * f[k].get("FETCH_SIZE", 0) + w.get(k, {}).get("WRITE_SIZE", 0)) * 1024) for k in f}
