@@ -36,7 +36,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "mp-reid_amd")):
+for p in (ROOT, os.path.join(ROOT, "mp-reid_amd"), os.path.join(ROOT, "tools")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
@@ -389,370 +389,7 @@ def parity_deltas(ops, sample, precision="split"):
     return out
 
 
-def live_gemm_traffic(epi_id, n, k, timeout_s=240):
-    """HBM bytes per launch of ONE encoder GEMM class, measured in THIS run: two child processes (never an exec of this
-    one) run tools/gemm_bench.py -- the same kernel at the same shape, M = 65 536, random data -- under
-    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes, counters only: MI355X_MICROARCH.md's HBM
-    section), bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (FETCH_SIZE reads 1/2 on gfx950).  Returns (bytes or None, note).
-    Skipped when this process itself runs under rocprofv3, when MPREID_BENCH_LIVE_TRAFFIC=0, or when the tool is missing:
-    the caller then REPLAYS the committed figure and says so (`traffic_replayed`)."""
-    import shutil
-    import tempfile
-    if os.environ.get("MPREID_BENCH_LIVE_TRAFFIC", "1") == "0":
-        return None, "MPREID_BENCH_LIVE_TRAFFIC=0"
-    if any(key.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for key in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
-        return None, "this run is itself under rocprofv3"
-    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.exists(exe):
-        return None, "rocprofv3 not found"
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    shapes = {"qkv": (2304, 768, 1), "out": (768, 768, 2), "fc1": (3072, 768, 3), "fc2": (768, 3072, 2),
-              "sqkv": (2304, 768, 10), "sout": (768, 768, 11), "sfc1": (3072, 768, 12), "sfc2": (768, 3072, 11)}   # = tools/gemm_bench.py SHAPES
-    name = next((nm for nm, v in shapes.items() if v == (n, k, epi_id)), None)
-    if name is None:
-        return None, f"no micro-benchmark shape for class ({epi_id}, {n}, {k})"
-    import pmc_traffic
-    tmp = tempfile.mkdtemp(prefix="mpreid_pmc_", dir="/tmp")
-    vals = {}
-    t0 = time.perf_counter()
-    try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, counter)
-            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "g", "--", sys.executable,
-                   os.path.join(ROOT, "tools", "gemm_bench.py"), "--reps", "2", "--rounds", "1", "--only", name]
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True,
-                               timeout=max(30.0, timeout_s - (time.perf_counter() - t0)))
-            if r.returncode != 0:
-                return None, f"rocprofv3 --pmc {counter} exited {r.returncode}"
-            per = pmc_traffic.collect(d, counter)
-            got = [v for kn, lst in per.items() if f"gemm_f16_big_kernel<{epi_id}," in kn for _, v in lst]
-            if not got:
-                return None, f"no {counter} rows for gemm_f16_big_kernel<{epi_id}>"
-            got.sort()
-            vals[counter] = got[len(got) // 2]
-    except (subprocess.TimeoutExpired, OSError) as e:
-        return None, f"{type(e).__name__}"
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
-    return int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), (
-        f"live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of tools/gemm_bench.py --only {name} "
-        f"({time.perf_counter() - t0:.0f} s)")
-
-
-#: kernels of each re-rank stage as rocprofv3 names them (prefix match) -> used to sum the committed PMC bytes per stage
-RERANK_STAGE_KERNELS = {
-    "rerank.candidates": ("sqnorm_kernel", "rr2_norm_stats_kernel", "_Z20rr2_cast_rows_kernel", "void gemm_f16_big_kernel<5, 0",
-                          "rr2_threshold_kernel", "void gemm_f16_big_kernel<9, 0"),   # (prefixes: the template list grew a parameter in round 3)
-    "rerank.refine": ("void rr2_refine_kernel", "rr2_fb_gather_kernel", "rowmax_topk_kernel", "rr2_fb_scatter_kernel"),
-    "rerank.krecip": ("recip_bits_kernel", "void krecip_kernel"),
-    "rerank.query_rows": ("void gemm_f32_exact_kernel",),
-    "rerank.qe": ("qe_count_kernel", "qe_fill_kernel", "max_i32_kernel"),
-    "rerank.csc": ("csc2_hist_kernel", "csc2_colscan_kernel", "scan_tile_sums_kernel", "scan_tile_bases_kernel",
-                   "scan_apply_kernel", "csc2_fill_kernel", "csc2_bounds_kernel"),
-    "rerank.jaccard": ("void jaccard_wave_kernel", "void jaccard_kernel"),
-}
-
-
-def _pmc_stage_bytes():
-    """HBM bytes per launch of every re-rank stage at N = 20 000 from the committed rocprofv3 PMC passes (FETCH_SIZE and
-    WRITE_SIZE in separate runs, gfx950 corrections applied by tools/pmc_summary.py): {stage: (bytes, source file)}"""
-    for fn in ("r06_pmc_summary.json", "r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json"):
-        try:
-            per = json.load(open(os.path.join(ROOT, "profiles", fn)))["rerank_N20000_hbm_bytes_per_launch"]
-        except Exception:
-            continue
-        out = {}
-        for stage, pre in RERANK_STAGE_KERNELS.items():
-            tot = sum(v for k, v in per.items() if k.startswith(pre))
-            if tot:
-                out[stage] = (int(tot), fn)
-        return out
-    return {}
-
-
-def rerank_roofline(st):
-    """per-stage roofline entries of one re-rank call from its logged nnz (SURVEY.md §8d byte formulas).  `traffic` = HBM
-    bytes from the committed PMC passes (same problem: N = 20 000, nq = 4000, D = 768).  The k-reciprocal and
-    query-expansion stages gather 4-byte words that live in L2 (rank table 4 MB, V rows): SURVEY's formula counts every
-    gathered word, which is L2 traffic, not HBM traffic -- they are reported as L2-gather-bound WITHOUT an HBM fraction
-    (round 2 printed 0.98 of HBM peak for a kernel that moves 0.39 GB)."""
-    N, k1, k2, h = st["n"], st["k1"], st["k2"], st["half_k1"]
-    nq = st.get("nq", 0)
-    ng = N - nq
-    rbar = st.get("krecip_r_sum", 0) / max(N, 1)
-    kr = max(k1 + 1, k2)
-    rows = []
-    pmc = _pmc_stage_bytes() if (N == 20000 and nq == 4000 and st.get("d") == 768) else {}
-
-    def add(stage, kernel, ms, bound, work, note=None):
-        if not ms or ms <= 0:
-            return
-        tr = pmc.get(stage)
-        if bound == "l2":
-            e = {"stage": stage, "kernel": kernel, "bound": "l2-gather", "achieved": round(work / ms / 1e6, 1), "peak": None,
-                 "unit": "GB/s of gathered words (served by L2)", "frac": None, "algorithmic_gather_bytes": int(work),
-                 "avg_launch_ms": round(ms, 4), "traffic": tr[0] if tr else None}
-            if tr:
-                e["hbm"] = {"achieved": round(tr[0] / ms / 1e6, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                            "frac": round(tr[0] / ms / 1e6 / PEAK_HBM_GBS, 4)}
-        else:
-            if bound == "hbm":
-                ach, peak, unit = work / ms / 1e6, PEAK_HBM_GBS, "GB/s"
-            else:
-                ach, peak, unit = work / ms / 1e9, (PEAK_F32_TFLOPS if bound == "mfma_f32" else PEAK_F16_TFLOPS), "TFLOP/s"
-            e = {"stage": stage, "kernel": kernel, "bound": "mfma" if bound.startswith("mfma") else "hbm",
-                 "achieved": round(ach, 1), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
-                 "algorithmic_" + ("bytes" if bound == "hbm" else "flop"): int(work), "avg_launch_ms": round(ms, 4),
-                 "traffic": tr[0] if tr else None}
-            if tr and bound == "hbm":
-                e["traffic_over_algorithmic"] = round(tr[0] / max(work, 1), 2)
-        if tr:
-            e["traffic_source"] = f"profiles/{tr[1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, N = 20 000)"
-        if note:
-            e["note"] = note
-        rows.append(e)
-
-    d = st.get("d", 0)
-    if st.get("algo", 1) == 2:
-        # sparse algorithm: no N x N matrix.  fp16 MFMA: symmetric candidate GEMM (N*N*D executed) + sample pass
-        add("rerank.candidates", "gemm_f16_big_kernel<cand> (+ cast, sample pass, thresholds)", st["ms_gemm"], "mfma_f16",
-            1.0 * N * N * d + 2.0 * N * (N / 16.0) * d,
-            "executed FLOPs: upper-triangular tiles of the symmetric N x N problem + the N x N/16 sample pass; nothing stored")
-        add("rerank.refine", "rr2_refine_kernel (+ fallback rows)", st["ms_topk"], "hbm",
-            4.0 * d * kr * N + 8.0 * st.get("cand_total", 0),
-            "algorithmic: the KR exact neighbour rows of every row (4*D*KR*N) + the candidate lists; the kernel evaluates "
-            "~1.5 KR rows per row (everything within 2 eps of the KR-th candidate)")
-        add("rerank.krecip", "recip_bits_kernel + krecip_kernel<sparse>", st["ms_krecip"], "l2",
-            4.0 * N * ((k1 + 1) ** 2 + rbar * (h + h * h)), f"mean |R| = {rbar:.1f}")
-        add("rerank.query_rows", "gemm_f32_exact_kernel", st.get("ms_dq", 0.0), "mfma_f32", 2.0 * nq * ng * d,
-            "exact fp32 distance rows of the queries over the gallery columns only ([nq][ng]): what the Jaccard blend reads")
-    else:
-        add("rerank.distance", "gemm_f32_exact_kernel<SYM>", st["ms_gemm"], "mfma_f32", 1.0 * N * N * d,
-            "executed FLOPs: the symmetric kernel computes the upper-triangular tiles only (2*N*N*D/2)")
-        add("rerank.topk", "rowmax_topk_kernel", st["ms_topk"], "hbm", 4.0 * N * N + 4.0 * N * kr)
-        add("rerank.krecip", "recip_bits_kernel + krecip_kernel", st["ms_krecip"], "l2",
-            4.0 * N * ((k1 + 1) ** 2 + rbar * (h + h * h)), f"mean |R| = {rbar:.1f}")
-    add("rerank.qe", "qe_count/fill_kernel", st["ms_qe"], "l2", 6.0 * st["v_nnz"] * (1 + k2),
-        "k2 neighbour rows of V merged per row: the rows are re-read from L2 by many rows' expansions")
-    # the inverted index holds the gallery rows only: ~ng/N of the V_qe entries are read (6 B) and written (6 B)
-    add("rerank.csc", "csc2_*", st["ms_csc"], "hbm", 10.0 * st["vqe_nnz"] * (ng / max(N, 1)),
-        "inverted index of the gallery rows (the accumulators of the query rows are never read)")
-    # packed index entries: 4 B per gathered (row, value) pair (6 B with the round-1 layout)
-    add("rerank.jaccard", "jaccard_wave_kernel", st["ms_jaccard"], "hbm", 4.0 * st["jaccard_pairs"] + 8.0 * nq * ng,
-        "algorithmic: 4 B per pair of the gallery-row inverted index + the distance row read and the result written")
-    return rows
-
-
-def sym_tiles_executed(n, tile_m, tile_n):
-    """tiles a symmetric all-pairs kernel computes: those that reach the upper triangle (tn * tile_n + tile_n > tm * tile_m)"""
-    tm_n, tn_n = -(-n // tile_m), -(-n // tile_n)
-    return sum(1 for tm in range(tm_n) for tn in range(tn_n) if (tn + 1) * tile_n > tm * tile_m)
-
-
-def sym_entry(stage, kernel, n, d, ms, peak, tile_m, tile_n, products=1, **more):
-    """roofline entry of a SYMMETRIC all-pairs kernel: `achieved` / `frac` count the matrix work the kernel EXECUTES (the tiles on
-    or above the diagonal, x `products` fp16 products per multiply-add) -- never above 1 --; the 2*N*N*D of SURVEY.md section 8d
-    (what a caller gets: the whole matrix) is reported beside it as algorithmic_*, without being called a fraction of a roofline"""
-    ex = 2.0 * sym_tiles_executed(n, tile_m, tile_n) * tile_m * tile_n * d * products
-    alg = 2.0 * n * n * d
-    e = {"stage": stage, "kernel": kernel, "bound": "mfma", "achieved": round(ex / ms / 1e9, 1), "peak": peak, "unit": "TFLOP/s",
-         "frac": round(ex / ms / 1e9 / peak, 4), "executed_flop": int(ex), "avg_launch_ms": round(ms, 4),
-         "algorithmic_flop": int(alg), "algorithmic_tflops": round(alg / ms / 1e9, 1),
-         "algorithmic_2NND_over_peak": round(alg / ms / 1e9 / peak, 4), "traffic": None}
-    e.update(more)
-    return e
-
-
-def extras(ops, dev, with_widened=True):
-    """secondary figures named by BASELINE.json's metric: 20k x 20k feat-GEMM and re-rank; returns (extras dict,
-    roofline entries)"""
-    import numpy as np
-    import torch
-    from mpreid import synth
-    out, roofs = {}, []
-    f, _ = synth.clustered_features(20000, 768, 3.0, seed=1234)
-    ft = torch.from_numpy(f).to(dev)
-    buf = torch.empty((20000, 20000), dtype=torch.float32, device=dev)
-    flop = 2.0 * 20000 * 20000 * 768
-    byts = 2.0 * 2 * 20000 * 768 + 4.0 * 20000 * 20000
-    # the 20k x 20k feat-GEMM is the all-pairs distance matrix of ONE feature set: euclidean_distance(f, f) (same tensor)
-    # takes the symmetric form of the kernel (tiles on or above the diagonal, mirrored stores: same bits, tested);
-    # "full" = the same matrix from two separate tensors (every tile computed), what round 3 reported
-    ft_copy = ft.clone()
-    ms_full = timed_ms(lambda: ops.euclidean_distance(ft, ft_copy, mode=ops.GEMM_F16_FAST, out=buf), 10, warm=3)
-    ms = timed_ms(lambda: ops.euclidean_distance(ft, ft, mode=ops.GEMM_F16_FAST, out=buf), 10, warm=3)   # mean of 10 whole calls
-    out["feat_gemm_20kx20k_d768_fp16_ms"] = round(ms, 4)
-    out["feat_gemm_20kx20k_d768_fp16_tflops"] = round(flop / ms / 1e9, 1)
-    out["feat_gemm_20kx20k_d768_fp16_frac_of_peak"] = round(flop / ms / 1e9 / PEAK_F16_TFLOPS, 4)
-    out["feat_gemm_20kx20k_d768_fp16_two_tensors_ms"] = round(ms_full, 4)
-    out["feat_gemm_20kx20k_d768_fp16_two_tensors_frac_of_peak"] = round(flop / ms_full / 1e9 / PEAK_F16_TFLOPS, 4)
-    fg_traffic = fg_src = None
-    for fn in ("r06_pmc_summary.json", "r05_pmc_summary.json", "r04_pmc_summary.json"):
-        try:
-            per = json.load(open(os.path.join(ROOT, "profiles", fn)))["featgemm_20kx20kx768_fp16_hbm_bytes_per_launch"]
-            fg_traffic = int(sum(v for k, v in per.items() if k.startswith(("void gemm_f16_big_kernel<5, 0", "void dist_sym_p2_kernel", "void gemm_f16_store"))))
-            fg_src = fn
-            break
-        except Exception:
-            continue
-    roofs.append({"stage": "feat_gemm_20kx20k_d768, two separate tensors (fp16 one pass, fp32 N x N stored, every tile computed)",
-                  "kernel": "gemm_f16_big_kernel<euclid>", "bound": "mfma", "achieved": round(flop / ms_full / 1e9, 1),
-                  "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(flop / ms_full / 1e9 / PEAK_F16_TFLOPS, 4),
-                  "algorithmic_flop": int(flop), "avg_launch_ms": round(ms_full, 4), "traffic": None})
-    roofs.append(sym_entry("feat_gemm_20kx20k_d768 (fp16 one pass, fp32 N x N stored; all pairs of one tensor: symmetric form)",
-                           "dist_sym_p2_kernel (two workgroups per CU, 256 x 128 tiles; MPREID_TUNE dist_sym_p2=0: gemm_f16_big_kernel<euclid, sym>)",
-                           20000, 768, ms, PEAK_F16_TFLOPS, 256, 128, traffic=fg_traffic,
-                           traffic_source=f"profiles/{fg_src}" if fg_src else None,
-                           hbm={"achieved": round(byts / ms / 1e6, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                "frac": round(byts / ms / 1e6 / PEAK_HBM_GBS, 4), "algorithmic_bytes": int(byts)}))
-    del ft_copy
-    if hasattr(ops, "GEMM_F16_SPLIT3"):
-        ms = timed_ms(lambda: ops.euclidean_distance(ft, ft, mode=ops.GEMM_F16_SPLIT3, out=buf), 10, warm=3)
-        out["feat_gemm_20kx20k_d768_split3_ms"] = round(ms, 4)
-        out["feat_gemm_20kx20k_d768_split3_executed_tflops"] = round(3 * flop / ms / 1e9, 1)
-        roofs.append(sym_entry("feat_gemm_20kx20k_d768 (3-term fp16 split, |err| <= 1e-6; all pairs of one tensor: symmetric form)",
-                               "gemm_f16_big_kernel<euclid, sym> (split3 operands, 256 x 256 tiles)", 20000, 768, ms, PEAK_F16_TFLOPS, 256, 256,
-                               products=3))
-    ms = timed_ms(lambda: ops.euclidean_distance(ft, ft, mode=ops.GEMM_F32_EXACT, out=buf), 3)
-    out["feat_gemm_20kx20k_d768_fp32exact_ms"] = round(ms, 4)
-    out["feat_gemm_20kx20k_d768_fp32exact_tflops"] = round(flop / ms / 1e9, 1)
-    roofs.append(sym_entry("feat_gemm_20kx20k_d768 (exact fp32 MFMA, bit-parity mode; all pairs of one tensor: symmetric kernel)",
-                           "gemm_f32_exact_kernel<SYM> (128 x 128 tiles)", 20000, 768, ms, PEAK_F32_TFLOPS, 128, 128))
-    del buf
-    ops.re_ranking(ft[:4000], ft[4000:], 50, 15, 0.3)
-    _, st = ops.re_ranking(ft[:4000], ft[4000:], 50, 15, 0.3, timing=True)
-    st.update(nq=4000, d=768)
-    out["rerank_N20000_nq4000_d768_k50_15_ms"] = round(st["ms_total"], 3)
-    out["rerank_stages_ms"] = {k[3:]: round(v, 3) for k, v in st.items() if k.startswith("ms_") and k != "ms_total"}
-    out["rerank_nnz"] = {"v": st["v_nnz"], "vqe": st["vqe_nnz"], "jaccard_pairs": st["jaccard_pairs"]}
-    out["rerank_algo"] = {1: "dense", 2: "sparse"}.get(st["algo"], st["algo"])
-    out["rerank_fallback_rows"] = st["fallback_rows"]
-    out["rerank_candidates"] = st["cand_total"]
-    roofs += rerank_roofline(st)
-    _, sd = ops.re_ranking(ft[:4000], ft[4000:], 50, 15, 0.3, timing=True, algo=ops.RERANK_DENSE)
-    sd.update(nq=4000, d=768)
-    out["rerank_dense_algorithm_ms"] = round(sd["ms_total"], 3)
-    out["rerank_dense_stages_ms"] = {k[3:]: round(v, 3) for k, v in sd.items() if k.startswith("ms_") and k != "ms_total"}
-    # the same call with the blend term's distance rows from the fp16 matrix cores (RERANK_SPARSE_SPLIT3: discrete
-    # results identical, outputs within 1e-6) -- reported beside the bit-parity figure, never instead of it
-    ref_out, _ = ops.re_ranking(ft[:4000], ft[4000:], 50, 15, 0.3)
-    s3_out, s3 = ops.re_ranking(ft[:4000], ft[4000:], 50, 15, 0.3, timing=True, algo=ops.RERANK_SPARSE_SPLIT3)
-    _, s3 = ops.re_ranking(ft[:4000], ft[4000:], 50, 15, 0.3, timing=True, algo=ops.RERANK_SPARSE_SPLIT3)
-    out["rerank_split3_rows_ms"] = round(s3["ms_total"], 3)
-    out["rerank_split3_rows_max_abs_diff_vs_exact"] = float((s3_out - ref_out).abs().max())
-    del ref_out, s3_out
-    ms = timed_ms(lambda: ops.re_ranking(ft[:4000], ft[4000:], 50, 15, 0.3), 3)
-    out["rerank_N20000_untimed_stages_ms"] = round(ms, 3)
-    out["distmat_plus_rerank_20kx20k_ms"] = round(ms, 3)   # the re-rank computes its own all-pairs distance matrix
-    del ft
-    if not with_widened:
-        return out, roofs
-    # the encoder alone in its three precision modes (one stream, batches of 508 resident in HBM): which of them meet
-    # north_star's 1e-4 mAP / Rank-1 bound is asserted in tests/test_gpu_map_parity.py
-    sdv = synth.vit_state_dict(synth.VIT_B16, seed=7)
-    gimg = torch.Generator(device=dev)
-    gimg.manual_seed(99)
-    img508 = torch.randn((508, 3, H, W), generator=gimg, device=dev).clamp_(-1.0, 1.0)
-    per_mode = {}
-    for prec, reps in (("split", 4), ("fp16", 6), ("fp32", 1)):
-        e_ = ops.VitEncoder(synth.VIT_B16, sdv, (H, W), precision=prec)
-        fo_ = torch.empty((508, e_.feat_dim), device=dev)
-        ms = timed_ms(lambda: e_(img508, out=fo_), reps)
-        per_mode[prec] = {"images_per_s": round(508 / ms * 1e3, 1), "ms_per_batch_of_508": round(ms, 3),
-                          "encode_tflops_algorithmic": round(508 * GFLOP_PER_IMG / ms, 1)}
-        del e_, fo_
-        ops.release_workspaces()
-    out["encoder_images_per_s_by_precision"] = per_mode
-    del img508
-    torch.cuda.empty_cache()
-    # widened rows (SURVEY.md §8f): the RN50 tower, the Pillow-exact Resize, the PCIe-inclusive encoder
-    enc = ops.Rn50Encoder(synth.RN50, synth.rn50_state_dict(synth.RN50, seed=11), (256, 128), precision="fp16")
-    img = torch.from_numpy(synth.synthetic_images(64, 256, 128, seed=1)).to(dev).repeat(4, 1, 1, 1).contiguous()
-    fo = torch.empty((256, enc.feat_dim), device=dev)
-    ms = timed_ms(lambda: enc(img, out=fo), 3)
-    out["rn50_images_per_s_batch256"] = round(256 / ms * 1e3, 1)
-    rn_gflop = 9.32 + 2.16 + 0.013   # conv trunk + attention pool as the reference computes it (K / V projections of all tokens)
-    roofs.append({"stage": "rn50 tower (MODEL.NAME RN50, fp16 activations), 256 images per call", "kernel": "conv_gemm_kernel / gemm_f16_* / rn50_*",
-                  "bound": "mfma", "achieved": round(256 * rn_gflop / ms, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                  "frac": round(256 * rn_gflop / ms / PEAK_F16_TFLOPS, 4), "algorithmic_flop": int(256 * rn_gflop * 1e9),
-                  "avg_launch_ms": round(ms, 4), "traffic": None,
-                  "note": "whole tower (about 60 launches); algorithmic = 11.49 GFLOP per image as the reference computes it "
-                          "(the attention pool here skips the K / V projections: 9.5 GFLOP executed); the 1x1 layers of "
-                          "layer1-2 are HBM-bound (K = 64..256)"})
-    del enc, fo
-    enc = ops.Rn50Encoder(synth.RN50, synth.rn50_state_dict(synth.RN50, seed=11), (256, 128), precision="fp32")
-    fo = torch.empty((64, enc.feat_dim), device=dev)
-    ms = timed_ms(lambda: enc(img[:64], out=fo), 2)
-    out["rn50_fp32_mode_images_per_s_batch64"] = round(64 / ms * 1e3, 1)   # everything on the exact fp32 matrix instruction (4.1e-6)
-    del enc, fo
-    ops.release_workspaces()
-    # the DEFAULT RN50 mode (MODEL.ENCODER_PRECISION split): fp32 activations, convolutions over fp16 pairs on the fp16 matrix cores
-    enc = ops.Rn50Encoder(synth.RN50, synth.rn50_state_dict(synth.RN50, seed=11), (256, 128), precision="split")
-    fo = torch.empty((256, enc.feat_dim), device=dev)
-    ms = timed_ms(lambda: enc(img, out=fo), 3)
-    out["rn50_split_mode_images_per_s_batch256"] = round(256 / ms * 1e3, 1)
-    roofs.append({"stage": "rn50 tower, split precision (the default, parity-grade: 3.4e-6 vs the reference), 256 images per call",
-                  "kernel": "conv_gemm_kernel<9, pair form> (3x3, implicit GEMM) + gemm_f16_big_kernel / gemm_f16_kernel <split_*> (1x1) + pack_pairs", "bound": "mfma",
-                  "achieved": round(256 * rn_gflop / ms, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                  "frac": round(256 * rn_gflop / ms / PEAK_F16_TFLOPS, 4), "algorithmic_flop": int(256 * rn_gflop * 1e9),
-                  "avg_launch_ms": round(ms, 4), "traffic": None,
-                  "note": "algorithmic 11.49 GFLOP per image (2*M*N*K of the reference's graph); the matrix cores execute 3x that on "
-                          "the pair GEMMs plus channel padding (64-channel layers in 128-wide tiles); the 3x3 convolutions are implicit "
-                          "GEMMs over the pair tensor (no im2col matrix), ~17 % of the time are the fp32 -> pair pack passes (HBM-bound)"})
-    del enc, img, fo
-    ops.release_workspaces()
-    rng = np.random.default_rng(5)
-    raws = [rng.integers(0, 256, (128, 64, 3), dtype=np.uint8) for _ in range(512)]   # Market-1501 native size
-    ops.resize_bilinear_u8(raws, (256, 128))
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3):
-        ops.resize_bilinear_u8(raws, (256, 128))
-    torch.cuda.synchronize()
-    dt_rs = (time.perf_counter() - t0) / 3
-    out["resize_128x64_to_256x128_images_per_s_incl_pack_and_h2d"] = round(512 / dt_rs, 1)
-    rs_bytes = 512 * (128 * 64 * 3 + 256 * 128 * 3)
-    roofs.append({"stage": "val_transforms Resize (512 decoded 128x64 images -> 256x128, uint8), incl. host packing + H2D",
-                  "kernel": "resize_h_kernel + resize_v_kernel", "bound": "hbm", "achieved": round(rs_bytes / dt_rs / 1e9, 2),
-                  "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(rs_bytes / dt_rs / 1e9 / PEAK_HBM_GBS, 6),
-                  "algorithmic_bytes": rs_bytes, "avg_launch_ms": round(dt_rs * 1e3, 3), "traffic": None,
-                  "note": "the call is host-bound (python packing of 512 ragged images into the pinned buffer + one H2D copy); "
-                          "the two kernels move 63 MB and take ~30 us: 4 orders of magnitude under the encoder's time"})
-    del raws
-    # PCIe-inclusive encode: uint8 HWC images in PINNED host memory -> H2D on a copy stream (double-buffered) ->
-    # forward_u8 (ToTensor + Normalize fused) on the compute stream.  Never the headline value (inputs there are
-    # resident in HBM); this is the rate a dataloader that hands over host buffers would see.
-    vit = ops.VitEncoder(synth.VIT_B16, synth.vit_state_dict(synth.VIT_B16, seed=7), (256, 128), precision="split")
-    B, nb = 508, 8
-    host = [torch.from_numpy(rng.integers(0, 256, (B, 256, 128, 3), dtype=np.uint8)).pin_memory() for _ in range(2)]
-    devb = [torch.empty((B, 256, 128, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
-    fo = torch.empty((B, vit.feat_dim), device=dev)
-    copy_s = torch.cuda.Stream(device=dev)
-    comp = torch.cuda.current_stream()
-    ready = [torch.cuda.Event() for _ in range(2)]
-    freed = [torch.cuda.Event() for _ in range(2)]
-
-    def run(nbatches):
-        for k in range(2):
-            freed[k].record(comp)
-        for it in range(nbatches):
-            k = it & 1
-            with torch.cuda.stream(copy_s):
-                copy_s.wait_event(freed[k])
-                devb[k].copy_(host[k], non_blocking=True)
-                ready[k].record(copy_s)
-            comp.wait_event(ready[k])
-            vit.forward_u8(devb[k], out=fo)
-            freed[k].record(comp)
-        torch.cuda.synchronize()
-
-    run(2)
-    t0 = time.perf_counter()
-    run(nb)
-    dt = time.perf_counter() - t0
-    out["encode_from_pinned_host_uint8_images_per_s"] = round(nb * B / dt, 1)   # split precision, one stream
-    out["encode_from_pinned_host_uint8_h2d_gb_per_s"] = round(nb * B * 256 * 128 * 3 / dt / 1e9, 2)
-    return out, roofs
+# (live_gemm_traffic, rerank_roofline, extras, drop_in_extras: tools/bench_extras.py)
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -833,70 +470,6 @@ def timed_do_inference(cfg, model, loader, nq, reps, pipeline_env=None):
                 os.environ["MPREID_PIPELINE"] = old
 
 
-def drop_in_extras(a, cfg, model, nq, ng, pids, camids, dev):
-    """the same do_inference call fed from the HOST (PCIe inclusive): (i) 64-image fp32 batches in pageable host memory --
-    the reference's loader type (datasets/make_dataloader.py:103-106: DataLoader without pin_memory, `img.to(device)`
-    in the loop, processor/processor.py:189); (ii) RawImageBatch batches of decoded uint8 images of ragged sizes (Resize +
-    ToTensor + Normalize on the GPU).  Never the headline value."""
-    import numpy as np
-    import torch
-    from datasets.make_dataloader import RawImageBatch
-    from processor.processor import do_inference
-    out = {}
-    n = nq + ng
-    g = torch.Generator(device=dev)
-    g.manual_seed(4321)
-    host = []
-    for s in range(0, n, 64):
-        e = min(n, s + 64)
-        host.append(torch.randn((e - s, 3, H, W), generator=g, device=dev).clamp_(-1.0, 1.0).cpu())   # pageable
-    ld = ValLoader(host, range(n), n, pids, camids)
-    for stage in ("pinned", "direct"):
-        dt = timed_do_inference(cfg, model, ld, nq, 2, pipeline_env=f"stage={stage},streams={max(1, a.streams)}")
-        out[f"do_inference_images_per_s_fp32_loader_{stage}"] = round(n / dt, 1)
-    best = max(("pinned", "direct"), key=lambda k: out[f"do_inference_images_per_s_fp32_loader_{k}"])
-    out["do_inference_images_per_s_fp32_loader"] = out[f"do_inference_images_per_s_fp32_loader_direct"]   # the default stage
-    out["do_inference_fp32_loader_best_stage"] = best
-    out["do_inference_fp32_loader_h2d_gb_per_s"] = round(out["do_inference_images_per_s_fp32_loader"] * 3 * H * W * 4 / 1e9, 2)
-    # the reference's own loop shape on the same loader, for scale: one 64-image batch at a time, pageable .to(device)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    k = 0
-    with torch.no_grad():
-        for img, *_ in ld:
-            model(img.to(dev))
-            k += img.shape[0]
-            if k >= 4096:
-                break
-    torch.cuda.synchronize()
-    out["reference_loop_shape_images_per_s_fp32_loader"] = round(k / (time.perf_counter() - t0), 1)
-    del ld, host
-    rng = np.random.default_rng(77)
-    pool = rng.integers(0, 256, 64 << 20, dtype=np.uint8)   # decoded-image stand-ins cut from one random pool
-    raws, off = [], 0
-    for s in range(0, n, 64):
-        b = []
-        for _ in range(min(n, s + 64) - s):
-            h, w = int(rng.integers(96, 200)), int(rng.integers(48, 100))
-            if off + h * w * 3 > pool.size:
-                off = int(rng.integers(0, 4096))
-            b.append(pool[off:off + h * w * 3].reshape(h, w, 3))
-            off += h * w * 3
-        raws.append(RawImageBatch(b))
-    ld = ValLoader(raws, range(n), n, pids, camids)
-    dt = timed_do_inference(cfg, model, ld, nq, 2, pipeline_env=f"streams={max(1, a.streams)}")
-    out["do_inference_images_per_s_raw_loader"] = round(n / dt, 1)
-    ev = do_inference.last_evaluator
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    import contextlib
-    with open(os.devnull, "w") as null, contextlib.redirect_stdout(null):
-        for _ in range(3):
-            ev.compute()
-    out["compute_ms"] = round((time.perf_counter() - t0) / 3 * 1e3, 2)   # R1_mAP_eval.compute(): normalise, distmat, ranking, D2H
-    return out
-
-
 # ----------------------------------------------------------------------------------------------------------------
 # one rank
 # ----------------------------------------------------------------------------------------------------------------
@@ -904,7 +477,9 @@ def run_rank(a):
     import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
+    import bench_extras as BX   # tools/bench_extras.py: the secondary legs (extras file)
     from mpreid import _lib, distributed as D, ops, synth
+    BX.bind(sys.modules[__name__])
 
     rank, world, local = D.init_from_env()
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
@@ -1109,7 +684,7 @@ def run_rank(a):
         traffic_src = None
         traffic_replayed = None
         if top and world == 1 and not a.small and not a.no_live_traffic:
-            traffic, traffic_src = live_gemm_traffic(top["epilogue_id"], top["N"], top["K"])
+            traffic, traffic_src = BX.live_gemm_traffic(top["epilogue_id"], top["N"], top["K"])
             traffic_replayed = False if traffic is not None else None
             live_note = traffic_src
         else:
@@ -1265,7 +840,7 @@ def run_rank(a):
         if world == 1 and not a.no_extras and not a.small:
             drop = {}
             if market is not None:
-                drop = drop_in_extras(a, market["cfg"], market["model"], nq, ng_total, pids_all, cams_all, dev)
+                drop = BX.drop_in_extras(a, market["cfg"], market["model"], nq, ng_total, pids_all, cams_all, dev)
                 market["loader"] = None
                 del loader
             else:
@@ -1276,7 +851,7 @@ def run_rank(a):
                 del feats
             ops.release_workspaces()
             torch.cuda.empty_cache()
-            res["extras"], roofs = extras(ops, dev, with_widened=(wl == "market"))
+            res["extras"], roofs = BX.extras(ops, dev, with_widened=(wl == "market"))
             res["extras"].update(drop)
             if drop:
                 res["extras"]["do_inference_fp32_loader_over_headline"] = round(drop["do_inference_images_per_s_fp32_loader"] / res["value"], 4)
