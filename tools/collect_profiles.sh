@@ -60,3 +60,11 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_
 python3 $R/tools/pmc_mfma.py $OUT/pmc_g_mfma $OUT/${TAG}_gemm_pmc_mfma.json > $OUT/pmc_mfma.log 2>&1
 python3 $R/tools/pmc_summary.py $OUT $TAG > $OUT/${TAG}_pmc_summary.json 2> $OUT/pmc_summary.err
 ls -la $OUT | head -40
+# 6. same-device A/B of this round's one encoder change (tile order of the split FC2: MPREID_TUNE=gemm_walk=0 is round 5's order),
+#    alternating processes, the headline step
+ab() { env "$@" python3 $R/bench.py --gpus 1 --steps 5 --warmup 2 --no-extras --no-cpu-baseline --no-live-traffic 2>/dev/null | python3 -c "import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$LABEL', j['value'], 'img/s', j['ms_per_step'], 'ms/step')"; }
+for i in 1 2 3; do
+  LABEL="round 6 (gemm_walk auto)" ab MPREID_AB=product >> $OUT/${TAG}_ab_gemm_walk.log
+  LABEL="round 5 order (gemm_walk=0)" ab MPREID_TUNE=gemm_walk=0 >> $OUT/${TAG}_ab_gemm_walk.log
+done
+cat $OUT/${TAG}_ab_gemm_walk.log
