@@ -63,3 +63,27 @@ def test_eval_func_device_market_scale():
     cmc_s, map_s = eval_func_device(d[torch.from_numpy(rows).cuda()].contiguous(), pid[:3368][rows], pid[3368:])
     assert np.array_equal(cmc_s, cmc_h) and abs(map_s - map_h) < 1e-12
     assert 0.0 < map_d <= 1.0 and cmc_d[0] <= cmc_d[-1] <= 1.0
+
+
+@pytest.mark.parametrize("ng,big,ties", [(12000, 5000, False), (12000, 8192, True), (20000, 9000, False)])
+def test_eval_func_device_many_relevant_items_per_query(ng, big, ties):
+    """A query with thousands of relevant gallery items (round 6: the kernel's sorted relevant keys live in dynamic LDS sized
+    for the largest identity, up to 8192 entries -- round 5 stopped at 2048): 5000 and exactly 8192 run on the device, 9000
+    takes the documented host fallback for THAT row only (logged once); every variant equals the host eval_func."""
+    import utils.metrics as M
+    rng = np.random.default_rng(ng + big)
+    nq = 12
+    d = rng.random((nq, ng)).astype(np.float32)
+    if ties:
+        d = np.round(d * 64) / 64
+    g_pid = np.full(ng, 7, np.int64)
+    g_pid[big:] = rng.integers(100, 140, ng - big)        # identity 7 owns `big` gallery items, the others ~100-200 each
+    g_pid = g_pid[rng.permutation(ng)]
+    q_pid = rng.integers(100, 140, nq)
+    q_pid[3] = 7
+    q_pid[8] = 7
+    M._warned_host_ranking = False        # (set when a row takes the host fallback: the warning is logged once per process)
+    cmc_d, map_d = M.eval_func_device(torch.from_numpy(d).cuda(), q_pid, g_pid)
+    cmc_h, map_h = M.eval_func(d, q_pid, g_pid, None, None)
+    assert np.array_equal(cmc_d, cmc_h) and abs(map_d - map_h) < 1e-12
+    assert M._warned_host_ranking == (big > 8192)
