@@ -101,6 +101,26 @@ def test_bench_self_launches_two_ranks(args):
     assert j["scaling"] == ("weak" if args[1] == "market" else "strong")
 
 
+def test_bench_under_the_drivers_launcher_two_ranks(tmp_path):
+    """the driver's multi-GPU form, verbatim: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W` (two gloo-staged ranks on the one GPU here): rank 0 prints the ONE
+    line, the others nothing, exit code 0"""
+    from conftest import free_port
+    env = dict(os.environ, MPREID_DIST_BACKEND="gloo", OMP_NUM_THREADS="4")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--small"], env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and len(lines[0].encode()) <= 4096
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["warmup"] == 1 and j["scaling"] == "weak" and j["value"] > 0
+    assert j["rccl_ranks"] == 0 and j["all_gather"]["calls_per_step"] >= 1 and j["cpu_baseline"] is None
+    assert "metric_20k" not in j or j["metric_20k"] is None or isinstance(j["metric_20k"], dict)
+
+
 # ---- the evaluator and do_inference behind the reference API under WORLD_SIZE > 1 -------------------------------------
 # Reference: processor/processor.py:178-182 goes multi-device inside do_inference (nn.DataParallel) and
 # utils/metrics.py:110-134 returns ONE distmat from compute().  Here: one R1_mAP_eval instance per rank; rank 0's 7-tuple
