@@ -11,6 +11,31 @@
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// the other fp16 shape: v_mfma_f32_32x32x16_f16 (twice the FLOPs per instruction, half the operand register reads per FLOP)
+__global__ __launch_bounds__(512) void rate_32x32(float *out, int iters, unsigned seed) {
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    const unsigned t = threadIdx.x * 2654435761u + seed;
+    f16x8 a, b;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        a[i] = (_Float16)(((t >> i) & 15) * 0.0625f);
+        b[i] = (_Float16)(((t >> (i + 8)) & 15) * 0.0625f);
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][7] + acc[i][15];
+    if (s == 123.456f) out[0] = s;
+}
 
 #define CK(x)                                                                       \
     do {                                                                            \
@@ -86,6 +111,30 @@ static int run(const char *name, int kdim, float *d, int cus, double *tf_out) {
     return 0;
 }
 
+static int run_32x32(float *d, int cus, double *tf_out) {
+    const int iters = 20000;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(rate_32x32, dim3(cus), dim3(512), 0, 0, d, 2000, 1u);
+    CK(hipDeviceSynchronize());
+    float best = 1e30f, sum = 0.f;
+    for (int r = 0; r < 5; ++r) {
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(rate_32x32, dim3(cus), dim3(512), 0, 0, d, iters, (unsigned)r);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        best = ms < best ? ms : best;
+        sum += ms;
+    }
+    const double flop = 2.0 * 32 * 32 * 16 * 4.0 * iters * 8.0 * cus;   // 4 chains x 8 waves x cus
+    *tf_out = flop / (sum / 5) / 1e9;
+    printf("%-44s %8.3f ms avg  %8.1f TFLOP/s (best %.1f)\n", "v_mfma_f32_32x32x16_f16 (4 chains)", sum / 5, flop / (sum / 5) / 1e9, flop / best / 1e9);
+    return 0;
+}
+
 int main() {
     hipDeviceProp_t p;
     CK(hipGetDeviceProperties(&p, 0));
@@ -96,6 +145,8 @@ int main() {
     printf("%d CUs x 8 waves, 8 accumulator chains per wave, 20 000 iterations, operands in registers\n", cus);
     for (int rep = 0; rep < 2; ++rep) {
         if (run<0>("v_mfma_f32_16x16x32_f16", 32, d, cus, &tf[0])) return 1;
+        double t32 = 0;
+        if (run_32x32(d, cus, &t32)) return 1;
         if (run<1>("v_mfma_scale_f32_16x16x128_f8f6f4  fp8 x fp8", 128, d, cus, &tf[1])) return 1;
         if (run<2>("v_mfma_scale_f32_16x16x128_f8f6f4  fp6 x fp6", 128, d, cus, &tf[2])) return 1;
         if (run<3>("v_mfma_scale_f32_16x16x128_f8f6f4  fp4 x fp4", 128, d, cus, &tf[3])) return 1;
