@@ -412,3 +412,56 @@ def test_split_mode_input_scale_edges(scale, finite):
     ev.update((got, (0, 1, 0, 1, 0, 1), (0,) * 6))
     with pytest.raises(RuntimeError, match="non-finite"):
         ev.compute()
+
+
+WALK_WORKER = """
+import ctypes as C, sys, os
+sys.path[:0] = [{root!r}, os.path.join({root!r}, "mp-reid_amd")]
+import numpy as np, torch
+from mpreid import _lib
+L = _lib.load(); dev = _lib.require_gpu()
+def pair(x, scale=1.0):
+    y = torch.empty((x.shape[0], 2 * x.shape[1]), dtype=torch.float16, device=dev)
+    _lib.check(L.mpreid_split_pack_f32(C.c_void_p(x.data_ptr()), x.shape[0], x.shape[1], scale, C.c_void_p(y.data_ptr()), _lib.stream_ptr()), "pack")
+    return y
+def gemm(a2, w2, out, bias, n, k, epi):
+    _lib.check(L.mpreid_gemm_f16_split_nt(C.c_void_p(a2.data_ptr()), C.c_void_p(w2.data_ptr()), C.c_void_p(out.data_ptr()),
+                                          C.c_void_p(bias.data_ptr()), a2.shape[0], n, k, 2.0 ** -13, epi, _lib.stream_ptr()), "gemm")
+gen = torch.Generator(device="cpu").manual_seed(5)
+for (m, n, k, epi) in {shapes!r}:
+    a = (torch.rand((m, k), generator=gen) * 2 - 1).to(dev)
+    w = ((torch.rand((n, k), generator=gen) * 2 - 1) * 0.05).to(dev)
+    bias = torch.randn(n, generator=gen).to(dev)
+    a2, w2 = pair(a), pair(w, 2.0 ** 13)
+    init = torch.randn((m, n), generator=gen).to(dev)
+    big = torch.empty((m, 2 * n), dtype=torch.float16, device=dev) if epi == 12 else init.clone()
+    gemm(a2, w2, big, bias, n, k, epi)                       # the persistent 256 x 256 kernel, tile order per MPREID_TUNE
+    ref = torch.empty_like(big) if epi == 12 else init.clone()
+    for s in range(0, m, 256):                               # the 128 x 128 kernel, 256 rows at a time: no tile walk at all
+        blk = ref[s:s + 256].clone()
+        gemm(a2[s:s + 256].contiguous(), w2, blk, bias, n, k, epi)
+        ref[s:s + 256] = blk
+    torch.cuda.synchronize()
+    assert torch.equal(big, ref), (m, n, k, epi, os.environ.get("MPREID_TUNE"))
+print("WALK OK")
+"""
+
+
+@pytest.mark.parametrize("tune", ["", "gemm_walk=0", "gemm_walk=2", "gemm_walk=3", "gemm_walk=4"])
+def test_persistent_gemm_tile_orders_are_bit_identical(tmp_path, tune):
+    """every tile order of the persistent split GEMM (MPREID_TUNE gemm_walk: auto = column-fastest for the FC2 shape and row
+    groups of 4 when 8 do not divide among the XCDs, row-fastest, column-fastest always, groups of 4 / 16 tile rows) writes the
+    FULL output the 128 x 128 kernel writes, bit for bit: FC2 / QKV / FC1 shapes at 64 tile rows, out-proj at 224 tile rows
+    (groups of 4) and at 96 (neither 8 nor 4 divides among the XCDs: the plain walk).  The tuning string is latched per process."""
+    import os
+    import subprocess
+    import sys
+    shapes = [(16384, 768, 3072, 11), (16384, 2304, 768, 10), (16384, 3072, 768, 12), (57344, 768, 768, 11), (24576, 768, 768, 11)]
+    script = tmp_path / "walk_worker.py"
+    script.write_text(WALK_WORKER.format(root=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), shapes=shapes))
+    env = dict(os.environ)
+    env.pop("MPREID_TUNE", None)
+    if tune:
+        env["MPREID_TUNE"] = tune
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "WALK OK" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
