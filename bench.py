@@ -184,6 +184,9 @@ def parse():
                     help="gather the per-shard distance blocks into one pinned host matrix on rank 0 inside every step "
                          "(north_star); auto = on for the market workload (214 MB per GPU shard), off for synth / msmt17 "
                          "(6.4 / 3.8 GB matrices: the step would measure PCIe)")
+    ap.add_argument("--group", type=int, default=0,
+                    help="images per encoder call of the do_inference pipeline (market workload; 0 = the model's encode_group: 508 "
+                         "images = one sweep of 256-row tiles over 256 CUs)")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the encoder batches alternate on (HBM-bound phases of one batch overlap "
                          "MFMA phases of the other)")
@@ -575,7 +578,8 @@ def run_rank(a):
     rr_holder = {}
 
     host_concat = a.host_concat == "on"   # (market: the hand-over to the host is part of R1_mAP_eval.compute())
-    os.environ["MPREID_PIPELINE"] = f"streams={nstreams}"
+    pipe_env = f"streams={nstreams}" + (f",group={a.group}" if a.group > 0 else "")
+    os.environ["MPREID_PIPELINE"] = pipe_env
 
     def step():
         if market is not None:
@@ -643,7 +647,7 @@ def run_rank(a):
         step()
         fence()
         L.mpreid_profile_enable(0)
-        os.environ["MPREID_PIPELINE"] = f"streams={nstreams}"
+        os.environ["MPREID_PIPELINE"] = pipe_env
         side[:], encs[:] = saved
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
@@ -787,7 +791,7 @@ def run_rank(a):
             "data": "synthetic",
             "config": {"workload": desc, "workload_long": desc_long, "images_per_step": images_per_step,
                        "rerank": bool(a.rerank), "distance_mode": a.dist_mode,
-                       "encoder_batch": (market["model"].encode_group if market else a.batch) if enc else None,
+                       "encoder_batch": ((a.group or market["model"].encode_group) if market else a.batch) if enc else None,
                        "encoder_precision": a.encoder_precision if enc else None,
                        "encoder_streams": nstreams if enc else None,
                        "sharding": f"gallery rows over {world} GPU(s); 1 all-gather of query feats; blocks concatenated on rank 0's host"},
