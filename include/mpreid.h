@@ -34,6 +34,8 @@ extern "C" {
  *                           has <= 4 tile columns (N = 768: out-proj, FC2), 2 column-fastest always, 3 / 4 groups of 4 / 16 tile
  *                           rows; auto = column-fastest for <= 4 tile columns with operand rows >= 8 KB (the split FC2: -2.4 %);
  *                           groups of 4 rows whenever groups of 8 do not divide among the XCDs but groups of 4 do
+ *   gemm_ragged (1)         XCD-owned row groups also when the groups do not divide among the XCDs (>= 24 groups: one XCD gets one
+ *                           group less, a short last group leaves unused slots); 0 = round 5's rule (such shapes take the blocked walk)
  *   gemm_grid (0 = all CUs) persistent GEMM workgroups on fewer CUs (experiments: profiles/r06_cu_partition_experiment.log)
  *   dist_sym_p2 (1)         all-pairs distances of ONE tensor (q == g), fp16 modes: 0 = the 256x256 kernel's symmetric form,
  *                           1 = the two-workgroups-per-CU kernel from 16 tile rows on (N >= 3841; one-pass fp16 mode only: the 3-term

@@ -21,7 +21,7 @@ struct TuneTable {
     std::vector<std::pair<std::string, int>> kv;
     TuneTable() {
         static const char *known[] = {"gemm_big", "gemm_stagger", "gemm_stagger_all", "jaccard_wave", "jaccard_wave_rows",
-                                      "jaccard_table", "csc_atomic", "rerank_overlap", "dist_sym_p2", "dist_sym_p2_naps", "dist_sym_p2_abl", "dist_sym_p2_grid", "dist_sym_p2_strip", "dist_p2_full", "gemm_walk", "gemm_grid", "verbose"};
+                                      "jaccard_table", "csc_atomic", "rerank_overlap", "dist_sym_p2", "dist_sym_p2_naps", "dist_sym_p2_abl", "dist_sym_p2_grid", "dist_sym_p2_strip", "dist_p2_full", "gemm_walk", "gemm_grid", "gemm_ragged", "verbose"};
         const char *e = getenv("MPREID_TUNE");
         if (!e) return;
         std::string s(e);

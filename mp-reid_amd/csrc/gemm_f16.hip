@@ -565,9 +565,15 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
     // the re-ranking -- two XCDs owned everything and the other six idled: 1.12 ms instead of 0.4)
     // g.walk: 0 = groups of 8 tile rows, row-fastest inside a group; 1 = column-fastest inside a group; 3 / 4 = groups of
     // 4 / 16 tile rows, row-fastest (32 CUs then cover 4 x 8 or 16 x 2 tiles at a time); | 8 = groups of 4 rows
-    const int GR = (g.walk == 3 || (g.walk & 8)) ? 4 : (g.walk == 4 ? 16 : 8);
+    const int GR = ((g.walk & 7) == 3 || (g.walk & 8)) ? 4 : ((g.walk & 7) == 4 ? 16 : 8);
     const bool colfast = (g.walk & 7) == 1;
-    const bool owned = (tiles_m % (8 * GR) == 0) && (nb % 8 == 0);
+    // RAGGED row counts (round 6): when the groups do not divide among the XCDs but there are at least three per XCD, the
+    // XCDs still own whole groups -- one XCD gets one group less, the last group may be short (its missing rows are unused
+    // slots) -- instead of falling to the blocked walk below, whose 8 x 4 blocks leave a quarter of the slots idle on a
+    // 3- or 9-column output (patch embedding, M = 254 tile rows: 0.298 -> 0.23 ms; the last, shorter encode group).
+    // Symmetric problems keep the exact rule (their block lists are balanced by construction).
+    const int ngroups = (tiles_m + GR - 1) / GR;
+    const bool owned = (nb % 8 == 0) && (tiles_m % (8 * GR) == 0 || (ngroups >= 24 && !(g.walk & 16) && !(SYM_EPI && g.sym)));
     // Any other shape on a full grid (the distance GEMMs: 79 x 79 tiles at N = 20 000): "blocked" walk.  In round r
     // XCD x works on block r*8 + x of the tile grid cut into blocks of 8 tile rows x (CUs per XCD / 8) tile columns
     // (8 x 4 on 256 CUs), one tile per CU: 12 operand panels feed 32 tiles.  (The plain grouped walk gave an XCD ONE
@@ -575,7 +581,7 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
     // 2.66 GB of fabric reads against 62 MB of operands on the 20k x 20k x 768 distance GEMM.)  Edge blocks have
     // unused slots, which are skipped.
     const bool blocked = !owned && (nb % 64 == 0) && ntiles >= nb;
-    const int xcd = (int)(blockIdx.x & 7), per_xcd = nb >> 3, per_group = GR * tiles_n, ngroups = tiles_m / GR;
+    const int xcd = (int)(blockIdx.x & 7), per_xcd = nb >> 3, per_group = GR * tiles_n;
     const int bc_w = per_xcd >> 3;                                   // tile columns per block (blocked mode)
     const int nbc = blocked ? (tiles_n + bc_w - 1) / bc_w : 1, nbr = (tiles_m + 7) >> 3;
     // SYM_STORE on the blocked walk: COMPACTED.  The blocks that straddle the diagonal (and the edge blocks) have unused
@@ -665,6 +671,7 @@ __global__ __launch_bounds__(512) void gemm_f16_big_kernel(GemmArgs g, int tiles
         // panel read by its three CUs at the same time, instead of 8 rows x 3 columns plus one column of the next group
         // whose A panels come back a round later
         const int wrow = colfast ? within / tiles_n : within % GR, wcol = colfast ? within % tiles_n : within / GR;
+        if (grp * GR + wrow >= tiles_m) return -2;   // a short last group
         if (SYM_EPI && g.sym && wcol < grp * GR + wrow) return -2;
         return (grp * GR + wrow) * tiles_n + wcol; // row-major tile id
     };
@@ -2341,6 +2348,8 @@ static int launch_one(const GemmArgs &a_in, hipStream_t stream) {
             // row groups of 4 tile rows when groups of 8 do not divide among the XCDs but groups of 4 do (e.g. tiles_m = 224):
             // bit 3 of walk
             if (walk_tune < 3 && tiles_m % 64 != 0 && tiles_m % 32 == 0) a.walk |= 8;
+            static const int ragged_tune = mpreid_tune("gemm_ragged", 1);   // 0: round 5's rule (owned walk only for exact divisions)
+            if (!ragged_tune) a.walk |= 16;
             const unsigned total_tiles = (unsigned)tiles_m * (unsigned)tiles_n;
 #ifdef MPREID_ABLATION
             if (const char *gg = getenv("MPREID_GEMM_GRID")) big_cus = atoi(gg);   // (ablation) fewer workgroups than CUs

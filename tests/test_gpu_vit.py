@@ -447,16 +447,20 @@ print("WALK OK")
 """
 
 
-@pytest.mark.parametrize("tune", ["", "gemm_walk=0", "gemm_walk=2", "gemm_walk=3", "gemm_walk=4"])
+@pytest.mark.parametrize("tune", ["", "gemm_walk=0", "gemm_walk=2", "gemm_walk=3", "gemm_walk=4", "gemm_ragged=0"])
 def test_persistent_gemm_tile_orders_are_bit_identical(tmp_path, tune):
     """every tile order of the persistent split GEMM (MPREID_TUNE gemm_walk: auto = column-fastest for the FC2 shape and row
     groups of 4 when 8 do not divide among the XCDs, row-fastest, column-fastest always, groups of 4 / 16 tile rows) writes the
     FULL output the 128 x 128 kernel writes, bit for bit: FC2 / QKV / FC1 shapes at 64 tile rows, out-proj at 224 tile rows
-    (groups of 4) and at 96 (neither 8 nor 4 divides among the XCDs: the plain walk).  The tuning string is latched per process."""
+    (groups of 4) and at 96 (neither 8 nor 4 divides among the XCDs: the plain walk), and three ragged row counts on the owned
+    walk.  The tuning string is latched per process."""
     import os
     import subprocess
     import sys
-    shapes = [(16384, 768, 3072, 11), (16384, 2304, 768, 10), (16384, 3072, 768, 12), (57344, 768, 768, 11), (24576, 768, 768, 11)]
+    shapes = [(16384, 768, 3072, 11), (16384, 2304, 768, 10), (16384, 3072, 768, 12), (57344, 768, 768, 11), (24576, 768, 768, 11),
+              # ragged row counts on the XCD-owned walk (round 6): 254 tile rows (the patch embedding's M), 245 (a 485-image encode
+              # group), 185 = 23 groups of 8 + one single row
+              (65024, 768, 768, 11), (62720, 2304, 768, 10), (47360, 768, 768, 11)]
     script = tmp_path / "walk_worker.py"
     script.write_text(WALK_WORKER.format(root=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), shapes=shapes))
     env = dict(os.environ)
