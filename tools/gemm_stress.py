@@ -32,7 +32,7 @@ SHAPES = [("qkv", 2304, 768, 1), ("out", 768, 768, 2), ("fc1", 3072, 768, 3), ("
           # split precision (round 3): k-block-major stage order with operand reuse, counted waits of 2 / 4 pieces
           ("s_qkv", 2304, 768, 10), ("s_out", 768, 768, 11), ("s_fc1", 3072, 768, 12), ("s_fc2", 768, 3072, 11),
           ("s_k64", 768, 64, 11), ("s_k128", 512, 128, 10)]
-MS = (16384, 32768 + 256)   # whole sweeps and a ragged tile count (non-owned walk)
+MS = (16384, 32768 + 256, 50944)   # whole sweeps, a ragged tile count on the blocked walk (129 tile rows), one on the owned walk (199)
 
 
 def inputs(name, N, K, epi, Mb, dev):
